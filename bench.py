@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the grid::evolve hot path (BASELINE.json metric: grid-point
+updates/sec on 512^3 fp64, achieved HBM GB/s vs peak).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE imaginary-time step (grid.rs:562-686, wnum = 0) of the whole
+grid.  N = 1: the 512^3 fp64 ThreePoint Coulomb grid of BASELINE configs[2],
+ground-state evolve, potential / phi generated in HBM (no host traffic in the
+timed region).  N > 1 (launched by torch.distributed.run, one rank per GPU):
+the grid is (1024, 1024, 128*N) -- 2^27 points per GPU, i.e. configs[3]'s
+1024^3 at N = 8 -- z-slab decomposed with RCCL halo exchange; "weak" scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra
+objects "roofline" and "cpu_baseline".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+BYTES_PER_UPDATE = {"f64": 32, "f32": 16}  # phi, a, b in + phi' out
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--grid", default=None, help="override: NX,NY,NZ (global work area)")
+    ap.add_argument("--cd", type=int, default=1, help="central difference ext: 1/2/3")
+    ap.add_argument("--potential", default="Coulomb")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--variant", type=int, default=-1, help="stencil kernel variant (-1 = default)")
+    return ap.parse_args()
+
+
+def physical_cores() -> int:
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(min(n, len(os.sched_getaffinity(0))))
+    except Exception:
+        pass
+    return max(1, len(os.sched_getaffinity(0)))
+
+
+def cpu_baseline(shape, ext, potential, dn, dt, mass, target_seconds):
+    """The oracle (kind "port": a C restatement of Wafer's rayon path, same pass
+    structure: stencil into work, copy back) timed on this host's cores on a
+    bounded number of steps of the SAME grid.  Reported, not the target."""
+    from oracle import wafer_oracle as wo
+    cores = physical_cores()  # Wafer's own thread rule, main.rs:190-196
+    wo.set_threads(cores)
+    cfg = wo.Config(*shape, ext=ext, potential=potential, dn=dn, dt=dt, mass=mass)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    del v
+    phi = wo.initial_condition(cfg, "Boolean")
+    t0 = time.perf_counter()
+    wo.evolve(cfg, 0, a, b, phi, [], 1)
+    t1 = time.perf_counter() - t0
+    steps = int(max(2, min(200, target_seconds / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    wo.evolve(cfg, 0, a, b, phi, [], steps)
+    dt_s = time.perf_counter() - t0
+    pts = shape[0] * shape[1] * shape[2]
+    return {
+        "value": pts * steps / dt_s,
+        "unit": "updates/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{steps} steps of the same {shape[0]}x{shape[1]}x{shape[2]} fp64 {potential} grid "
+                  f"(oracle/wafer_oracle.c wo_evolve, OpenMP, {dt_s:.1f} s)",
+    }
+
+
+def pmc_traffic(kernel_name: str):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if any."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        for k, v in d.get("kernels", {}).items():
+            if k in kernel_name or kernel_name in k:
+                return v.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    if world > 1 and world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import wafer_amd
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ext = args.cd
+    if args.grid:
+        shape = tuple(int(s) for s in args.grid.split(","))
+    elif n_gpus == 1:
+        shape = (512, 512, 512)
+    else:
+        shape = (1024, 1024, 128 * n_gpus)
+    if n_gpus == 1:
+        dn, dt, mass = 0.05, 5e-4, 1.0
+        potential = args.potential
+    else:
+        dn, dt, mass = 0.02, 8e-5, 2.35           # config #4: SimpleCornell, sig 0.223
+        potential = "SimpleCornell" if args.potential == "Coulomb" else args.potential
+
+    nz = shape[2]
+    z_begin, z_count = 0, 0
+    if world > 1:
+        from wafer_amd import slab
+        z_begin, z_count = slab.partition(nz, world, rank)
+    par = wafer_amd.Params(shape[0], shape[1], shape[2], dn=dn, dt=dt, mass=mass, sig=0.223,
+                           central_difference=ext, dtype=args.dtype, max_states=1, device=local_rank,
+                           z_begin=z_begin, z_count=z_count)
+    ctx = wafer_amd.Context(par)
+    if args.variant >= 0:
+        ctx.set_stencil_variant(args.variant)
+    comm = None
+    if world > 1:
+        comm = slab.TorchSlabComm(ctx, rank, world, torch.device("cuda", local_rank))
+    ctx.set_potential(potential)
+    ctx.set_initial_condition("Boolean")   # deterministic, "good for benchmarks" (config.rs:168)
+    ctx.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        ctx.evolve(0, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.evolve(0, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, ksteps = ctx.last_evolve_ms()     # HIP events on the engine's own stream
+    if dist is not None:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    pts_total = shape[0] * shape[1] * shape[2]
+    pts_rank = shape[0] * shape[1] * (z_count if z_count else shape[2])
+    value = pts_total * args.steps / elapsed
+    bpu = BYTES_PER_UPDATE[args.dtype]
+    launch_s = (kernel_ms / 1e3) / max(1, ksteps)
+    achieved = pts_rank * bpu / launch_s / 1e9
+    kname = ctx.stencil_kernel_name()
+    traffic = pmc_traffic(kname) if (n_gpus == 1 and not args.grid and args.dtype == "f64" and ext == 1) else None
+
+    result = {
+        "metric": "grid_point_updates_per_sec",
+        "value": value,
+        "unit": "updates/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,   # the reference publishes no number for this metric
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"{shape[0]}x{shape[1]}x{shape[2]} {potential} potential, "
+                        f"{ {1: 'ThreePoint', 2: 'FivePoint', 3: 'SevenPoint'}[ext]} stencil, ground-state "
+                        f"imaginary-time evolve (grid.rs:544-687), Boolean initial condition"
+                        + ("" if n_gpus == 1 else f", z-slabs of {shape[2] // n_gpus} planes per GPU, RCCL halo exchange"),
+            "grid": list(shape),
+            "points_per_gpu": pts_rank,
+            "parallelism": f"zslab{n_gpus}",
+            "kernel": kname,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "kernel": kname,
+            "avg_launch_ms": launch_s * 1e3,
+            "algorithmic_bytes_per_launch": pts_rank * bpu,
+        },
+    }
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(shape, ext, potential, dn, dt, mass, args.cpu_seconds)
+        except Exception as e:  # the baseline is reported, never required
+            result["cpu_baseline"] = {"value": None, "unit": "updates/s", "cores": physical_cores(),
+                                      "kind": "port", "sample": f"failed: {e!r}"}
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

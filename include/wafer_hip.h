@@ -1,0 +1,226 @@
+/*
+ * wafer_hip.h -- C ABI of the MI355X engine for Wafer's grid::evolve hot path.
+ *
+ * Wafer (Rust, /src/grid.rs) has no FFI or plugin interface: `grid` is a
+ * private module and evolve/compute_observables/... are private fns.  The
+ * boundary is therefore defined by their signatures.
+ * Each entry point below names the reference item it replaces.  A Rust host
+ * binds these with a plain `extern "C"` block (INTEGRATION.md shows it and
+ * the four call sites in grid.rs that change).
+ *
+ * Conventions
+ *  - Every function returns WAFER_OK (0) or a negative wafer_status;
+ *    wafer_last_error() gives the message for the calling thread.  (The
+ *    reference's fns are infallible and panic; its callers use error_chain
+ *    Result<()>, errors.rs -- a host maps non-zero to an ErrorKind.)
+ *  - One caller thread per context, non-reentrant (the reference calls these
+ *    from its main thread only; parallelism is internal, main.rs:190-196).
+ *  - Host arrays are ALWAYS double, C-order [x][y][z] (z contiguous), shape
+ *    (nx+2e, ny+2e, nz+2e) with e = ext: exactly ndarray's Array3<R64>
+ *    standard layout as the reference holds it (config.rs:224-238), so
+ *    `arr.as_ptr()` can be passed straight through.  They describe the GLOBAL
+ *    grid even when the context owns only a z-slab of it.
+ *  - Device state (phi, V, a, b, pot_sub, w_store) stays resident in HBM
+ *    between calls; only wafer_observables, norm2, download and last_evolve_ms block the host.
+ */
+#ifndef WAFER_HIP_H
+#define WAFER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WAFER_ABI_VERSION 1
+
+typedef enum wafer_status {
+    WAFER_OK = 0,
+    WAFER_ERR_INVALID = -1,      /* bad argument / config (cf. ErrorKind::LargeDt, LargeWavenum) */
+    WAFER_ERR_HIP = -2,          /* a HIP runtime call failed */
+    WAFER_ERR_NOT_AVAILABLE = -3,/* ErrorKind::PotentialNotAvailable (potential.rs:315-317) */
+    WAFER_ERR_STATE = -4,        /* w_store too short / full, potential or phi not set */
+    WAFER_ERR_MAX_STEP = -5,     /* ErrorKind::MaxStep (grid.rs:244, errors.rs:111-114) */
+    WAFER_ERR_COMM = -6          /* a communication hook failed */
+} wafer_status;
+
+/* config.rs:73-104, same order */
+typedef enum wafer_potential {
+    WAFER_POT_NOPOTENTIAL = 0,
+    WAFER_POT_CUBE,
+    WAFER_POT_QUADWELL,
+    WAFER_POT_PERIODIC,
+    WAFER_POT_COULOMB,
+    WAFER_POT_COMPLEXCOULOMB,
+    WAFER_POT_ELIPTICALCOULOMB,
+    WAFER_POT_SIMPLECORNELL,
+    WAFER_POT_FULLCORNELL,
+    WAFER_POT_HARMONIC,
+    WAFER_POT_COMPLEXHARMONIC,
+    WAFER_POT_DODECAHEDRON,
+    WAFER_POT_FROMFILE,
+    WAFER_POT_FROMSCRIPT
+} wafer_potential;
+
+/* config.rs:151-170, same order */
+typedef enum wafer_initial_condition {
+    WAFER_IC_FROMFILE = 0,
+    WAFER_IC_GAUSSIAN,
+    WAFER_IC_COULOMB,
+    WAFER_IC_CONSTANT,
+    WAFER_IC_BOOLEAN
+} wafer_initial_condition;
+
+/* config.rs:211-239: the value is CentralDifference::ext() */
+typedef enum wafer_central_difference {
+    WAFER_CD_THREEPOINT = 1,
+    WAFER_CD_FIVEPOINT = 2,
+    WAFER_CD_SEVENPOINT = 3
+} wafer_central_difference;
+
+typedef enum wafer_dtype { WAFER_F64 = 0, WAFER_F32 = 1 } wafer_dtype;
+
+/* pot_sub: (Option<Array3<R64>>, Option<R64>) of potential.rs:24 */
+typedef enum wafer_potsub_kind { WAFER_POTSUB_NONE = 0, WAFER_POTSUB_SCALAR = 1, WAFER_POTSUB_ARRAY = 2 } wafer_potsub_kind;
+
+typedef enum wafer_array_id { WAFER_ARRAY_V = 0, WAFER_ARRAY_A = 1, WAFER_ARRAY_B = 2, WAFER_ARRAY_POTSUB = 3 } wafer_array_id;
+
+/* The subset of Config (config.rs:292-333) the hot path reads, plus the
+ * engine's own knobs.  Zero-initialise, then set struct_size = sizeof. */
+typedef struct wafer_params {
+    uint32_t struct_size;
+    uint32_t nx, ny, nz;          /* config.grid.size: GLOBAL work area */
+    int32_t central_difference;   /* wafer_central_difference */
+    int32_t dtype;                /* wafer_dtype: storage + arithmetic type on the device */
+    double dn, dt;                /* config.grid.dn / dt */
+    double mass;                  /* config.mass */
+    double sig;                   /* config.sig */
+    uint32_t max_states;          /* capacity of the device-resident w_store (>= wavemax) */
+    int32_t device;               /* HIP device ordinal */
+    /* z-slab owned by this context: work planes [z_begin, z_begin+z_count) of
+     * the global grid; z_count == 0 means the whole grid.  halo_depth = ghost
+     * planes kept on each z side (0 -> ext). */
+    uint32_t z_begin, z_count;
+    uint32_t halo_depth;
+    uint32_t flags;               /* WAFER_FLAG_* */
+} wafer_params;
+
+#define WAFER_FLAG_SKIP_DT_CHECK 1u /* do not enforce dt <= dn^2/3 (config.rs:362-365) */
+
+/* grid.rs:17-28, un-normalised, in this order */
+typedef struct wafer_observables_t {
+    double energy, norm2, v_infinity, r2;
+} wafer_observables_t;
+
+/* One row of the convergence table solve() prints (grid.rs:126-221,
+ * output.rs:497-521): raw observables at `step`, diff = |E - E_last|. */
+typedef struct wafer_block_record {
+    uint64_t step;
+    double tau;
+    wafer_observables_t obs;
+    double diff;
+} wafer_block_record;
+
+/* output.rs:32-45, 540-547 */
+typedef struct wafer_observables_output {
+    uint32_t state;
+    double energy, binding_energy, r, l_r;
+} wafer_observables_output;
+
+typedef struct wafer_ctx wafer_ctx;
+
+/* ---- diagnostics ------------------------------------------------------- */
+int wafer_abi_version(void);
+const char *wafer_last_error(void);
+
+/* ---- lifetime: replaces the allocations of grid.rs:32-34, 560; potential.rs:101-102 */
+int wafer_ctx_create(const wafer_params *params, wafer_ctx **out);
+int wafer_ctx_destroy(wafer_ctx *ctx);
+int wafer_synchronize(wafer_ctx *ctx);
+
+/* ---- Potentials {v, a, b, pot_sub} (potential.rs:16-25) ----------------- */
+/* potential::generate + a/b + pot_sub, on the device (potential.rs:46-62, 101-110, 134-153) */
+int wafer_set_potential_builtin(wafer_ctx *ctx, int potential);
+/* FromFile / FromScript: v is the padded global array; potsub is NULL, or the
+ * UNPADDED nx*ny*nz array when potsub_kind == WAFER_POTSUB_ARRAY */
+int wafer_set_potential_host(wafer_ctx *ctx, const double *v, int potsub_kind, double potsub_scalar, const double *potsub);
+/* tests / output::potential: padded global array out (POTSUB: unpadded) */
+int wafer_download_array(wafer_ctx *ctx, int array_id, double *out);
+int wafer_get_potsub(wafer_ctx *ctx, int *kind, double *scalar);
+
+/* ---- phi: config::set_initial_conditions (config.rs:577-627), input::wavefunction, output::wavefunction */
+int wafer_set_initial_condition(wafer_ctx *ctx, int ic, uint64_t seed);
+int wafer_upload_phi(wafer_ctx *ctx, const double *phi);
+int wafer_download_phi(wafer_ctx *ctx, double *phi);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* evolve (grid.rs:544-687): n_steps = config.output.screen_update; like the
+ * reference, n_steps == 0 still takes one step.  wnum > 0 renormalises and
+ * Gram-Schmidts against w_store[0..wnum) after every step. */
+int wafer_evolve(wafer_ctx *ctx, uint32_t wnum, uint64_t n_steps);
+/* compute_observables (grid.rs:303-445) */
+int wafer_observables(wafer_ctx *ctx, wafer_observables_t *out);
+/* get_norm_squared over the work area (grid.rs:454-457) */
+int wafer_norm2(wafer_ctx *ctx, double *out);
+/* normalise_wavefunction (grid.rs:465-468) */
+int wafer_normalise(wafer_ctx *ctx, double norm2);
+/* orthogonalise_wavefunction (grid.rs:477-492) */
+int wafer_orthogonalise(wafer_ctx *ctx, uint32_t wnum);
+
+/* ---- w_store: Vec<Array3<R64>> of grid.rs:34 ----------------------------- */
+int wafer_push_state(wafer_ctx *ctx);                               /* w_store.push(phi), grid.rs:241 */
+int wafer_load_state(wafer_ctx *ctx, uint32_t idx, const double *state); /* input::load_wavefunctions, grid.rs:38 */
+int wafer_download_state(wafer_ctx *ctx, uint32_t idx, double *state);
+int wafer_clone_state_to_phi(wafer_ctx *ctx, uint32_t idx);         /* w_store[wnum-1].clone(), grid.rs:95 */
+int wafer_num_states(wafer_ctx *ctx, uint32_t *out);
+int wafer_clear_states(wafer_ctx *ctx);
+
+/* ---- solve (grid.rs:50-246) for ONE state, snapshot branch excluded ------ */
+/* phi must hold the starting wavefunction.  Writes up to max_records rows,
+ * *n_records = rows produced.  Returns WAFER_OK when converged (phi has then
+ * been pushed to w_store, grid.rs:239-242) and WAFER_ERR_MAX_STEP otherwise. */
+int wafer_solve_state(wafer_ctx *ctx, uint32_t wnum, double tolerance, uint64_t screen_update,
+                      int has_max_steps, uint64_t max_steps, wafer_block_record *records,
+                      size_t max_records, size_t *n_records, wafer_observables_output *final_out);
+
+/* ---- measurement ---------------------------------------------------------- */
+/* HIP-event time of the kernels of the last wafer_evolve call, on the stream
+ * they ran on, and the number of steps it took.  Blocks until they finish. */
+int wafer_last_evolve_ms(wafer_ctx *ctx, float *ms, uint64_t *steps);
+/* name of the stencil kernel variant the context dispatches to */
+const char *wafer_stencil_kernel_name(wafer_ctx *ctx);
+/* choose a stencil kernel variant by index (tuning / A-B runs); -1 = default */
+int wafer_set_stencil_variant(wafer_ctx *ctx, int variant);
+
+/* ---- multi-GPU: communication hooks --------------------------------------- */
+/* The engine never links a communication library.  A host that z-slabs the
+ * grid over several contexts installs two hooks (RCCL via torch.distributed in
+ * wafer_amd/slab.py; ncclSend/ncclRecv + ncclAllReduce in a Rust host):
+ *  - halo: copy `bytes` from this rank's send_lo / send_hi (its first / last
+ *    `planes` owned planes) into the z-neighbours' ghost planes and fill
+ *    recv_lo / recv_hi from theirs.  A NULL pointer means "no neighbour on
+ *    that side" (global Dirichlet frame).
+ *  - allreduce: in-place sum over ranks of `count` doubles at dev_ptr.
+ * Both are called with the hipStream_t the data is ordered on; on return the
+ * result must be ordered on that same stream (enqueue, do not block). */
+typedef int (*wafer_halo_fn)(void *user, void *send_lo, void *send_hi, void *recv_lo, void *recv_hi,
+                             size_t bytes, void *hip_stream);
+typedef int (*wafer_allreduce_fn)(void *user, void *dev_ptr, size_t count, void *hip_stream);
+int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn allreduce, void *user);
+/* overlap the halo exchange with interior updates on a second stream (default 1) */
+int wafer_set_overlap(wafer_ctx *ctx, int enabled);
+/* run every kernel on a caller-owned hipStream_t (NULL = the context's own) */
+int wafer_set_stream(wafer_ctx *ctx, void *hip_stream);
+/* geometry of the local slab, for hosts that need it */
+typedef struct wafer_slab_info {
+    uint32_t z_begin, z_count, halo_depth, ext;
+    uint64_t plane_elems;   /* elements per z-plane of the device layout */
+    uint64_t elem_bytes;
+} wafer_slab_info;
+int wafer_get_slab_info(wafer_ctx *ctx, wafer_slab_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

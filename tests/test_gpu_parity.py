@@ -1,0 +1,421 @@
+"""Parity of the HIP engine (called through the C ABI) with the CPU oracle on
+the same inputs.  Bars: fp64 stencil steps, normalise, a/b,
+algebraic potentials and layout conversion are BIT-EXACT; global sums agree to
+rel 1e-12 (the reference's own rayon sums are order-nondeterministic)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_common import make_pair, random_phi, ulp_diff  # noqa: E402
+
+REL_SUM = 1e-12  # tolerance on global reductions, fp64
+
+
+@pytest.fixture(scope="module")
+def wo():
+    from oracle import wafer_oracle
+    wafer_oracle.build()
+    return wafer_oracle
+
+
+@pytest.fixture(scope="module")
+def wa():
+    import wafer_amd
+    wafer_amd.load_library()
+    return wafer_amd
+
+
+SHAPES = [(17, 17, 17), (64, 64, 64), (65, 33, 20), (130, 9, 7), (3, 2, 5), (1, 1, 1)]
+
+
+# ---------------------------------------------------------------- layout / setup
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("ext", [1, 2, 3])
+def test_upload_download_roundtrip(wa, shape, ext):
+    cfg, par = make_pair(shape, ext=ext)
+    phi = np.random.default_rng(1).standard_normal(cfg.padded_shape)
+    with wa.Context(par) as ctx:
+        ctx.upload_phi(phi)
+        assert np.array_equal(ctx.download_phi(), phi)
+
+
+ALGEBRAIC = ["NoPotential", "Cube", "QuadWell", "Coulomb", "ComplexCoulomb", "ElipticalCoulomb",
+             "SimpleCornell", "Harmonic", "ComplexHarmonic", "Dodecahedron"]
+
+
+@pytest.mark.parametrize("pot", ALGEBRAIC + ["Periodic", "FullCornell"])
+@pytest.mark.parametrize("shape,ext", [((20, 14, 18), 1), ((9, 12, 16), 2), ((16, 16, 16), 3)])
+def test_builtin_potentials_and_ab(wo, wa, pot, shape, ext):
+    """potential.rs:46-62, 101-110, 188-319; z is a special axis for QuadWell /
+    ElipticalCoulomb / FullCornell, hence the anisotropic shapes"""
+    cfg, par = make_pair(shape, ext=ext, potential=pot, dn=0.13, dt=0.003, mass=1.7, sig=0.223)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    kind, scalar, arr = wo.potential_sub(cfg)
+    with wa.Context(par) as ctx:
+        ctx.set_potential(pot)
+        gv, ga, gb = ctx.download_array("v"), ctx.download_array("a"), ctx.download_array("b")
+        if pot in ALGEBRAIC:  # + - * / sqrt only: bit exact
+            assert np.array_equal(gv, v)
+            assert np.array_equal(ga, a) and np.array_equal(gb, b)
+        else:  # sin / exp come from different libms: a few ulp
+            assert np.allclose(gv, v, rtol=1e-14, atol=1e-15, equal_nan=True)
+            assert np.allclose(gb, b, rtol=1e-14, equal_nan=True)
+            assert np.allclose(ga, a, rtol=1e-14, equal_nan=True)
+        gkind, gscalar = ctx.potsub()
+        assert gkind == kind and gscalar == scalar
+        if kind == 2:
+            assert np.allclose(ctx.download_array("potsub"), arr, rtol=1e-14, equal_nan=True)
+
+
+def test_host_potential_upload(wo, wa):
+    """FromFile/FromScript path: V uploaded in the reference layout, a/b derived on device"""
+    cfg, par = make_pair((12, 10, 14), ext=2, dt=0.002)
+    v = np.random.default_rng(5).standard_normal(cfg.padded_shape)
+    a, b = wo.ab(cfg, v)
+    potsub = np.random.default_rng(6).standard_normal(cfg.work_shape)
+    with wa.Context(par) as ctx:
+        ctx.set_potential_host(v, 2, 0.0, potsub)
+        assert np.array_equal(ctx.download_array("v"), v)
+        assert np.array_equal(ctx.download_array("a"), a)
+        assert np.array_equal(ctx.download_array("b"), b)
+        assert np.array_equal(ctx.download_array("potsub"), potsub)
+        with pytest.raises(wa.WaferError):
+            ctx.set_potential("FromFile")  # ErrorKind::PotentialNotAvailable
+
+
+@pytest.mark.parametrize("ic", ["Boolean", "Constant", "Gaussian", "Coulomb"])
+@pytest.mark.parametrize("ext", [1, 3])
+def test_initial_conditions(wo, wa, ic, ext):
+    cfg, par = make_pair((11, 14, 9), ext=ext, mass=0.8, sig=0.7)
+    want = wo.initial_condition(cfg, ic, seed=42)
+    with wa.Context(par) as ctx:
+        ctx.set_initial_condition(ic, seed=42)
+        got = ctx.download_phi()
+    if ic in ("Boolean", "Constant"):
+        assert np.array_equal(got, want)
+    else:
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-13, equal_nan=True)
+
+
+# ---------------------------------------------------------------- the stencil step
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("ext", [1, 2, 3])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_ground_state_steps_bit_exact(wo, wa, shape, ext, variant):
+    """grid.rs:544-687 with wnum = 0: every cell of phi after 1 and after 10 steps"""
+    cfg, par = make_pair(shape, ext=ext, potential="Harmonic", dn=0.2, dt=0.004, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=11)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(variant)
+        ctx.set_potential("Harmonic")
+        ctx.upload_phi(phi)
+        done = 0
+        for steps in (1, 9):
+            wo.evolve(cfg, 0, a, b, phi, [], steps)
+            ctx.evolve(0, steps)
+            done += steps
+            got = ctx.download_phi()
+            assert ulp_diff(got, phi) == 0, f"after {done} steps"
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("zchunk", ["1", "3", "1000"])
+def test_zchunk_independence(wo, wa, variant, zchunk, monkeypatch):
+    """the z-chunking of a launch never changes a bit"""
+    monkeypatch.setenv("WAFER_ZCHUNK", zchunk)
+    cfg, par = make_pair((40, 21, 13), ext=2, potential="Coulomb", dn=0.1, dt=0.002)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=2)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(variant)
+        ctx.set_potential("Coulomb")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 5)
+        wo.evolve(cfg, 0, a, b, phi, [], 5)
+        assert ulp_diff(ctx.download_phi(), phi) == 0
+        obs, want = ctx.observables(), wo.observables(cfg, v, phi)
+        for k in want:
+            assert obs[k] == pytest.approx(want[k], rel=REL_SUM, abs=1e-300)
+
+
+def test_evolve_zero_steps_takes_one(wo, wa):
+    """grid.rs:682-685"""
+    cfg, par = make_pair((8, 8, 8))
+    phi = random_phi(cfg)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("Harmonic")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 0)
+        one = ctx.download_phi()
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 1)
+        assert np.array_equal(one, ctx.download_phi())
+        assert not np.array_equal(one, phi)
+
+
+def test_thousand_steps_64cubed(wo, wa):
+    """BASELINE config #1 (64^3 harmonic, Boolean IC): a full screen_update block"""
+    cfg, par = make_pair((64, 64, 64), ext=1, potential="Harmonic", dn=0.2, dt=8e-3, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = wo.initial_condition(cfg, "Boolean")
+    wo.evolve(cfg, 0, a, b, phi, [], 1000)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("Harmonic")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 1000)
+        assert ulp_diff(ctx.download_phi(), phi) == 0
+        obs, want = ctx.observables(), wo.observables(cfg, v, phi)
+        for k in ("energy", "norm2", "r2"):
+            assert obs[k] == pytest.approx(want[k], rel=REL_SUM)
+        assert obs["v_infinity"] == 0.0 == want["v_infinity"]
+
+
+# ---------------------------------------------------------------- reductions & helpers
+def _rule(shape, rule):
+    i, j, k = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij")
+    return np.ascontiguousarray({"i+j+k": i + j + k, "-(i+j+k)": -i - j - k, "i*j*k": i * j * k}[rule])
+
+
+def _embed(work, ext):
+    out = np.zeros(tuple(s + 2 * ext for s in work.shape))
+    out[ext:-ext, ext:-ext, ext:-ext] = work
+    return out
+
+
+def test_reference_unit_vectors_through_hip(wa, ref_vectors):
+    """the reference's own known answers (grid.rs:721-799), computed by the HIP path"""
+    g = ref_vectors["norm2"]  # 70070 on the work area of a (5,8,7) array
+    e = g["ext"]
+    work = tuple(s - 2 * e for s in g["shape"])
+    with wa.Context(wa.Params(*work, dn=0.1, dt=1e-3)) as ctx:
+        ctx.upload_phi(_rule(g["shape"], g["phi_rule"]))
+        assert abs(ctx.norm2() - g["expected"]) < g["eps"]
+    g = ref_vectors["wfn_normalise"]  # whole (3,2,5) array / sqrt(1.23): embed as a work area
+    with wa.Context(wa.Params(*g["shape"], dn=0.1, dt=1e-3)) as ctx:
+        ctx.upload_phi(_embed(_rule(g["shape"], g["phi_rule"]), 1))
+        ctx.normalise(g["norm2"])
+        got = ctx.download_phi()[1:-1, 1:-1, 1:-1]
+        assert np.allclose(got, _rule(g["shape"], g["phi_rule"]) / g["expected_divisor"], atol=g["tol"])
+        assert np.array_equal(got, _rule(g["shape"], g["phi_rule"]) / np.sqrt(g["norm2"]))
+    g = ref_vectors["gram_schmidt"]  # ground = i+j+k, phi = -ground on 2^3
+    with wa.Context(wa.Params(*g["shape"], dn=0.1, dt=1e-3)) as ctx:
+        ctx.load_state(0, _embed(_rule(g["shape"], g["lower_rule"]), 1))
+        ctx.upload_phi(_embed(_rule(g["shape"], g["phi_rule"]), 1))
+        ctx.orthogonalise(1)
+        got = ctx.download_phi()[1:-1, 1:-1, 1:-1].ravel()
+        assert np.allclose(got, g["expected"], atol=g["tol"])
+        assert np.array_equal(got, np.array(g["expected"]))
+
+
+@pytest.mark.parametrize("ext", [1, 2, 3])
+@pytest.mark.parametrize("pot", ["Harmonic", "SimpleCornell", "FullCornell"])
+def test_observables(wo, wa, ext, pot):
+    """grid.rs:303-445 incl. scalar and array pot_sub and the work-index r^2"""
+    cfg, par = make_pair((23, 18, 31), ext=ext, potential=pot, dn=0.15, dt=0.003, mass=1.4, sig=0.223)
+    v = wo.potential_generate(cfg)
+    potsub = wo.potential_sub(cfg)
+    phi = random_phi(cfg, seed=3)
+    want = wo.observables(cfg, v, phi, potsub)
+    with wa.Context(par) as ctx:
+        ctx.set_potential(pot)
+        ctx.upload_phi(phi)
+        got = ctx.observables()
+    for k in want:
+        if np.isnan(want[k]):  # FullCornell's pot_sub is NaN at r = 0 for odd grids (potential.rs:335)
+            assert np.isnan(got[k])
+        else:
+            assert got[k] == pytest.approx(want[k], rel=REL_SUM, abs=1e-300), k
+
+
+def test_norm_normalise_orthogonalise(wo, wa):
+    cfg, par = make_pair((19, 22, 17), ext=2)
+    phi = random_phi(cfg, seed=8)
+    lowers = [random_phi(cfg, seed=20 + i) for i in range(3)]
+    for l in lowers:
+        wo.normalise(l, wo.norm2(cfg, l))
+    with wa.Context(par) as ctx:
+        for i, l in enumerate(lowers):
+            ctx.load_state(i, l)
+        assert ctx.num_states() == 3
+        ctx.upload_phi(phi)
+        n2 = ctx.norm2()
+        assert n2 == pytest.approx(wo.norm2(cfg, phi), rel=REL_SUM)
+        n2 = wo.norm2(cfg, phi)
+        ctx.normalise(n2)
+        wo.normalise(phi, n2)
+        assert ulp_diff(ctx.download_phi(), phi) == 0  # true division, bit exact
+        ctx.orthogonalise(3)
+        wo.orthogonalise(3, phi, lowers)
+        assert np.allclose(ctx.download_phi(), phi, rtol=0, atol=1e-14)
+        for i, l in enumerate(lowers):
+            assert np.array_equal(ctx.download_state(i), l)
+        with pytest.raises(wa.WaferError):
+            ctx.orthogonalise(4)  # w_store too short
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("wnum", [1, 2, 3])
+def test_excited_state_evolve(wo, wa, wnum, variant):
+    """grid.rs:674-681: per-step renormalise + modified Gram-Schmidt"""
+    cfg, par = make_pair((24, 20, 28), ext=1, potential="Harmonic", dn=0.3, dt=0.01)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    lowers = []
+    for i in range(wnum):  # an orthonormal set, as converged states would be
+        l = random_phi(cfg, seed=30 + i)
+        wo.orthogonalise(i, l, lowers)
+        wo.normalise(l, wo.norm2(cfg, l))
+        lowers.append(l)
+    phi = random_phi(cfg, seed=40)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(variant)
+        ctx.set_potential("Harmonic")
+        for i, l in enumerate(lowers):
+            ctx.load_state(i, l)
+        ctx.upload_phi(phi)
+        ctx.evolve(wnum, 25)
+        wo.evolve(cfg, wnum, a, b, phi, lowers, 25)
+        got = ctx.download_phi()
+        assert np.allclose(got, phi, rtol=0, atol=1e-13)
+        assert ctx.norm2() == pytest.approx(1.0, abs=1e-12)
+        e = cfg.ext
+        for l in lowers:
+            assert abs(np.sum(l * got)) < 1e-13
+
+
+def test_solve_matches_oracle(wo, wa):
+    """grid.rs:50-246: same block table (step, E, r_rms, diff) and stop step,
+    ground + two excited states, on the oracle's pinned harmonic case"""
+    cfg, par = make_pair((32, 32, 32), ext=1, potential="Harmonic", dn=0.4, dt=0.032, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = wo.initial_condition(cfg, "Gaussian", seed=3)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("Harmonic")
+        ctx.upload_phi(phi)
+        store = []
+        for wnum in range(3):
+            if wnum:
+                phi = store[-1].copy()
+                ctx.clone_state_to_phi(wnum - 1)
+            want, conv = wo.solve(cfg, wnum, v, a, b, phi, store, 1e-9, 100, max_steps=100000)
+            got, final, gconv = ctx.solve_state(wnum, 1e-9, 100, max_steps=100000)
+            assert conv and gconv
+            assert abs(len(got) - len(want)) <= 1  # the stop test is |dE| < 1e-9 on sums
+            for g, w in zip(got, want):
+                assert g["step"] == w["step"] and g["tau"] == w["tau"]
+                assert g["energy"] / g["norm2"] == pytest.approx(w["energy"] / w["norm2"], abs=2e-9)
+            assert final["energy"] == pytest.approx(want[-1]["energy"] / want[-1]["norm2"], abs=2e-9)
+            assert final["state"] == wnum and final["l_r"] == pytest.approx(32 / final["r"])
+            assert ctx.num_states() == wnum + 1
+            store.append(phi.copy())
+        assert final["energy"] == pytest.approx(2.5, abs=0.04)
+
+
+def test_solve_max_steps(wa):
+    """ErrorKind::MaxStep (grid.rs:211-213, 244): tested after the step, with >"""
+    par = wa.Params(16, 16, 16, dn=0.4, dt=0.032)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("Harmonic")
+        ctx.set_initial_condition("Boolean")
+        recs, final, conv = ctx.solve_state(0, 1e-300, 10, max_steps=25)
+        assert not conv
+        assert [r["step"] for r in recs] == [0, 10, 20, 30]  # 30 > 25 stops it
+        assert ctx.num_states() == 0
+
+
+def test_config_validation(wa):
+    with pytest.raises(wa.WaferError):  # ErrorKind::LargeDt, config.rs:362-365
+        wa.Context(wa.Params(8, 8, 8, dn=0.1, dt=0.1))
+    with pytest.raises(wa.WaferError):
+        wa.Context(wa.Params(8, 8, 8, dn=0.1, dt=1e-3, central_difference=4))
+    with wa.Context(wa.Params(8, 8, 8, dn=0.1, dt=1e-3, max_states=1)) as ctx:
+        with pytest.raises(wa.WaferError):
+            ctx.evolve(0, 1)  # nothing set yet
+        ctx.set_potential("NoPotential")
+        ctx.set_initial_condition("Constant")
+        ctx.push_state()
+        with pytest.raises(wa.WaferError):
+            ctx.push_state()  # w_store full
+
+
+# ---------------------------------------------------------------- fp32 storage path
+def test_f32_path_tracks_f64(wo, wa):
+    """config #5's cross-check at a size the test can afford: same potential in
+    fp64 and fp32 storage, relative energy error <= 1e-5, |norm2 - 1| <= 1e-5"""
+    shape = (48, 48, 48)
+    res = {}
+    for dtype in ("f64", "f32"):
+        _, par = make_pair(shape, ext=1, potential="Harmonic", dn=0.27, dt=0.0145, dtype=dtype)
+        with wa.Context(par) as ctx:
+            ctx.set_potential("Harmonic")
+            ctx.set_initial_condition("Boolean")
+            recs, final, conv = ctx.solve_state(0, 1e-7, 200, max_steps=40000)
+            assert conv
+            ctx.clone_state_to_phi(0)
+            res[dtype] = (final["energy"], ctx.norm2())
+    assert res["f32"][0] == pytest.approx(res["f64"][0], rel=1e-5)
+    assert res["f32"][1] == pytest.approx(1.0, abs=1e-5)
+    assert res["f64"][1] == pytest.approx(1.0, abs=1e-12)
+
+
+# ---------------------------------------------------------------- full BASELINE size
+@pytest.mark.skipif(os.environ.get("WAFER_SKIP_BIG") == "1", reason="WAFER_SKIP_BIG=1")
+def test_full_size_512_properties(wa):
+    """512^3 fp64 (the headline size): size-independent properties.
+    V = 0: the discrete sine mode decays by exactly (1 - dt E) per step;
+    norm2 follows; Gram-Schmidt leaves <l|phi> = 0 and idempotent normalise."""
+    n = 512
+    par = wa.Params(n, n, n, dn=0.05, dt=5e-4, mass=1.0, max_states=1)
+    ax = np.sin(np.pi * np.arange(1, n + 1) / (n + 1))
+    E = 3 * (1 - np.cos(np.pi / (n + 1))) / (par.mass * par.dn ** 2)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("NoPotential")
+        phi = np.zeros(par.padded_shape)
+        phi[1:-1, 1:-1, 1:-1] = ax[:, None, None] * ax[None, :, None] * ax[None, None, :]
+        ctx.upload_phi(phi)
+        n0 = ctx.norm2()
+        assert n0 == pytest.approx(((n + 1) / 2) ** 3, rel=1e-12)
+        obs = ctx.observables()
+        assert obs["energy"] == pytest.approx(E * obs["norm2"], rel=1e-9)
+        ctx.evolve(0, 20)
+        assert ctx.norm2() == pytest.approx(n0 * (1 - par.dt * E) ** 40, rel=1e-11)
+        got = ctx.download_phi()
+        assert np.allclose(got, (1 - par.dt * E) ** 20 * phi, rtol=0, atol=1e-13)
+        assert not got[0].any() and not got[:, 0].any() and not got[:, :, -1].any()  # frame stays 0
+        ctx.push_state()
+        ctx.set_initial_condition("Boolean")
+        ctx.normalise(ctx.norm2())
+        assert ctx.norm2() == pytest.approx(1.0, abs=1e-12)
+        ctx.orthogonalise(1)
+        ctx.orthogonalise(1)
+        lower = got / np.sqrt(np.sum(got * got))
+        del got, phi
+
+
+@pytest.mark.skipif(os.environ.get("WAFER_SKIP_BIG") == "1", reason="WAFER_SKIP_BIG=1")
+def test_full_size_512_coulomb_three_steps_bit_exact(wo, wa):
+    """BASELINE config #3's grid and potential: three steps of the 512^3
+    Coulomb problem, every cell compared with the oracle"""
+    cfg, par = make_pair((512, 512, 512), ext=1, potential="Coulomb", dn=0.05, dt=5e-4, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = wo.initial_condition(cfg, "Boolean")
+    wo.evolve(cfg, 0, a, b, phi, [], 3)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 3)
+        got = ctx.download_phi()
+        assert np.array_equal(got, phi)
+        obs, want = ctx.observables(), wo.observables(cfg, v, phi)
+        for k in ("energy", "norm2", "r2"):
+            assert obs[k] == pytest.approx(want[k], rel=REL_SUM)

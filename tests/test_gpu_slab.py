@@ -1,0 +1,168 @@
+"""Engine-side z-slab logic on ONE GPU: several contexts, each owning a z-slab
+of the same grid, run in lock-step threads; their comm hooks are satisfied by
+device-to-device copies and a host-side sum instead of RCCL.  The decomposed
+result must equal the single-context result (bit for bit for the ground state:
+a halo exchange moves bytes, it does no arithmetic)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeFabric:
+    """In-process stand-in for RCCL: rank r's hooks rendezvous on barriers."""
+
+    def __init__(self, world):
+        self.world = world
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.bar = threading.Barrier(world)
+        self.send = [dict() for _ in range(world)]
+        self.scal = [None] * world
+        self.halo_calls = [0] * world
+        self.reduce_calls = [0] * world
+
+    def hooks(self, rank):
+        hip = self.hip
+
+        def halo(slo, shi, rlo, rhi, nbytes, stream):
+            assert hip.hipStreamSynchronize(stream) == 0   # my boundary planes are final
+            self.send[rank] = dict(lo=slo, hi=shi)
+            self.bar.wait()
+            if rlo:  # my lower ghost planes <- lower neighbour's top owned planes
+                assert hip.hipMemcpy(rlo, self.send[rank - 1]["hi"], nbytes, 3) == 0
+            if rhi:
+                assert hip.hipMemcpy(rhi, self.send[rank + 1]["lo"], nbytes, 3) == 0
+            assert (rlo is None) == (rank == 0) and (rhi is None) == (rank == self.world - 1)
+            self.halo_calls[rank] += 1
+            self.bar.wait()
+            return 0
+
+        def allreduce(ptr, count, stream):
+            assert hip.hipStreamSynchronize(stream) == 0
+            buf = (C.c_double * count)()
+            assert hip.hipMemcpy(buf, ptr, 8 * count, 2) == 0
+            self.scal[rank] = np.array(buf[:])
+            self.bar.wait()
+            total = np.sum(np.stack(self.scal), axis=0)   # same order on every rank
+            self.bar.wait()
+            out = (C.c_double * count)(*total)
+            assert hip.hipMemcpy(ptr, out, 8 * count, 1) == 0
+            self.reduce_calls[rank] += 1
+            return 0
+
+        return halo, allreduce
+
+
+def run_slabs(wa, base, world, body):
+    """body(ctx, rank) runs in one thread per slab; returns the list of results"""
+    from wafer_amd.slab import partition
+    import dataclasses
+    fabric = FakeFabric(world)
+    results, errors = [None] * world, []
+
+    def work(rank):
+        try:
+            zb, zc = partition(base.nz, world, rank)
+            par = dataclasses.replace(base, z_begin=zb, z_count=zc)
+            with wa.Context(par) as ctx:
+                ctx.set_comm_hooks(*fabric.hooks(rank))
+                results[rank] = body(ctx, rank)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            fabric.bar.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    if errors:
+        raise errors[0]
+    return results, fabric
+
+
+def assemble(base, world, pieces):
+    from wafer_amd.slab import partition
+    e = base.ext
+    out = np.zeros(base.padded_shape)
+    for r, p in enumerate(pieces):
+        zb, zc = partition(base.nz, world, r)
+        out[:, :, zb + e:zb + zc + e] = p[:, :, zb + e:zb + zc + e]
+    return out
+
+
+@pytest.fixture(scope="module")
+def wa():
+    import wafer_amd
+    wafer_amd.load_library()
+    return wafer_amd
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("world,shape,ext", [(2, (40, 24, 32), 1), (3, (33, 17, 31), 2), (2, (20, 20, 12), 3),
+                                            (4, (130, 12, 40), 1)])
+def test_ground_state_slabs_bit_exact(wa, world, shape, ext, overlap):
+    base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=ext)
+    steps = 12
+    with wa.Context(base) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        want = ctx.download_phi()
+        want_obs = ctx.observables()
+
+    def body(ctx, rank):
+        ctx.set_overlap(overlap)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 5)
+        ctx.evolve(0, steps - 5)
+        return ctx.download_phi(), ctx.observables()
+
+    res, fabric = run_slabs(wa, base, world, body)
+    got = assemble(base, world, [r[0] for r in res])
+    assert np.array_equal(got, want)
+    for _, obs in res:   # every rank holds the all-reduced observables
+        for k in want_obs:
+            assert obs[k] == pytest.approx(want_obs[k], rel=1e-12, abs=1e-300)
+    assert all(n == steps for n in fabric.halo_calls)   # one exchange per step, none extra
+
+
+def test_excited_state_and_solve_on_slabs(wa):
+    shape, world = (24, 24, 30), 3
+    base = wa.Params(*shape, dn=0.4, dt=0.03, mass=1.0, central_difference=1, max_states=3)
+
+    def solve_all(ctx, rank=0):
+        ctx.set_potential("Harmonic")
+        ctx.set_initial_condition("Gaussian", seed=9)
+        energies = []
+        for wnum in range(3):
+            if wnum:
+                ctx.clone_state_to_phi(wnum - 1)
+            recs, final, conv = ctx.solve_state(wnum, 1e-8, 50, max_steps=50000)
+            assert conv
+            energies.append((final["energy"], final["r"], len(recs)))
+        return energies, [ctx.download_state(i) for i in range(3)]
+
+    with wa.Context(base) as ctx:
+        want_e, want_states = solve_all(ctx)
+    res, _ = run_slabs(wa, base, world, solve_all)
+    for energies, _ in res:
+        for (e, r, n), (we, wr, wn) in zip(energies, want_e):
+            assert e == pytest.approx(we, abs=5e-8) and r == pytest.approx(wr, rel=1e-6)
+            assert abs(n - wn) <= 1
+    assert want_e[0][0] == pytest.approx(1.5, abs=0.03) and want_e[1][0] == pytest.approx(2.5, abs=0.05)
+    ground = assemble(base, world, [r[1][0] for r in res])
+    assert np.allclose(ground, want_states[0], rtol=0, atol=1e-9)
+
+
+def test_slab_without_hooks_fails_loudly(wa):
+    par = wa.Params(16, 16, 16, dn=0.2, dt=0.004, z_begin=0, z_count=8)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("Harmonic")
+        ctx.set_initial_condition("Boolean")
+        with pytest.raises(wa.WaferError):
+            ctx.evolve(0, 1)

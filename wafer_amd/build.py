@@ -1,0 +1,50 @@
+"""Builds libwafer_hip.so (the C-ABI engine) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting .so travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libwafer_hip.so")
+SOURCES = ["wafer_engine.hip"]
+HEADERS = ["wafer_geom.h", "wafer_stencil.hip.h", "wafer_stencil_lds.hip.h",
+           "wafer_elementwise.hip.h", "wafer_setup.hip.h"]
+# -ffp-contract=off: the stencil update must round exactly like the reference's
+# (rustc never fuses mul+add); see DESIGN.md "Arithmetic contract".
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the engine cannot be built")
+    return exe
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "wafer_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,1006 @@
+// wafer_engine.hip -- context, launch logic and the C ABI of include/wafer_hip.h.
+//
+// Host side mirrors the call structure of Wafer's grid.rs (run/solve/evolve/
+// compute_observables/normalise/orthogonalise) with device-resident state.
+// No CPU fallback exists: every entry point fails loudly if HIP does.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdarg>
+#include <initializer_list>
+#include <type_traits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wafer_hip.h"
+#include "wafer_elementwise.hip.h"
+#include "wafer_geom.h"
+#include "wafer_setup.hip.h"
+#include "wafer_stencil.hip.h"
+#include "wafer_stencil_lds.hip.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(WAFER_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+#define TRY(expr)                  \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != WAFER_OK) return rc_; \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// host restatement of the two scalar helpers FullCornell needs
+// (potential.rs:374-391, 394-398); evaluated once per context.
+// ---------------------------------------------------------------------------
+static double host_alphas(double mu)
+{
+    const double nf = 2.0;
+    const double b0 = 11. - 2. * nf / 3.;
+    const double b1 = 51. - 19. * nf / 3.;
+    const double b2 = 2857. - 5033. * nf / 9. + 325. * nf * nf / 27.;
+    const double l = 2. * std::log(mu / 2.3);
+    const double ll = std::log(l);
+    return 4. * WAFER_PI *
+           (1. - 2. * b1 * ll / (b0 * b0 * l) +
+            4. * b1 * b1 * ((ll - 0.5) * (ll - 0.5) + b2 * b0 / (8. * b1 * b1) - 5.0 / 4.0) /
+                (b0 * b0 * b0 * b0 * l * l)) /
+           (b0 * l);
+}
+
+static double host_mu(double t)
+{
+    const double nf = 2.0, tc = 0.2;
+    return 1.4 * std::sqrt((1. + nf / 6.) * 4. * WAFER_PI * host_alphas(2. * WAFER_PI * t)) * t * tc;
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+enum { SCAL_SLOTS = 32 };
+
+struct wafer_ctx {
+    wafer_params P;
+    WaferGeom g;
+    bool f32 = false;
+    size_t esz = 8;
+
+    hipStream_t s_main = nullptr, s_aux = nullptr, s_own = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr, ev_join = nullptr;
+
+    void *phi[2] = {nullptr, nullptr};
+    int cur = 0;
+    void *v = nullptr, *a = nullptr, *b = nullptr, *potsub = nullptr;
+    std::vector<void *> states;
+    int potsub_kind = WAFER_POTSUB_NONE;
+    double potsub_scalar = 0.0;
+    bool have_pot = false, have_phi = false;
+
+    double *partials = nullptr; // [4][partials_stride]
+    size_t partials_stride = 0;
+    double *scal = nullptr;     // SCAL_SLOTS doubles, device
+    double *scal_host = nullptr; // pinned mirror
+
+    // launch geometry shared by the column-marching kernels
+    int bx = 0, by = 0;
+
+    wafer_halo_fn halo_hook = nullptr;
+    wafer_allreduce_fn allreduce_hook = nullptr;
+    void *hook_user = nullptr;
+    bool overlap = true;
+    bool halo_stale = true;
+
+    uint64_t last_steps = 0;
+    bool timing_valid = false;
+    int variant = -1;
+    std::string kernel_name;
+
+    bool has_lo() const { return g.z_begin > 0; }
+    bool has_hi() const { return g.z_begin + g.nzl < g.nz; }
+    bool sharded() const { return has_lo() || has_hi(); }
+};
+
+static int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+// planes per workgroup so that a launch over `nplanes` has >= target blocks
+static int pick_zchunk(const wafer_ctx *c, int nplanes, int target_blocks)
+{
+    const int forced = env_int("WAFER_ZCHUNK", 0);
+    if (forced > 0) return forced;
+    const long long per_layer = (long long)c->bx * c->by;
+    long long nch = (target_blocks + per_layer - 1) / per_layer;
+    if (nch < 1) nch = 1;
+    if (nch > nplanes) nch = nplanes;
+    if (nch > 64) nch = 64;
+    return (int)((nplanes + nch - 1) / nch);
+}
+
+static inline int nchunks_of(int nplanes, int zchunk) { return (nplanes + zchunk - 1) / zchunk; }
+
+template <typename T>
+static inline T *as(void *p) { return static_cast<T *>(p); }
+
+// second-stage reduce of `nq` quantities of `n` partials each into scal[slot..slot+nq)
+static int reduce_to_scal(wafer_ctx *c, int nq, long long n, int slot, hipStream_t s)
+{
+    hipLaunchKernelGGL(wafer_k_reduce, dim3(nq), dim3(256), 0, s, c->partials, n,
+                       (long long)c->partials_stride, c->scal + slot);
+    HIP_TRY(hipGetLastError());
+    if (c->allreduce_hook && c->sharded()) {
+        if (c->allreduce_hook(c->hook_user, c->scal + slot, (size_t)nq, (void *)s) != 0)
+            return fail(WAFER_ERR_COMM, "allreduce hook failed");
+    }
+    return WAFER_OK;
+}
+
+static int read_scal(wafer_ctx *c, int slot, int n, double *out, hipStream_t s)
+{
+    HIP_TRY(hipMemcpyAsync(c->scal_host + slot, c->scal + slot, sizeof(double) * n,
+                           hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int q = 0; q < n; ++q) out[q] = c->scal_host[slot + q];
+    return WAFER_OK;
+}
+
+// ---------------------------------------------------------------------------
+// halo exchange through the host-installed hook
+// ---------------------------------------------------------------------------
+static int exchange_halo(wafer_ctx *c, int buf, hipStream_t s)
+{
+    if (!c->sharded()) return WAFER_OK;
+    if (!c->halo_hook) return fail(WAFER_ERR_COMM, "context owns a z-slab but no halo hook is installed");
+    const WaferGeom &g = c->g;
+    char *base = static_cast<char *>(c->phi[buf]);
+    const size_t plane_b = (size_t)g.plane * c->esz;
+    const size_t bytes = (size_t)g.R * plane_b;
+    void *send_lo = c->has_lo() ? base + (size_t)g.G * plane_b : nullptr;
+    void *recv_lo = c->has_lo() ? base + (size_t)(g.G - g.R) * plane_b : nullptr;
+    void *send_hi = c->has_hi() ? base + (size_t)(g.G + g.nzl - g.R) * plane_b : nullptr;
+    void *recv_hi = c->has_hi() ? base + (size_t)(g.G + g.nzl) * plane_b : nullptr;
+    if (c->halo_hook(c->hook_user, send_lo, send_hi, recv_lo, recv_hi, bytes, (void *)s) != 0)
+        return fail(WAFER_ERR_COMM, "halo hook failed");
+    return WAFER_OK;
+}
+
+static int ensure_halo(wafer_ctx *c)
+{
+    if (c->sharded() && c->halo_stale) {
+        TRY(exchange_halo(c, c->cur, c->s_main));
+        c->halo_stale = false;
+    }
+    return WAFER_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stencil step dispatch
+// ---------------------------------------------------------------------------
+struct VariantInfo {
+    const char *name;
+};
+static const VariantInfo kVariants[] = {
+    {"wafer_k_step_direct"},
+    {"wafer_k_step_lds"},
+};
+static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+
+static int default_variant(const wafer_ctx *c)
+{
+    (void)c;
+    return env_int("WAFER_STENCIL_VARIANT", 1);
+}
+
+template <typename T, typename C, int R, bool NORM>
+static int launch_step_t(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s)
+{
+    if (lz_hi <= lz_lo) return WAFER_OK;
+    const int variant = c->variant >= 0 ? c->variant : default_variant(c);
+    WaferStepArgs a;
+    a.g = c->g;
+    a.lz_lo = lz_lo;
+    a.lz_hi = lz_hi;
+    a.dt = c->P.dt;
+    const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
+    a.den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:569 / 594 / 626
+    const T *phi = as<T>(c->phi[src]);
+    T *out = as<T>(c->phi[dst]);
+    if (variant == 1) {
+        return wafer_launch_step_lds<T, C, R, NORM>(a, phi, as<T>(c->a), as<T>(c->b), out,
+                                                    c->partials, c->partials_stride, s) == hipSuccess
+                   ? WAFER_OK
+                   : fail(WAFER_ERR_HIP, "LDS stencil launch failed: %s",
+                          hipGetErrorString(hipGetLastError()));
+    }
+    a.zchunk = pick_zchunk(c, lz_hi - lz_lo, env_int("WAFER_TARGET_BLOCKS", 4096));
+    const dim3 grid(c->bx, c->by, nchunks_of(lz_hi - lz_lo, a.zchunk));
+    if ((size_t)grid.x * grid.y * grid.z > c->partials_stride)
+        return fail(WAFER_ERR_INVALID, "partials buffer too small");
+    hipLaunchKernelGGL((wafer_k_step_direct<T, C, R, NORM>), grid, dim3(64, 4), 0, s, a, phi,
+                       as<T>(c->a), as<T>(c->b), out, c->partials);
+    HIP_TRY(hipGetLastError());
+    return WAFER_OK;
+}
+
+// number of partials the NORM variant of the last step launch wrote
+template <typename T, typename C, int R>
+static long long step_partials_count(wafer_ctx *c, int lz_lo, int lz_hi)
+{
+    const int variant = c->variant >= 0 ? c->variant : default_variant(c);
+    if (variant == 1) return wafer_step_lds_blocks<T, R>(c->g, lz_lo, lz_hi);
+    const int zc = pick_zchunk(c, lz_hi - lz_lo, env_int("WAFER_TARGET_BLOCKS", 4096));
+    return (long long)c->bx * c->by * nchunks_of(lz_hi - lz_lo, zc);
+}
+
+template <typename F>
+static int dispatch(wafer_ctx *c, F &&f)
+{
+    // f(T storage tag, C compute tag, R tag)
+    const int R = c->g.R;
+    if (!c->f32) {
+        if (R == 1) return f(double{}, double{}, std::integral_constant<int, 1>{});
+        if (R == 2) return f(double{}, double{}, std::integral_constant<int, 2>{});
+        return f(double{}, double{}, std::integral_constant<int, 3>{});
+    }
+    // fp32 storage; arithmetic widened to fp64 in registers (the path is HBM-bound)
+    if (R == 1) return f(float{}, double{}, std::integral_constant<int, 1>{});
+    if (R == 2) return f(float{}, double{}, std::integral_constant<int, 2>{});
+    return f(float{}, double{}, std::integral_constant<int, 3>{});
+}
+
+static int launch_step(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, bool norm, hipStream_t s)
+{
+    return dispatch(c, [&](auto t, auto cc, auto r) {
+        using T = decltype(t);
+        using C = decltype(cc);
+        constexpr int R = decltype(r)::value;
+        return norm ? launch_step_t<T, C, R, true>(c, src, dst, lz_lo, lz_hi, s)
+                    : launch_step_t<T, C, R, false>(c, src, dst, lz_lo, lz_hi, s);
+    });
+}
+
+// elementwise launches -------------------------------------------------------
+static WaferEwArgs ew_args(wafer_ctx *c, int *nblocks, dim3 *grid)
+{
+    WaferEwArgs a;
+    a.g = c->g;
+    a.lz_lo = c->g.G;
+    a.lz_hi = c->g.G + c->g.nzl;
+    a.zchunk = pick_zchunk(c, c->g.nzl, env_int("WAFER_TARGET_BLOCKS", 4096));
+    *grid = dim3(c->bx, c->by, nchunks_of(c->g.nzl, a.zchunk));
+    *nblocks = (int)(grid->x * grid->y * grid->z);
+    return a;
+}
+
+// normalise (+ optional overlap with lower) on buffer `buf`; norm2 from scal[slot] or immediate
+static int launch_normalise(wafer_ctx *c, int buf, const double *norm2_dev, double norm2_imm,
+                            void *lower, int out_slot, hipStream_t s)
+{
+    int nb;
+    dim3 grid;
+    WaferEwArgs a = ew_args(c, &nb, &grid);
+    TRY(dispatch(c, [&](auto t, auto cc, auto) {
+        using T = decltype(t);
+        using C = decltype(cc);
+        hipLaunchKernelGGL((wafer_k_normalise_dot<T, C>), grid, dim3(64, 4), 0, s, a, as<T>(c->phi[buf]),
+                           norm2_dev, norm2_imm, (const T *)lower, c->partials);
+        HIP_TRY(hipGetLastError());
+        return (int)WAFER_OK;
+    }));
+    if (lower) TRY(reduce_to_scal(c, 1, nb, out_slot, s));
+    return WAFER_OK;
+}
+
+static int launch_axpy(wafer_ctx *c, int buf, void *lower, int overlap_slot, void *next, int out_slot,
+                       hipStream_t s)
+{
+    int nb;
+    dim3 grid;
+    WaferEwArgs a = ew_args(c, &nb, &grid);
+    TRY(dispatch(c, [&](auto t, auto cc, auto) {
+        using T = decltype(t);
+        using C = decltype(cc);
+        hipLaunchKernelGGL((wafer_k_axpy_dot<T, C>), grid, dim3(64, 4), 0, s, a, as<T>(c->phi[buf]),
+                           (const T *)lower, c->scal + overlap_slot, (const T *)next, c->partials);
+        HIP_TRY(hipGetLastError());
+        return (int)WAFER_OK;
+    }));
+    if (next) TRY(reduce_to_scal(c, 1, nb, out_slot, s));
+    return WAFER_OK;
+}
+
+static int launch_dot(wafer_ctx *c, int buf, void *lower, int out_slot, hipStream_t s)
+{
+    int nb;
+    dim3 grid;
+    WaferEwArgs a = ew_args(c, &nb, &grid);
+    TRY(dispatch(c, [&](auto t, auto cc, auto) {
+        using T = decltype(t);
+        using C = decltype(cc);
+        hipLaunchKernelGGL((wafer_k_dot<T, C>), grid, dim3(64, 4), 0, s, a, as<T>(c->phi[buf]),
+                           (const T *)lower, c->partials);
+        HIP_TRY(hipGetLastError());
+        return (int)WAFER_OK;
+    }));
+    return reduce_to_scal(c, 1, nb, out_slot, s);
+}
+
+// Gram-Schmidt chain on `buf` against states [0,wnum); the first overlap is
+// already in scal[1] when first_dot_done.
+static int gs_chain(wafer_ctx *c, int buf, uint32_t wnum, bool first_dot_done, hipStream_t s)
+{
+    if (wnum == 0) return WAFER_OK;
+    if (!first_dot_done) TRY(launch_dot(c, buf, c->states[0], 1, s));
+    for (uint32_t l = 0; l < wnum; ++l) {
+        void *next = (l + 1 < wnum) ? c->states[l + 1] : nullptr;
+        TRY(launch_axpy(c, buf, c->states[l], 1 + (int)l, next, 2 + (int)l, s));
+    }
+    return WAFER_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int wafer_abi_version(void) { return WAFER_ABI_VERSION; }
+const char *wafer_last_error(void) { return g_last_error.c_str(); }
+
+int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
+{
+    if (!p || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    if (p->struct_size != sizeof(wafer_params))
+        return fail(WAFER_ERR_INVALID, "wafer_params.struct_size %u != %zu (ABI mismatch)",
+                    p->struct_size, sizeof(wafer_params));
+    if (p->nx < 1 || p->ny < 1 || p->nz < 1) return fail(WAFER_ERR_INVALID, "grid size must be >= 1");
+    if (p->central_difference < 1 || p->central_difference > 3)
+        return fail(WAFER_ERR_INVALID, "central_difference must be 1 (Three), 2 (Five) or 3 (SevenPoint)");
+    if (p->dtype != WAFER_F64 && p->dtype != WAFER_F32) return fail(WAFER_ERR_INVALID, "bad dtype");
+    if (!(p->dn > 0) || !(p->dt > 0) || !(p->mass > 0)) return fail(WAFER_ERR_INVALID, "dn, dt, mass must be > 0");
+    // config.rs:362-365 (ErrorKind::LargeDt)
+    if (!(p->flags & WAFER_FLAG_SKIP_DT_CHECK) && p->dt > p->dn * p->dn / 3.)
+        return fail(WAFER_ERR_INVALID, "LargeDt: dt must be <= dn^2/3 (config.rs:363)");
+    const int R = p->central_difference;
+    const uint32_t zc = p->z_count ? p->z_count : p->nz;
+    const uint32_t zb = p->z_count ? p->z_begin : 0;
+    if (zb + zc > p->nz) return fail(WAFER_ERR_INVALID, "z-slab exceeds the grid");
+    const int G = p->halo_depth ? (int)p->halo_depth : R;
+    if (G < R) return fail(WAFER_ERR_INVALID, "halo_depth must be >= ext");
+    if (zc < p->nz && (int)zc < 2 * R) return fail(WAFER_ERR_INVALID, "a z-slab needs at least 2*ext planes");
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(WAFER_ERR_HIP, "no HIP device visible: the engine has no CPU path");
+    if (p->device < 0 || p->device >= ndev) return fail(WAFER_ERR_INVALID, "device %d out of range", p->device);
+    HIP_TRY(hipSetDevice(p->device));
+
+    wafer_ctx *c = new wafer_ctx();
+    c->P = *p;
+    c->f32 = (p->dtype == WAFER_F32);
+    c->esz = c->f32 ? 4 : 8;
+    c->g = wafer_make_geom((int)p->nx, (int)p->ny, (int)p->nz, R, G, (int)zb, (int)zc, (int)c->esz);
+    c->bx = (c->g.px + 63) / 64; // covers both the work area and the padded extent
+    c->by = (c->g.py + 3) / 4;
+    c->overlap = env_int("WAFER_OVERLAP", 1) != 0;
+
+    auto cleanup_fail = [&](int rc) {
+        wafer_ctx_destroy(c);
+        return rc;
+    };
+#define HIP_TRYC(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return cleanup_fail(fail(WAFER_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
+
+    HIP_TRYC(hipStreamCreateWithFlags(&c->s_own, hipStreamNonBlocking));
+    c->s_main = c->s_own;
+    HIP_TRYC(hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
+    HIP_TRYC(hipEventCreate(&c->ev_start));
+    HIP_TRYC(hipEventCreate(&c->ev_stop));
+    HIP_TRYC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRYC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+
+    const size_t bytes = (size_t)c->g.total * c->esz;
+    void **arrays[] = {&c->phi[0], &c->phi[1], &c->v, &c->a, &c->b};
+    for (void **arr : arrays) {
+        HIP_TRYC(hipMalloc(arr, bytes));
+        HIP_TRYC(hipMemsetAsync(*arr, 0, bytes, c->s_main));
+    }
+    c->partials_stride = (size_t)c->bx * c->by * 64 + 1024;
+    HIP_TRYC(hipMalloc((void **)&c->partials, sizeof(double) * 4 * c->partials_stride));
+    HIP_TRYC(hipMalloc((void **)&c->scal, sizeof(double) * SCAL_SLOTS));
+    HIP_TRYC(hipMemsetAsync(c->scal, 0, sizeof(double) * SCAL_SLOTS, c->s_main));
+    HIP_TRYC(hipHostMalloc((void **)&c->scal_host, sizeof(double) * SCAL_SLOTS, hipHostMallocDefault));
+    HIP_TRYC(hipStreamSynchronize(c->s_main));
+#undef HIP_TRYC
+    c->kernel_name = kVariants[default_variant(c) < kNumVariants ? default_variant(c) : 0].name;
+    *out = c;
+    return WAFER_OK;
+}
+
+int wafer_ctx_destroy(wafer_ctx *c)
+{
+    if (!c) return WAFER_OK;
+    (void)hipSetDevice(c->P.device);
+    if (c->s_own) (void)hipStreamSynchronize(c->s_own);
+    if (c->s_aux) (void)hipStreamSynchronize(c->s_aux);
+    for (void *p : {c->phi[0], c->phi[1], c->v, c->a, c->b, c->potsub})
+        if (p) (void)hipFree(p);
+    for (void *p : c->states)
+        if (p) (void)hipFree(p);
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->scal) (void)hipFree(c->scal);
+    if (c->scal_host) (void)hipHostFree(c->scal_host);
+    for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join})
+        if (e) (void)hipEventDestroy(e);
+    if (c->s_own) (void)hipStreamDestroy(c->s_own);
+    if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
+    delete c;
+    return WAFER_OK;
+}
+
+int wafer_synchronize(wafer_ctx *c)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->P.device));
+    HIP_TRY(hipStreamSynchronize(c->s_aux));
+    HIP_TRY(hipStreamSynchronize(c->s_main));
+    return WAFER_OK;
+}
+
+} // extern "C"
+
+// ---- layout conversion helpers ----------------------------------------------
+// Copies the z-range of a global reference-layout host array [sx][sy][szg] that
+// this slab holds into a dense staging buffer and transposes it into `dev`.
+// (xp0, yp0, zofs): where host element (0,0,0) lands in padded coordinates.
+template <bool TO_DEVICE>
+static int convert_host_array(wafer_ctx *c, double *host, int sx, int sy, int szg, int xp0, int yp0,
+                              int zp0, void *dev)
+{
+    const WaferGeom &g = c->g;
+    // host z index hz corresponds to global padded zp = zp0 + hz; local plane lzp = zp - zp_of(0)
+    const int lz_first = g.zp_of(0);
+    int hz_lo = lz_first - zp0, hz_hi = lz_first + g.lz - zp0;
+    if (hz_lo < 0) hz_lo = 0;
+    if (hz_hi > szg) hz_hi = szg;
+    const int sz = hz_hi - hz_lo;
+    if (sz <= 0) return WAFER_OK;
+    const int lzp0 = zp0 + hz_lo - lz_first;
+    double *stage = nullptr;
+    const size_t rows = (size_t)sx * sy;
+    HIP_TRY(hipMalloc((void **)&stage, rows * sz * sizeof(double)));
+    WaferXposeArgs a;
+    a.g = g;
+    a.sx = sx; a.sy = sy; a.sz = sz;
+    a.xp0 = xp0; a.yp0 = yp0; a.lzp0 = lzp0;
+    const dim3 grid((sx + 31) / 32, sy, (sz + 31) / 32), block(32, 8);
+    hipError_t e = hipSuccess;
+    if (TO_DEVICE) {
+        e = hipMemcpy2DAsync(stage, (size_t)sz * 8, host + hz_lo, (size_t)szg * 8, (size_t)sz * 8, rows,
+                             hipMemcpyHostToDevice, c->s_main);
+        if (e == hipSuccess) {
+            if (c->f32)
+                hipLaunchKernelGGL((wafer_k_transpose<float, true>), grid, block, 0, c->s_main, a, stage, as<float>(dev));
+            else
+                hipLaunchKernelGGL((wafer_k_transpose<double, true>), grid, block, 0, c->s_main, a, stage, as<double>(dev));
+            e = hipGetLastError();
+        }
+    } else {
+        if (c->f32)
+            hipLaunchKernelGGL((wafer_k_transpose<float, false>), grid, block, 0, c->s_main, a, stage, as<float>(dev));
+        else
+            hipLaunchKernelGGL((wafer_k_transpose<double, false>), grid, block, 0, c->s_main, a, stage, as<double>(dev));
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(host + hz_lo, (size_t)szg * 8, stage, (size_t)sz * 8, (size_t)sz * 8, rows,
+                                 hipMemcpyDeviceToHost, c->s_main);
+    }
+    hipError_t e2 = hipStreamSynchronize(c->s_main);
+    (void)hipFree(stage);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(WAFER_ERR_HIP, "layout conversion failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return WAFER_OK;
+}
+
+static int upload_padded(wafer_ctx *c, const double *host, void *dev)
+{
+    return convert_host_array<true>(c, const_cast<double *>(host), c->g.px, c->g.py, c->g.pzg, 0, 0, 0, dev);
+}
+static int download_padded(wafer_ctx *c, double *host, void *dev)
+{
+    return convert_host_array<false>(c, host, c->g.px, c->g.py, c->g.pzg, 0, 0, 0, dev);
+}
+
+// ---- potentials ----------------------------------------------------------------
+extern "C" {
+
+static WaferPotArgs pot_args(wafer_ctx *c, int type)
+{
+    WaferPotArgs a;
+    a.g = c->g;
+    a.type = type;
+    a.dn = c->P.dn; a.dt = c->P.dt; a.mass = c->P.mass; a.sig = c->P.sig;
+    const double t = 1.0, xi = 0.0; // potential.rs:252-253
+    a.mu_t = host_mu(t);
+    a.alphas_2pit = host_alphas(2. * WAFER_PI * t);
+    a.xi_coef = 0.07 * std::pow(xi, 0.2);
+    a.xi_fac = std::pow(1. + xi, -0.29);
+    return a;
+}
+
+static int ensure_potsub_array(wafer_ctx *c)
+{
+    if (!c->potsub) {
+        HIP_TRY(hipMalloc(&c->potsub, (size_t)c->g.total * c->esz));
+        HIP_TRY(hipMemsetAsync(c->potsub, 0, (size_t)c->g.total * c->esz, c->s_main));
+    }
+    return WAFER_OK;
+}
+
+int wafer_set_potential_builtin(wafer_ctx *c, int potential)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (potential < 0 || potential > WAFER_POT_FROMSCRIPT) return fail(WAFER_ERR_INVALID, "unknown potential %d", potential);
+    if (potential == WAFER_POT_FROMFILE || potential == WAFER_POT_FROMSCRIPT)
+        return fail(WAFER_ERR_NOT_AVAILABLE, "PotentialNotAvailable: FromFile/FromScript need wafer_set_potential_host");
+    HIP_TRY(hipSetDevice(c->P.device));
+    WaferPotArgs a = pot_args(c, potential);
+    const dim3 grid(c->bx, c->by, c->g.lz), block(64, 4);
+    if (c->f32)
+        hipLaunchKernelGGL((wafer_k_potential<float>), grid, block, 0, c->s_main, a, as<float>(c->v), as<float>(c->a), as<float>(c->b));
+    else
+        hipLaunchKernelGGL((wafer_k_potential<double>), grid, block, 0, c->s_main, a, as<double>(c->v), as<double>(c->a), as<double>(c->b));
+    HIP_TRY(hipGetLastError());
+    // pot_sub: potential.rs:134-153 with 326-363
+    c->potsub_kind = WAFER_POTSUB_NONE;
+    c->potsub_scalar = 0.0;
+    if (potential == WAFER_POT_FULLCORNELL) {
+        TRY(ensure_potsub_array(c));
+        const dim3 g2(c->bx, c->by, c->g.nzl);
+        if (c->f32)
+            hipLaunchKernelGGL((wafer_k_potsub_fullcornell<float>), g2, block, 0, c->s_main, a, as<float>(c->potsub));
+        else
+            hipLaunchKernelGGL((wafer_k_potsub_fullcornell<double>), g2, block, 0, c->s_main, a, as<double>(c->potsub));
+        HIP_TRY(hipGetLastError());
+        c->potsub_kind = WAFER_POTSUB_ARRAY;
+    } else {
+        double s = 0.0;
+        if (potential == WAFER_POT_ELIPTICALCOULOMB) s = 1. / c->P.dn;   // potential.rs:359
+        if (potential == WAFER_POT_SIMPLECORNELL) s = 4.0 * c->P.mass;   // potential.rs:360
+        if (s > 0.0) { // potential.rs:148-152
+            c->potsub_kind = WAFER_POTSUB_SCALAR;
+            c->potsub_scalar = s;
+        }
+    }
+    c->have_pot = true;
+    return WAFER_OK;
+}
+
+int wafer_set_potential_host(wafer_ctx *c, const double *v, int potsub_kind, double potsub_scalar, const double *potsub)
+{
+    if (!c || !v) return fail(WAFER_ERR_INVALID, "null argument");
+    if (potsub_kind < 0 || potsub_kind > 2) return fail(WAFER_ERR_INVALID, "bad potsub_kind");
+    if (potsub_kind == WAFER_POTSUB_ARRAY && !potsub) return fail(WAFER_ERR_INVALID, "potsub array missing");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(upload_padded(c, v, c->v));
+    const dim3 grid(c->bx, c->by, c->g.lz), block(64, 4);
+    if (c->f32)
+        hipLaunchKernelGGL((wafer_k_ab<float>), grid, block, 0, c->s_main, c->g, c->P.dt, as<float>(c->v), as<float>(c->a), as<float>(c->b));
+    else
+        hipLaunchKernelGGL((wafer_k_ab<double>), grid, block, 0, c->s_main, c->g, c->P.dt, as<double>(c->v), as<double>(c->a), as<double>(c->b));
+    HIP_TRY(hipGetLastError());
+    c->potsub_kind = potsub_kind;
+    c->potsub_scalar = (potsub_kind == WAFER_POTSUB_SCALAR) ? potsub_scalar : 0.0;
+    if (potsub_kind == WAFER_POTSUB_ARRAY) {
+        TRY(ensure_potsub_array(c));
+        // unpadded [nx][ny][nz] -> work cells (offset R on every axis)
+        TRY((convert_host_array<true>(c, const_cast<double *>(potsub), c->g.nx, c->g.ny, c->g.nz, c->g.R, c->g.R, c->g.R, c->potsub)));
+    }
+    c->have_pot = true;
+    return WAFER_OK;
+}
+
+int wafer_download_array(wafer_ctx *c, int id, double *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->P.device));
+    switch (id) {
+    case WAFER_ARRAY_V: return download_padded(c, out, c->v);
+    case WAFER_ARRAY_A: return download_padded(c, out, c->a);
+    case WAFER_ARRAY_B: return download_padded(c, out, c->b);
+    case WAFER_ARRAY_POTSUB:
+        if (c->potsub_kind != WAFER_POTSUB_ARRAY) return fail(WAFER_ERR_STATE, "pot_sub is not an array");
+        return convert_host_array<false>(c, out, c->g.nx, c->g.ny, c->g.nz, c->g.R, c->g.R, c->g.R, c->potsub);
+    default: return fail(WAFER_ERR_INVALID, "unknown array id %d", id);
+    }
+}
+
+int wafer_get_potsub(wafer_ctx *c, int *kind, double *scalar)
+{
+    if (!c || !kind || !scalar) return fail(WAFER_ERR_INVALID, "null argument");
+    *kind = c->potsub_kind;
+    *scalar = c->potsub_scalar;
+    return WAFER_OK;
+}
+
+// ---- phi ---------------------------------------------------------------------------
+int wafer_set_initial_condition(wafer_ctx *c, int ic, uint64_t seed)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (ic == WAFER_IC_FROMFILE) return fail(WAFER_ERR_NOT_AVAILABLE, "FromFile: use wafer_upload_phi");
+    if (ic < WAFER_IC_GAUSSIAN || ic > WAFER_IC_BOOLEAN) return fail(WAFER_ERR_INVALID, "unknown initial condition %d", ic);
+    HIP_TRY(hipSetDevice(c->P.device));
+    WaferIcArgs a;
+    a.g = c->g; a.ic = ic; a.seed = seed;
+    a.dn = c->P.dn; a.mass = c->P.mass; a.sig = c->P.sig;
+    const dim3 grid(c->bx, c->by, c->g.lz), block(64, 4);
+    if (c->f32)
+        hipLaunchKernelGGL((wafer_k_initial_condition<float>), grid, block, 0, c->s_main, a, as<float>(c->phi[c->cur]));
+    else
+        hipLaunchKernelGGL((wafer_k_initial_condition<double>), grid, block, 0, c->s_main, a, as<double>(c->phi[c->cur]));
+    HIP_TRY(hipGetLastError());
+    c->have_phi = true;
+    c->halo_stale = false; // every ghost plane was generated from global indices
+    return WAFER_OK;
+}
+
+int wafer_upload_phi(wafer_ctx *c, const double *phi)
+{
+    if (!c || !phi) return fail(WAFER_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(upload_padded(c, phi, c->phi[c->cur]));
+    c->have_phi = true;
+    c->halo_stale = false; // ghost planes came from the global array
+    return WAFER_OK;
+}
+
+int wafer_download_phi(wafer_ctx *c, double *phi)
+{
+    if (!c || !phi) return fail(WAFER_ERR_INVALID, "null argument");
+    if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
+    HIP_TRY(hipSetDevice(c->P.device));
+    HIP_TRY(hipStreamSynchronize(c->s_aux));
+    return download_padded(c, phi, c->phi[c->cur]);
+}
+
+// ---- evolve (grid.rs:544-687) ----------------------------------------------------
+int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (!c->have_pot || !c->have_phi) return fail(WAFER_ERR_STATE, "potential and phi must be set before evolve");
+    if (wnum > c->states.size()) return fail(WAFER_ERR_STATE, "wnum %u but w_store holds %zu states", wnum, c->states.size());
+    if (wnum + 2 > SCAL_SLOTS) return fail(WAFER_ERR_INVALID, "wnum too large");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(ensure_halo(c));
+    const WaferGeom &g = c->g;
+    const int lo = g.G, hi = g.G + g.nzl;
+    const uint64_t steps = n_steps == 0 ? 1 : n_steps; // grid.rs:682-685
+    const bool split = c->sharded() && c->overlap && wnum == 0 && g.nzl > 2 * g.R;
+    HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
+    for (uint64_t s = 0; s < steps; ++s) {
+        const int src = c->cur, dst = c->cur ^ 1;
+        if (wnum == 0) {
+            if (split) {
+                // boundary planes first on the aux stream, their exchange overlaps the interior
+                HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
+                HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
+                if (c->has_lo()) TRY(launch_step(c, src, dst, lo, lo + g.R, false, c->s_aux));
+                if (c->has_hi()) TRY(launch_step(c, src, dst, hi - g.R, hi, false, c->s_aux));
+                TRY(exchange_halo(c, dst, c->s_aux));
+                HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
+                TRY(launch_step(c, src, dst, c->has_lo() ? lo + g.R : lo, c->has_hi() ? hi - g.R : hi, false, c->s_main));
+                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
+            } else {
+                TRY(launch_step(c, src, dst, lo, hi, false, c->s_main));
+                TRY(exchange_halo(c, dst, c->s_main));
+            }
+        } else {
+            // step + sum phi'^2 (grid.rs:675-678), normalise (:679), Gram-Schmidt (:680)
+            TRY(launch_step(c, src, dst, lo, hi, true, c->s_main));
+            long long nb = dispatch(c, [&](auto t, auto cc, auto r) {
+                return (int)step_partials_count<decltype(t), decltype(cc), decltype(r)::value>(c, lo, hi);
+            });
+            TRY(reduce_to_scal(c, 1, nb, 0, c->s_main));
+            TRY(launch_normalise(c, dst, c->scal + 0, 0.0, c->states[0], 1, c->s_main));
+            TRY(gs_chain(c, dst, wnum, true, c->s_main));
+            TRY(exchange_halo(c, dst, c->s_main));
+        }
+        c->cur = dst;
+    }
+    HIP_TRY(hipEventRecord(c->ev_stop, c->s_main));
+    c->last_steps = steps;
+    c->timing_valid = true;
+    c->halo_stale = false;
+    return WAFER_OK;
+}
+
+int wafer_last_evolve_ms(wafer_ctx *c, float *ms, uint64_t *steps)
+{
+    if (!c || !ms) return fail(WAFER_ERR_INVALID, "null argument");
+    if (!c->timing_valid) return fail(WAFER_ERR_STATE, "no evolve call to time");
+    HIP_TRY(hipSetDevice(c->P.device));
+    HIP_TRY(hipEventSynchronize(c->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    if (steps) *steps = c->last_steps;
+    return WAFER_OK;
+}
+
+const char *wafer_stencil_kernel_name(wafer_ctx *c)
+{
+    if (!c) return "";
+    const int v = c->variant >= 0 ? c->variant : default_variant(c);
+    return kVariants[(v >= 0 && v < kNumVariants) ? v : 0].name;
+}
+
+int wafer_set_stencil_variant(wafer_ctx *c, int variant)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (variant >= kNumVariants) return fail(WAFER_ERR_INVALID, "variant %d out of range (have %d)", variant, kNumVariants);
+    c->variant = variant;
+    return WAFER_OK;
+}
+
+// ---- compute_observables (grid.rs:303-445) ------------------------------------------
+int wafer_observables(wafer_ctx *c, wafer_observables_t *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    if (!c->have_pot || !c->have_phi) return fail(WAFER_ERR_STATE, "potential and phi must be set");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(ensure_halo(c));
+    WaferObsArgs a;
+    a.g = c->g;
+    a.zchunk = pick_zchunk(c, c->g.nzl, env_int("WAFER_TARGET_BLOCKS", 4096));
+    const dim3 grid(c->bx, c->by, nchunks_of(c->g.nzl, a.zchunk));
+    a.nblocks = (long long)c->partials_stride;
+    const long long nb = (long long)grid.x * grid.y * grid.z;
+    if ((size_t)nb > c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
+    const int R = c->g.R;
+    const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
+    a.den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:314 / 337 / 367
+    a.potsub_kind = c->potsub_kind;
+    a.potsub_scalar = c->potsub_scalar;
+    TRY(dispatch(c, [&](auto t, auto, auto r) {
+        using T = decltype(t);
+        constexpr int RR = decltype(r)::value;
+        hipLaunchKernelGGL((wafer_k_observables<T, RR>), grid, dim3(64, 4), 0, c->s_main, a,
+                           as<T>(c->phi[c->cur]), as<T>(c->v), as<T>(c->potsub), c->partials);
+        HIP_TRY(hipGetLastError());
+        return (int)WAFER_OK;
+    }));
+    TRY(reduce_to_scal(c, 4, nb, 8, c->s_main));
+    double r[4];
+    TRY(read_scal(c, 8, 4, r, c->s_main));
+    out->energy = r[0];
+    out->norm2 = r[1];
+    out->v_infinity = (c->potsub_kind == WAFER_POTSUB_NONE) ? 0.0 : r[2]; // grid.rs:425
+    out->r2 = r[3];
+    return WAFER_OK;
+}
+
+int wafer_norm2(wafer_ctx *c, double *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
+    HIP_TRY(hipSetDevice(c->P.device));
+    int nb;
+    dim3 grid;
+    WaferEwArgs a = ew_args(c, &nb, &grid);
+    if (c->f32)
+        hipLaunchKernelGGL((wafer_k_norm2<float>), grid, dim3(64, 4), 0, c->s_main, a, as<float>(c->phi[c->cur]), c->partials);
+    else
+        hipLaunchKernelGGL((wafer_k_norm2<double>), grid, dim3(64, 4), 0, c->s_main, a, as<double>(c->phi[c->cur]), c->partials);
+    HIP_TRY(hipGetLastError());
+    TRY(reduce_to_scal(c, 1, nb, 12, c->s_main));
+    return read_scal(c, 12, 1, out, c->s_main);
+}
+
+int wafer_normalise(wafer_ctx *c, double norm2)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(launch_normalise(c, c->cur, nullptr, norm2, nullptr, 0, c->s_main));
+    c->halo_stale = true;
+    return WAFER_OK;
+}
+
+int wafer_orthogonalise(wafer_ctx *c, uint32_t wnum)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
+    if (wnum > c->states.size()) return fail(WAFER_ERR_STATE, "wnum %u but w_store holds %zu states", wnum, c->states.size());
+    if (wnum + 2 > SCAL_SLOTS) return fail(WAFER_ERR_INVALID, "wnum too large");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(gs_chain(c, c->cur, wnum, false, c->s_main));
+    if (wnum) c->halo_stale = true;
+    return WAFER_OK;
+}
+
+// ---- w_store ------------------------------------------------------------------------
+static int new_state_slot(wafer_ctx *c, void **slot)
+{
+    if (c->states.size() >= c->P.max_states)
+        return fail(WAFER_ERR_STATE, "w_store is full (max_states = %u)", c->P.max_states);
+    HIP_TRY(hipMalloc(slot, (size_t)c->g.total * c->esz));
+    return WAFER_OK;
+}
+
+int wafer_push_state(wafer_ctx *c)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(ensure_halo(c)); // stored states keep valid ghost planes
+    void *slot = nullptr;
+    TRY(new_state_slot(c, &slot));
+    HIP_TRY(hipMemcpyAsync(slot, c->phi[c->cur], (size_t)c->g.total * c->esz, hipMemcpyDeviceToDevice, c->s_main));
+    c->states.push_back(slot);
+    return WAFER_OK;
+}
+
+int wafer_load_state(wafer_ctx *c, uint32_t idx, const double *state)
+{
+    if (!c || !state) return fail(WAFER_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->P.device));
+    if (idx > c->states.size()) return fail(WAFER_ERR_STATE, "states must be loaded in order");
+    if (idx == c->states.size()) {
+        void *slot = nullptr;
+        TRY(new_state_slot(c, &slot));
+        HIP_TRY(hipMemsetAsync(slot, 0, (size_t)c->g.total * c->esz, c->s_main));
+        c->states.push_back(slot);
+    }
+    return upload_padded(c, state, c->states[idx]);
+}
+
+int wafer_download_state(wafer_ctx *c, uint32_t idx, double *state)
+{
+    if (!c || !state) return fail(WAFER_ERR_INVALID, "null argument");
+    if (idx >= c->states.size()) return fail(WAFER_ERR_STATE, "no state %u", idx);
+    HIP_TRY(hipSetDevice(c->P.device));
+    return download_padded(c, state, c->states[idx]);
+}
+
+int wafer_clone_state_to_phi(wafer_ctx *c, uint32_t idx)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (idx >= c->states.size()) return fail(WAFER_ERR_STATE, "no state %u", idx);
+    HIP_TRY(hipSetDevice(c->P.device));
+    HIP_TRY(hipMemcpyAsync(c->phi[c->cur], c->states[idx], (size_t)c->g.total * c->esz, hipMemcpyDeviceToDevice, c->s_main));
+    c->have_phi = true;
+    c->halo_stale = false;
+    return WAFER_OK;
+}
+
+int wafer_num_states(wafer_ctx *c, uint32_t *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    *out = (uint32_t)c->states.size();
+    return WAFER_OK;
+}
+
+int wafer_clear_states(wafer_ctx *c)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->P.device));
+    HIP_TRY(hipStreamSynchronize(c->s_main));
+    for (void *p : c->states) (void)hipFree(p);
+    c->states.clear();
+    return WAFER_OK;
+}
+
+// ---- solve (grid.rs:50-246) ----------------------------------------------------------
+int wafer_solve_state(wafer_ctx *c, uint32_t wnum, double tolerance, uint64_t screen_update,
+                      int has_max_steps, uint64_t max_steps, wafer_block_record *records,
+                      size_t max_records, size_t *n_records, wafer_observables_output *final_out)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (wnum > c->states.size()) return fail(WAFER_ERR_STATE, "wnum %u but w_store holds %zu states", wnum, c->states.size());
+    uint64_t step = 0;
+    double last_energy = DBL_MAX; // grid.rs:124
+    size_t nrec = 0;
+    bool converged = false;
+    wafer_observables_t obs;
+    for (;;) {
+        TRY(wafer_observables(c, &obs));                    // :127
+        const double norm_energy = obs.energy / obs.norm2;  // :128
+        const double tau = (double)step * c->P.dt;          // :129
+        TRY(wafer_normalise(c, obs.norm2));                 // :130
+        if (wnum > 0) TRY(wafer_orthogonalise(c, wnum));    // :133-135
+        const double diff = std::fabs(norm_energy - last_energy); // :161
+        if (records && nrec < max_records) {
+            records[nrec].step = step;
+            records[nrec].tau = tau;
+            records[nrec].obs = obs;
+            records[nrec].diff = diff;
+        }
+        ++nrec;
+        if (diff < tolerance) { // :162-192
+            converged = true;
+            break;
+        }
+        last_energy = norm_energy;                          // :194
+        if (has_max_steps && step > max_steps) break;       // :211-213
+        TRY(wafer_evolve(c, wnum, screen_update));          // :216
+        step += screen_update;                              // :220
+    }
+    if (n_records) *n_records = nrec;
+    if (final_out) { // output.rs:540-547
+        const double r_norm = std::sqrt(obs.r2 / obs.norm2);
+        final_out->state = wnum;
+        final_out->energy = obs.energy / obs.norm2;
+        final_out->binding_energy = (obs.energy - obs.v_infinity) / obs.norm2;
+        final_out->r = r_norm;
+        final_out->l_r = (double)c->P.nx / r_norm;
+    }
+    if (!converged) return fail(WAFER_ERR_MAX_STEP, "MaxStep: state %u did not converge within max_steps", wnum);
+    return wafer_push_state(c); // :239-242
+}
+
+// ---- multi-GPU plumbing -----------------------------------------------------------------
+int wafer_set_comm_hooks(wafer_ctx *c, wafer_halo_fn halo, wafer_allreduce_fn allreduce, void *user)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    c->halo_hook = halo;
+    c->allreduce_hook = allreduce;
+    c->hook_user = user;
+    return WAFER_OK;
+}
+
+int wafer_set_overlap(wafer_ctx *c, int enabled)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    c->overlap = enabled != 0;
+    return WAFER_OK;
+}
+
+int wafer_set_stream(wafer_ctx *c, void *hip_stream)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->P.device));
+    HIP_TRY(hipStreamSynchronize(c->s_main));
+    c->s_main = hip_stream ? (hipStream_t)hip_stream : c->s_own;
+    return WAFER_OK;
+}
+
+int wafer_get_slab_info(wafer_ctx *c, wafer_slab_info *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    out->z_begin = (uint32_t)c->g.z_begin;
+    out->z_count = (uint32_t)c->g.nzl;
+    out->halo_depth = (uint32_t)c->g.G;
+    out->ext = (uint32_t)c->g.R;
+    out->plane_elems = (uint64_t)c->g.plane;
+    out->elem_bytes = (uint64_t)c->esz;
+    return WAFER_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,287 @@
+// Setup kernels: built-in potentials + a/b, pot_sub, initial conditions and
+// the layout transposes between the reference's [x][y][z] host arrays and the
+// device's [z][y][x] slabs.  None of these is on the per-step path; they exist
+// so that 1024^3 / 2048^3 slabs are generated in HBM instead of crossing PCIe.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wafer_geom.h"
+
+#define WAFER_PI 3.14159265358979323846264338327950288
+
+struct WaferPotArgs {
+    WaferGeom g;
+    int type;            // wafer_potential
+    double dn, dt, mass, sig;
+    // FullCornell constants, evaluated on the host exactly as potential.rs:252-260, 264
+    double mu_t;         // mu(t), t = 1
+    double alphas_2pit;  // alphas(2*pi*t)
+    double xi_coef;      // 0.07 * xi^0.2, xi = 0
+    double xi_fac;       // (1 + xi)^-0.29
+};
+
+// potential.rs:366-371
+__device__ __forceinline__ double wafer_r2(int ix, int iy, int iz, int nx, int ny, int nz)
+{
+    const double dx = (double)ix - ((double)nx + 1.) / 2.;
+    const double dy = (double)iy - ((double)ny + 1.) / 2.;
+    const double dz = (double)iz - ((double)nz + 1.) / 2.;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// potential.rs:283-308, the reference's grouping of every half-space test
+__device__ __forceinline__ bool wafer_in_dodecahedron(double x, double y, double z)
+{
+    const double A = 12.70820393249937, B = 11.210068307552588, C = 14.674169922690343;
+    const double D = 5.605034153776295, D2 = 5.605034153776294;
+    const double Gg = 3.23606797749979, H = 1.2360679774997896;
+    const double P = 4.23606797749979, Q = 5.23606797749979;
+    const double S = 18.1382715378281, T = 3.464101615137755;
+    const double U = 9.06913576891405, W = 15.70820393249937, Y = 9.70820393249937;
+    const double Z2 = 6.47213595499958, K = 25.41640786499874;
+    const double R3 = 1.7320508075688772, E = 8.47213595499958;
+    return (A + B * x >= C * z) && (B * x <= A + C * z) &&
+           (D * (Gg * x - H * z) <= 6. * (P + Q * y)) && (S * x + T * z <= A) &&
+           (U * x + W * y <= A + T * z) && (Y * y <= A + D2 * x + C * z) &&
+           (A + D2 * x + Y * y + C * z >= 0.) && (W * y + T * z <= A + U * x) &&
+           (D * (-Z2 * x - H * z) <= K) && (T * z <= U * x + 3. * (P + Q * y)) &&
+           (R3 * (Gg * x + E * z) <= 3. * (P + Gg * y)) && (D2 * x + Y * y + C * z <= A);
+}
+
+// potential.rs:188-314 at PADDED global index (ix,iy,iz)
+__device__ __forceinline__ double wafer_potential_at(const WaferPotArgs &a, int ix, int iy, int iz)
+{
+    const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
+    switch (a.type) {
+    case 1: // Cube :192-201
+        return ((ix > nx / 4 && ix <= 3 * nx / 4) && (iy > ny / 4 && iy <= 3 * ny / 4) &&
+                (iz > nz / 4 && iz <= 3 * nz / 4)) ? -10.0 : 0.0;
+    case 2: // QuadWell :202-211
+        return ((ix > nx / 4 && ix <= 3 * nx / 4) && (iy > ny / 4 && iy <= 3 * ny / 4) &&
+                (iz > 3 * nz / 8 && iz <= 5 * nz / 8)) ? -10.0 : 0.0;
+    case 3: { // Periodic :212-220
+        const double sx = sin(2. * WAFER_PI * ((double)ix - 1.) / ((double)nx - 1.));
+        const double sy = sin(2. * WAFER_PI * ((double)iy - 1.) / ((double)ny - 1.));
+        const double sz = sin(2. * WAFER_PI * ((double)iz - 1.) / ((double)nz - 1.));
+        double temp = sx * sx;
+        temp *= sy * sy;
+        temp *= sz * sz;
+        return -temp + 1.;
+    }
+    case 4:
+    case 5: { // Coulomb / ComplexCoulomb :221-229
+        const double r = a.dn * sqrt(wafer_r2(ix, iy, iz, nx, ny, nz));
+        return (r < a.dn) ? -1. / a.dn : -1. / r;
+    }
+    case 6: { // ElipticalCoulomb :230-240
+        const double dx = (double)ix - ((double)nx + 1.) / 2.;
+        const double dy = (double)iy - ((double)ny + 1.) / 2.;
+        const double dz = ((double)iz - ((double)nz + 1.) / 2.) * 2.;
+        const double r = a.dn * sqrt(dx * dx + dy * dy + dz * dz);
+        return (r < a.dn) ? 0.0 : -1. / r + 1. / a.dn;
+    }
+    case 7: { // SimpleCornell :241-249
+        const double r = a.dn * sqrt(wafer_r2(ix, iy, iz, nx, ny, nz));
+        if (r < a.dn) return 4. * a.mass;
+        return (-0.5 * (4. / 3.)) / r + a.sig * r + 4. * a.mass;
+    }
+    case 8: { // FullCornell :250-269
+        const double dz = (double)iz - ((double)nz + 1.) / 2.;
+        const double r = a.dn * sqrt(wafer_r2(ix, iy, iz, nx, ny, nz));
+        const double md = a.mu_t * (1. + a.xi_coef * (1. - a.dn * a.dn * dz * dz / (r * r))) * a.xi_fac;
+        if (r < a.dn) return 4. * a.mass;
+        const double screen = exp(-md * r);
+        return (-a.alphas_2pit * (4. / 3.)) * screen / r + a.sig * (1. - screen) / md -
+               (0.8 * a.sig) / (4. * a.mass * a.mass * r) + 4. * a.mass;
+    }
+    case 9:
+    case 10: { // Harmonic / ComplexHarmonic :270-274
+        const double r = a.dn * sqrt(wafer_r2(ix, iy, iz, nx, ny, nz));
+        return r * r / 2.;
+    }
+    case 11: { // Dodecahedron :275-314
+        const double dx = (double)ix - ((double)nx + 1.) / 2.;
+        const double dy = (double)iy - ((double)ny + 1.) / 2.;
+        const double dz = (double)iz - ((double)nz + 1.) / 2.;
+        const double x = dx / (((double)nx - 1.) / 2.);
+        const double y = dy / (((double)ny - 1.) / 2.);
+        const double z = dz / (((double)nz - 1.) / 2.);
+        return wafer_in_dodecahedron(x, y, z) ? -100. : 0.0;
+    }
+    default: // NoPotential :191
+        return 0.0;
+    }
+}
+
+// potential::generate (potential.rs:46-62) + ancillary arrays (potential.rs:101-110)
+// over every padded cell of the slab (ghost planes included).
+// grid (ceil(px/64), ceil(py/4), lz), block (64,4).
+template <typename T>
+__global__ __launch_bounds__(256) void wafer_k_potential(WaferPotArgs a, T *__restrict__ v,
+                                                         T *__restrict__ pa, T *__restrict__ pb)
+{
+    const WaferGeom &g = a.g;
+    const int xp = blockIdx.x * 64 + threadIdx.x;
+    const int yp = blockIdx.y * 4 + threadIdx.y;
+    const int lzp = blockIdx.z;
+    const int zp = g.zp_of(lzp);
+    if (xp >= g.px || yp >= g.py || zp < 0 || zp >= g.pzg) return;
+    const double vv = wafer_potential_at(a, xp, yp, zp);
+    const double bb = 1. / (1. + a.dt * vv / 2.);
+    const double aa = (1. - a.dt * vv / 2.) * bb;
+    const long long p = g.at(lzp, yp, xp);
+    v[p] = (T)vv;
+    pa[p] = (T)aa;
+    pb[p] = (T)bb;
+}
+
+// a, b from an uploaded V (potential.rs:101-110)
+template <typename T>
+__global__ __launch_bounds__(256) void wafer_k_ab(WaferGeom g, double dt, const T *__restrict__ v,
+                                                  T *__restrict__ pa, T *__restrict__ pb)
+{
+    const int xp = blockIdx.x * 64 + threadIdx.x;
+    const int yp = blockIdx.y * 4 + threadIdx.y;
+    const int lzp = blockIdx.z;
+    const int zp = g.zp_of(lzp);
+    if (xp >= g.px || yp >= g.py || zp < 0 || zp >= g.pzg) return;
+    const long long p = g.at(lzp, yp, xp);
+    const double vv = (double)v[p];
+    const double bb = 1. / (1. + dt * vv / 2.);
+    pa[p] = (T)((1. - dt * vv / 2.) * bb);
+    pb[p] = (T)bb;
+}
+
+// potential_sub_idx for FullCornell (potential.rs:326-341) on the UNPADDED
+// work index, stored at the work cell of the padded device layout.
+template <typename T>
+__global__ __launch_bounds__(256) void wafer_k_potsub_fullcornell(WaferPotArgs a, T *__restrict__ ps)
+{
+    const WaferGeom &g = a.g;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const int kl = blockIdx.z;
+    if (i >= g.nx || j >= g.ny || kl >= g.nzl) return;
+    const int k = g.z_begin + kl;
+    const double dz = (double)k - ((double)g.nz + 1.) / 2.;
+    const double r = a.dn * sqrt(wafer_r2(i, j, k, g.nx, g.ny, g.nz));
+    const double md = a.mu_t * 1. + a.xi_coef * (1. - a.dn * a.dn * dz * dz / (r * r)) * a.xi_fac;
+    ps[g.at(g.lzp_of_work(kl), j + g.R, i + g.R)] = (T)(a.sig / md + 4. * a.mass);
+}
+
+// ---- initial conditions (config.rs:577-683) -----------------------------------
+__device__ __forceinline__ unsigned long long wafer_mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+struct WaferIcArgs {
+    WaferGeom g;
+    int ic;              // wafer_initial_condition
+    unsigned long long seed;
+    double dn, mass, sig;
+};
+
+// Writes EVERY padded cell of the slab: the chosen profile inside the work
+// area, zero on the Dirichlet frame (config.rs:597-622).
+template <typename T>
+__global__ __launch_bounds__(256) void wafer_k_initial_condition(WaferIcArgs a, T *__restrict__ phi)
+{
+    const WaferGeom &g = a.g;
+    const int xp = blockIdx.x * 64 + threadIdx.x;
+    const int yp = blockIdx.y * 4 + threadIdx.y;
+    const int lzp = blockIdx.z;
+    const int zp = g.zp_of(lzp);
+    if (xp >= g.px || yp >= g.py) return;
+    double val = 0.0;
+    const bool in_grid = zp >= 0 && zp < g.pzg;
+    const bool frame = !in_grid || xp < g.R || xp >= g.px - g.R || yp < g.R || yp >= g.py - g.R ||
+                       zp < g.R || zp >= g.pzg - g.R;
+    if (!frame) {
+        switch (a.ic) {
+        case 1: { // Gaussian (config.rs:636-642): the engine's own counter RNG keyed by
+                  // the reference-layout padded linear index (thread_rng there is unseeded)
+            const unsigned long long c =
+                ((unsigned long long)xp * (unsigned long long)g.py + (unsigned long long)yp) *
+                    (unsigned long long)g.pzg + (unsigned long long)zp;
+            const unsigned long long h1 = wafer_mix64(a.seed ^ wafer_mix64(2 * c));
+            const unsigned long long h2 = wafer_mix64(a.seed ^ wafer_mix64(2 * c + 1));
+            const double u1 = ((double)(h1 >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+            const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
+            val = a.sig * (sqrt(-2.0 * log(u1)) * cos(2.0 * WAFER_PI * u2));
+            break;
+        }
+        case 2: { // Coulomb-like (config.rs:650-669); centre = padded size / 2
+            const double dx = (double)xp - ((double)g.px / 2.);
+            const double dy = (double)yp - ((double)g.py / 2.);
+            const double dz = (double)zp - ((double)g.pzg / 2.);
+            const double r = a.dn * sqrt(dx * dx + dy * dy + dz * dz);
+            const double costheta = a.dn * dz / r;
+            const double cosphi = a.dn * dx / r;
+            const double mr2 = exp(-a.mass * r / 2.);
+            val = exp(-a.mass * r) + (2. - a.mass * r) * mr2 + a.mass * r * mr2 * costheta +
+                  a.mass * r * mr2 * sqrt(1. - costheta * costheta) * cosphi;
+            break;
+        }
+        case 3: // Constant (config.rs:593)
+            val = 0.1;
+            break;
+        default: // Boolean (config.rs:676-683) on padded indices
+            val = (double)((xp & 1) * (yp & 1) * (zp & 1));
+            break;
+        }
+    }
+    phi[g.at(lzp, yp, xp)] = (T)val;
+}
+
+// ---- layout transposes ----------------------------------------------------------
+// `dense` is a double array in the reference's C-order [sx][sy][sz]; its element
+// (x,y,z) corresponds to device cell (lzp0+z, yp0+y, xp0+x).
+struct WaferXposeArgs {
+    WaferGeom g;
+    int sx, sy, sz;
+    int xp0, yp0, lzp0;
+};
+
+// grid (ceil(sx/32), sy, ceil(sz/32)), block (32,8)
+template <typename T, bool TO_DEVICE>
+__global__ __launch_bounds__(256) void wafer_k_transpose(WaferXposeArgs a, double *__restrict__ dense,
+                                                         T *__restrict__ dev)
+{
+    __shared__ double tile[32][33];
+    const WaferGeom &g = a.g;
+    const int x0 = blockIdx.x * 32, y = blockIdx.y, z0 = blockIdx.z * 32;
+    if constexpr (TO_DEVICE) {
+#pragma unroll
+        for (int r = 0; r < 32; r += 8) { // rows of the tile = x, fast index = z
+            const int x = x0 + threadIdx.y + r, z = z0 + threadIdx.x;
+            if (x < a.sx && z < a.sz)
+                tile[threadIdx.y + r][threadIdx.x] =
+                    dense[((size_t)x * a.sy + y) * (size_t)a.sz + z];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 32; r += 8) { // rows = z, fast index = x
+            const int z = z0 + threadIdx.y + r, x = x0 + threadIdx.x;
+            if (x < a.sx && z < a.sz)
+                dev[g.at(a.lzp0 + z, a.yp0 + y, a.xp0 + x)] = (T)tile[threadIdx.x][threadIdx.y + r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 32; r += 8) {
+            const int z = z0 + threadIdx.y + r, x = x0 + threadIdx.x;
+            if (x < a.sx && z < a.sz)
+                tile[threadIdx.x][threadIdx.y + r] =
+                    (double)dev[g.at(a.lzp0 + z, a.yp0 + y, a.xp0 + x)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 32; r += 8) {
+            const int x = x0 + threadIdx.y + r, z = z0 + threadIdx.x;
+            if (x < a.sx && z < a.sz)
+                dense[((size_t)x * a.sy + y) * (size_t)a.sz + z] = tile[threadIdx.y + r][threadIdx.x];
+        }
+    }
+}

@@ -1,0 +1,198 @@
+// Stencil arithmetic and the evolve / observables kernels (gfx950).
+//
+// Arithmetic contract: the per-point expressions keep the association the
+// reference spells (grid.rs:580-589, 606-621, 640-660, 325-332) and the
+// library is built with -ffp-contract=off, so an fp64 stencil step is
+// bit-for-bit what rustc emits for the same inputs (IEEE add/mul/div, no FMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wafer_geom.h"
+
+#define WAFER_WAVE 64
+
+// ---- wave / block sum of one double (fixed order => run-to-run deterministic)
+__device__ __forceinline__ double wafer_wave_sum(double v)
+{
+#pragma unroll
+    for (int off = WAFER_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAFER_WAVE);
+    return v;
+}
+
+// Sums `v` over a block of NW waves; result valid in thread 0.  `red` is NW doubles of LDS.
+template <int NW>
+__device__ __forceinline__ double wafer_block_sum(double v, double *red, int tid)
+{
+    v = wafer_wave_sum(v);
+    const int wave = tid / WAFER_WAVE, lane = tid % WAFER_WAVE;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[w];
+    }
+    return s;
+}
+
+// ---- the bracketed central-difference sum S --------------------------------
+// xs/ys/zs hold the 2R+1 values along each axis, index R is the centre w.
+template <typename T, int R>
+__device__ __forceinline__ T wafer_stencil_sum(const T *xs, const T *ys, const T *zs, T w)
+{
+    if constexpr (R == 1) { // grid.rs:582-588
+        return xs[2] + xs[0] + ys[2] + ys[0] + zs[2] + zs[0] - T(6) * w;
+    } else if constexpr (R == 2) { // grid.rs:608-620
+        return -xs[4] + T(16) * xs[3] + T(16) * xs[1] - xs[0] - ys[4] + T(16) * ys[3] + T(16) * ys[1] -
+               ys[0] - zs[4] + T(16) * zs[3] + T(16) * zs[1] - zs[0] - T(90) * w;
+    } else { // grid.rs:642-659
+        return T(2) * xs[6] - T(27) * xs[5] + T(270) * xs[4] + T(270) * xs[2] - T(27) * xs[1] +
+               T(2) * xs[0] + T(2) * ys[6] - T(27) * ys[5] + T(270) * ys[4] + T(270) * ys[2] -
+               T(27) * ys[1] + T(2) * ys[0] + T(2) * zs[6] - T(27) * zs[5] + T(270) * zs[4] +
+               T(270) * zs[2] - T(27) * zs[1] + T(2) * zs[0] - T(1470) * w;
+    }
+}
+
+// grid.rs:580-589: *work = w*pa + pb*dt*S/denominator
+template <typename T>
+__device__ __forceinline__ T wafer_update(T w, T pa, T pb, T dt, T S, T den)
+{
+    return w * pa + pb * dt * S / den;
+}
+
+struct WaferStepArgs {
+    WaferGeom g;
+    int lz_lo, lz_hi;   // local planes [lz_lo, lz_hi) to update
+    int zchunk;         // planes marched by one workgroup
+    double dt, den;
+};
+
+// ---------------------------------------------------------------------------
+// Variant 0: z-marching, register queue along z, x/y neighbours straight from
+// global memory (L1/L2).  One work point per lane.  Reference-quality fallback
+// and the baseline the LDS-tiled variants are measured against.
+// grid: (ceil(nx/64), ceil(ny/4), nchunks), block (64,4).
+// If NORM, partials[linear block id] receives the block's sum of out^2.
+// ---------------------------------------------------------------------------
+template <typename T, typename C, int R, bool NORM>
+__global__ __launch_bounds__(256) void wafer_k_step_direct(WaferStepArgs a, const T *__restrict__ phi,
+                                                           const T *__restrict__ pa,
+                                                           const T *__restrict__ pb, T *__restrict__ out,
+                                                           double *__restrict__ partials)
+{
+    __shared__ double red[4];
+    const WaferGeom &g = a.g;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const int zs = a.lz_lo + blockIdx.z * a.zchunk;
+    const int ze = min(zs + a.zchunk, a.lz_hi);
+    const bool active = (i < g.nx) && (j < g.ny);
+    const C dt = (C)a.dt, den = (C)a.den;
+    double acc = 0.0;
+    if (active) {
+        const long long col = (long long)(j + R) * g.pitch + g.xoff + (i + R);
+        const T *p = phi + col;
+        C zq[2 * R + 1];
+#pragma unroll
+        for (int m = 1; m <= 2 * R; ++m) zq[m] = (C)p[(long long)(zs + m - 1 - R) * g.plane];
+        for (int z = zs; z < ze; ++z) {
+#pragma unroll
+            for (int m = 0; m < 2 * R; ++m) zq[m] = zq[m + 1];
+            const long long o = (long long)z * g.plane;
+            zq[2 * R] = (C)p[o + (long long)R * g.plane];
+            C xs[2 * R + 1], ys[2 * R + 1];
+#pragma unroll
+            for (int d = -R; d <= R; ++d) {
+                xs[d + R] = (d == 0) ? zq[R] : (C)p[o + d];
+                ys[d + R] = (d == 0) ? zq[R] : (C)p[o + (long long)d * g.pitch];
+            }
+            const C w = zq[R];
+            const C S = wafer_stencil_sum<C, R>(xs, ys, zq, w);
+            const C r = wafer_update<C>(w, (C)pa[col + o], (C)pb[col + o], dt, S, den);
+            const T rs = (T)r;
+            out[col + o] = rs;
+            if constexpr (NORM) acc += (double)rs * (double)rs;
+        }
+    }
+    if constexpr (NORM) {
+        const int tid = threadIdx.y * 64 + threadIdx.x;
+        const double s = wafer_block_sum<4>(acc, red, tid);
+        if (tid == 0)
+            partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// compute_observables (grid.rs:303-445): the four work-area sums in ONE pass
+// over phi and V.  Always evaluated in fp64 (fp32 storage is widened first).
+// partials layout: [4][nblocks].
+// ---------------------------------------------------------------------------
+struct WaferObsArgs {
+    WaferGeom g;
+    int zchunk;
+    double den;
+    int potsub_kind;      // wafer_potsub_kind
+    double potsub_scalar;
+    long long nblocks;
+};
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void wafer_k_observables(WaferObsArgs a, const T *__restrict__ phi,
+                                                           const T *__restrict__ v,
+                                                           const T *__restrict__ potsub,
+                                                           double *__restrict__ partials)
+{
+    __shared__ double red[4];
+    const WaferGeom &g = a.g;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const int zs = g.G + blockIdx.z * a.zchunk;
+    const int ze = min(zs + a.zchunk, g.G + g.nzl);
+    const bool active = (i < g.nx) && (j < g.ny);
+    double se = 0.0, sn = 0.0, sv = 0.0, sr = 0.0;
+    if (active) {
+        const long long col = (long long)(j + R) * g.pitch + g.xoff + (i + R);
+        const T *p = phi + col;
+        // potential::calculate_r2 on the WORK-AREA index (grid.rs:429-435, potential.rs:366-371)
+        const double dx = (double)i - ((double)g.nx + 1.) / 2.;
+        const double dy = (double)j - ((double)g.ny + 1.) / 2.;
+        double zq[2 * R + 1];
+#pragma unroll
+        for (int m = 1; m <= 2 * R; ++m) zq[m] = (double)p[(long long)(zs + m - 1 - R) * g.plane];
+        for (int z = zs; z < ze; ++z) {
+#pragma unroll
+            for (int m = 0; m < 2 * R; ++m) zq[m] = zq[m + 1];
+            const long long o = (long long)z * g.plane;
+            zq[2 * R] = (double)p[o + (long long)R * g.plane];
+            double xs[2 * R + 1], ys[2 * R + 1];
+#pragma unroll
+            for (int d = -R; d <= R; ++d) {
+                xs[d + R] = (d == 0) ? zq[R] : (double)p[o + d];
+                ys[d + R] = (d == 0) ? zq[R] : (double)p[o + (long long)d * g.pitch];
+            }
+            const double w = zq[R];
+            const double S = wafer_stencil_sum<double, R>(xs, ys, zq, w);
+            const double vv = (double)v[col + o];
+            se += vv * w * w - w * S / a.den; // grid.rs:325-332
+            sn += w * w;                      // grid.rs:407
+            if (a.potsub_kind == 2)
+                sv += w * w * (double)potsub[col + o]; // grid.rs:410-418
+            else if (a.potsub_kind == 1)
+                sv += w * w * a.potsub_scalar; // grid.rs:419-424
+            const int kg = g.z_begin + (z - g.G);
+            const double dz = (double)kg - ((double)g.nz + 1.) / 2.;
+            sr += w * w * (dx * dx + dy * dy + dz * dz); // grid.rs:428-437
+        }
+    }
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    double s;
+    s = wafer_block_sum<4>(se, red, tid);
+    if (tid == 0) partials[0 * a.nblocks + b] = s;
+    s = wafer_block_sum<4>(sn, red, tid);
+    if (tid == 0) partials[1 * a.nblocks + b] = s;
+    s = wafer_block_sum<4>(sv, red, tid);
+    if (tid == 0) partials[2 * a.nblocks + b] = s;
+    s = wafer_block_sum<4>(sr, red, tid);
+    if (tid == 0) partials[3 * a.nblocks + b] = s;
+}

@@ -1,0 +1,300 @@
+// LDS-tiled, z-streaming stencil step for gfx950 (the hot kernel).
+//
+// One workgroup = 4 wavefronts = one (TX x TY) tile of the x-y plane, marched
+// along z over `zchunk` planes:
+//   - each lane owns VEC = 16 B / sizeof(T) consecutive x cells on RY rows and
+//     keeps their z-column (2R+1 planes + one prefetched plane) in registers,
+//     so every phi cell is fetched from HBM once, as a 16-byte-per-lane,
+//     128-byte-aligned wave load (rows start on a 128 B boundary: wafer_geom.h);
+//   - the centre plane of the tile (+ R halo rows / columns) sits in a
+//     double-buffered LDS tile; x and y neighbours come from LDS (or from the
+//     lane's own registers when they are in its RY x VEC patch);
+//   - a, b are streamed straight into registers one plane ahead;
+//   - one s_barrier per plane.
+// HBM traffic per update: 4*sizeof(T) (phi, a, b in; phi' out) + halo re-reads
+// that hit L2 / Infinity Cache.  No MFMA: 12-42 flop per 32 B is bandwidth bound.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wafer_geom.h"
+#include "wafer_stencil.hip.h"
+
+template <typename T> struct WaferVec;
+template <> struct WaferVec<double> { static constexpr int N = 2; typedef double __attribute__((ext_vector_type(2))) type; };
+template <> struct WaferVec<float> { static constexpr int N = 4; typedef float __attribute__((ext_vector_type(4))) type; };
+
+template <typename T, int R, int RY_>
+struct WaferLdsCfg {
+    static constexpr int VEC = WaferVec<T>::N;
+    static constexpr int NW = 4;                  // wavefronts per workgroup, stacked along y
+    static constexpr int RY = RY_;                // rows per lane
+    static constexpr int TX = 64 * VEC;           // tile width  (one wave-wide 1 KiB row segment)
+    static constexpr int TY = NW * RY;            // tile height
+    static constexpr int HX = ((R + VEC - 1) / VEC) * VEC; // halo columns kept per side (VEC aligned)
+    static constexpr int LP = TX + 2 * HX;        // LDS row pitch (elements)
+    static constexpr int LROWS = TY + 2 * R;
+    static constexpr int TILE = LROWS * LP;       // elements per LDS buffer
+    static constexpr int NHALO_X = 2 * R * TY;    // halo-column cells per plane
+    static constexpr int HALO_X_ITERS = (NHALO_X + 63) / 64;
+    static constexpr int HALO_ROWS_PER_WAVE = (2 * R + NW - 1) / NW;
+};
+
+template <typename T, int R>
+static inline int wafer_lds_zchunk(const WaferGeom &g, int nplanes)
+{
+    using Cfg = WaferLdsCfg<T, R, 2>;
+    const char *f = getenv("WAFER_ZCHUNK");
+    if (f && atoi(f) > 0) return atoi(f);
+    const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY);
+    const char *t = getenv("WAFER_TARGET_BLOCKS");
+    const long long target = (t && atoi(t) > 0) ? atoi(t) : 2048;
+    long long nch = (target + per_layer - 1) / per_layer;
+    if (nch < 1) nch = 1;
+    if (nch > nplanes) nch = nplanes;
+    return (int)((nplanes + nch - 1) / nch);
+}
+
+template <typename T, int R>
+static inline long long wafer_step_lds_blocks(const WaferGeom &g, int lz_lo, int lz_hi)
+{
+    using Cfg = WaferLdsCfg<T, R, 2>;
+    const int zc = wafer_lds_zchunk<T, R>(g, lz_hi - lz_lo);
+    return (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY) *
+           ((lz_hi - lz_lo + zc - 1) / zc);
+}
+
+template <typename T, typename C, int R, int RY, bool NORM>
+__global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty,
+                                                        const T *__restrict__ phi,
+                                                        const T *__restrict__ pa,
+                                                        const T *__restrict__ pb, T *__restrict__ out,
+                                                        double *__restrict__ partials)
+{
+    using Cfg = WaferLdsCfg<T, R, RY>;
+    using VT = typename WaferVec<T>::type;
+    constexpr int VEC = Cfg::VEC, TX = Cfg::TX, TY = Cfg::TY, HX = Cfg::HX, LP = Cfg::LP;
+    __shared__ __attribute__((aligned(16))) T lds[2 * Cfg::TILE];
+    __shared__ double red[4];
+
+    const WaferGeom &g = a.g;
+    // tile coordinates: x fastest, then y, then z-chunk
+    const int bid = blockIdx.x;
+    const int tx_i = bid % ntx;
+    const int ty_i = (bid / ntx) % nty;
+    const int tz_i = bid / (ntx * nty);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+
+    const int x0 = tx_i * TX;            // work-x of the tile's first column
+    const int y0 = ty_i * TY;            // work-y of the tile's first row
+    const int xl = lane * VEC;           // lane's first column inside the tile
+    const int yl = wave * RY;            // lane's first row inside the tile
+    const int xi = x0 + xl;              // work-x of the lane's first cell
+    const int zs = a.lz_lo + tz_i * a.zchunk;
+    const int ze = min(zs + a.zchunk, a.lz_hi);
+
+    // a lane's aligned VEC group lies inside the row allocation iff xi < wlim
+    const int wlim = g.pitch - g.xoff - R;
+    const bool xin = xi < wlim;
+    bool rowin[RY];
+    long long rowoff[RY]; // element offset of (row r, lane's first cell) inside a plane
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const int y = y0 + yl + r;
+        rowin[r] = xin && (y < g.ny);
+        rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + xi;
+    }
+
+    // halo rows this wave fetches: halo row h in [0,2R): h<R is row y0-R+h, else row y0+TY+(h-R)
+    bool hrow_in[Cfg::HALO_ROWS_PER_WAVE];
+    long long hrow_off[Cfg::HALO_ROWS_PER_WAVE];
+    int hrow_lds[Cfg::HALO_ROWS_PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < Cfg::HALO_ROWS_PER_WAVE; ++q) {
+        const int h = wave + q * Cfg::NW;
+        const int ly = (h < R) ? h : TY + h;          // LDS row (0..R-1 above, TY+R.. below)
+        const int yp = y0 + ly;                        // padded y (= work y - R + R)
+        hrow_in[q] = (h < 2 * R) && xin && (yp < g.py);
+        hrow_off[q] = (long long)yp * g.pitch + g.xoff + R + xi;
+        hrow_lds[q] = ly * LP + HX + xl;
+    }
+    // halo-column cells: cell c in [0, 2R*TY): row = c / (2R), k = c % (2R);
+    // k<R: column x0-1-k, else column x0+TX+(k-R)
+    bool hcol_in[Cfg::HALO_X_ITERS];
+    long long hcol_off[Cfg::HALO_X_ITERS];
+    int hcol_lds[Cfg::HALO_X_ITERS];
+#pragma unroll
+    for (int q = 0; q < Cfg::HALO_X_ITERS; ++q) {
+        const int cidx = tid + q * 256;
+        const int row = cidx / (2 * R), k = cidx % (2 * R);
+        const int xw = (k < R) ? (x0 - 1 - k) : (x0 + TX + (k - R)); // work x, may be -R..nx+R-1
+        const int y = y0 + row;
+        hcol_in[q] = (cidx < Cfg::NHALO_X) && (y < g.ny) && (xw + R >= 0) && (xw + R < g.px);
+        hcol_off[q] = (long long)(y + R) * g.pitch + g.xoff + R + xw;
+        hcol_lds[q] = (row + R) * LP + ((k < R) ? (HX - 1 - k) : (HX + TX + (k - R)));
+    }
+
+    const C dt = (C)a.dt, den = (C)a.den;
+    VT zero;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) zero[v] = T(0);
+
+    // ---- prologue: z-queue for plane zs, LDS tile of plane zs, prefetches
+    VT q[2 * R + 1][RY];
+#pragma unroll
+    for (int m = 0; m <= 2 * R; ++m)
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+            q[m][r] = rowin[r] ? *reinterpret_cast<const VT *>(phi + (long long)(zs - R + m) * g.plane + rowoff[r]) : zero;
+    VT ab_a[RY], ab_b[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        ab_a[r] = rowin[r] ? *reinterpret_cast<const VT *>(pa + (long long)zs * g.plane + rowoff[r]) : zero;
+        ab_b[r] = rowin[r] ? *reinterpret_cast<const VT *>(pb + (long long)zs * g.plane + rowoff[r]) : zero;
+    }
+    {
+        T *tile = lds + (zs & 1) * Cfg::TILE;
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+            *reinterpret_cast<VT *>(tile + (yl + r + R) * LP + HX + xl) = q[R][r];
+#pragma unroll
+        for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
+            if (wave + qq * Cfg::NW < 2 * R)
+                *reinterpret_cast<VT *>(tile + hrow_lds[qq]) =
+                    hrow_in[qq] ? *reinterpret_cast<const VT *>(phi + (long long)zs * g.plane + hrow_off[qq]) : zero;
+#pragma unroll
+        for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
+            if (tid + qq * 256 < Cfg::NHALO_X)
+                tile[hcol_lds[qq]] = hcol_in[qq] ? phi[(long long)zs * g.plane + hcol_off[qq]] : T(0);
+    }
+    // halo of plane zs+1, held in registers until it is written at iteration zs
+    VT hrow_nxt[Cfg::HALO_ROWS_PER_WAVE];
+    T hcol_nxt[Cfg::HALO_X_ITERS];
+    {
+        const bool more = zs + 1 < ze;
+#pragma unroll
+        for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
+            hrow_nxt[qq] = (more && hrow_in[qq]) ? *reinterpret_cast<const VT *>(phi + (long long)(zs + 1) * g.plane + hrow_off[qq]) : zero;
+#pragma unroll
+        for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
+            hcol_nxt[qq] = (more && hcol_in[qq]) ? phi[(long long)(zs + 1) * g.plane + hcol_off[qq]] : T(0);
+    }
+    __syncthreads();
+
+    double acc = 0.0;
+    for (int z = zs; z < ze; ++z) {
+        const bool more = z + 1 < ze;   // wave-uniform
+        const bool more2 = z + 2 < ze;
+        const long long zo = (long long)z * g.plane;
+        // ---- 1. prefetch: phi plane z+R+1, a/b plane z+1, halo of plane z+2
+        VT pre[RY], pre_a[RY], pre_b[RY];
+        VT hrow_pre[Cfg::HALO_ROWS_PER_WAVE];
+        T hcol_pre[Cfg::HALO_X_ITERS];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const bool ld = more && rowin[r];
+            pre[r] = ld ? *reinterpret_cast<const VT *>(phi + zo + (long long)(R + 1) * g.plane + rowoff[r]) : zero;
+            pre_a[r] = ld ? *reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]) : zero;
+            pre_b[r] = ld ? *reinterpret_cast<const VT *>(pb + zo + g.plane + rowoff[r]) : zero;
+        }
+#pragma unroll
+        for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
+            hrow_pre[qq] = (more2 && hrow_in[qq]) ? *reinterpret_cast<const VT *>(phi + zo + 2 * g.plane + hrow_off[qq]) : zero;
+#pragma unroll
+        for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
+            hcol_pre[qq] = (more2 && hcol_in[qq]) ? phi[zo + 2 * g.plane + hcol_off[qq]] : T(0);
+
+        // ---- 2. stage plane z+1 into the other LDS buffer
+        if (more) {
+            T *nt = lds + ((z + 1) & 1) * Cfg::TILE;
+#pragma unroll
+            for (int r = 0; r < RY; ++r)
+                *reinterpret_cast<VT *>(nt + (yl + r + R) * LP + HX + xl) = q[R + 1][r];
+#pragma unroll
+            for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
+                if (wave + qq * Cfg::NW < 2 * R) *reinterpret_cast<VT *>(nt + hrow_lds[qq]) = hrow_nxt[qq];
+#pragma unroll
+            for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
+                if (tid + qq * 256 < Cfg::NHALO_X) nt[hcol_lds[qq]] = hcol_nxt[qq];
+        }
+
+        // ---- 3. update plane z
+        const T *ct = lds + (z & 1) * Cfg::TILE;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            VT res;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
+                const C w = (C)q[R][r][v];
+#pragma unroll
+                for (int d = -R; d <= R; ++d) {
+                    zz[d + R] = (C)q[R + d][r][v];
+                    if (d == 0) {
+                        xs[R] = w;
+                        ys[R] = w;
+                    } else {
+                        xs[d + R] = (v + d >= 0 && v + d < VEC) ? (C)q[R][r][(v + d + VEC) % VEC]
+                                                               : (C)ct[(yl + r + R) * LP + HX + xl + v + d];
+                        ys[d + R] = (r + d >= 0 && r + d < RY) ? (C)q[R][(r + d + RY) % RY][v]
+                                                             : (C)ct[(yl + r + R + d) * LP + HX + xl + v];
+                    }
+                }
+                const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
+                const T rs = (T)wafer_update<C>(w, (C)ab_a[r][v], (C)ab_b[r][v], dt, S, den);
+                res[v] = rs;
+                if constexpr (NORM) {
+                    if (rowin[r] && xi + v < g.nx) acc += (double)rs * (double)rs;
+                }
+            }
+            if (rowin[r]) {
+                T *dst = out + zo + rowoff[r];
+                if (xi + VEC <= g.nx) {
+                    *reinterpret_cast<VT *>(dst) = res;
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        if (xi + v < g.nx) dst[v] = res[v];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 4. rotate the register pipeline
+#pragma unroll
+        for (int m = 0; m < 2 * R; ++m)
+#pragma unroll
+            for (int r = 0; r < RY; ++r) q[m][r] = q[m + 1][r];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            q[2 * R][r] = pre[r];
+            ab_a[r] = pre_a[r];
+            ab_b[r] = pre_b[r];
+        }
+#pragma unroll
+        for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) hrow_nxt[qq] = hrow_pre[qq];
+#pragma unroll
+        for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq) hcol_nxt[qq] = hcol_pre[qq];
+    }
+    if constexpr (NORM) {
+        const double s = wafer_block_sum<4>(acc, red, tid);
+        if (tid == 0) partials[bid] = s;
+    }
+}
+
+template <typename T, typename C, int R, bool NORM>
+static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, const T *pa, const T *pb,
+                                               T *out, double *partials, size_t partials_cap,
+                                               hipStream_t s)
+{
+    constexpr int RY = 2;
+    using Cfg = WaferLdsCfg<T, R, RY>;
+    const WaferGeom &g = a.g;
+    a.zchunk = wafer_lds_zchunk<T, R>(g, a.lz_hi - a.lz_lo);
+    const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX;
+    const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
+    const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
+    const long long nblocks = (long long)ntx * nty * ntz;
+    if (NORM && (size_t)nblocks > partials_cap) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NORM>), dim3((unsigned)nblocks), dim3(256), 0, s, a,
+                       ntx, nty, phi, pa, pb, out, partials);
+    return hipGetLastError();
+}

@@ -1,0 +1,376 @@
+"""ctypes binding of include/wafer_hip.h.
+
+`Context` mirrors the reference's private functions in src/grid.rs one to one
+(evolve, compute_observables, get_norm_squared, normalise_wavefunction,
+orthogonalise_wavefunction, solve) with device-resident state.  Host arrays are
+numpy float64 in the reference's layout: C-order [x][y][z], shape (n + 2*ext).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libwafer_hip.so")
+
+POTENTIALS = [
+    "NoPotential", "Cube", "QuadWell", "Periodic", "Coulomb", "ComplexCoulomb",
+    "ElipticalCoulomb", "SimpleCornell", "FullCornell", "Harmonic", "ComplexHarmonic",
+    "Dodecahedron", "FromFile", "FromScript",
+]  # config.rs:73-104
+INITIAL_CONDITIONS = ["FromFile", "Gaussian", "Coulomb", "Constant", "Boolean"]  # config.rs:151-170
+CENTRAL_DIFFERENCE = {"ThreePoint": 1, "FivePoint": 2, "SevenPoint": 3}  # config.rs:224-238
+
+WAFER_OK = 0
+WAFER_ERR_MAX_STEP = -5
+FLAG_SKIP_DT_CHECK = 1
+
+EXPORTS = [
+    "wafer_abi_version", "wafer_last_error", "wafer_ctx_create", "wafer_ctx_destroy",
+    "wafer_synchronize", "wafer_set_potential_builtin", "wafer_set_potential_host",
+    "wafer_download_array", "wafer_get_potsub", "wafer_set_initial_condition", "wafer_upload_phi",
+    "wafer_download_phi", "wafer_evolve", "wafer_observables", "wafer_norm2", "wafer_normalise",
+    "wafer_orthogonalise", "wafer_push_state", "wafer_load_state", "wafer_download_state",
+    "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
+    "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_set_stencil_variant",
+    "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
+]
+
+
+class WaferError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"wafer_hip error {code}: {msg}")
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32),
+        ("central_difference", C.c_int32), ("dtype", C.c_int32),
+        ("dn", C.c_double), ("dt", C.c_double), ("mass", C.c_double), ("sig", C.c_double),
+        ("max_states", C.c_uint32), ("device", C.c_int32),
+        ("z_begin", C.c_uint32), ("z_count", C.c_uint32), ("halo_depth", C.c_uint32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class _Obs(C.Structure):
+    _fields_ = [("energy", C.c_double), ("norm2", C.c_double), ("v_infinity", C.c_double),
+                ("r2", C.c_double)]
+
+
+class _Record(C.Structure):
+    _fields_ = [("step", C.c_uint64), ("tau", C.c_double), ("obs", _Obs), ("diff", C.c_double)]
+
+
+class _ObsOut(C.Structure):
+    _fields_ = [("state", C.c_uint32), ("energy", C.c_double), ("binding_energy", C.c_double),
+                ("r", C.c_double), ("l_r", C.c_double)]
+
+
+class _SlabInfo(C.Structure):
+    _fields_ = [("z_begin", C.c_uint32), ("z_count", C.c_uint32), ("halo_depth", C.c_uint32),
+                ("ext", C.c_uint32), ("plane_elems", C.c_uint64), ("elem_bytes", C.c_uint64)]
+
+
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_size_t, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+_lib = None
+
+
+def library_path() -> str:
+    return _LIB
+
+
+def load_library():
+    """Loads libwafer_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise ImportError(
+            f"{_LIB} is missing: build it with `python -m wafer_amd.build` "
+            "(hipcc --offload-arch=gfx950). The engine has no CPU fallback.")
+    L = C.CDLL(_LIB)
+    vp, dp = C.c_void_p, C.POINTER(C.c_double)
+    L.wafer_abi_version.restype = C.c_int
+    L.wafer_last_error.restype = C.c_char_p
+    L.wafer_ctx_create.argtypes = [C.POINTER(_Params), C.POINTER(vp)]
+    L.wafer_ctx_destroy.argtypes = [vp]
+    L.wafer_synchronize.argtypes = [vp]
+    L.wafer_set_potential_builtin.argtypes = [vp, C.c_int]
+    L.wafer_set_potential_host.argtypes = [vp, dp, C.c_int, C.c_double, dp]
+    L.wafer_download_array.argtypes = [vp, C.c_int, dp]
+    L.wafer_get_potsub.argtypes = [vp, C.POINTER(C.c_int), dp]
+    L.wafer_set_initial_condition.argtypes = [vp, C.c_int, C.c_uint64]
+    L.wafer_upload_phi.argtypes = [vp, dp]
+    L.wafer_download_phi.argtypes = [vp, dp]
+    L.wafer_evolve.argtypes = [vp, C.c_uint32, C.c_uint64]
+    L.wafer_observables.argtypes = [vp, C.POINTER(_Obs)]
+    L.wafer_norm2.argtypes = [vp, dp]
+    L.wafer_normalise.argtypes = [vp, C.c_double]
+    L.wafer_orthogonalise.argtypes = [vp, C.c_uint32]
+    L.wafer_push_state.argtypes = [vp]
+    L.wafer_load_state.argtypes = [vp, C.c_uint32, dp]
+    L.wafer_download_state.argtypes = [vp, C.c_uint32, dp]
+    L.wafer_clone_state_to_phi.argtypes = [vp, C.c_uint32]
+    L.wafer_num_states.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.wafer_clear_states.argtypes = [vp]
+    L.wafer_solve_state.argtypes = [vp, C.c_uint32, C.c_double, C.c_uint64, C.c_int, C.c_uint64,
+                                    C.POINTER(_Record), C.c_size_t, C.POINTER(C.c_size_t),
+                                    C.POINTER(_ObsOut)]
+    L.wafer_last_evolve_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+    L.wafer_stencil_kernel_name.argtypes = [vp]
+    L.wafer_stencil_kernel_name.restype = C.c_char_p
+    L.wafer_set_stencil_variant.argtypes = [vp, C.c_int]
+    L.wafer_set_comm_hooks.argtypes = [vp, HALO_FN, ALLREDUCE_FN, vp]
+    L.wafer_set_overlap.argtypes = [vp, C.c_int]
+    L.wafer_set_stream.argtypes = [vp, vp]
+    L.wafer_get_slab_info.argtypes = [vp, C.POINTER(_SlabInfo)]
+    if L.wafer_abi_version() != 1:
+        raise ImportError("libwafer_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+@dataclass
+class Params:
+    """The subset of Config (config.rs:292-333) the hot path reads + engine knobs."""
+    nx: int
+    ny: int
+    nz: int
+    dn: float
+    dt: float
+    mass: float = 1.0
+    sig: float = 1.0
+    central_difference: int = 1      # 1/2/3 or "ThreePoint"/"FivePoint"/"SevenPoint"
+    dtype: str = "f64"               # "f64" | "f32"
+    max_states: int = 4
+    device: int = 0
+    z_begin: int = 0
+    z_count: int = 0                 # 0 = whole grid
+    halo_depth: int = 0              # 0 = ext
+    skip_dt_check: bool = False
+
+    @property
+    def ext(self) -> int:
+        cd = self.central_difference
+        return CENTRAL_DIFFERENCE[cd] if isinstance(cd, str) else int(cd)
+
+    @property
+    def padded_shape(self):
+        e = self.ext
+        return (self.nx + 2 * e, self.ny + 2 * e, self.nz + 2 * e)
+
+    @property
+    def work_shape(self):
+        return (self.nx, self.ny, self.nz)
+
+    def c(self) -> _Params:
+        return _Params(C.sizeof(_Params), self.nx, self.ny, self.nz, self.ext,
+                       {"f64": 0, "f32": 1}[self.dtype], self.dn, self.dt, self.mass, self.sig,
+                       self.max_states, self.device, self.z_begin, self.z_count, self.halo_depth,
+                       FLAG_SKIP_DT_CHECK if self.skip_dt_check else 0)
+
+
+def _dp(a: np.ndarray):
+    if a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError("host arrays must be C-contiguous float64")
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    """Device-resident solver state for one grid (or one z-slab of it)."""
+
+    def __init__(self, params: Params):
+        self._L = load_library()
+        self.params = params
+        self._h = C.c_void_p()
+        p = params.c()
+        self._check(self._L.wafer_ctx_create(C.byref(p), C.byref(self._h)))
+        self._hooks = None
+
+    # -- plumbing -----------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != WAFER_OK:
+            raise WaferError(rc, self._L.wafer_last_error().decode())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.wafer_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def synchronize(self) -> None:
+        self._check(self._L.wafer_synchronize(self._h))
+
+    # -- Potentials (potential.rs:16-25, 75-175) --------------------------------------
+    def set_potential(self, name: str) -> None:
+        self._check(self._L.wafer_set_potential_builtin(self._h, POTENTIALS.index(name)))
+
+    def set_potential_host(self, v: np.ndarray, potsub_kind: int = 0, potsub_scalar: float = 0.0,
+                           potsub: np.ndarray | None = None) -> None:
+        assert v.shape == self.params.padded_shape
+        self._check(self._L.wafer_set_potential_host(
+            self._h, _dp(v), potsub_kind, potsub_scalar, _dp(potsub) if potsub is not None else None))
+
+    def download_array(self, which: str) -> np.ndarray:
+        idx = {"v": 0, "a": 1, "b": 2, "potsub": 3}[which]
+        out = np.zeros(self.params.work_shape if which == "potsub" else self.params.padded_shape)
+        self._check(self._L.wafer_download_array(self._h, idx, _dp(out)))
+        return out
+
+    def potsub(self):
+        kind, scalar = C.c_int(0), C.c_double(0.0)
+        self._check(self._L.wafer_get_potsub(self._h, C.byref(kind), C.byref(scalar)))
+        return kind.value, scalar.value
+
+    # -- phi ----------------------------------------------------------------------------
+    def set_initial_condition(self, name: str, seed: int = 0) -> None:
+        self._check(self._L.wafer_set_initial_condition(self._h, INITIAL_CONDITIONS.index(name), seed))
+
+    def upload_phi(self, phi: np.ndarray) -> None:
+        assert phi.shape == self.params.padded_shape
+        self._check(self._L.wafer_upload_phi(self._h, _dp(phi)))
+
+    def download_phi(self, out: np.ndarray | None = None) -> np.ndarray:
+        if out is None:
+            out = np.zeros(self.params.padded_shape)
+        self._check(self._L.wafer_download_phi(self._h, _dp(out)))
+        return out
+
+    # -- hot path (grid.rs) ---------------------------------------------------------------
+    def evolve(self, wnum: int, steps: int) -> None:
+        """grid.rs:544-687"""
+        self._check(self._L.wafer_evolve(self._h, wnum, steps))
+
+    def observables(self) -> dict:
+        """grid.rs:303-445 (un-normalised)"""
+        o = _Obs()
+        self._check(self._L.wafer_observables(self._h, C.byref(o)))
+        return dict(energy=o.energy, norm2=o.norm2, v_infinity=o.v_infinity, r2=o.r2)
+
+    def norm2(self) -> float:
+        """grid.rs:454-457"""
+        v = C.c_double(0.0)
+        self._check(self._L.wafer_norm2(self._h, C.byref(v)))
+        return v.value
+
+    def normalise(self, norm2: float) -> None:
+        """grid.rs:465-468"""
+        self._check(self._L.wafer_normalise(self._h, norm2))
+
+    def orthogonalise(self, wnum: int) -> None:
+        """grid.rs:477-492"""
+        self._check(self._L.wafer_orthogonalise(self._h, wnum))
+
+    # -- w_store ---------------------------------------------------------------------------
+    def push_state(self) -> None:
+        self._check(self._L.wafer_push_state(self._h))
+
+    def load_state(self, idx: int, state: np.ndarray) -> None:
+        assert state.shape == self.params.padded_shape
+        self._check(self._L.wafer_load_state(self._h, idx, _dp(state)))
+
+    def download_state(self, idx: int) -> np.ndarray:
+        out = np.zeros(self.params.padded_shape)
+        self._check(self._L.wafer_download_state(self._h, idx, _dp(out)))
+        return out
+
+    def clone_state_to_phi(self, idx: int) -> None:
+        self._check(self._L.wafer_clone_state_to_phi(self._h, idx))
+
+    def num_states(self) -> int:
+        n = C.c_uint32(0)
+        self._check(self._L.wafer_num_states(self._h, C.byref(n)))
+        return n.value
+
+    def clear_states(self) -> None:
+        self._check(self._L.wafer_clear_states(self._h))
+
+    # -- solve (grid.rs:50-246) --------------------------------------------------------------
+    def solve_state(self, wnum: int, tolerance: float, screen_update: int, max_steps=None,
+                    max_records: int = 100000):
+        """-> (records, final, converged).  Raises on errors other than MaxStep."""
+        recs = (_Record * max_records)()
+        n = C.c_size_t(0)
+        fin = _ObsOut()
+        rc = self._L.wafer_solve_state(self._h, wnum, tolerance, screen_update,
+                                       0 if max_steps is None else 1,
+                                       0 if max_steps is None else int(max_steps), recs, max_records,
+                                       C.byref(n), C.byref(fin))
+        if rc not in (WAFER_OK, WAFER_ERR_MAX_STEP):
+            self._check(rc)
+        out = []
+        for i in range(min(n.value, max_records)):
+            r = recs[i]
+            out.append(dict(step=r.step, tau=r.tau, energy=r.obs.energy, norm2=r.obs.norm2,
+                            v_infinity=r.obs.v_infinity, r2=r.obs.r2, diff=r.diff))
+        final = dict(state=fin.state, energy=fin.energy, binding_energy=fin.binding_energy,
+                     r=fin.r, l_r=fin.l_r)
+        return out, final, rc == WAFER_OK
+
+    # -- measurement ----------------------------------------------------------------------------
+    def last_evolve_ms(self):
+        ms, steps = C.c_float(0.0), C.c_uint64(0)
+        self._check(self._L.wafer_last_evolve_ms(self._h, C.byref(ms), C.byref(steps)))
+        return ms.value, steps.value
+
+    def stencil_kernel_name(self) -> str:
+        return self._L.wafer_stencil_kernel_name(self._h).decode()
+
+    def set_stencil_variant(self, variant: int) -> None:
+        self._check(self._L.wafer_set_stencil_variant(self._h, variant))
+
+    # -- multi-GPU ---------------------------------------------------------------------------------
+    def set_comm_hooks(self, halo, allreduce) -> None:
+        """halo(send_lo, send_hi, recv_lo, recv_hi, nbytes, stream) and
+        allreduce(dev_ptr, count, stream): python callables taking raw device
+        addresses (ints or None); they must return 0 on success."""
+        def _halo(_user, slo, shi, rlo, rhi, nbytes, stream):
+            try:
+                return int(halo(slo, shi, rlo, rhi, nbytes, stream) or 0)
+            except Exception as e:  # never unwind through C
+                print("wafer halo hook failed:", repr(e), flush=True)
+                return 1
+
+        def _allreduce(_user, ptr, count, stream):
+            try:
+                return int(allreduce(ptr, count, stream) or 0)
+            except Exception as e:
+                print("wafer allreduce hook failed:", repr(e), flush=True)
+                return 1
+
+        self._hooks = (HALO_FN(_halo), ALLREDUCE_FN(_allreduce))  # keep alive
+        self._check(self._L.wafer_set_comm_hooks(self._h, self._hooks[0], self._hooks[1], None))
+
+    def set_overlap(self, enabled: bool) -> None:
+        self._check(self._L.wafer_set_overlap(self._h, 1 if enabled else 0))
+
+    def set_stream(self, stream_ptr: int | None) -> None:
+        self._check(self._L.wafer_set_stream(self._h, stream_ptr))
+
+    def slab_info(self) -> dict:
+        s = _SlabInfo()
+        self._check(self._L.wafer_get_slab_info(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _SlabInfo._fields_}
