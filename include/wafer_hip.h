@@ -193,6 +193,11 @@ const char *wafer_stencil_kernel_name(wafer_ctx *ctx);
 /* choose a stencil kernel variant by index (tuning / A-B runs); -1 = default */
 int wafer_set_stencil_variant(wafer_ctx *ctx, int variant);
 
+/* Diagnostic: achieved GB/s of a flat 16-B/lane streaming kernel with n_reads
+ * (1..3) read streams + 1 write stream over the context's own buffers -- the
+ * measured HBM ceiling next to which the stencil's rate is reported. */
+int wafer_diag_stream_bw(wafer_ctx *ctx, int n_reads, int iters, double *gbps);
+
 /* ---- multi-GPU: communication hooks --------------------------------------- */
 /* The engine never links a communication library.  A host that z-slabs the
  * grid over several contexts installs two hooks (RCCL via torch.distributed in

@@ -141,3 +141,25 @@ __global__ __launch_bounds__(256) void wafer_k_reduce(const double *__restrict__
     }
     if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
+
+// ---------------------------------------------------------------------------
+// Diagnostics: flat streaming kernels over the same buffers, to measure the
+// HBM ceiling of this device for (a) a copy and (b) the stencil's stream mix
+// (3 reads + 1 write per element) without any neighbour traffic.
+// ---------------------------------------------------------------------------
+typedef float __attribute__((ext_vector_type(4))) wafer_f4;
+
+template <int NREAD>
+__global__ __launch_bounds__(256) void wafer_k_stream(const wafer_f4 *__restrict__ r0,
+                                                      const wafer_f4 *__restrict__ r1,
+                                                      const wafer_f4 *__restrict__ r2,
+                                                      wafer_f4 *__restrict__ w, long long n16)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        wafer_f4 v = r0[i];
+        if constexpr (NREAD >= 2) v += r1[i];
+        if constexpr (NREAD >= 3) v += r2[i];
+        w[i] = v;
+    }
+}

@@ -22,6 +22,7 @@
 #include "wafer_setup.hip.h"
 #include "wafer_stencil.hip.h"
 #include "wafer_stencil_lds.hip.h"
+#include "wafer_stencil_fused2.hip.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -107,12 +108,13 @@ struct wafer_ctx {
 
     // launch geometry shared by the column-marching kernels
     int bx = 0, by = 0;
+    int num_cus = 256;
 
     wafer_halo_fn halo_hook = nullptr;
     wafer_allreduce_fn allreduce_hook = nullptr;
     void *hook_user = nullptr;
     bool overlap = true;
-    bool halo_stale = true;
+    int halo_valid = 0; // ghost planes of phi[cur] (counted from the owned region) known to be current
 
     uint64_t last_steps = 0;
     bool timing_valid = false;
@@ -147,6 +149,8 @@ static inline int nchunks_of(int nplanes, int zchunk) { return (nplanes + zchunk
 
 template <typename T>
 static inline T *as(void *p) { return static_cast<T *>(p); }
+template <typename T>
+static inline const T *as(const void *p) { return static_cast<const T *>(p); }
 
 // second-stage reduce of `nq` quantities of `n` partials each into scal[slot..slot+nq)
 static int reduce_to_scal(wafer_ctx *c, int nq, long long n, int slot, hipStream_t s)
@@ -173,28 +177,30 @@ static int read_scal(wafer_ctx *c, int slot, int n, double *out, hipStream_t s)
 // ---------------------------------------------------------------------------
 // halo exchange through the host-installed hook
 // ---------------------------------------------------------------------------
-static int exchange_halo(wafer_ctx *c, int buf, hipStream_t s)
+static int exchange_halo(wafer_ctx *c, int buf, hipStream_t s, int planes)
 {
     if (!c->sharded()) return WAFER_OK;
     if (!c->halo_hook) return fail(WAFER_ERR_COMM, "context owns a z-slab but no halo hook is installed");
     const WaferGeom &g = c->g;
+    if (planes > g.G || planes > g.nzl) return fail(WAFER_ERR_INVALID, "halo exchange deeper than the slab allows");
     char *base = static_cast<char *>(c->phi[buf]);
     const size_t plane_b = (size_t)g.plane * c->esz;
-    const size_t bytes = (size_t)g.R * plane_b;
+    const size_t bytes = (size_t)planes * plane_b;
     void *send_lo = c->has_lo() ? base + (size_t)g.G * plane_b : nullptr;
-    void *recv_lo = c->has_lo() ? base + (size_t)(g.G - g.R) * plane_b : nullptr;
-    void *send_hi = c->has_hi() ? base + (size_t)(g.G + g.nzl - g.R) * plane_b : nullptr;
+    void *recv_lo = c->has_lo() ? base + (size_t)(g.G - planes) * plane_b : nullptr;
+    void *send_hi = c->has_hi() ? base + (size_t)(g.G + g.nzl - planes) * plane_b : nullptr;
     void *recv_hi = c->has_hi() ? base + (size_t)(g.G + g.nzl) * plane_b : nullptr;
     if (c->halo_hook(c->hook_user, send_lo, send_hi, recv_lo, recv_hi, bytes, (void *)s) != 0)
         return fail(WAFER_ERR_COMM, "halo hook failed");
     return WAFER_OK;
 }
 
-static int ensure_halo(wafer_ctx *c)
+// makes at least `need` ghost planes of phi[cur] current
+static int ensure_halo(wafer_ctx *c, int need)
 {
-    if (c->sharded() && c->halo_stale) {
-        TRY(exchange_halo(c, c->cur, c->s_main));
-        c->halo_stale = false;
+    if (c->sharded() && c->halo_valid < need) {
+        TRY(exchange_halo(c, c->cur, c->s_main, need));
+        c->halo_valid = need;
     }
     return WAFER_OK;
 }
@@ -208,6 +214,7 @@ struct VariantInfo {
 static const VariantInfo kVariants[] = {
     {"wafer_k_step_direct"},
     {"wafer_k_step_lds"},
+    {"wafer_k_step2_fused"},
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -217,22 +224,25 @@ static int default_variant(const wafer_ctx *c)
     return env_int("WAFER_STENCIL_VARIANT", 1);
 }
 
+static int active_variant(const wafer_ctx *c) { return c->variant >= 0 ? c->variant : default_variant(c); }
+
 template <typename T, typename C, int R, bool NORM>
 static int launch_step_t(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s)
 {
     if (lz_hi <= lz_lo) return WAFER_OK;
-    const int variant = c->variant >= 0 ? c->variant : default_variant(c);
+    const int variant = active_variant(c);
     WaferStepArgs a;
     a.g = c->g;
     a.lz_lo = lz_lo;
     a.lz_hi = lz_hi;
     a.dt = c->P.dt;
+    a.target_blocks = c->num_cus;
     const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
     a.den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:569 / 594 / 626
     const T *phi = as<T>(c->phi[src]);
     T *out = as<T>(c->phi[dst]);
-    if (variant == 1) {
-        return wafer_launch_step_lds<T, C, R, NORM>(a, phi, as<T>(c->a), as<T>(c->b), out,
+    if (variant >= 1) {
+        return wafer_launch_step_lds<T, C, R, NORM>(a, phi, as<T>(c->a), as<T>(c->b), as<T>(c->v), out,
                                                     c->partials, c->partials_stride, s) == hipSuccess
                    ? WAFER_OK
                    : fail(WAFER_ERR_HIP, "LDS stencil launch failed: %s",
@@ -252,8 +262,8 @@ static int launch_step_t(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, h
 template <typename T, typename C, int R>
 static long long step_partials_count(wafer_ctx *c, int lz_lo, int lz_hi)
 {
-    const int variant = c->variant >= 0 ? c->variant : default_variant(c);
-    if (variant == 1) return wafer_step_lds_blocks<T, R>(c->g, lz_lo, lz_hi);
+    const int variant = active_variant(c);
+    if (variant >= 1) return wafer_step_lds_blocks<T, R>(c->g, lz_lo, lz_hi, c->num_cus);
     const int zc = pick_zchunk(c, lz_hi - lz_lo, env_int("WAFER_TARGET_BLOCKS", 4096));
     return (long long)c->bx * c->by * nchunks_of(lz_hi - lz_lo, zc);
 }
@@ -284,6 +294,29 @@ static int launch_step(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, boo
                     : launch_step_t<T, C, R, false>(c, src, dst, lz_lo, lz_hi, s);
     });
 }
+
+// two fused steps over planes [lz_lo, lz_hi): phi[dst] = step(step(phi[src]))
+static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s)
+{
+    if (lz_hi <= lz_lo) return WAFER_OK;
+    return dispatch(c, [&](auto t, auto cc, auto r) {
+        using T = decltype(t);
+        using C = decltype(cc);
+        constexpr int R = decltype(r)::value;
+        WaferStepArgs a;
+        a.g = c->g;
+        a.lz_lo = lz_lo;
+        a.lz_hi = lz_hi;
+        a.dt = c->P.dt;
+        a.target_blocks = c->num_cus;
+        const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
+        a.den = lead * c->P.dn * c->P.dn * c->P.mass;
+        if (wafer_launch_step2_fused<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->v), as<T>(c->phi[dst]), s) != hipSuccess)
+            return fail(WAFER_ERR_HIP, "fused stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return (int)WAFER_OK;
+    });
+}
+
 
 // elementwise launches -------------------------------------------------------
 static WaferEwArgs ew_args(wafer_ctx *c, int *nblocks, dim3 *grid)
@@ -399,8 +432,11 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     if (ndev < 1) return fail(WAFER_ERR_HIP, "no HIP device visible: the engine has no CPU path");
     if (p->device < 0 || p->device >= ndev) return fail(WAFER_ERR_INVALID, "device %d out of range", p->device);
     HIP_TRY(hipSetDevice(p->device));
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device));
 
     wafer_ctx *c = new wafer_ctx();
+    c->num_cus = cus > 0 ? cus : 256;
     c->P = *p;
     c->f32 = (p->dtype == WAFER_F32);
     c->esz = c->f32 ? 4 : 8;
@@ -669,7 +705,7 @@ int wafer_set_initial_condition(wafer_ctx *c, int ic, uint64_t seed)
         hipLaunchKernelGGL((wafer_k_initial_condition<double>), grid, block, 0, c->s_main, a, as<double>(c->phi[c->cur]));
     HIP_TRY(hipGetLastError());
     c->have_phi = true;
-    c->halo_stale = false; // every ghost plane was generated from global indices
+    c->halo_valid = c->g.G; // every ghost plane was generated from global indices
     return WAFER_OK;
 }
 
@@ -679,7 +715,7 @@ int wafer_upload_phi(wafer_ctx *c, const double *phi)
     HIP_TRY(hipSetDevice(c->P.device));
     TRY(upload_padded(c, phi, c->phi[c->cur]));
     c->have_phi = true;
-    c->halo_stale = false; // ghost planes came from the global array
+    c->halo_valid = c->g.G; // ghost planes came from the global array
     return WAFER_OK;
 }
 
@@ -700,28 +736,53 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     if (wnum > c->states.size()) return fail(WAFER_ERR_STATE, "wnum %u but w_store holds %zu states", wnum, c->states.size());
     if (wnum + 2 > SCAL_SLOTS) return fail(WAFER_ERR_INVALID, "wnum too large");
     HIP_TRY(hipSetDevice(c->P.device));
-    TRY(ensure_halo(c));
     const WaferGeom &g = c->g;
+    const int R = g.R;
     const int lo = g.G, hi = g.G + g.nzl;
     const uint64_t steps = n_steps == 0 ? 1 : n_steps; // grid.rs:682-685
-    const bool split = c->sharded() && c->overlap && wnum == 0 && g.nzl > 2 * g.R;
+    // two steps per pass where nothing happens between steps (ground state) and, when the grid
+    // is sharded, the slab carries 2R ghost planes
+    const bool fuse = wnum == 0 && active_variant(c) == 2 && (!c->sharded() || (g.G >= 2 * R && g.nzl >= 2 * R));
     HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
-    for (uint64_t s = 0; s < steps; ++s) {
+    for (uint64_t s = 0; s < steps;) {
         const int src = c->cur, dst = c->cur ^ 1;
+        if (fuse && steps - s >= 2) {
+            TRY(ensure_halo(c, 2 * R));
+            const bool split = c->sharded() && c->overlap && g.nzl > 4 * R;
+            if (split) {
+                HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
+                HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
+                if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + 2 * R, c->s_aux));
+                if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - 2 * R, hi, c->s_aux));
+                TRY(exchange_halo(c, dst, c->s_aux, 2 * R));
+                HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
+                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + 2 * R : lo, c->has_hi() ? hi - 2 * R : hi, c->s_main));
+                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
+            } else {
+                TRY(launch_step2(c, src, dst, lo, hi, c->s_main));
+                TRY(exchange_halo(c, dst, c->s_main, 2 * R));
+            }
+            c->halo_valid = 2 * R;
+            c->cur = dst;
+            s += 2;
+            continue;
+        }
+        TRY(ensure_halo(c, R));
         if (wnum == 0) {
+            const bool split = c->sharded() && c->overlap && g.nzl > 2 * R;
             if (split) {
                 // boundary planes first on the aux stream, their exchange overlaps the interior
                 HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
                 HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
-                if (c->has_lo()) TRY(launch_step(c, src, dst, lo, lo + g.R, false, c->s_aux));
-                if (c->has_hi()) TRY(launch_step(c, src, dst, hi - g.R, hi, false, c->s_aux));
-                TRY(exchange_halo(c, dst, c->s_aux));
+                if (c->has_lo()) TRY(launch_step(c, src, dst, lo, lo + R, false, c->s_aux));
+                if (c->has_hi()) TRY(launch_step(c, src, dst, hi - R, hi, false, c->s_aux));
+                TRY(exchange_halo(c, dst, c->s_aux, R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
-                TRY(launch_step(c, src, dst, c->has_lo() ? lo + g.R : lo, c->has_hi() ? hi - g.R : hi, false, c->s_main));
+                TRY(launch_step(c, src, dst, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi, false, c->s_main));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
             } else {
                 TRY(launch_step(c, src, dst, lo, hi, false, c->s_main));
-                TRY(exchange_halo(c, dst, c->s_main));
+                TRY(exchange_halo(c, dst, c->s_main, R));
             }
         } else {
             // step + sum phi'^2 (grid.rs:675-678), normalise (:679), Gram-Schmidt (:680)
@@ -732,14 +793,15 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             TRY(reduce_to_scal(c, 1, nb, 0, c->s_main));
             TRY(launch_normalise(c, dst, c->scal + 0, 0.0, c->states[0], 1, c->s_main));
             TRY(gs_chain(c, dst, wnum, true, c->s_main));
-            TRY(exchange_halo(c, dst, c->s_main));
+            TRY(exchange_halo(c, dst, c->s_main, R));
         }
+        c->halo_valid = R;
         c->cur = dst;
+        s += 1;
     }
     HIP_TRY(hipEventRecord(c->ev_stop, c->s_main));
     c->last_steps = steps;
     c->timing_valid = true;
-    c->halo_stale = false;
     return WAFER_OK;
 }
 
@@ -775,7 +837,7 @@ int wafer_observables(wafer_ctx *c, wafer_observables_t *out)
     if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
     if (!c->have_pot || !c->have_phi) return fail(WAFER_ERR_STATE, "potential and phi must be set");
     HIP_TRY(hipSetDevice(c->P.device));
-    TRY(ensure_halo(c));
+    TRY(ensure_halo(c, c->g.R));
     WaferObsArgs a;
     a.g = c->g;
     a.zchunk = pick_zchunk(c, c->g.nzl, env_int("WAFER_TARGET_BLOCKS", 4096));
@@ -829,7 +891,7 @@ int wafer_normalise(wafer_ctx *c, double norm2)
     if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
     HIP_TRY(hipSetDevice(c->P.device));
     TRY(launch_normalise(c, c->cur, nullptr, norm2, nullptr, 0, c->s_main));
-    c->halo_stale = true;
+    c->halo_valid = 0;
     return WAFER_OK;
 }
 
@@ -841,7 +903,7 @@ int wafer_orthogonalise(wafer_ctx *c, uint32_t wnum)
     if (wnum + 2 > SCAL_SLOTS) return fail(WAFER_ERR_INVALID, "wnum too large");
     HIP_TRY(hipSetDevice(c->P.device));
     TRY(gs_chain(c, c->cur, wnum, false, c->s_main));
-    if (wnum) c->halo_stale = true;
+    if (wnum) c->halo_valid = 0;
     return WAFER_OK;
 }
 
@@ -859,7 +921,6 @@ int wafer_push_state(wafer_ctx *c)
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
     if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
     HIP_TRY(hipSetDevice(c->P.device));
-    TRY(ensure_halo(c)); // stored states keep valid ghost planes
     void *slot = nullptr;
     TRY(new_state_slot(c, &slot));
     HIP_TRY(hipMemcpyAsync(slot, c->phi[c->cur], (size_t)c->g.total * c->esz, hipMemcpyDeviceToDevice, c->s_main));
@@ -896,7 +957,7 @@ int wafer_clone_state_to_phi(wafer_ctx *c, uint32_t idx)
     HIP_TRY(hipSetDevice(c->P.device));
     HIP_TRY(hipMemcpyAsync(c->phi[c->cur], c->states[idx], (size_t)c->g.total * c->esz, hipMemcpyDeviceToDevice, c->s_main));
     c->have_phi = true;
-    c->halo_stale = false;
+    c->halo_valid = 0; // stored states carry no ghost-plane guarantee
     return WAFER_OK;
 }
 
@@ -932,6 +993,11 @@ int wafer_solve_state(wafer_ctx *c, uint32_t wnum, double tolerance, uint64_t sc
     for (;;) {
         TRY(wafer_observables(c, &obs));                    // :127
         const double norm_energy = obs.energy / obs.norm2;  // :128
+        // R64 panics on NaN in the reference's debug builds (noisy_float); in release it would
+        // iterate on NaNs forever.  Report it instead of spinning until max_steps.
+        if (!std::isfinite(norm_energy))
+            return fail(WAFER_ERR_STATE, "state %u: energy is not finite at step %llu (norm2 = %g): "
+                        "the wavefunction vanished or diverged", wnum, (unsigned long long)step, obs.norm2);
         const double tau = (double)step * c->P.dt;          // :129
         TRY(wafer_normalise(c, obs.norm2));                 // :130
         if (wnum > 0) TRY(wafer_orthogonalise(c, wnum));    // :133-135
@@ -963,6 +1029,37 @@ int wafer_solve_state(wafer_ctx *c, uint32_t wnum, double tolerance, uint64_t sc
     }
     if (!converged) return fail(WAFER_ERR_MAX_STEP, "MaxStep: state %u did not converge within max_steps", wnum);
     return wafer_push_state(c); // :239-242
+}
+
+// ---- diagnostics: device streaming ceilings ---------------------------------------------------
+int wafer_diag_stream_bw(wafer_ctx *c, int n_reads, int iters, double *gbps)
+{
+    if (!c || !gbps) return fail(WAFER_ERR_INVALID, "null argument");
+    if (n_reads < 1 || n_reads > 3 || iters < 1) return fail(WAFER_ERR_INVALID, "n_reads in 1..3, iters >= 1");
+    HIP_TRY(hipSetDevice(c->P.device));
+    const long long n16 = (long long)c->g.total * (long long)c->esz / 16;
+    const wafer_f4 *r0 = as<const wafer_f4>(c->a), *r1 = as<const wafer_f4>(c->b), *r2 = as<const wafer_f4>(c->v);
+    wafer_f4 *w = as<wafer_f4>(c->phi[c->cur ^ 1]); // scratch between steps
+    const dim3 grid(256 * 8), block(256);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int it = -2; it < iters; ++it) { // two warm-up launches
+        if (it == 0) HIP_TRY(hipEventRecord(e0, c->s_main));
+        if (n_reads == 1) hipLaunchKernelGGL((wafer_k_stream<1>), grid, block, 0, c->s_main, r0, r1, r2, w, n16);
+        else if (n_reads == 2) hipLaunchKernelGGL((wafer_k_stream<2>), grid, block, 0, c->s_main, r0, r1, r2, w, n16);
+        else hipLaunchKernelGGL((wafer_k_stream<3>), grid, block, 0, c->s_main, r0, r1, r2, w, n16);
+    }
+    HIP_TRY(hipEventRecord(e1, c->s_main));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    // the scratch buffer's frame must be zero again
+    HIP_TRY(hipMemsetAsync(c->phi[c->cur ^ 1], 0, (size_t)c->g.total * c->esz, c->s_main));
+    *gbps = (double)n16 * 16.0 * (n_reads + 1) * iters / (ms * 1e-3) / 1e9;
+    return WAFER_OK;
 }
 
 // ---- multi-GPU plumbing -----------------------------------------------------------------

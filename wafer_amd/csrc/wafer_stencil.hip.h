@@ -64,6 +64,7 @@ struct WaferStepArgs {
     WaferGeom g;
     int lz_lo, lz_hi;   // local planes [lz_lo, lz_hi) to update
     int zchunk;         // planes marched by one workgroup
+    int target_blocks;  // workgroups a launch should aim for (the device's CU count)
     double dt, den;
 };
 

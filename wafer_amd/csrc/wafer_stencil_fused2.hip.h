@@ -1,0 +1,447 @@
+// Two imaginary-time steps per pass over HBM (temporal blocking) for the
+// ground-state evolve loop (grid.rs:562-686 with wnum == 0, where nothing but
+// the stencil happens between two steps).
+//
+//   phi0 --step--> phi1 --step--> phi2
+//
+// A workgroup marches a (TX x TY) tile along z like wafer_k_step_lds, but keeps
+// TWO register pipelines: plane z of phi1 is produced from the phi0 z-queue and
+// immediately feeds the phi1 z-queue from which plane z-R of phi2 is produced.
+// phi1 never touches HBM.  a and b are formed from V in registers
+// (potential.rs:104-110, same expressions => same bits), so the pass reads
+// phi0 and V once and writes phi2 once: 24 B of HBM traffic per TWO updates
+// (12 B/update against the 32 B/update the roofline figure is priced at).
+// Arithmetic per update is unchanged, so results stay bit-identical to two
+// single steps.
+//
+// Tile roles (RY = 2 rows per lane, VEC = 16 B of x per lane):
+//   waves 0..3            "main": own rows y0..y0+7 in both steps;
+//   waves 4..4+R-1        "halo-row": own the 2R phi1 halo rows (y0-R.., y0+TY..),
+//                         step 1 only;
+//   last wave             "halo-column": each lane owns a few phi0 halo-column
+//                         cells (2R columns each side, z-queue in registers) and
+//                         produces the phi1 halo-column cells (R columns each side).
+// phi0's outermost 2R halo rows are plain vector loads staged through LDS.
+// LDS: double-buffered phi0 centre tile (TY+4R rows) + ring of R+1 phi1 tiles
+// (TY+2R rows).  One s_barrier per plane.
+//
+// Cells of phi1 outside the work area (Dirichlet frame, config.rs:597-622) are
+// forced to 0 exactly as the reference never updates them; phi1 planes outside
+// the global work range likewise.  z-chunks recompute R planes of phi1 on each
+// side; slabs of a sharded grid need 2R valid ghost planes of phi0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wafer_geom.h"
+#include "wafer_stencil.hip.h"
+#include "wafer_stencil_lds.hip.h"
+
+template <typename T, int R>
+struct WaferF2Cfg {
+    static constexpr int VEC = WaferVec<T>::N;
+    static constexpr int RY = 2;
+    static constexpr int NW2 = 4;                        // main waves
+    static constexpr int NWH = (2 * R) / RY;             // halo-row waves (R)
+    static constexpr int NW = NW2 + NWH + 1;             // + halo-column wave
+    static constexpr int NT_ = NW * 64;                  // threads per workgroup
+    static constexpr int TX = 64 * VEC, TY = NW2 * RY;
+    static constexpr int HC0 = 2 * R, HC1 = R;           // halo columns per side: phi0, phi1
+    static constexpr int HX0 = ((HC0 + VEC - 1) / VEC) * VEC;
+    static constexpr int HX1 = ((HC1 + VEC - 1) / VEC) * VEC;
+    static constexpr int LP0 = TX + 2 * HX0, LP1 = TX + 2 * HX1;
+    static constexpr int ROWS0 = TY + 4 * R, ROWS1 = TY + 2 * R;
+    static constexpr int TILE0 = ROWS0 * LP0, TILE1 = ROWS1 * LP1;
+    static constexpr int NB1 = R + 1;                    // phi1 ring depth
+    static constexpr int NCOL = 2 * HC0 * ROWS0;         // phi0 halo-column cells per plane
+    static constexpr int CPL = (NCOL + 63) / 64;         // cells per lane of the halo-column wave
+    static constexpr int OUTER = 2 * R;                  // outermost phi0 halo rows (vector loads)
+    static constexpr int OPW = (OUTER + NW2 - 1) / NW2;  // of which per main wave
+};
+
+// a, b from V, then the update: potential.rs:104-110 + grid.rs:580-589
+template <typename C>
+__device__ __forceinline__ C wafer_update_v(C w, C vv, C dt, C S, C den)
+{
+    const C cb = C(1) / (C(1) + dt * vv / C(2));
+    const C ca = (C(1) - dt * vv / C(2)) * cb;
+    return w * ca + cb * dt * S / den;
+}
+
+template <typename T, typename C, int R, bool NT>
+__global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
+    WaferStepArgs a, int ntx, int nty, int swz, const T *__restrict__ phi, const T *__restrict__ pv,
+    T *__restrict__ out)
+{
+    using Cfg = WaferF2Cfg<T, R>;
+    using VT = typename WaferVec<T>::type;
+    constexpr int VEC = Cfg::VEC, RY = Cfg::RY, TX = Cfg::TX, TY = Cfg::TY;
+    constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, LP0 = Cfg::LP0, LP1 = Cfg::LP1;
+    __shared__ __attribute__((aligned(16))) T lds0[2 * Cfg::TILE0];
+    __shared__ __attribute__((aligned(16))) T lds1[Cfg::NB1 * Cfg::TILE1];
+
+    const WaferGeom &g = a.g;
+    int bid = blockIdx.x;
+    if (swz) {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, k = bid & 7;
+        bid = k * q + min(k, r) + (bid >> 3);
+    }
+    const int tx_i = bid % ntx, ty_i = (bid / ntx) % nty, tz_i = bid / (ntx * nty);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int x0 = tx_i * TX, y0 = ty_i * TY;
+    const int zs = a.lz_lo + tz_i * a.zchunk;
+    const int ze = min(zs + a.zchunk, a.lz_hi);
+    const C dt = (C)a.dt, den = (C)a.den;
+    const bool is_main = wave < Cfg::NW2;
+    const bool is_hrow = wave >= Cfg::NW2 && wave < Cfg::NW2 + Cfg::NWH;
+    const bool is_hcol = wave == Cfg::NW - 1;
+
+    VT zero;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) zero[v] = T(0);
+
+    // ---- row slots of the main and halo-row waves ---------------------------------
+    const int xl = lane * VEC, xi = x0 + xl;
+    const int wlim = g.pitch - g.xoff - R;        // aligned VEC group inside the row allocation
+    const bool xin = xi < wlim;
+    int yrow[RY];          // work y of slot r
+    bool rowld[RY];        // the row exists in memory (frame rows included) and the group is in the row
+    bool rowwk[RY];        // the row is a work row
+    long long rowoff[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        int y;
+        if (is_hrow) {
+            const int h = (wave - Cfg::NW2) * RY + r;                 // 0..2R-1
+            y = (h < R) ? (y0 - R + h) : (y0 + TY + (h - R));
+        } else {
+            y = y0 + wave * RY + r;                                   // main (unused for hcol)
+        }
+        yrow[r] = y;
+        rowld[r] = !is_hcol && xin && (y >= -R) && (y < g.ny + R);
+        rowwk[r] = (y >= 0) && (y < g.ny);
+        rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + xi;
+    }
+    // ---- outermost phi0 halo rows, fetched by the main waves -------------------------
+    bool orow_ld[Cfg::OPW];
+    long long orow_off[Cfg::OPW];
+    int orow_lds[Cfg::OPW];
+#pragma unroll
+    for (int q = 0; q < Cfg::OPW; ++q) {
+        const int o = wave + q * Cfg::NW2;                            // 0..2R-1 valid
+        const int y = (o < R) ? (y0 - 2 * R + o) : (y0 + TY + R + (o - R));
+        orow_ld[q] = is_main && (o < Cfg::OUTER) && xin && (y >= -R) && (y < g.ny + R);
+        orow_off[q] = (long long)(y + R) * g.pitch + g.xoff + R + xi;
+        orow_lds[q] = (y - (y0 - 2 * R)) * LP0 + HX0 + xl;
+    }
+    // ---- halo-column cells of the last wave ------------------------------------------------
+    bool c_ld[Cfg::CPL], c_p1[Cfg::CPL];
+    long long c_off[Cfg::CPL];
+    int c_lds0[Cfg::CPL], c_lds1[Cfg::CPL];
+#pragma unroll
+    for (int q = 0; q < Cfg::CPL; ++q) {
+        const int cidx = lane + q * 64;
+        const int row = cidx / (2 * Cfg::HC0), k = cidx % (2 * Cfg::HC0);
+        const int kk = (k < Cfg::HC0) ? k : k - Cfg::HC0;             // distance-1 from the tile edge
+        const int lc = (k < Cfg::HC0) ? (-1 - kk) : (TX + kk);        // column relative to x0
+        const int xw = x0 + lc, y = y0 - 2 * R + row;
+        const bool valid = is_hcol && cidx < Cfg::NCOL;
+        c_ld[q] = valid && (y >= -R) && (y < g.ny + R) && (xw >= -R) && (xw < g.nx + R);
+        // phi1 is produced on the inner R columns and rows y0-R .. y0+TY+R-1, work cells only
+        c_p1[q] = valid && (kk < R) && (row >= R) && (row < Cfg::ROWS0 - R) && (y >= 0) && (y < g.ny) &&
+                  (xw >= 0) && (xw < g.nx);
+        c_off[q] = (long long)(y + R) * g.pitch + g.xoff + R + xw;
+        c_lds0[q] = row * LP0 + HX0 + lc;
+        c_lds1[q] = (row - R) * LP1 + HX1 + lc;
+    }
+    const bool c_p1slot_valid = is_hcol;
+
+    auto plane_ok = [&](int p) { return p >= 0 && p < g.lz; };
+    auto work_plane = [&](int p) {
+        const int kg = g.z_begin + (p - g.G);
+        return kg >= 0 && kg < g.nz;
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------
+    // first phi1 plane is z1 = zs - R; phi0 z-queue holds planes z1-R .. z1+R
+    const int z1 = zs - R;
+    VT q0[2 * R + 1][RY];
+    VT vq[R + 1][RY];     // V of planes z-R .. z (oldest first); only vq[R] is used by step 1
+    T cq[Cfg::CPL][2 * R + 1];
+    T cv[Cfg::CPL];       // V at the halo-column cells, plane z
+#pragma unroll
+    for (int m = 0; m <= 2 * R; ++m) {
+        const int p = z1 - R + m;
+        const bool ok = plane_ok(p);
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+            q0[m][r] = (ok && rowld[r]) ? *reinterpret_cast<const VT *>(phi + (long long)p * g.plane + rowoff[r]) : zero;
+#pragma unroll
+        for (int q = 0; q < Cfg::CPL; ++q)
+            cq[q][m] = (ok && c_ld[q]) ? phi[(long long)p * g.plane + c_off[q]] : T(0);
+    }
+#pragma unroll
+    for (int m = 0; m <= R; ++m)
+#pragma unroll
+        for (int r = 0; r < RY; ++r) vq[m][r] = zero;
+    {
+        const bool ok = plane_ok(z1);
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+            vq[R][r] = (ok && rowld[r]) ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pv + (long long)z1 * g.plane + rowoff[r])) : zero;
+#pragma unroll
+        for (int q = 0; q < Cfg::CPL; ++q)
+            cv[q] = (ok && c_ld[q]) ? pv[(long long)z1 * g.plane + c_off[q]] : T(0);
+    }
+    // phi1 z-queue (main waves), planes z-2R .. z; starts empty (zeros never reach an output:
+    // the first output plane zs is produced at z = zs + R, by when all 2R+1 entries are real)
+    VT q1[2 * R + 1][RY];
+#pragma unroll
+    for (int m = 0; m <= 2 * R; ++m)
+#pragma unroll
+        for (int r = 0; r < RY; ++r) q1[m][r] = zero;
+
+    // LDS: zero the phi0 pad columns once (they stay zero), stage the centre plane z1
+    for (int i = tid; i < 2 * Cfg::TILE0; i += Cfg::NT_) lds0[i] = T(0);
+    for (int i = tid; i < Cfg::NB1 * Cfg::TILE1; i += Cfg::NT_) lds1[i] = T(0);
+    __syncthreads();
+    {
+        T *t0 = lds0 + (z1 & 1) * Cfg::TILE0;
+        if (!is_hcol) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r)
+                *reinterpret_cast<VT *>(t0 + (yrow[r] - (y0 - 2 * R)) * LP0 + HX0 + xl) = q0[R][r];
+        }
+        const bool ok = plane_ok(z1);
+#pragma unroll
+        for (int q = 0; q < Cfg::OPW; ++q)
+            if (is_main && wave + q * Cfg::NW2 < Cfg::OUTER)
+                *reinterpret_cast<VT *>(t0 + orow_lds[q]) =
+                    (ok && orow_ld[q]) ? *reinterpret_cast<const VT *>(phi + (long long)z1 * g.plane + orow_off[q]) : zero;
+#pragma unroll
+        for (int q = 0; q < Cfg::CPL; ++q)
+            if (is_hcol && lane + q * 64 < Cfg::NCOL) t0[c_lds0[q]] = cq[q][R];
+    }
+    VT orow_nxt[Cfg::OPW];
+    {
+        const bool ok = plane_ok(z1 + 1);
+#pragma unroll
+        for (int q = 0; q < Cfg::OPW; ++q)
+            orow_nxt[q] = (ok && orow_ld[q]) ? *reinterpret_cast<const VT *>(phi + (long long)(z1 + 1) * g.plane + orow_off[q]) : zero;
+    }
+    __syncthreads();
+
+    const int zend = ze + R; // phi1 planes z1 .. zend-1
+    for (int z = z1; z < zend; ++z) {
+        const bool more = z + 1 < zend;
+        const long long zo = (long long)z * g.plane;
+        // ---- 1. prefetch: phi0 plane z+R+1, V plane z+1, outer halo rows of plane z+2 ---------------
+        VT pre[RY], pre_v[RY], orow_pre[Cfg::OPW];
+        T cpre[Cfg::CPL], cvpre[Cfg::CPL];
+        {
+            const bool okp = more && plane_ok(z + R + 1);
+            const bool okv = more && plane_ok(z + 1);
+            const bool oko = (z + 2 < zend) && plane_ok(z + 2);
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                pre[r] = (okp && rowld[r]) ? *reinterpret_cast<const VT *>(phi + zo + (long long)(R + 1) * g.plane + rowoff[r]) : zero;
+                pre_v[r] = (okv && rowld[r]) ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pv + zo + g.plane + rowoff[r])) : zero;
+            }
+#pragma unroll
+            for (int q = 0; q < Cfg::OPW; ++q)
+                orow_pre[q] = (oko && orow_ld[q]) ? *reinterpret_cast<const VT *>(phi + zo + 2 * g.plane + orow_off[q]) : zero;
+#pragma unroll
+            for (int q = 0; q < Cfg::CPL; ++q) {
+                cpre[q] = (okp && c_ld[q]) ? phi[zo + (long long)(R + 1) * g.plane + c_off[q]] : T(0);
+                cvpre[q] = (okv && c_ld[q]) ? pv[zo + g.plane + c_off[q]] : T(0);
+            }
+        }
+        // ---- 2. stage phi0 plane z+1 into the other buffer ------------------------------------------------
+        if (more) {
+            T *nt = lds0 + ((z + 1) & 1) * Cfg::TILE0;
+            if (!is_hcol) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r)
+                    *reinterpret_cast<VT *>(nt + (yrow[r] - (y0 - 2 * R)) * LP0 + HX0 + xl) = q0[R + 1][r];
+            }
+#pragma unroll
+            for (int q = 0; q < Cfg::OPW; ++q)
+                if (is_main && wave + q * Cfg::NW2 < Cfg::OUTER) *reinterpret_cast<VT *>(nt + orow_lds[q]) = orow_nxt[q];
+#pragma unroll
+            for (int q = 0; q < Cfg::CPL; ++q)
+                if (is_hcol && lane + q * 64 < Cfg::NCOL) nt[c_lds0[q]] = cq[q][R + 1];
+        }
+        // ---- 3. step 1: phi1 plane z ---------------------------------------------------------------------------
+        const T *c0 = lds0 + (z & 1) * Cfg::TILE0;
+        T *w1 = lds1 + (((z % Cfg::NB1) + Cfg::NB1) % Cfg::NB1) * Cfg::TILE1;
+        const bool wplane = work_plane(z);
+        VT p1new[RY];
+        if (!is_hcol) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                VT res = zero;
+                if (wplane && rowwk[r]) {
+                    const int ly = yrow[r] - (y0 - 2 * R);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
+                        const C w = (C)q0[R][r][v];
+#pragma unroll
+                        for (int d = -R; d <= R; ++d) {
+                            zz[d + R] = (C)q0[R + d][r][v];
+                            if (d == 0) {
+                                xs[R] = w;
+                                ys[R] = w;
+                            } else {
+                                xs[d + R] = (v + d >= 0 && v + d < VEC) ? (C)q0[R][r][(v + d + VEC) % VEC]
+                                                                       : (C)c0[ly * LP0 + HX0 + xl + v + d];
+                                ys[d + R] = (C)c0[(ly + d) * LP0 + HX0 + xl + v];
+                            }
+                        }
+                        const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
+                        const T rs = (T)wafer_update_v<C>(w, (C)vq[R][r][v], dt, S, den);
+                        res[v] = (xi + v < g.nx) ? rs : T(0);
+                    }
+                }
+                p1new[r] = res;
+                *reinterpret_cast<VT *>(w1 + (yrow[r] - (y0 - R)) * LP1 + HX1 + xl) = res;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Cfg::CPL; ++q) {
+                if (lane + q * 64 < Cfg::NCOL) {
+                    const int cidx = lane + q * 64;
+                    const int row = cidx / (2 * Cfg::HC0), k = cidx % (2 * Cfg::HC0);
+                    const int kk = (k < Cfg::HC0) ? k : k - Cfg::HC0;
+                    if (kk < R && row >= R && row < Cfg::ROWS0 - R) {
+                        T rs = T(0);
+                        if (wplane && c_p1[q]) {
+                            const int o0 = c_lds0[q];
+                            C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
+                            const C w = (C)cq[q][R];
+#pragma unroll
+                            for (int d = -R; d <= R; ++d) {
+                                zz[d + R] = (C)cq[q][R + d];
+                                xs[d + R] = (d == 0) ? w : (C)c0[o0 + d];
+                                ys[d + R] = (d == 0) ? w : (C)c0[o0 + d * LP0];
+                            }
+                            const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
+                            rs = (T)wafer_update_v<C>(w, (C)cv[q], dt, S, den);
+                        }
+                        w1[c_lds1[q]] = rs;
+                    }
+                }
+            }
+        }
+        (void)c_p1slot_valid;
+        // the phi1 tile of plane z-R (written R iterations ago) is complete: barriers in between
+        // ---- 4. step 2: phi2 plane z-R from the phi1 queue (main waves) --------------------------------------
+        if (is_main) {
+#pragma unroll
+            for (int m = 0; m < 2 * R; ++m)
+#pragma unroll
+                for (int r = 0; r < RY; ++r) q1[m][r] = q1[m + 1][r];
+#pragma unroll
+            for (int r = 0; r < RY; ++r) q1[2 * R][r] = p1new[r];
+            const int zo2 = z - R;
+            if (zo2 >= zs) {
+                const T *c1 = lds1 + (((zo2 % Cfg::NB1) + Cfg::NB1) % Cfg::NB1) * Cfg::TILE1;
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    if (rowld[r] && rowwk[r]) {
+                        const int ly = yrow[r] - (y0 - R);
+                        VT res;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
+                            const C w = (C)q1[R][r][v];
+#pragma unroll
+                            for (int d = -R; d <= R; ++d) {
+                                zz[d + R] = (C)q1[R + d][r][v];
+                                if (d == 0) {
+                                    xs[R] = w;
+                                    ys[R] = w;
+                                } else {
+                                    xs[d + R] = (v + d >= 0 && v + d < VEC) ? (C)q1[R][r][(v + d + VEC) % VEC]
+                                                                           : (C)c1[ly * LP1 + HX1 + xl + v + d];
+                                    ys[d + R] = (r + d >= 0 && r + d < RY) ? (C)q1[R][(r + d + RY) % RY][v]
+                                                                         : (C)c1[(ly + d) * LP1 + HX1 + xl + v];
+                                }
+                            }
+                            const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
+                            res[v] = (T)wafer_update_v<C>(w, (C)vq[0][r][v], dt, S, den);
+                        }
+                        T *dst = out + (long long)zo2 * g.plane + rowoff[r];
+                        if (xi + VEC <= g.nx) {
+                            wafer_st_stream<NT>(reinterpret_cast<VT *>(dst), res);
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v)
+                                if (xi + v < g.nx) dst[v] = res[v];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 5. rotate ---------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int m = 0; m < 2 * R; ++m) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r) q0[m][r] = q0[m + 1][r];
+#pragma unroll
+            for (int q = 0; q < Cfg::CPL; ++q) cq[q][m] = cq[q][m + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < RY; ++r) q0[2 * R][r] = pre[r];
+#pragma unroll
+        for (int q = 0; q < Cfg::CPL; ++q) {
+            cq[q][2 * R] = cpre[q];
+            cv[q] = cvpre[q];
+        }
+#pragma unroll
+        for (int m = 0; m < R; ++m)
+#pragma unroll
+            for (int r = 0; r < RY; ++r) vq[m][r] = vq[m + 1][r];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) vq[R][r] = pre_v[r];
+#pragma unroll
+        for (int q = 0; q < Cfg::OPW; ++q) orow_nxt[q] = orow_pre[q];
+    }
+}
+
+// planes per workgroup / launch size for the fused kernel
+template <typename T, int R>
+static inline int wafer_f2_zchunk(const WaferGeom &g, int nplanes, int target_blocks)
+{
+    using Cfg = WaferF2Cfg<T, R>;
+    const char *f = getenv("WAFER_ZCHUNK");
+    if (f && atoi(f) > 0) return atoi(f);
+    const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY);
+    const char *t = getenv("WAFER_TARGET_BLOCKS");
+    const long long target = (t && atoi(t) > 0) ? atoi(t) : (target_blocks > 0 ? target_blocks : 256);
+    long long nch = (target + per_layer / 2) / per_layer;
+    if (nch < 1) nch = 1;
+    if (nch > nplanes) nch = nplanes;
+    return (int)((nplanes + nch - 1) / nch);
+}
+
+// Advances planes [lz_lo, lz_hi) by TWO steps: out = step(step(phi)).
+template <typename T, typename C, int R>
+static inline hipError_t wafer_launch_step2_fused(WaferStepArgs a, const T *phi, const T *pv, T *out,
+                                                  hipStream_t s)
+{
+    using Cfg = WaferF2Cfg<T, R>;
+    const WaferLdsOpts o = wafer_lds_opts();
+    const WaferGeom &g = a.g;
+    a.zchunk = wafer_f2_zchunk<T, R>(g, a.lz_hi - a.lz_lo, a.target_blocks);
+    const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX;
+    const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
+    const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
+    const long long nblocks = (long long)ntx * nty * ntz;
+    if (o.nt)
+        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, true>), dim3((unsigned)nblocks), dim3(Cfg::NT_),
+                           (size_t)o.pad, s, a, ntx, nty, o.swz, phi, pv, out);
+    else
+        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false>), dim3((unsigned)nblocks), dim3(Cfg::NT_),
+                           (size_t)o.pad, s, a, ntx, nty, o.swz, phi, pv, out);
+    return hipGetLastError();
+}

@@ -34,36 +34,84 @@ struct WaferLdsCfg {
     static constexpr int LROWS = TY + 2 * R;
     static constexpr int TILE = LROWS * LP;       // elements per LDS buffer
     static constexpr int NHALO_X = 2 * R * TY;    // halo-column cells per plane
-    static constexpr int HALO_X_ITERS = (NHALO_X + 63) / 64;
+    static constexpr int HALO_X_ITERS = (NHALO_X + 255) / 256; // cells are dealt over all 256 lanes
     static constexpr int HALO_ROWS_PER_WAVE = (2 * R + NW - 1) / NW;
 };
 
-template <typename T, int R>
-static inline int wafer_lds_zchunk(const WaferGeom &g, int nplanes)
+// launch-time tuning knobs (tools/stencil_sweep.py drives them through the environment)
+struct WaferLdsOpts {
+    int ry;   // rows per lane: 2 or 4 -> tile height 8, 16
+    int swz;  // XCD-aware workgroup -> tile mapping
+    int nt;   // non-temporal a/b loads and phi' stores
+    int pad;  // extra dynamic LDS bytes per workgroup (caps workgroups per CU; tuning only)
+    int abv;  // form a, b from V in registers instead of streaming them
+};
+static inline WaferLdsOpts wafer_lds_opts()
 {
-    using Cfg = WaferLdsCfg<T, R, 2>;
+    WaferLdsOpts o{2, 1, 1, 0, 0};
+    const char *e;
+    if ((e = getenv("WAFER_LDS_RY")) && *e) o.ry = atoi(e);
+    if ((e = getenv("WAFER_XCD_SWIZZLE")) && *e) o.swz = atoi(e);
+    if ((e = getenv("WAFER_NT")) && *e) o.nt = atoi(e);
+    if ((e = getenv("WAFER_LDS_PAD")) && *e) o.pad = atoi(e);
+    if ((e = getenv("WAFER_ABV")) && *e) o.abv = atoi(e);
+    if (o.ry != 2 && o.ry != 4) o.ry = 2;
+    return o;
+}
+
+// Planes per workgroup.  Measured on MI355X (profiles/r01_sweep.md): the step
+// kernel streams fastest with ONE workgroup per CU marching a long z-column
+// (256 workgroups at 512^3: 0.73 ms/step) and loses 5-12 % when the same work
+// is cut into 2-8x more, shorter columns -- more concurrent streams than CUs
+// only add DRAM/L2 contention.  So z is chunked only as far as needed to give
+// every CU a workgroup.
+template <typename T, int R>
+static inline int wafer_lds_zchunk(const WaferGeom &g, int nplanes, int ry, int target_blocks)
+{
+    using Cfg = WaferLdsCfg<T, R, 1>;
+    const int TY = Cfg::NW * ry;
     const char *f = getenv("WAFER_ZCHUNK");
     if (f && atoi(f) > 0) return atoi(f);
-    const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY);
+    const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + TY - 1) / TY);
     const char *t = getenv("WAFER_TARGET_BLOCKS");
-    const long long target = (t && atoi(t) > 0) ? atoi(t) : 2048;
-    long long nch = (target + per_layer - 1) / per_layer;
+    const long long target = (t && atoi(t) > 0) ? atoi(t) : (target_blocks > 0 ? target_blocks : 256);
+    long long nch = (target + per_layer / 2) / per_layer; // nearest, so 256 tiles on 256 CUs stay unchunked
     if (nch < 1) nch = 1;
     if (nch > nplanes) nch = nplanes;
     return (int)((nplanes + nch - 1) / nch);
 }
 
 template <typename T, int R>
-static inline long long wafer_step_lds_blocks(const WaferGeom &g, int lz_lo, int lz_hi)
+static inline long long wafer_step_lds_blocks(const WaferGeom &g, int lz_lo, int lz_hi, int target_blocks)
 {
-    using Cfg = WaferLdsCfg<T, R, 2>;
-    const int zc = wafer_lds_zchunk<T, R>(g, lz_hi - lz_lo);
-    return (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY) *
+    using Cfg = WaferLdsCfg<T, R, 1>;
+    const int ry = wafer_lds_opts().ry;
+    const int TY = Cfg::NW * ry;
+    const int zc = wafer_lds_zchunk<T, R>(g, lz_hi - lz_lo, ry, target_blocks);
+    return (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + TY - 1) / TY) *
            ((lz_hi - lz_lo + zc - 1) / zc);
 }
 
-template <typename T, typename C, int R, int RY, bool NORM>
-__global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty,
+// streamed-once data (a, b, phi') can bypass the caches' retention
+template <bool NT, typename VT>
+__device__ __forceinline__ VT wafer_ld_stream(const VT *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename VT>
+__device__ __forceinline__ void wafer_st_stream(VT *p, VT v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// ABV: `pa` is the potential V and a, b are formed in registers exactly as
+// potential.rs:104-110 does (same expressions => the same bits as the stored
+// arrays), which removes one of the four HBM streams: 24 B instead of 32 B of
+// traffic per update, at the price of one more fp64 division.
+template <typename T, typename C, int R, int RY, bool NORM, bool NT, bool ABV>
+__global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty, int swz,
                                                         const T *__restrict__ phi,
                                                         const T *__restrict__ pa,
                                                         const T *__restrict__ pb, T *__restrict__ out,
@@ -77,7 +125,15 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
 
     const WaferGeom &g = a.g;
     // tile coordinates: x fastest, then y, then z-chunk
-    const int bid = blockIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).
+    // With swz the tiles an XCD works on form one contiguous range of the
+    // (x, y, z-chunk) order, so neighbouring tiles -- which re-read each other's
+    // halo rows -- share an L2.  Bijective for any grid size; speed only.
+    int bid = blockIdx.x;
+    if (swz) {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, k = bid & 7;
+        bid = k * q + min(k, r) + (bid >> 3);
+    }
     const int tx_i = bid % ntx;
     const int ty_i = (bid / ntx) % nty;
     const int tz_i = bid / (ntx * nty);
@@ -148,8 +204,9 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     VT ab_a[RY], ab_b[RY];
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-        ab_a[r] = rowin[r] ? *reinterpret_cast<const VT *>(pa + (long long)zs * g.plane + rowoff[r]) : zero;
-        ab_b[r] = rowin[r] ? *reinterpret_cast<const VT *>(pb + (long long)zs * g.plane + rowoff[r]) : zero;
+        ab_a[r] = rowin[r] ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + (long long)zs * g.plane + rowoff[r])) : zero;
+        if constexpr (!ABV)
+            ab_b[r] = rowin[r] ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + (long long)zs * g.plane + rowoff[r])) : zero;
     }
     {
         T *tile = lds + (zs & 1) * Cfg::TILE;
@@ -193,8 +250,9 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
         for (int r = 0; r < RY; ++r) {
             const bool ld = more && rowin[r];
             pre[r] = ld ? *reinterpret_cast<const VT *>(phi + zo + (long long)(R + 1) * g.plane + rowoff[r]) : zero;
-            pre_a[r] = ld ? *reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]) : zero;
-            pre_b[r] = ld ? *reinterpret_cast<const VT *>(pb + zo + g.plane + rowoff[r]) : zero;
+            pre_a[r] = ld ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r])) : zero;
+            if constexpr (!ABV)
+                pre_b[r] = ld ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + zo + g.plane + rowoff[r])) : zero;
         }
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
@@ -240,7 +298,16 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
                     }
                 }
                 const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                const T rs = (T)wafer_update<C>(w, (C)ab_a[r][v], (C)ab_b[r][v], dt, S, den);
+                C ca, cb;
+                if constexpr (ABV) { // potential.rs:104-110
+                    const C vv = (C)ab_a[r][v];
+                    cb = C(1) / (C(1) + dt * vv / C(2));
+                    ca = (C(1) - dt * vv / C(2)) * cb;
+                } else {
+                    ca = (C)ab_a[r][v];
+                    cb = (C)ab_b[r][v];
+                }
+                const T rs = (T)wafer_update<C>(w, ca, cb, dt, S, den);
                 res[v] = rs;
                 if constexpr (NORM) {
                     if (rowin[r] && xi + v < g.nx) acc += (double)rs * (double)rs;
@@ -249,7 +316,7 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
             if (rowin[r]) {
                 T *dst = out + zo + rowoff[r];
                 if (xi + VEC <= g.nx) {
-                    *reinterpret_cast<VT *>(dst) = res;
+                    wafer_st_stream<NT>(reinterpret_cast<VT *>(dst), res);
                 } else {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v)
@@ -267,7 +334,7 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
         for (int r = 0; r < RY; ++r) {
             q[2 * R][r] = pre[r];
             ab_a[r] = pre_a[r];
-            ab_b[r] = pre_b[r];
+            if constexpr (!ABV) ab_b[r] = pre_b[r];
         }
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) hrow_nxt[qq] = hrow_pre[qq];
@@ -276,25 +343,47 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     }
     if constexpr (NORM) {
         const double s = wafer_block_sum<4>(acc, red, tid);
-        if (tid == 0) partials[bid] = s;
+        if (tid == 0) partials[blockIdx.x] = s;
     }
 }
 
-template <typename T, typename C, int R, bool NORM>
-static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, const T *pa, const T *pb,
-                                               T *out, double *partials, size_t partials_cap,
-                                               hipStream_t s)
+template <typename T, typename C, int R, int RY, bool NORM, bool NT, bool ABV>
+static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLdsOpts &o, const T *phi,
+                                                  const T *pa, const T *pb, T *out, double *partials,
+                                                  size_t partials_cap, hipStream_t s)
 {
-    constexpr int RY = 2;
     using Cfg = WaferLdsCfg<T, R, RY>;
     const WaferGeom &g = a.g;
-    a.zchunk = wafer_lds_zchunk<T, R>(g, a.lz_hi - a.lz_lo);
+    a.zchunk = wafer_lds_zchunk<T, R>(g, a.lz_hi - a.lz_lo, RY, a.target_blocks);
     const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX;
     const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
     const long long nblocks = (long long)ntx * nty * ntz;
     if (NORM && (size_t)nblocks > partials_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NORM>), dim3((unsigned)nblocks), dim3(256), 0, s, a,
-                       ntx, nty, phi, pa, pb, out, partials);
+    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NORM, NT, ABV>), dim3((unsigned)nblocks), dim3(256), (size_t)o.pad, s,
+                       a, ntx, nty, o.swz, phi, pa, pb, out, partials);
     return hipGetLastError();
+}
+
+template <typename T, typename C, int R, bool NORM>
+static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, const T *pa, const T *pb,
+                                               const T *pv, T *out, double *partials,
+                                               size_t partials_cap, hipStream_t s)
+{
+    const WaferLdsOpts o = wafer_lds_opts();
+    // with ABV, V takes a's slot and b is not read
+#define WAFER_LDS_CASE(RY_, NT_, ABV_)                                                               \
+    if (o.ry == RY_ && (o.nt != 0) == NT_ && (o.abv != 0) == ABV_)                                   \
+        return wafer_launch_step_lds_ry<T, C, R, RY_, NORM, NT_, ABV_>(a, o, phi, ABV_ ? pv : pa, pb, \
+                                                                       out, partials, partials_cap, s);
+    WAFER_LDS_CASE(2, false, false)
+    WAFER_LDS_CASE(2, true, false)
+    WAFER_LDS_CASE(2, false, true)
+    WAFER_LDS_CASE(2, true, true)
+    WAFER_LDS_CASE(4, false, false)
+    WAFER_LDS_CASE(4, true, false)
+    WAFER_LDS_CASE(4, false, true)
+    WAFER_LDS_CASE(4, true, true)
+#undef WAFER_LDS_CASE
+    return hipErrorInvalidValue;
 }

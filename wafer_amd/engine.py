@@ -36,7 +36,7 @@ EXPORTS = [
     "wafer_orthogonalise", "wafer_push_state", "wafer_load_state", "wafer_download_state",
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_set_stencil_variant",
-    "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
+    "wafer_diag_stream_bw", "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
 ]
 
 
@@ -128,6 +128,7 @@ def load_library():
     L.wafer_stencil_kernel_name.argtypes = [vp]
     L.wafer_stencil_kernel_name.restype = C.c_char_p
     L.wafer_set_stencil_variant.argtypes = [vp, C.c_int]
+    L.wafer_diag_stream_bw.argtypes = [vp, C.c_int, C.c_int, dp]
     L.wafer_set_comm_hooks.argtypes = [vp, HALO_FN, ALLREDUCE_FN, vp]
     L.wafer_set_overlap.argtypes = [vp, C.c_int]
     L.wafer_set_stream.argtypes = [vp, vp]
@@ -341,6 +342,12 @@ class Context:
 
     def set_stencil_variant(self, variant: int) -> None:
         self._check(self._L.wafer_set_stencil_variant(self._h, variant))
+
+    def stream_bandwidth(self, n_reads: int = 3, iters: int = 20) -> float:
+        """measured GB/s of a flat streaming kernel (n_reads reads + 1 write)"""
+        v = C.c_double(0.0)
+        self._check(self._L.wafer_diag_stream_bw(self._h, n_reads, iters, C.byref(v)))
+        return v.value
 
     # -- multi-GPU ---------------------------------------------------------------------------------
     def set_comm_hooks(self, halo, allreduce) -> None:
