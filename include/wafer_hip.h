@@ -190,6 +190,8 @@ int wafer_solve_state(wafer_ctx *ctx, uint32_t wnum, double tolerance, uint64_t 
 int wafer_last_evolve_ms(wafer_ctx *ctx, float *ms, uint64_t *steps);
 /* name of the stencil kernel variant the context dispatches to */
 const char *wafer_stencil_kernel_name(wafer_ctx *ctx);
+/* time steps one launch of that kernel advances in a ground-state evolve (2 for the fused kernel) */
+int wafer_stencil_steps_per_launch(wafer_ctx *ctx);
 /* choose a stencil kernel variant by index (tuning / A-B runs); -1 = default */
 int wafer_set_stencil_variant(wafer_ctx *ctx, int variant);
 

@@ -167,6 +167,56 @@ def test_lds_kernel_options_bit_exact(wo, wa, ext, opts, monkeypatch):
         assert ulp_diff(ctx.download_phi(), phi) == 0
 
 
+@pytest.mark.parametrize("steps", [2, 7, 10])
+@pytest.mark.parametrize("ext", [1, 2, 3])
+@pytest.mark.parametrize("shape", SHAPES + [(150, 37, 29), (257, 20, 11)])
+def test_fused_two_step_kernel_bit_exact(wo, wa, shape, ext, steps):
+    """variant 2 (two time steps per pass over HBM, a/b formed from V): the same
+    bits as `steps` single reference steps -- even and odd counts, ragged tiles,
+    grids smaller than a tile, every frame cell still exactly zero"""
+    cfg, par = make_pair(shape, ext=ext, potential="Coulomb", dn=0.2, dt=0.004, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=12)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(2)
+        ctx.set_potential("Coulomb")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, steps)
+        wo.evolve(cfg, 0, a, b, phi, [], steps)
+        assert ulp_diff(ctx.download_phi(), phi) == 0
+
+
+@pytest.mark.parametrize("zchunk", ["1", "2", "5", "1000"])
+def test_fused_zchunk_independence(wo, wa, zchunk, monkeypatch):
+    monkeypatch.setenv("WAFER_ZCHUNK", zchunk)
+    cfg, par = make_pair((70, 21, 13), ext=1, potential="Harmonic", dn=0.1, dt=0.002)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=2)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(2)
+        ctx.set_potential("Harmonic")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 6)
+        wo.evolve(cfg, 0, a, b, phi, [], 6)
+        assert ulp_diff(ctx.download_phi(), phi) == 0
+
+
+def test_fused_thousand_steps_64cubed(wo, wa):
+    cfg, par = make_pair((64, 64, 64), ext=1, potential="Harmonic", dn=0.2, dt=8e-3, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = wo.initial_condition(cfg, "Boolean")
+    wo.evolve(cfg, 0, a, b, phi, [], 1000)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(2)
+        ctx.set_potential("Harmonic")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 1000)
+        assert ulp_diff(ctx.download_phi(), phi) == 0
+
+
 def test_evolve_zero_steps_takes_one(wo, wa):
     """grid.rs:682-685"""
     cfg, par = make_pair((8, 8, 8))

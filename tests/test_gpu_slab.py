@@ -131,6 +131,32 @@ def test_ground_state_slabs_bit_exact(wa, world, shape, ext, overlap):
     assert all(n == steps for n in fabric.halo_calls)   # one exchange per step, none extra
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("world,shape,ext,steps", [(2, (40, 24, 32), 1, 12), (3, (33, 17, 31), 2, 7), (4, (130, 12, 40), 1, 9)])
+def test_fused_kernel_on_slabs_bit_exact(wa, world, shape, ext, steps, overlap):
+    """two fused steps per pass on z-slabs: 2*ext ghost planes, one exchange of
+    2*ext planes per pass (plus ext planes after an odd trailing step)"""
+    base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=ext, halo_depth=2 * ext)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=ext)) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)
+        want = ctx.download_phi()
+
+    def body(ctx, rank):
+        ctx.set_stencil_variant(2)
+        ctx.set_overlap(overlap)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)
+        return ctx.download_phi()
+
+    res, fabric = run_slabs(wa, base, world, body)
+    assert np.array_equal(assemble(base, world, res), want)
+
+
 def test_excited_state_and_solve_on_slabs(wa):
     import sys
     sys.setswitchinterval(1e-4)   # three lock-step threads hand the GIL over at every hook

@@ -221,7 +221,7 @@ static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 static int default_variant(const wafer_ctx *c)
 {
     (void)c;
-    return env_int("WAFER_STENCIL_VARIANT", 1);
+    return env_int("WAFER_STENCIL_VARIANT", 2);
 }
 
 static int active_variant(const wafer_ctx *c) { return c->variant >= 0 ? c->variant : default_variant(c); }
@@ -311,7 +311,7 @@ static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
         a.target_blocks = c->num_cus;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
-        if (wafer_launch_step2_fused<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->v), as<T>(c->phi[dst]), s) != hipSuccess)
+        if (wafer_launch_step2_fused<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->a), as<T>(c->b), as<T>(c->v), as<T>(c->phi[dst]), s) != hipSuccess)
             return fail(WAFER_ERR_HIP, "fused stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
         return (int)WAFER_OK;
     });
@@ -742,7 +742,9 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     const uint64_t steps = n_steps == 0 ? 1 : n_steps; // grid.rs:682-685
     // two steps per pass where nothing happens between steps (ground state) and, when the grid
     // is sharded, the slab carries 2R ghost planes
-    const bool fuse = wnum == 0 && active_variant(c) == 2 && (!c->sharded() || (g.G >= 2 * R && g.nzl >= 2 * R));
+    // (ext = 3 spills registers in the fused kernel and stays on the single-step path)
+    const bool fuse = wnum == 0 && active_variant(c) == 2 && R <= 2 &&
+                      (!c->sharded() || (g.G >= 2 * R && g.nzl >= 2 * R));
     HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
     for (uint64_t s = 0; s < steps;) {
         const int src = c->cur, dst = c->cur ^ 1;
@@ -816,11 +818,21 @@ int wafer_last_evolve_ms(wafer_ctx *c, float *ms, uint64_t *steps)
     return WAFER_OK;
 }
 
+int wafer_stencil_steps_per_launch(wafer_ctx *c);
 const char *wafer_stencil_kernel_name(wafer_ctx *c)
 {
     if (!c) return "";
-    const int v = c->variant >= 0 ? c->variant : default_variant(c);
+    int v = active_variant(c);
+    if (v == 2 && wafer_stencil_steps_per_launch(c) == 1) v = 1; // fused not applicable: LDS single-step
     return kVariants[(v >= 0 && v < kNumVariants) ? v : 0].name;
+}
+
+int wafer_stencil_steps_per_launch(wafer_ctx *c)
+{
+    if (!c) return 0;
+    const bool fuse = active_variant(c) == 2 && c->g.R <= 2 &&
+                      (!c->sharded() || (c->g.G >= 2 * c->g.R && c->g.nzl >= 2 * c->g.R));
+    return fuse ? 2 : 1;
 }
 
 int wafer_set_stencil_variant(wafer_ctx *c, int variant)

@@ -66,10 +66,12 @@ __device__ __forceinline__ C wafer_update_v(C w, C vv, C dt, C S, C den)
     return w * ca + cb * dt * S / den;
 }
 
-template <typename T, typename C, int R, bool NT>
+// ABV: pv is V and a, b are formed in registers (24 B per two updates);
+// !ABV: pv is a, pb is b, streamed (32 B per two updates, ~14 fp64 ops fewer per update).
+template <typename T, typename C, int R, bool NT, bool ABV>
 __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
     WaferStepArgs a, int ntx, int nty, int swz, const T *__restrict__ phi, const T *__restrict__ pv,
-    T *__restrict__ out)
+    const T *__restrict__ pb, T *__restrict__ out)
 {
     using Cfg = WaferF2Cfg<T, R>;
     using VT = typename WaferVec<T>::type;
@@ -164,9 +166,11 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
     // first phi1 plane is z1 = zs - R; phi0 z-queue holds planes z1-R .. z1+R
     const int z1 = zs - R;
     VT q0[2 * R + 1][RY];
-    VT vq[R + 1][RY];     // V of planes z-R .. z (oldest first); only vq[R] is used by step 1
+    VT vq[R + 1][RY];     // V (or a) of planes z-R .. z (oldest first); only vq[R] is used by step 1
+    VT bq[R + 1][RY];     // b of the same planes (!ABV only)
     T cq[Cfg::CPL][2 * R + 1];
-    T cv[Cfg::CPL];       // V at the halo-column cells, plane z
+    T cv[Cfg::CPL];       // V (or a) at the halo-column cells, plane z
+    T cb[Cfg::CPL];       // b there (!ABV only)
 #pragma unroll
     for (int m = 0; m <= 2 * R; ++m) {
         const int p = z1 - R + m;
@@ -181,15 +185,25 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
 #pragma unroll
     for (int m = 0; m <= R; ++m)
 #pragma unroll
-        for (int r = 0; r < RY; ++r) vq[m][r] = zero;
+        for (int r = 0; r < RY; ++r) {
+            vq[m][r] = zero;
+            bq[m][r] = zero;
+        }
     {
         const bool ok = plane_ok(z1);
 #pragma unroll
         for (int r = 0; r < RY; ++r)
+        {
             vq[R][r] = (ok && rowld[r]) ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pv + (long long)z1 * g.plane + rowoff[r])) : zero;
+            if constexpr (!ABV)
+                bq[R][r] = (ok && rowld[r]) ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + (long long)z1 * g.plane + rowoff[r])) : zero;
+        }
 #pragma unroll
-        for (int q = 0; q < Cfg::CPL; ++q)
+        for (int q = 0; q < Cfg::CPL; ++q) {
             cv[q] = (ok && c_ld[q]) ? pv[(long long)z1 * g.plane + c_off[q]] : T(0);
+            cb[q] = T(0);
+            if constexpr (!ABV) cb[q] = (ok && c_ld[q]) ? pb[(long long)z1 * g.plane + c_off[q]] : T(0);
+        }
     }
     // phi1 z-queue (main waves), planes z-2R .. z; starts empty (zeros never reach an output:
     // the first output plane zs is produced at z = zs + R, by when all 2R+1 entries are real)
@@ -234,8 +248,8 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
         const bool more = z + 1 < zend;
         const long long zo = (long long)z * g.plane;
         // ---- 1. prefetch: phi0 plane z+R+1, V plane z+1, outer halo rows of plane z+2 ---------------
-        VT pre[RY], pre_v[RY], orow_pre[Cfg::OPW];
-        T cpre[Cfg::CPL], cvpre[Cfg::CPL];
+        VT pre[RY], pre_v[RY], pre_b[RY], orow_pre[Cfg::OPW];
+        T cpre[Cfg::CPL], cvpre[Cfg::CPL], cbpre[Cfg::CPL];
         {
             const bool okp = more && plane_ok(z + R + 1);
             const bool okv = more && plane_ok(z + 1);
@@ -244,6 +258,8 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
             for (int r = 0; r < RY; ++r) {
                 pre[r] = (okp && rowld[r]) ? *reinterpret_cast<const VT *>(phi + zo + (long long)(R + 1) * g.plane + rowoff[r]) : zero;
                 pre_v[r] = (okv && rowld[r]) ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pv + zo + g.plane + rowoff[r])) : zero;
+                if constexpr (!ABV)
+                    pre_b[r] = (okv && rowld[r]) ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + zo + g.plane + rowoff[r])) : zero;
             }
 #pragma unroll
             for (int q = 0; q < Cfg::OPW; ++q)
@@ -252,6 +268,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
             for (int q = 0; q < Cfg::CPL; ++q) {
                 cpre[q] = (okp && c_ld[q]) ? phi[zo + (long long)(R + 1) * g.plane + c_off[q]] : T(0);
                 cvpre[q] = (okv && c_ld[q]) ? pv[zo + g.plane + c_off[q]] : T(0);
+                if constexpr (!ABV) cbpre[q] = (okv && c_ld[q]) ? pb[zo + g.plane + c_off[q]] : T(0);
             }
         }
         // ---- 2. stage phi0 plane z+1 into the other buffer ------------------------------------------------
@@ -297,7 +314,9 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
                             }
                         }
                         const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                        const T rs = (T)wafer_update_v<C>(w, (C)vq[R][r][v], dt, S, den);
+                        T rs;
+                        if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)vq[R][r][v], dt, S, den);
+                        else rs = (T)wafer_update<C>(w, (C)vq[R][r][v], (C)bq[R][r][v], dt, S, den);
                         res[v] = (xi + v < g.nx) ? rs : T(0);
                     }
                 }
@@ -324,7 +343,8 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
                                 ys[d + R] = (d == 0) ? w : (C)c0[o0 + d * LP0];
                             }
                             const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                            rs = (T)wafer_update_v<C>(w, (C)cv[q], dt, S, den);
+                            if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)cv[q], dt, S, den);
+                            else rs = (T)wafer_update<C>(w, (C)cv[q], (C)cb[q], dt, S, den);
                         }
                         w1[c_lds1[q]] = rs;
                     }
@@ -367,7 +387,8 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
                                 }
                             }
                             const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                            res[v] = (T)wafer_update_v<C>(w, (C)vq[0][r][v], dt, S, den);
+                            if constexpr (ABV) res[v] = (T)wafer_update_v<C>(w, (C)vq[0][r][v], dt, S, den);
+                            else res[v] = (T)wafer_update<C>(w, (C)vq[0][r][v], (C)bq[0][r][v], dt, S, den);
                         }
                         T *dst = out + (long long)zo2 * g.plane + rowoff[r];
                         if (xi + VEC <= g.nx) {
@@ -396,13 +417,20 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
         for (int q = 0; q < Cfg::CPL; ++q) {
             cq[q][2 * R] = cpre[q];
             cv[q] = cvpre[q];
+            if constexpr (!ABV) cb[q] = cbpre[q];
         }
 #pragma unroll
         for (int m = 0; m < R; ++m)
 #pragma unroll
-            for (int r = 0; r < RY; ++r) vq[m][r] = vq[m + 1][r];
+            for (int r = 0; r < RY; ++r) {
+                vq[m][r] = vq[m + 1][r];
+                if constexpr (!ABV) bq[m][r] = bq[m + 1][r];
+            }
 #pragma unroll
-        for (int r = 0; r < RY; ++r) vq[R][r] = pre_v[r];
+        for (int r = 0; r < RY; ++r) {
+            vq[R][r] = pre_v[r];
+            if constexpr (!ABV) bq[R][r] = pre_b[r];
+        }
 #pragma unroll
         for (int q = 0; q < Cfg::OPW; ++q) orow_nxt[q] = orow_pre[q];
     }
@@ -426,22 +454,30 @@ static inline int wafer_f2_zchunk(const WaferGeom &g, int nplanes, int target_bl
 
 // Advances planes [lz_lo, lz_hi) by TWO steps: out = step(step(phi)).
 template <typename T, typename C, int R>
-static inline hipError_t wafer_launch_step2_fused(WaferStepArgs a, const T *phi, const T *pv, T *out,
-                                                  hipStream_t s)
+static inline hipError_t wafer_launch_step2_fused(WaferStepArgs a, const T *phi, const T *pa, const T *pb,
+                                                  const T *pv, T *out, hipStream_t s)
 {
     using Cfg = WaferF2Cfg<T, R>;
-    const WaferLdsOpts o = wafer_lds_opts();
+    WaferLdsOpts o = wafer_lds_opts();
+    // default: stream a and b.  The fused kernel is issue-bound, not HBM-bound, and forming a, b
+    // from V costs a second fp64 division per update (0.426 vs 0.449 ms/step at 512^3).
+    if (o.abv < 0) o.abv = 0;
     const WaferGeom &g = a.g;
     a.zchunk = wafer_f2_zchunk<T, R>(g, a.lz_hi - a.lz_lo, a.target_blocks);
     const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX;
     const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
-    const long long nblocks = (long long)ntx * nty * ntz;
-    if (o.nt)
-        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, true>), dim3((unsigned)nblocks), dim3(Cfg::NT_),
-                           (size_t)o.pad, s, a, ntx, nty, o.swz, phi, pv, out);
-    else
-        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false>), dim3((unsigned)nblocks), dim3(Cfg::NT_),
-                           (size_t)o.pad, s, a, ntx, nty, o.swz, phi, pv, out);
-    return hipGetLastError();
+    const dim3 grid((unsigned)((long long)ntx * nty * ntz)), block(Cfg::NT_);
+#define WAFER_F2_CASE(NT_, ABV_)                                                                          \
+    if ((o.nt != 0) == NT_ && (o.abv != 0) == ABV_) {                                                     \
+        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, NT_, ABV_>), grid, block, (size_t)o.pad, s, a,   \
+                           ntx, nty, o.swz, phi, ABV_ ? pv : pa, pb, out);                                 \
+        return hipGetLastError();                                                                         \
+    }
+    WAFER_F2_CASE(true, true)
+    WAFER_F2_CASE(false, true)
+    WAFER_F2_CASE(true, false)
+    WAFER_F2_CASE(false, false)
+#undef WAFER_F2_CASE
+    return hipErrorInvalidValue;
 }

@@ -48,13 +48,14 @@ struct WaferLdsOpts {
 };
 static inline WaferLdsOpts wafer_lds_opts()
 {
-    WaferLdsOpts o{2, 1, 1, 0, 0};
+    WaferLdsOpts o{2, 1, 1, 0, 1};
     const char *e;
     if ((e = getenv("WAFER_LDS_RY")) && *e) o.ry = atoi(e);
     if ((e = getenv("WAFER_XCD_SWIZZLE")) && *e) o.swz = atoi(e);
     if ((e = getenv("WAFER_NT")) && *e) o.nt = atoi(e);
     if ((e = getenv("WAFER_LDS_PAD")) && *e) o.pad = atoi(e);
     if ((e = getenv("WAFER_ABV")) && *e) o.abv = atoi(e);
+    else o.abv = -1; // kernel default: single-step forms a, b from V; the fused kernel streams them
     if (o.ry != 2 && o.ry != 4) o.ry = 2;
     return o;
 }
@@ -74,8 +75,10 @@ static inline int wafer_lds_zchunk(const WaferGeom &g, int nplanes, int ry, int 
     if (f && atoi(f) > 0) return atoi(f);
     const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + TY - 1) / TY);
     const char *t = getenv("WAFER_TARGET_BLOCKS");
-    const long long target = (t && atoi(t) > 0) ? atoi(t) : (target_blocks > 0 ? target_blocks : 256);
-    long long nch = (target + per_layer / 2) / per_layer; // nearest, so 256 tiles on 256 CUs stay unchunked
+    // two workgroups per CU: with a, b formed from V the kernel does more arithmetic per byte and
+    // a second resident workgroup hides it (0.539 vs 0.574 ms at 512^3, profiles/r01_sweep_d_512.jsonl)
+    const long long target = (t && atoi(t) > 0) ? atoi(t) : 2 * (target_blocks > 0 ? target_blocks : 256);
+    long long nch = (target + per_layer / 2) / per_layer; // nearest
     if (nch < 1) nch = 1;
     if (nch > nplanes) nch = nplanes;
     return (int)((nplanes + nch - 1) / nch);
@@ -370,7 +373,8 @@ static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, co
                                                const T *pv, T *out, double *partials,
                                                size_t partials_cap, hipStream_t s)
 {
-    const WaferLdsOpts o = wafer_lds_opts();
+    WaferLdsOpts o = wafer_lds_opts();
+    if (o.abv < 0) o.abv = 1;
     // with ABV, V takes a's slot and b is not read
 #define WAFER_LDS_CASE(RY_, NT_, ABV_)                                                               \
     if (o.ry == RY_ && (o.nt != 0) == NT_ && (o.abv != 0) == ABV_)                                   \

@@ -35,7 +35,7 @@ EXPORTS = [
     "wafer_download_phi", "wafer_evolve", "wafer_observables", "wafer_norm2", "wafer_normalise",
     "wafer_orthogonalise", "wafer_push_state", "wafer_load_state", "wafer_download_state",
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
-    "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_set_stencil_variant",
+    "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_diag_stream_bw", "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
 ]
 
@@ -127,6 +127,7 @@ def load_library():
     L.wafer_last_evolve_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     L.wafer_stencil_kernel_name.argtypes = [vp]
     L.wafer_stencil_kernel_name.restype = C.c_char_p
+    L.wafer_stencil_steps_per_launch.argtypes = [vp]
     L.wafer_set_stencil_variant.argtypes = [vp, C.c_int]
     L.wafer_diag_stream_bw.argtypes = [vp, C.c_int, C.c_int, dp]
     L.wafer_set_comm_hooks.argtypes = [vp, HALO_FN, ALLREDUCE_FN, vp]
@@ -339,6 +340,9 @@ class Context:
 
     def stencil_kernel_name(self) -> str:
         return self._L.wafer_stencil_kernel_name(self._h).decode()
+
+    def steps_per_launch(self) -> int:
+        return int(self._L.wafer_stencil_steps_per_launch(self._h))
 
     def set_stencil_variant(self, variant: int) -> None:
         self._check(self._L.wafer_set_stencil_variant(self._h, variant))
