@@ -363,6 +363,32 @@ def test_excited_state_evolve(wo, wa, wnum, variant):
             assert abs(np.sum(l * got)) < 1e-13
 
 
+@pytest.mark.parametrize("wnum", [2, 4, 5])
+def test_excited_state_evolve_nonorthogonal_store(wo, wa, wnum):
+    """stored states that are NOT orthonormal: the one-pass Gram-Schmidt (raw
+    overlaps + Gram-matrix recurrence) must still reproduce the reference's
+    sequential modified Gram-Schmidt; wnum = 5 exceeds the fused kernel's
+    capacity and takes the kernel-per-projection path"""
+    cfg, par = make_pair((26, 19, 23), ext=2, potential="Coulomb", dn=0.25, dt=0.006, max_states=5)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    lowers = []
+    for i in range(wnum):
+        l = random_phi(cfg, seed=60 + i) + (0.4 * lowers[0] if lowers else 0.0)   # correlated on purpose
+        wo.normalise(l, wo.norm2(cfg, l))
+        lowers.append(np.ascontiguousarray(l))
+    phi = random_phi(cfg, seed=70)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("Coulomb")
+        for i, l in enumerate(lowers):
+            ctx.load_state(i, l)
+        ctx.upload_phi(phi)
+        ctx.evolve(wnum, 6)
+        wo.evolve(cfg, wnum, a, b, phi, lowers, 6)
+        assert np.allclose(ctx.download_phi(), phi, rtol=0, atol=2e-13)
+        assert ctx.norm2() == pytest.approx(wo.norm2(cfg, phi), rel=1e-11)
+
+
 def test_solve_matches_oracle(wo, wa):
     """grid.rs:50-246: same block table (step, tau, E, diff) and stop step for the
     ground state and two excited states.  Excited states start here from a fresh

@@ -143,6 +143,79 @@ __global__ __launch_bounds__(256) void wafer_k_reduce(const double *__restrict__
 }
 
 // ---------------------------------------------------------------------------
+// Row-vectorised elementwise kernels: each wave walks 1 KiB row segments
+// (16 B per lane, 128 B-aligned: wafer_geom.h) of the work area in memory order.
+// ---------------------------------------------------------------------------
+struct WaferRowArgs {
+    WaferGeom g;
+    int lz_lo, lz_hi;
+};
+
+template <typename T> struct WaferRowVec;
+template <> struct WaferRowVec<double> { static constexpr int N = 2; typedef double __attribute__((ext_vector_type(2))) type; };
+template <> struct WaferRowVec<float> { static constexpr int N = 4; typedef float __attribute__((ext_vector_type(4))) type; };
+
+// Normalise + the whole modified Gram-Schmidt chain of one excited-state step
+// (grid.rs:679-680) in ONE pass.  The step kernel has left in scal[]:
+//   scal[0] = sum phi'^2,  scal[1+j] = t_j = sum l_j * phi'   (un-normalised phi').
+// With norm = sqrt(scal[0]) and the Gram matrix G_ji = sum l_j * l_i of the
+// stored states (kept current by the engine), the reference's sequential overlaps
+//   s_j = sum l_j * (phi'/norm - sum_{i<j} l_i s_i)            (grid.rs:482-487)
+// are s_j = t_j/norm - sum_{i<j} s_i G_ji  -- modified Gram-Schmidt exactly, not
+// classical: only the association of the sums differs (rel ~1e-16, inside the
+// 1e-12 bar on reductions).  Per cell the reference's own operation order is kept:
+// w /= norm (true division), then w -= l_j * s_j for j = 0..k-1.
+template <typename T, typename C, int NLOW>
+__global__ __launch_bounds__(256) void wafer_k_gs_apply(WaferRowArgs a, T *__restrict__ phi, WaferLowPtrs low,
+                                                        const double *__restrict__ scal,
+                                                        const double *__restrict__ gram)
+{
+    using VT = typename WaferRowVec<T>::type;
+    constexpr int VEC = WaferRowVec<T>::N;
+    const WaferGeom &g = a.g;
+    const C norm = (C)sqrt(scal[0]);
+    C sj[NLOW];
+#pragma unroll
+    for (int j = 0; j < NLOW; ++j) {
+        double s = scal[1 + j] / (double)norm;
+#pragma unroll
+        for (int i = 0; i < j; ++i) s -= (double)sj[i] * gram[j * WAFER_MAX_LOW + i];
+        sj[j] = (C)s;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nsegx = (g.nx + 64 * VEC - 1) / (64 * VEC);
+    const long long total = (long long)(a.lz_hi - a.lz_lo) * g.ny * nsegx;
+    const int wlim = g.pitch - g.xoff - g.R;
+    for (long long seg = (long long)blockIdx.x * 4 + wave; seg < total; seg += (long long)gridDim.x * 4) {
+        const int xs = (int)(seg % nsegx);
+        const long long t = seg / nsegx;
+        const int y = (int)(t % g.ny), z = a.lz_lo + (int)(t / g.ny);
+        const int xi = xs * 64 * VEC + lane * VEC;
+        if (xi >= wlim || xi >= g.nx) continue;
+        const long long p = (long long)z * g.plane + (long long)(y + g.R) * g.pitch + g.xoff + g.R + xi;
+        VT w = *reinterpret_cast<const VT *>(phi + p);
+        VT l[NLOW];
+#pragma unroll
+        for (int j = 0; j < NLOW; ++j) l[j] = __builtin_nontemporal_load(reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + p));
+        VT r;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            C x = (C)w[v] / norm;                 // grid.rs:467
+#pragma unroll
+            for (int j = 0; j < NLOW; ++j) x = x - (C)l[j][v] * sj[j]; // grid.rs:488-490
+            r[v] = (T)x;
+        }
+        if (xi + VEC <= g.nx) {
+            *reinterpret_cast<VT *>(phi + p) = r;
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (xi + v < g.nx) phi[p + v] = r[v];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Diagnostics: flat streaming kernels over the same buffers, to measure the
 // HBM ceiling of this device for (a) a copy and (b) the stencil's stream mix
 // (3 reads + 1 write per element) without any neighbour traffic.

@@ -101,8 +101,10 @@ struct wafer_ctx {
     double potsub_scalar = 0.0;
     bool have_pot = false, have_phi = false;
 
-    double *partials = nullptr; // [4][partials_stride]
+    double *partials = nullptr; // [1 + WAFER_MAX_LOW][partials_stride]
     size_t partials_stride = 0;
+    double *gram = nullptr;     // WAFER_MAX_LOW^2 doubles, device: G_ji = <state j | state i>
+    double gram_host[WAFER_MAX_LOW * WAFER_MAX_LOW] = {0};
     double *scal = nullptr;     // SCAL_SLOTS doubles, device
     double *scal_host = nullptr; // pinned mirror
 
@@ -242,11 +244,14 @@ static int launch_step_t(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, h
     const T *phi = as<T>(c->phi[src]);
     T *out = as<T>(c->phi[dst]);
     if (variant >= 1) {
-        return wafer_launch_step_lds<T, C, R, NORM>(a, phi, as<T>(c->a), as<T>(c->b), as<T>(c->v), out,
-                                                    c->partials, c->partials_stride, s) == hipSuccess
-                   ? WAFER_OK
-                   : fail(WAFER_ERR_HIP, "LDS stencil launch failed: %s",
-                          hipGetErrorString(hipGetLastError()));
+        hipError_t e;
+        if (NORM) // norm only (more stored states than the fused-overlap kernel carries)
+            e = wafer_launch_step_lds_excited<T, C, R>(a, phi, as<T>(c->v), out, c->partials, c->partials_stride, 0,
+                                                       WaferLowPtrs(), s);
+        else
+            e = wafer_launch_step_lds<T, C, R>(a, phi, as<T>(c->a), as<T>(c->b), as<T>(c->v), out, s);
+        return e == hipSuccess ? WAFER_OK
+                               : fail(WAFER_ERR_HIP, "LDS stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
     a.zchunk = pick_zchunk(c, lz_hi - lz_lo, env_int("WAFER_TARGET_BLOCKS", 4096));
     const dim3 grid(c->bx, c->by, nchunks_of(lz_hi - lz_lo, a.zchunk));
@@ -263,7 +268,7 @@ template <typename T, typename C, int R>
 static long long step_partials_count(wafer_ctx *c, int lz_lo, int lz_hi)
 {
     const int variant = active_variant(c);
-    if (variant >= 1) return wafer_step_lds_blocks<T, R>(c->g, lz_lo, lz_hi, c->num_cus);
+    if (variant >= 1) return wafer_step_lds_excited_blocks<T, R>(c->g, lz_lo, lz_hi, c->num_cus);
     const int zc = pick_zchunk(c, lz_hi - lz_lo, env_int("WAFER_TARGET_BLOCKS", 4096));
     return (long long)c->bx * c->by * nchunks_of(lz_hi - lz_lo, zc);
 }
@@ -397,6 +402,76 @@ static int gs_chain(wafer_ctx *c, int buf, uint32_t wnum, bool first_dot_done, h
     return WAFER_OK;
 }
 
+// Gram matrix of the stored states (lower triangle), recomputed whenever w_store changes.
+static int recompute_gram(wafer_ctx *c)
+{
+    const size_t n = c->states.size() < WAFER_MAX_LOW ? c->states.size() : WAFER_MAX_LOW;
+    memset(c->gram_host, 0, sizeof c->gram_host);
+    for (size_t j = 1; j < n; ++j)
+        for (size_t i = 0; i < j; ++i) {
+            int nb;
+            dim3 grid;
+            WaferEwArgs a = ew_args(c, &nb, &grid);
+            TRY(dispatch(c, [&](auto t, auto cc, auto) {
+                using T = decltype(t);
+                using C = decltype(cc);
+                hipLaunchKernelGGL((wafer_k_dot<T, C>), grid, dim3(64, 4), 0, c->s_main, a, as<T>(c->states[j]),
+                                   as<T>(c->states[i]), c->partials);
+                HIP_TRY(hipGetLastError());
+                return (int)WAFER_OK;
+            }));
+            TRY(reduce_to_scal(c, 1, nb, 13, c->s_main));
+            TRY(read_scal(c, 13, 1, &c->gram_host[j * WAFER_MAX_LOW + i], c->s_main));
+        }
+    HIP_TRY(hipMemcpyAsync(c->gram, c->gram_host, sizeof c->gram_host, hipMemcpyHostToDevice, c->s_main));
+    HIP_TRY(hipStreamSynchronize(c->s_main));
+    return WAFER_OK;
+}
+
+// one excited-state step with everything fused that can be (wnum <= WAFER_MAX_LOW):
+//   pass 1  phi' = step(phi), sum phi'^2, t_j = sum l_j phi'        (reads phi, V, l_0..l_{k-1})
+//   reduce  1 + k scalars (one all-reduce when sharded)
+//   pass 2  phi = phi'/norm - sum_j l_j s_j                          (reads phi', l_0..l_{k-1})
+static int excited_step_fused(wafer_ctx *c, int src, int dst, uint32_t wnum, hipStream_t s)
+{
+    const WaferGeom &g = c->g;
+    const int lo = g.G, hi = g.G + g.nzl;
+    WaferLowPtrs low;
+    for (uint32_t j = 0; j < wnum; ++j) low.p[j] = c->states[j];
+    return dispatch(c, [&](auto t, auto cc, auto r) {
+        using T = decltype(t);
+        using C = decltype(cc);
+        constexpr int R = decltype(r)::value;
+        WaferStepArgs a;
+        a.g = g;
+        a.lz_lo = lo;
+        a.lz_hi = hi;
+        a.dt = c->P.dt;
+        a.target_blocks = c->num_cus;
+        const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
+        a.den = lead * c->P.dn * c->P.dn * c->P.mass;
+        if (wafer_launch_step_lds_excited<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->v), as<T>(c->phi[dst]), c->partials,
+                                                   c->partials_stride, (int)wnum, low, s) != hipSuccess)
+            return fail(WAFER_ERR_HIP, "excited-state stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+        const long long nb = wafer_step_lds_excited_blocks<T, R>(g, lo, hi, c->num_cus);
+        TRY(reduce_to_scal(c, 1 + (int)wnum, nb, 0, s));
+        WaferRowArgs ra;
+        ra.g = g;
+        ra.lz_lo = lo;
+        ra.lz_hi = hi;
+        const dim3 grid(c->num_cus * 8), block(256);
+        T *p = as<T>(c->phi[dst]);
+        switch (wnum) {
+        case 1: hipLaunchKernelGGL((wafer_k_gs_apply<T, C, 1>), grid, block, 0, s, ra, p, low, c->scal, c->gram); break;
+        case 2: hipLaunchKernelGGL((wafer_k_gs_apply<T, C, 2>), grid, block, 0, s, ra, p, low, c->scal, c->gram); break;
+        case 3: hipLaunchKernelGGL((wafer_k_gs_apply<T, C, 3>), grid, block, 0, s, ra, p, low, c->scal, c->gram); break;
+        default: hipLaunchKernelGGL((wafer_k_gs_apply<T, C, 4>), grid, block, 0, s, ra, p, low, c->scal, c->gram); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return (int)WAFER_OK;
+    });
+}
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -471,7 +546,9 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
         HIP_TRYC(hipMemsetAsync(*arr, 0, bytes, c->s_main));
     }
     c->partials_stride = (size_t)c->bx * c->by * 64 + 1024;
-    HIP_TRYC(hipMalloc((void **)&c->partials, sizeof(double) * 4 * c->partials_stride));
+    HIP_TRYC(hipMalloc((void **)&c->partials, sizeof(double) * (WAFER_MAX_LOW + 1) * c->partials_stride));
+    HIP_TRYC(hipMalloc((void **)&c->gram, sizeof(double) * WAFER_MAX_LOW * WAFER_MAX_LOW));
+    HIP_TRYC(hipMemsetAsync(c->gram, 0, sizeof(double) * WAFER_MAX_LOW * WAFER_MAX_LOW, c->s_main));
     HIP_TRYC(hipMalloc((void **)&c->scal, sizeof(double) * SCAL_SLOTS));
     HIP_TRYC(hipMemsetAsync(c->scal, 0, sizeof(double) * SCAL_SLOTS, c->s_main));
     HIP_TRYC(hipHostMalloc((void **)&c->scal_host, sizeof(double) * SCAL_SLOTS, hipHostMallocDefault));
@@ -494,6 +571,7 @@ int wafer_ctx_destroy(wafer_ctx *c)
         if (p) (void)hipFree(p);
     if (c->partials) (void)hipFree(c->partials);
     if (c->scal) (void)hipFree(c->scal);
+    if (c->gram) (void)hipFree(c->gram);
     if (c->scal_host) (void)hipHostFree(c->scal_host);
     for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join})
         if (e) (void)hipEventDestroy(e);
@@ -788,6 +866,14 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             }
         } else {
             // step + sum phi'^2 (grid.rs:675-678), normalise (:679), Gram-Schmidt (:680)
+            if (wnum <= WAFER_MAX_LOW && active_variant(c) >= 1) {
+                TRY(excited_step_fused(c, src, dst, wnum, c->s_main));
+                TRY(exchange_halo(c, dst, c->s_main, R));
+                c->halo_valid = R;
+                c->cur = dst;
+                s += 1;
+                continue;
+            }
             TRY(launch_step(c, src, dst, lo, hi, true, c->s_main));
             long long nb = dispatch(c, [&](auto t, auto cc, auto r) {
                 return (int)step_partials_count<decltype(t), decltype(cc), decltype(r)::value>(c, lo, hi);
@@ -937,7 +1023,7 @@ int wafer_push_state(wafer_ctx *c)
     TRY(new_state_slot(c, &slot));
     HIP_TRY(hipMemcpyAsync(slot, c->phi[c->cur], (size_t)c->g.total * c->esz, hipMemcpyDeviceToDevice, c->s_main));
     c->states.push_back(slot);
-    return WAFER_OK;
+    return recompute_gram(c);
 }
 
 int wafer_load_state(wafer_ctx *c, uint32_t idx, const double *state)
@@ -951,7 +1037,8 @@ int wafer_load_state(wafer_ctx *c, uint32_t idx, const double *state)
         HIP_TRY(hipMemsetAsync(slot, 0, (size_t)c->g.total * c->esz, c->s_main));
         c->states.push_back(slot);
     }
-    return upload_padded(c, state, c->states[idx]);
+    TRY(upload_padded(c, state, c->states[idx]));
+    return recompute_gram(c);
 }
 
 int wafer_download_state(wafer_ctx *c, uint32_t idx, double *state)
@@ -987,7 +1074,7 @@ int wafer_clear_states(wafer_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->s_main));
     for (void *p : c->states) (void)hipFree(p);
     c->states.clear();
-    return WAFER_OK;
+    return recompute_gram(c);
 }
 
 // ---- solve (grid.rs:50-246) ----------------------------------------------------------

@@ -60,6 +60,11 @@ __device__ __forceinline__ T wafer_update(T w, T pa, T pb, T dt, T S, T den)
     return w * pa + pb * dt * S / den;
 }
 
+#define WAFER_MAX_LOW 4 // stored states whose overlaps ride along with the excited-state step
+struct WaferLowPtrs {
+    const void *p[WAFER_MAX_LOW] = {nullptr, nullptr, nullptr, nullptr};
+};
+
 struct WaferStepArgs {
     WaferGeom g;
     int lz_lo, lz_hi;   // local planes [lz_lo, lz_hi) to update

@@ -113,13 +113,20 @@ __device__ __forceinline__ void wafer_st_stream(VT *p, VT v)
 // potential.rs:104-110 does (same expressions => the same bits as the stored
 // arrays), which removes one of the four HBM streams: 24 B instead of 32 B of
 // traffic per update, at the price of one more fp64 division.
-template <typename T, typename C, int R, int RY, bool NORM, bool NT, bool ABV>
+// NLOW: -1 = plain step; >= 0 = the excited-state step: also accumulates
+// sum(phi'^2) (grid.rs:675-678) and the raw overlaps t_j = sum(l_j * phi') with
+// NLOW stored states in the same pass (partials[q * pstride + workgroup]),
+// from which wafer_k_gs_apply forms the modified Gram-Schmidt coefficients.
+template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV>
 __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty, int swz,
                                                         const T *__restrict__ phi,
                                                         const T *__restrict__ pa,
                                                         const T *__restrict__ pb, T *__restrict__ out,
-                                                        double *__restrict__ partials)
+                                                        double *__restrict__ partials, long long pstride,
+                                                        WaferLowPtrs low)
 {
+    constexpr bool NORM = NLOW >= 0;
+    constexpr int NL = NLOW > 0 ? NLOW : 0;
     using Cfg = WaferLdsCfg<T, R, RY>;
     using VT = typename WaferVec<T>::type;
     constexpr int VEC = Cfg::VEC, TX = Cfg::TX, TY = Cfg::TY, HX = Cfg::HX, LP = Cfg::LP;
@@ -241,6 +248,9 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     __syncthreads();
 
     double acc = 0.0;
+    double acc_t[NL > 0 ? NL : 1];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) acc_t[j] = 0.0;
     for (int z = zs; z < ze; ++z) {
         const bool more = z + 1 < ze;   // wave-uniform
         const bool more2 = z + 2 < ze;
@@ -264,6 +274,13 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
             hcol_pre[qq] = (more2 && hcol_in[qq]) ? phi[zo + 2 * g.plane + hcol_off[qq]] : T(0);
 
+        // stored states at this plane (only the cells this lane updates)
+        VT lw[NL > 0 ? NL : 1][RY];
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+#pragma unroll
+            for (int r = 0; r < RY; ++r)
+                lw[j][r] = rowin[r] ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + zo + rowoff[r])) : zero;
         // ---- 2. stage plane z+1 into the other LDS buffer
         if (more) {
             T *nt = lds + ((z + 1) & 1) * Cfg::TILE;
@@ -313,7 +330,11 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
                 const T rs = (T)wafer_update<C>(w, ca, cb, dt, S, den);
                 res[v] = rs;
                 if constexpr (NORM) {
-                    if (rowin[r] && xi + v < g.nx) acc += (double)rs * (double)rs;
+                    if (rowin[r] && xi + v < g.nx) {
+                        acc += (double)rs * (double)rs;
+#pragma unroll
+                        for (int j = 0; j < NL; ++j) acc_t[j] += (double)((C)lw[j][r][v] * (C)rs);
+                    }
                 }
             }
             if (rowin[r]) {
@@ -347,13 +368,19 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     if constexpr (NORM) {
         const double s = wafer_block_sum<4>(acc, red, tid);
         if (tid == 0) partials[blockIdx.x] = s;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const double t = wafer_block_sum<4>(acc_t[j], red, tid);
+            if (tid == 0) partials[(size_t)(1 + j) * pstride + blockIdx.x] = t;
+        }
     }
 }
 
-template <typename T, typename C, int R, int RY, bool NORM, bool NT, bool ABV>
+template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV>
 static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLdsOpts &o, const T *phi,
                                                   const T *pa, const T *pb, T *out, double *partials,
-                                                  size_t partials_cap, hipStream_t s)
+                                                  size_t partials_cap, hipStream_t s,
+                                                  const WaferLowPtrs &low = WaferLowPtrs())
 {
     using Cfg = WaferLdsCfg<T, R, RY>;
     const WaferGeom &g = a.g;
@@ -362,23 +389,51 @@ static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLd
     const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
     const long long nblocks = (long long)ntx * nty * ntz;
-    if (NORM && (size_t)nblocks > partials_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NORM, NT, ABV>), dim3((unsigned)nblocks), dim3(256), (size_t)o.pad, s,
-                       a, ntx, nty, o.swz, phi, pa, pb, out, partials);
+    if (NLOW >= 0 && (size_t)nblocks > partials_cap) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NLOW, NT, ABV>), dim3((unsigned)nblocks), dim3(256), (size_t)o.pad, s,
+                       a, ntx, nty, o.swz, phi, pa, pb, out, partials, (long long)partials_cap, low);
     return hipGetLastError();
 }
 
-template <typename T, typename C, int R, bool NORM>
+// excited-state step with `nlow` raw overlaps fused in (fixed tuning: RY 2, NT, a/b from V)
+template <typename T, typename C, int R>
+static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T *phi, const T *pv, T *out,
+                                                       double *partials, size_t partials_cap, int nlow,
+                                                       const WaferLowPtrs &low, hipStream_t s)
+{
+    WaferLdsOpts o = wafer_lds_opts();
+    o.ry = 2;
+    switch (nlow) {
+    case 0: return wafer_launch_step_lds_ry<T, C, R, 2, 0, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+    case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+    case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+    case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+    case 4: return wafer_launch_step_lds_ry<T, C, R, 2, 4, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename T, int R>
+static inline long long wafer_step_lds_excited_blocks(const WaferGeom &g, int lz_lo, int lz_hi, int target_blocks)
+{
+    using Cfg = WaferLdsCfg<T, R, 2>;
+    const int zc = wafer_lds_zchunk<T, R>(g, lz_hi - lz_lo, 2, target_blocks);
+    return (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY) *
+           ((lz_hi - lz_lo + zc - 1) / zc);
+}
+
+template <typename T, typename C, int R>
 static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, const T *pa, const T *pb,
-                                               const T *pv, T *out, double *partials,
-                                               size_t partials_cap, hipStream_t s)
+                                               const T *pv, T *out, hipStream_t s)
 {
     WaferLdsOpts o = wafer_lds_opts();
     if (o.abv < 0) o.abv = 1;
+    double *partials = nullptr;
+    const size_t partials_cap = 0;
     // with ABV, V takes a's slot and b is not read
 #define WAFER_LDS_CASE(RY_, NT_, ABV_)                                                               \
     if (o.ry == RY_ && (o.nt != 0) == NT_ && (o.abv != 0) == ABV_)                                   \
-        return wafer_launch_step_lds_ry<T, C, R, RY_, NORM, NT_, ABV_>(a, o, phi, ABV_ ? pv : pa, pb, \
+        return wafer_launch_step_lds_ry<T, C, R, RY_, -1, NT_, ABV_>(a, o, phi, ABV_ ? pv : pa, pb,   \
                                                                        out, partials, partials_cap, s);
     WAFER_LDS_CASE(2, false, false)
     WAFER_LDS_CASE(2, true, false)
