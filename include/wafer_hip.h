@@ -153,6 +153,14 @@ int wafer_get_potsub(wafer_ctx *ctx, int *kind, double *scalar);
 int wafer_set_initial_condition(wafer_ctx *ctx, int ic, uint64_t seed);
 int wafer_upload_phi(wafer_ctx *ctx, const double *phi);
 int wafer_download_phi(wafer_ctx *ctx, double *phi);
+/* Restart from another resolution: input::fill_data / read_csv's resampling branch with
+ * trilerp_resize (input.rs:149-176, 640-656, 667-716).  src is an UNPADDED [sx][sy][sz] array;
+ * basis = the `size` the reference builds its linspace from (NULL = the padded target size, which
+ * is what the reference's production call passes; its unit test passes the work-area dims). */
+int wafer_upload_phi_resampled(wafer_ctx *ctx, const double *src, uint32_t sx, uint32_t sy, uint32_t sz,
+                               const uint32_t *basis);
+int wafer_set_potential_resampled(wafer_ctx *ctx, const double *src, uint32_t sx, uint32_t sy, uint32_t sz,
+                                  const uint32_t *basis);
 
 /* ---- the hot path -------------------------------------------------------- */
 /* evolve (grid.rs:544-687): n_steps = config.output.screen_update; like the

@@ -639,8 +639,13 @@ static void bracket(int64_t n, double look, int64_t *lo, int64_t *hi)
 
 static inline double lerp1(double c0, double c1, double t) { return c0 * (1. - t) + c1 * t; }
 
-void wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
-                       int64_t sx, int64_t sy, int64_t sz)
+/* `out` has dims (sx,sy,sz); the sample positions are the first sx (sy, sz)
+ * points of linspace(0, n, bx) (by, bz): input.rs:672-675 builds the basis from
+ * the `size` argument while the loop runs over `output`'s own dims -- the
+ * production call passes the PADDED target size with the unpadded work view
+ * (input.rs:156-173, 640-656), the unit test passes the view's own dims. */
+void wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
+                             int64_t sx, int64_t sy, int64_t sz, int64_t bx, int64_t by, int64_t bz)
 {
     const int64_t nx = vx - 1, ny = vy - 1, nz = vz - 1;
 #define VAT(x, y, z) v[(((size_t)(x)) * (size_t)vy + (size_t)(y)) * (size_t)vz + (size_t)(z)]
@@ -648,9 +653,9 @@ void wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, doub
     for (int64_t x = 0; x < sx; ++x)
         for (int64_t y = 0; y < sy; ++y)
             for (int64_t z = 0; z < sz; ++z) {
-                double xl = linspace_at(0., (double)nx, sx, x);
-                double yl = linspace_at(0., (double)ny, sy, y);
-                double zl = linspace_at(0., (double)nz, sz, z);
+                double xl = linspace_at(0., (double)nx, bx, x);
+                double yl = linspace_at(0., (double)ny, by, y);
+                double zl = linspace_at(0., (double)nz, bz, z);
                 int64_t x0, x1, y0, y1, z0, z1;
                 bracket(nx, xl, &x0, &x1);
                 bracket(ny, yl, &y0, &y1);
@@ -668,4 +673,10 @@ void wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, doub
                     lerp1(c0, c1, zd);
             }
 #undef VAT
+}
+
+void wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
+                       int64_t sx, int64_t sy, int64_t sz)
+{
+    wo_trilerp_resize_basis(v, vx, vy, vz, out, sx, sy, sz, sx, sy, sz);
 }

@@ -122,6 +122,10 @@ size_t wo_solve(const wo_config *c, int wnum, const double *v, const double *a, 
 void wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
                        int64_t sx, int64_t sy, int64_t sz);
 
+/* same, with the linspace basis built for (bx,by,bz) points (the production call, see .c) */
+void wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
+                             int64_t sx, int64_t sy, int64_t sz, int64_t bx, int64_t by, int64_t bz);
+
 void wo_set_threads(int n);
 int wo_get_threads(void);
 

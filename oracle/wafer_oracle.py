@@ -99,6 +99,8 @@ def lib():
         L.wo_trilerp_resize.restype = None
         L.wo_trilerp_resize.argtypes = [dp, C.c_int64, C.c_int64, C.c_int64, dp,
                                         C.c_int64, C.c_int64, C.c_int64]
+        L.wo_trilerp_resize_basis.restype = None
+        L.wo_trilerp_resize_basis.argtypes = [dp] + [C.c_int64] * 3 + [dp] + [C.c_int64] * 6
         L.wo_set_threads.argtypes = [C.c_int]
         L.wo_get_threads.restype = C.c_int
         _lib = L
@@ -257,9 +259,13 @@ def solve(cfg: Config, wnum: int, v, a, b, phi, w_store, tolerance: float, scree
     return out, bool(conv.value)
 
 
-def trilerp_resize(v: np.ndarray, size) -> np.ndarray:
+def trilerp_resize(v: np.ndarray, size, basis=None) -> np.ndarray:
+    """input.rs:667-716.  `basis` = the `size` argument the reference builds its
+    linspace from (defaults to the output dims, as in the reference's unit test;
+    the production call passes the padded target size)."""
     v = np.ascontiguousarray(v, dtype=np.float64)
     out = np.zeros(tuple(size))
-    lib().wo_trilerp_resize(_dp(v), v.shape[0], v.shape[1], v.shape[2], _dp(out),
-                            size[0], size[1], size[2])
+    basis = tuple(size) if basis is None else tuple(basis)
+    lib().wo_trilerp_resize_basis(_dp(v), v.shape[0], v.shape[1], v.shape[2], _dp(out),
+                                  size[0], size[1], size[2], basis[0], basis[1], basis[2])
     return out

@@ -64,6 +64,12 @@ def main():
     out["interpolation"] = {"cite": "input.rs:732-824", "source_shape": [2, 2, 2],
                             "source": src_vals, "target_shape": [4, 4, 4], "expected": exp,
                             "exact": True}
+    # output.rs:758-762 directory_string
+    with open(f"{REF}/output.rs") as f:
+        osrc = f.read()
+    m = re.search(r'let bad_string = "(.*)";\s*assert_eq!\(sanitize_string\(&bad_string\), "(.*)"\);', osrc)
+    out["directory_string"] = {"cite": "output.rs:758-762",
+                               "input": m.group(1).encode().decode("unicode_escape"), "expected": m.group(2)}
     with open(os.path.join(HERE, "reference_unit_vectors.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", len(out), "vectors")

@@ -101,6 +101,30 @@ def test_initial_conditions(wo, wa, ic, ext):
         assert np.allclose(got, want, rtol=1e-12, atol=1e-13, equal_nan=True)
 
 
+def test_trilinear_resample(wo, wa, ref_vectors):
+    """input.rs:667-716 on the device: the reference's 64-value table (its unit test's
+    basis = the view's dims) and the production basis (padded target size), bit exact"""
+    g = ref_vectors["interpolation"]
+    src = np.array(g["source"]).reshape(g["source_shape"])
+    n = g["target_shape"]
+    with wa.Context(wa.Params(*n, dn=0.1, dt=1e-3)) as ctx:
+        ctx.upload_phi_resampled(src, basis=n)
+        got = ctx.download_phi()
+        assert np.array_equal(got[1:-1, 1:-1, 1:-1].ravel(), np.array(g["expected"]))
+        assert got.sum() == got[1:-1, 1:-1, 1:-1].sum()          # frame untouched
+    rng = np.random.default_rng(1)
+    src = rng.standard_normal((7, 5, 9))
+    for ext, shape in ((1, (20, 13, 33)), (3, (9, 30, 12))):
+        with wa.Context(wa.Params(*shape, dn=0.1, dt=1e-3, central_difference=ext)) as ctx:
+            ctx.upload_phi_resampled(src)                         # basis = padded target size
+            want = wo.trilerp_resize(src, shape, basis=tuple(s + 2 * ext for s in shape))
+            assert np.array_equal(ctx.download_phi()[ext:-ext, ext:-ext, ext:-ext], want)
+            ctx.set_potential_resampled(src)
+            v = ctx.download_array("v")
+            assert np.array_equal(v[ext:-ext, ext:-ext, ext:-ext], want)
+            assert np.array_equal(ctx.download_array("b"), 1. / (1. + 1e-3 * v / 2.))
+
+
 # ---------------------------------------------------------------- the stencil step
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("ext", [1, 2, 3])

@@ -67,3 +67,30 @@ def test_interpolation(oracle, ref_vectors):
     src = np.array(g["source"]).reshape(g["source_shape"])
     out = oracle.trilerp_resize(src, g["target_shape"])
     assert np.array_equal(out.ravel(), np.array(g["expected"]))
+
+
+def test_interpolation_production_basis(oracle):
+    """the reference's production call builds the basis from the PADDED target size while
+    filling the unpadded work view (input.rs:156-173, 640-656): the first N of N+bb samples"""
+    rng = np.random.default_rng(0)
+    src = rng.standard_normal((5, 4, 6))
+    n, bb = (9, 7, 11), 2
+    out = oracle.trilerp_resize(src, n, basis=tuple(s + bb for s in n))
+    full = oracle.trilerp_resize(src, tuple(s + bb for s in n))      # the whole padded-size basis
+    assert np.array_equal(out, full[:n[0], :n[1], :n[2]])
+    # independent numpy form of the same rule
+    def axis(m, count):
+        pos = np.arange(count) * ((m - 1) / (count - 1))
+        lo = np.minimum(np.floor(pos).astype(int), m - 2)
+        return lo, pos - lo
+    (x0, xd), (y0, yd), (z0, zd) = [axis(m, c + bb) for m, c in zip(src.shape, n)]
+    x0, xd, y0, yd, z0, zd = x0[:n[0]], xd[:n[0]], y0[:n[1]], yd[:n[1]], z0[:n[2]], zd[:n[2]]
+    X0, Y0, Z0 = np.ix_(x0, y0, z0)
+    XD, YD, ZD = np.ix_(xd, yd, zd)
+    lerp = lambda a, b, t: a * (1 - t) + b * t
+    c00 = lerp(src[X0, Y0, Z0], src[X0 + 1, Y0, Z0], XD)
+    c01 = lerp(src[X0, Y0, Z0 + 1], src[X0 + 1, Y0, Z0 + 1], XD)
+    c10 = lerp(src[X0, Y0 + 1, Z0], src[X0 + 1, Y0 + 1, Z0], XD)
+    c11 = lerp(src[X0, Y0 + 1, Z0 + 1], src[X0 + 1, Y0 + 1, Z0 + 1], XD)
+    want = lerp(lerp(c00, c10, YD), lerp(c01, c11, YD), ZD)
+    assert np.allclose(out, want, rtol=1e-13, atol=1e-14)

@@ -36,13 +36,28 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB
-    cmd = [hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+CLI = os.path.join(HERE, "wafer-hip")
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> str:
+    """The host driver (wafer.yaml -> table + observables/wavefunction files), plain g++."""
+    src = os.path.join(CSRC, "wafer_cli.cpp")
+    if not force and os.path.exists(CLI) and os.path.getmtime(CLI) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return CLI
+    cmd = ["g++", "-O2", "-std=c++17", src, "-o", CLI, "-L", HERE, "-lwafer_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    return CLI
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if force or is_stale():
+        cmd = [hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+    build_cli(force=force, verbose=verbose)
     return LIB
 
 

@@ -797,6 +797,66 @@ int wafer_upload_phi(wafer_ctx *c, const double *phi)
     return WAFER_OK;
 }
 
+// fill_data / read_csv's resampling branch (input.rs:149-176, 640-656, 667-716): `src` is an
+// UNPADDED array of another resolution; the work area is filled by trilinear interpolation with
+// the reference's basis (the padded target size), the frame is zero.
+static int resample_into(wafer_ctx *c, const double *src, uint32_t sx, uint32_t sy, uint32_t sz,
+                         const uint32_t *basis, void *dst)
+{
+    if (sx < 2 || sy < 2 || sz < 2) return fail(WAFER_ERR_INVALID, "resampling needs at least 2 points per axis");
+    double *dsrc = nullptr;
+    const size_t n = (size_t)sx * sy * sz;
+    HIP_TRY(hipMalloc((void **)&dsrc, n * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(dsrc, src, n * sizeof(double), hipMemcpyHostToDevice, c->s_main);
+    if (e == hipSuccess) e = hipMemsetAsync(dst, 0, (size_t)c->g.total * c->esz, c->s_main);
+    if (e == hipSuccess) {
+        WaferResampleArgs a;
+        a.g = c->g;
+        a.sx = (int)sx; a.sy = (int)sy; a.sz = (int)sz;
+        a.bx = basis ? (int)basis[0] : c->g.px;
+        a.by = basis ? (int)basis[1] : c->g.py;
+        a.bz = basis ? (int)basis[2] : c->g.pzg;
+        const dim3 grid(c->bx, c->by, c->g.lz), block(64, 4);
+        if (c->f32) hipLaunchKernelGGL((wafer_k_trilerp<float>), grid, block, 0, c->s_main, a, dsrc, as<float>(dst));
+        else hipLaunchKernelGGL((wafer_k_trilerp<double>), grid, block, 0, c->s_main, a, dsrc, as<double>(dst));
+        e = hipGetLastError();
+    }
+    hipError_t e2 = hipStreamSynchronize(c->s_main);
+    (void)hipFree(dsrc);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(WAFER_ERR_HIP, "resample failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return WAFER_OK;
+}
+
+int wafer_upload_phi_resampled(wafer_ctx *c, const double *src, uint32_t sx, uint32_t sy, uint32_t sz,
+                               const uint32_t *basis)
+{
+    if (!c || !src) return fail(WAFER_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(resample_into(c, src, sx, sy, sz, basis, c->phi[c->cur]));
+    c->have_phi = true;
+    c->halo_valid = c->g.G; // ghost planes were interpolated from the same source
+    return WAFER_OK;
+}
+
+int wafer_set_potential_resampled(wafer_ctx *c, const double *src, uint32_t sx, uint32_t sy, uint32_t sz,
+                                  const uint32_t *basis)
+{
+    if (!c || !src) return fail(WAFER_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(resample_into(c, src, sx, sy, sz, basis, c->v));
+    const dim3 grid(c->bx, c->by, c->g.lz), block(64, 4);
+    if (c->f32)
+        hipLaunchKernelGGL((wafer_k_ab<float>), grid, block, 0, c->s_main, c->g, c->P.dt, as<float>(c->v), as<float>(c->a), as<float>(c->b));
+    else
+        hipLaunchKernelGGL((wafer_k_ab<double>), grid, block, 0, c->s_main, c->g, c->P.dt, as<double>(c->v), as<double>(c->a), as<double>(c->b));
+    HIP_TRY(hipGetLastError());
+    c->potsub_kind = WAFER_POTSUB_NONE; // potential.rs:357-358: FromFile has no pot_sub of its own
+    c->potsub_scalar = 0.0;
+    c->have_pot = true;
+    return WAFER_OK;
+}
+
 int wafer_download_phi(wafer_ctx *c, double *phi)
 {
     if (!c || !phi) return fail(WAFER_ERR_INVALID, "null argument");

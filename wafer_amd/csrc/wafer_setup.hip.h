@@ -285,3 +285,60 @@ __global__ __launch_bounds__(256) void wafer_k_transpose(WaferXposeArgs a, doubl
         }
     }
 }
+
+// ---- trilinear resample (input.rs:667-716) -----------------------------------------------
+// `src` is a dense double array [sx][sy][sz] (reference layout).  Fills the WORK
+// cells of `dst` (device layout); the sample position of work cell (i,j,k) is
+// linspace(0, s-1, basis)[i] per axis, exactly as the reference computes it
+// (ndarray linspace: a + i*(b-a)/(n-1); bracket = first integer > position).
+struct WaferResampleArgs {
+    WaferGeom g;
+    int sx, sy, sz;     // source dims
+    int bx, by, bz;     // basis sizes (the reference passes the padded target size)
+};
+
+__device__ __forceinline__ void wafer_bracket(int n, double look, int *lo, int *hi)
+{
+    // (0..n).position(|q| q as f64 > look): the first integer above `look`, if below n
+    const int q = (int)floor(look) + 1;
+    if (q < n) {
+        *lo = q - 1;
+        *hi = q;
+    } else {
+        *lo = n - 1;
+        *hi = n;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wafer_k_trilerp(WaferResampleArgs a, const double *__restrict__ src,
+                                                       T *__restrict__ dst)
+{
+    const WaferGeom &g = a.g;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const int lzp = blockIdx.z;                 // every local plane, ghost planes included
+    const int k = g.z_begin + (lzp - g.G);      // global work-z
+    if (i >= g.nx || j >= g.ny || k < 0 || k >= g.nz) return;
+    const int nx = a.sx - 1, ny = a.sy - 1, nz = a.sz - 1;
+    const double stx = a.bx > 1 ? ((double)nx - 0.) / (double)(a.bx - 1) : 0.;
+    const double sty = a.by > 1 ? ((double)ny - 0.) / (double)(a.by - 1) : 0.;
+    const double stz = a.bz > 1 ? ((double)nz - 0.) / (double)(a.bz - 1) : 0.;
+    const double xl = 0. + stx * (double)i, yl = 0. + sty * (double)j, zl = 0. + stz * (double)k;
+    int x0, x1, y0, y1, z0, z1;
+    wafer_bracket(nx, xl, &x0, &x1);
+    wafer_bracket(ny, yl, &y0, &y1);
+    wafer_bracket(nz, zl, &z0, &z1);
+    const double xd = (xl - (double)x0) / ((double)x1 - (double)x0);
+    const double yd = (yl - (double)y0) / ((double)y1 - (double)y0);
+    const double zd = (zl - (double)z0) / ((double)z1 - (double)z0);
+    auto at = [&](int x, int y, int z) { return src[((size_t)x * a.sy + y) * (size_t)a.sz + z]; };
+    auto op = [](double c0, double c1, double d) { return c0 * (1. - d) + c1 * d; };
+    const double c00 = op(at(x0, y0, z0), at(x1, y0, z0), xd);
+    const double c01 = op(at(x0, y0, z1), at(x1, y0, z1), xd);
+    const double c10 = op(at(x0, y1, z0), at(x1, y1, z0), xd);
+    const double c11 = op(at(x0, y1, z1), at(x1, y1, z1), xd);
+    const double c0 = op(c00, c10, yd);
+    const double c1 = op(c01, c11, yd);
+    dst[g.at(lzp, j + g.R, i + g.R)] = (T)op(c0, c1, zd);
+}

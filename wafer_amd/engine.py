@@ -32,7 +32,7 @@ EXPORTS = [
     "wafer_abi_version", "wafer_last_error", "wafer_ctx_create", "wafer_ctx_destroy",
     "wafer_synchronize", "wafer_set_potential_builtin", "wafer_set_potential_host",
     "wafer_download_array", "wafer_get_potsub", "wafer_set_initial_condition", "wafer_upload_phi",
-    "wafer_download_phi", "wafer_evolve", "wafer_observables", "wafer_norm2", "wafer_normalise",
+    "wafer_download_phi", "wafer_upload_phi_resampled", "wafer_set_potential_resampled", "wafer_evolve", "wafer_observables", "wafer_norm2", "wafer_normalise",
     "wafer_orthogonalise", "wafer_push_state", "wafer_load_state", "wafer_download_state",
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
@@ -110,6 +110,9 @@ def load_library():
     L.wafer_set_initial_condition.argtypes = [vp, C.c_int, C.c_uint64]
     L.wafer_upload_phi.argtypes = [vp, dp]
     L.wafer_download_phi.argtypes = [vp, dp]
+    u32p = C.POINTER(C.c_uint32)
+    L.wafer_upload_phi_resampled.argtypes = [vp, dp, C.c_uint32, C.c_uint32, C.c_uint32, u32p]
+    L.wafer_set_potential_resampled.argtypes = [vp, dp, C.c_uint32, C.c_uint32, C.c_uint32, u32p]
     L.wafer_evolve.argtypes = [vp, C.c_uint32, C.c_uint64]
     L.wafer_observables.argtypes = [vp, C.POINTER(_Obs)]
     L.wafer_norm2.argtypes = [vp, dp]
@@ -254,6 +257,17 @@ class Context:
     def upload_phi(self, phi: np.ndarray) -> None:
         assert phi.shape == self.params.padded_shape
         self._check(self._L.wafer_upload_phi(self._h, _dp(phi)))
+
+    @staticmethod
+    def _basis(basis):
+        return None if basis is None else (C.c_uint32 * 3)(*basis)
+
+    def upload_phi_resampled(self, src: np.ndarray, basis=None) -> None:
+        """input.rs:667-716: trilinear resample of an unpadded array of another resolution"""
+        self._check(self._L.wafer_upload_phi_resampled(self._h, _dp(src), *src.shape, self._basis(basis)))
+
+    def set_potential_resampled(self, src: np.ndarray, basis=None) -> None:
+        self._check(self._L.wafer_set_potential_resampled(self._h, _dp(src), *src.shape, self._basis(basis)))
 
     def download_phi(self, out: np.ndarray | None = None) -> np.ndarray:
         if out is None:
