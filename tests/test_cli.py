@@ -86,6 +86,7 @@ def test_full_run_matches_oracle(cli, tmp_path):
     assert sorted(os.listdir(od)) == ["cli_case.yaml", "observables_0.csv", "observables_1.csv", "potential.csv",
                                       "wavefunction_0.csv", "wavefunction_1.csv"]
 
+    wo.set_threads(4)   # a 24x20x28 grid: hundreds of OpenMP threads would only spin
     cfg = wo.Config(24, 20, 28, ext=1, potential="Harmonic", dn=0.5, dt=0.04, mass=1.0)
     v = wo.potential_generate(cfg)
     a, b = wo.ab(cfg, v)
