@@ -12,12 +12,24 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _loaded_hip_runtime():
+    """the libamdhip64 this process already runs on (torch's bundled one when torch is present):
+    a second copy would be a second, unrelated HIP runtime"""
+    import wafer_amd
+    wafer_amd.load_library()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                return line.split()[-1]
+    return "libamdhip64.so"
+
+
 class FakeFabric:
     """In-process stand-in for RCCL: rank r's hooks rendezvous on barriers."""
 
     def __init__(self, world):
         self.world = world
-        self.hip = C.CDLL("libamdhip64.so")
+        self.hip = C.CDLL(_loaded_hip_runtime())
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         self.bar = threading.Barrier(world)
@@ -197,3 +209,77 @@ def test_slab_without_hooks_fails_loudly(wa):
         ctx.set_initial_condition("Boolean")
         with pytest.raises(wa.WaferError):
             ctx.evolve(0, 1)
+
+
+def test_torch_hooks_alias_engine_memory(wa):
+    """wafer_amd.slab.TorchSlabComm's plumbing on one GPU: the tensors it builds from the
+    hooks' raw device addresses (__cuda_array_interface__), the ExternalStream it issues
+    under, and the hook signatures -- with the collective itself replaced by an in-process
+    exchange (RCCL needs one GPU per rank).  3 slabs, fused two-step path, bit exact."""
+    import dataclasses
+    import torch
+    from wafer_amd.slab import TorchSlabComm, partition
+
+    world, shape, ext, steps = 3, (40, 24, 36), 1, 9
+    base = wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, halo_depth=2 * ext, max_states=1)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext)) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        want = ctx.download_phi()
+        want_obs = ctx.observables()
+
+    bar = threading.Barrier(world)
+    mail = [dict() for _ in range(world)]
+    scal = [None] * world
+
+    class Loopback(TorchSlabComm):
+        def exchange(self, send_lo, send_hi, recv_lo, recv_hi):
+            torch.cuda.current_stream().synchronize()
+            mail[self.rank] = dict(lo=send_lo, hi=send_hi)
+            bar.wait()
+            if recv_lo is not None:
+                assert recv_lo.dtype == torch.uint8 and recv_lo.is_cuda
+                recv_lo.copy_(mail[self.rank - 1]["hi"])
+            if recv_hi is not None:
+                recv_hi.copy_(mail[self.rank + 1]["lo"])
+            torch.cuda.current_stream().synchronize()
+            bar.wait()
+            return []
+
+        def allreduce(self, t):
+            assert t.dtype == torch.float64 and t.is_cuda
+            torch.cuda.current_stream().synchronize()
+            scal[self.rank] = t.clone()
+            bar.wait()
+            total = torch.stack(scal).sum(dim=0)
+            bar.wait()
+            t.copy_(total)
+            torch.cuda.current_stream().synchronize()
+            return t
+
+    results, errors = [None] * world, []
+
+    def work(rank):
+        try:
+            zb, zc = partition(base.nz, world, rank)
+            with wa.Context(dataclasses.replace(base, z_begin=zb, z_count=zc)) as c:
+                comm = Loopback(c, rank, world, torch.device("cuda", 0))
+                c.set_potential("Coulomb")
+                c.set_initial_condition("Boolean")
+                c.evolve(0, steps)
+                results[rank] = (c.download_phi(), c.observables())
+                del comm
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            bar.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    if errors:
+        raise errors[0]
+    assert np.array_equal(assemble(base, world, [r[0] for r in results]), want)
+    for _, obs in results:
+        for k in want_obs:
+            assert obs[k] == pytest.approx(want_obs[k], rel=1e-12, abs=1e-300)

@@ -92,6 +92,17 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process.  PyTorch's ROCm wheels bundle their own libamdhip64.so.7 /
+    # libhsa-runtime64 with the SAME sonames as /opt/rocm's, so whichever loads first serves
+    # every later user.  If this library pulled in /opt/rocm's first, a later torch.cuda init
+    # fails ("No HIP GPUs are available") and slab.py could not alias the engine's buffers and
+    # streams.  Importing torch first makes its runtime the process-wide one.  A host without
+    # torch (a Rust binary, WAFER_PRELOAD_TORCH=0) simply links /opt/rocm's.
+    if os.environ.get("WAFER_PRELOAD_TORCH", "1") != "0":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(_LIB):
         raise ImportError(
             f"{_LIB} is missing: build it with `python -m wafer_amd.build` "
