@@ -151,6 +151,26 @@ static inline int nchunks_of(int nplanes, int zchunk) { return (nplanes + zchunk
 
 template <typename T>
 static inline T *as(void *p) { return static_cast<T *>(p); }
+
+// Arrays are held as LOGICAL pointers to (plane 0, row 0); the allocation starts
+// base_off elements earlier (guard planes / rows, wafer_geom.h).
+static inline void *alloc_base(const wafer_ctx *c, void *logical)
+{
+    return logical ? static_cast<char *>(logical) - (size_t)c->g.base_off * c->esz : nullptr;
+}
+static int alloc_grid_array(wafer_ctx *c, void **logical, hipStream_t s)
+{
+    void *raw = nullptr;
+    const size_t bytes = (size_t)c->g.total * c->esz;
+    HIP_TRY(hipMalloc(&raw, bytes));
+    hipError_t e = hipMemsetAsync(raw, 0, bytes, s);
+    if (e != hipSuccess) {
+        (void)hipFree(raw);
+        return fail(WAFER_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+    *logical = static_cast<char *>(raw) + (size_t)c->g.base_off * c->esz;
+    return WAFER_OK;
+}
 template <typename T>
 static inline const T *as(const void *p) { return static_cast<const T *>(p); }
 
@@ -187,7 +207,8 @@ static int exchange_halo(wafer_ctx *c, int buf, hipStream_t s, int planes)
     if (planes > g.G || planes > g.nzl) return fail(WAFER_ERR_INVALID, "halo exchange deeper than the slab allows");
     char *base = static_cast<char *>(c->phi[buf]);
     const size_t plane_b = (size_t)g.plane * c->esz;
-    const size_t bytes = (size_t)planes * plane_b;
+    // from row 0 of the first plane to the last padded row of the last plane (guard rows in between ride along)
+    const size_t bytes = ((size_t)(planes - 1) * (size_t)g.plane + (size_t)g.py * (size_t)g.pitch) * c->esz;
     void *send_lo = c->has_lo() ? base + (size_t)g.G * plane_b : nullptr;
     void *recv_lo = c->has_lo() ? base + (size_t)(g.G - planes) * plane_b : nullptr;
     void *send_hi = c->has_hi() ? base + (size_t)(g.G + g.nzl - planes) * plane_b : nullptr;
@@ -539,12 +560,9 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 
-    const size_t bytes = (size_t)c->g.total * c->esz;
     void **arrays[] = {&c->phi[0], &c->phi[1], &c->v, &c->a, &c->b};
-    for (void **arr : arrays) {
-        HIP_TRYC(hipMalloc(arr, bytes));
-        HIP_TRYC(hipMemsetAsync(*arr, 0, bytes, c->s_main));
-    }
+    for (void **arr : arrays)
+        if (alloc_grid_array(c, arr, c->s_main) != WAFER_OK) return cleanup_fail(WAFER_ERR_HIP);
     c->partials_stride = (size_t)c->bx * c->by * 64 + 1024;
     HIP_TRYC(hipMalloc((void **)&c->partials, sizeof(double) * (WAFER_MAX_LOW + 1) * c->partials_stride));
     HIP_TRYC(hipMalloc((void **)&c->gram, sizeof(double) * WAFER_MAX_LOW * WAFER_MAX_LOW));
@@ -566,9 +584,9 @@ int wafer_ctx_destroy(wafer_ctx *c)
     if (c->s_own) (void)hipStreamSynchronize(c->s_own);
     if (c->s_aux) (void)hipStreamSynchronize(c->s_aux);
     for (void *p : {c->phi[0], c->phi[1], c->v, c->a, c->b, c->potsub})
-        if (p) (void)hipFree(p);
+        if (p) (void)hipFree(alloc_base(c, p));
     for (void *p : c->states)
-        if (p) (void)hipFree(p);
+        if (p) (void)hipFree(alloc_base(c, p));
     if (c->partials) (void)hipFree(c->partials);
     if (c->scal) (void)hipFree(c->scal);
     if (c->gram) (void)hipFree(c->gram);
@@ -674,8 +692,7 @@ static WaferPotArgs pot_args(wafer_ctx *c, int type)
 static int ensure_potsub_array(wafer_ctx *c)
 {
     if (!c->potsub) {
-        HIP_TRY(hipMalloc(&c->potsub, (size_t)c->g.total * c->esz));
-        HIP_TRY(hipMemsetAsync(c->potsub, 0, (size_t)c->g.total * c->esz, c->s_main));
+        TRY(alloc_grid_array(c, &c->potsub, c->s_main));
     }
     return WAFER_OK;
 }
@@ -808,7 +825,7 @@ static int resample_into(wafer_ctx *c, const double *src, uint32_t sx, uint32_t 
     const size_t n = (size_t)sx * sy * sz;
     HIP_TRY(hipMalloc((void **)&dsrc, n * sizeof(double)));
     hipError_t e = hipMemcpyAsync(dsrc, src, n * sizeof(double), hipMemcpyHostToDevice, c->s_main);
-    if (e == hipSuccess) e = hipMemsetAsync(dst, 0, (size_t)c->g.total * c->esz, c->s_main);
+    if (e == hipSuccess) e = hipMemsetAsync(alloc_base(c, dst), 0, (size_t)c->g.total * c->esz, c->s_main);
     if (e == hipSuccess) {
         WaferResampleArgs a;
         a.g = c->g;
@@ -1070,8 +1087,7 @@ static int new_state_slot(wafer_ctx *c, void **slot)
 {
     if (c->states.size() >= c->P.max_states)
         return fail(WAFER_ERR_STATE, "w_store is full (max_states = %u)", c->P.max_states);
-    HIP_TRY(hipMalloc(slot, (size_t)c->g.total * c->esz));
-    return WAFER_OK;
+    return alloc_grid_array(c, slot, c->s_main);
 }
 
 int wafer_push_state(wafer_ctx *c)
@@ -1081,7 +1097,7 @@ int wafer_push_state(wafer_ctx *c)
     HIP_TRY(hipSetDevice(c->P.device));
     void *slot = nullptr;
     TRY(new_state_slot(c, &slot));
-    HIP_TRY(hipMemcpyAsync(slot, c->phi[c->cur], (size_t)c->g.total * c->esz, hipMemcpyDeviceToDevice, c->s_main));
+    HIP_TRY(hipMemcpyAsync(alloc_base(c, slot), alloc_base(c, c->phi[c->cur]), (size_t)c->g.total * c->esz, hipMemcpyDeviceToDevice, c->s_main));
     c->states.push_back(slot);
     return recompute_gram(c);
 }
@@ -1094,7 +1110,6 @@ int wafer_load_state(wafer_ctx *c, uint32_t idx, const double *state)
     if (idx == c->states.size()) {
         void *slot = nullptr;
         TRY(new_state_slot(c, &slot));
-        HIP_TRY(hipMemsetAsync(slot, 0, (size_t)c->g.total * c->esz, c->s_main));
         c->states.push_back(slot);
     }
     TRY(upload_padded(c, state, c->states[idx]));
@@ -1114,7 +1129,7 @@ int wafer_clone_state_to_phi(wafer_ctx *c, uint32_t idx)
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
     if (idx >= c->states.size()) return fail(WAFER_ERR_STATE, "no state %u", idx);
     HIP_TRY(hipSetDevice(c->P.device));
-    HIP_TRY(hipMemcpyAsync(c->phi[c->cur], c->states[idx], (size_t)c->g.total * c->esz, hipMemcpyDeviceToDevice, c->s_main));
+    HIP_TRY(hipMemcpyAsync(alloc_base(c, c->phi[c->cur]), alloc_base(c, c->states[idx]), (size_t)c->g.total * c->esz, hipMemcpyDeviceToDevice, c->s_main));
     c->have_phi = true;
     c->halo_valid = 0; // stored states carry no ghost-plane guarantee
     return WAFER_OK;
@@ -1132,7 +1147,7 @@ int wafer_clear_states(wafer_ctx *c)
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->P.device));
     HIP_TRY(hipStreamSynchronize(c->s_main));
-    for (void *p : c->states) (void)hipFree(p);
+    for (void *p : c->states) (void)hipFree(alloc_base(c, p));
     c->states.clear();
     return recompute_gram(c);
 }
@@ -1197,8 +1212,9 @@ int wafer_diag_stream_bw(wafer_ctx *c, int n_reads, int iters, double *gbps)
     if (n_reads < 1 || n_reads > 3 || iters < 1) return fail(WAFER_ERR_INVALID, "n_reads in 1..3, iters >= 1");
     HIP_TRY(hipSetDevice(c->P.device));
     const long long n16 = (long long)c->g.total * (long long)c->esz / 16;
-    const wafer_f4 *r0 = as<const wafer_f4>(c->a), *r1 = as<const wafer_f4>(c->b), *r2 = as<const wafer_f4>(c->v);
-    wafer_f4 *w = as<wafer_f4>(c->phi[c->cur ^ 1]); // scratch between steps
+    const wafer_f4 *r0 = as<const wafer_f4>(alloc_base(c, c->a)), *r1 = as<const wafer_f4>(alloc_base(c, c->b)),
+                   *r2 = as<const wafer_f4>(alloc_base(c, c->v));
+    wafer_f4 *w = as<wafer_f4>(alloc_base(c, c->phi[c->cur ^ 1])); // scratch between steps
     const dim3 grid(256 * 8), block(256);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -1216,7 +1232,7 @@ int wafer_diag_stream_bw(wafer_ctx *c, int n_reads, int iters, double *gbps)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     // the scratch buffer's frame must be zero again
-    HIP_TRY(hipMemsetAsync(c->phi[c->cur ^ 1], 0, (size_t)c->g.total * c->esz, c->s_main));
+    HIP_TRY(hipMemsetAsync(alloc_base(c, c->phi[c->cur ^ 1]), 0, (size_t)c->g.total * c->esz, c->s_main));
     *gbps = (double)n16 * 16.0 * (n_reads + 1) * iters / (ms * 1e-3) / 1e9;
     return WAFER_OK;
 }

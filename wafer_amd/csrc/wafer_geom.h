@@ -12,6 +12,14 @@
 // row (padded x index R) sits on a 128-byte boundary; `pitch` is a multiple of
 // 128 bytes.  Frame cells (the Dirichlet zero frame of config.rs:597-622) and
 // the pad cells are stored as zeros and are never written by any kernel.
+//
+// Guard zone: every array is allocated with `gy` extra zero rows on both sides
+// of each plane, `gz` extra zero planes on both sides of the slab, and a row
+// pitch that covers whole 1 KiB tiles.  Device pointers handed to kernels
+// point at (plane 0, row 0), `base_off` elements into the allocation, so a
+// tile may read rows / planes / columns just outside the padded grid without a
+// bounds predicate -- they exist and hold zeros.  (Per-lane "load or zero"
+// selects make hipcc branch around every load and serialise them.)
 #pragma once
 #include <stdint.h>
 
@@ -24,8 +32,10 @@ struct WaferGeom {
     int lz;             // local planes = nzl + 2G
     int xoff;           // element offset of padded x index 0 inside a row
     int pitch;          // row stride in elements
-    long long plane;    // plane stride in elements (= py * pitch)
-    long long total;    // lz * plane
+    int gy, gz;         // guard rows per plane side / guard planes per slab side (zeros)
+    long long plane;    // plane stride in elements (= (py + 2 gy) * pitch)
+    long long total;    // allocation size in elements (= (lz + 2 gz) * plane)
+    long long base_off; // element offset of (plane 0, row 0) inside the allocation
 
     // element offset of (local plane lzp, padded y, padded x)
     __host__ __device__ inline long long at(int lzp, int yp, int xp) const
@@ -47,8 +57,13 @@ static inline WaferGeom wafer_make_geom(int nx, int ny, int nz, int R, int G, in
     g.z_begin = z_begin; g.nzl = nzl; g.lz = nzl + 2 * G;
     const int align = 128 / elem_bytes;           // elements per 128-byte line
     g.xoff = align - R;                           // R <= 3 < align
-    g.pitch = ((g.xoff + g.px + align - 1) / align) * align;
-    g.plane = (long long)g.py * g.pitch;
-    g.total = (long long)g.lz * g.plane;
+    const int tile = 8 * align;                   // tile width: 64 lanes x 16 B = 1 KiB of x
+    const int nx_tiles = ((nx + tile - 1) / tile) * tile;
+    g.pitch = ((g.xoff + R + nx_tiles + 2 * R + align - 1) / align) * align;
+    g.gy = 16 + 2 * R + R;                        // tallest tile (16 rows) overhang + 2R halo rows
+    g.gz = 3 * R;                                 // the fused kernel reaches 2R planes past the slab
+    g.plane = (long long)(g.py + 2 * g.gy) * g.pitch;
+    g.total = (long long)(g.lz + 2 * g.gz) * g.plane;
+    g.base_off = (long long)g.gz * g.plane + (long long)g.gy * g.pitch;
     return g;
 }

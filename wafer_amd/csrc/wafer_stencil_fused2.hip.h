@@ -35,11 +35,11 @@
 #include "wafer_stencil.hip.h"
 #include "wafer_stencil_lds.hip.h"
 
-template <typename T, int R>
+template <typename T, int R, int NW2_ = 4>
 struct WaferF2Cfg {
     static constexpr int VEC = WaferVec<T>::N;
     static constexpr int RY = 2;
-    static constexpr int NW2 = 4;                        // main waves
+    static constexpr int NW2 = NW2_;                     // main waves (tile height = 2 * NW2)
     static constexpr int NWH = (2 * R) / RY;             // halo-row waves (R)
     static constexpr int NW = NW2 + NWH + 1;             // + halo-column wave
     static constexpr int NT_ = NW * 64;                  // threads per workgroup
@@ -68,12 +68,12 @@ __device__ __forceinline__ C wafer_update_v(C w, C vv, C dt, C S, C den)
 
 // ABV: pv is V and a, b are formed in registers (24 B per two updates);
 // !ABV: pv is a, pb is b, streamed (32 B per two updates, ~14 fp64 ops fewer per update).
-template <typename T, typename C, int R, bool NT, bool ABV>
-__global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
+template <typename T, typename C, int R, bool NT, bool ABV, int NW2 = 4>
+__global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fused(
     WaferStepArgs a, int ntx, int nty, int swz, const T *__restrict__ phi, const T *__restrict__ pv,
     const T *__restrict__ pb, T *__restrict__ out)
 {
-    using Cfg = WaferF2Cfg<T, R>;
+    using Cfg = WaferF2Cfg<T, R, NW2>;
     using VT = typename WaferVec<T>::type;
     constexpr int VEC = Cfg::VEC, RY = Cfg::RY, TX = Cfg::TX, TY = Cfg::TY;
     constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, LP0 = Cfg::LP0, LP1 = Cfg::LP1;
@@ -87,7 +87,8 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
         bid = k * q + min(k, r) + (bid >> 3);
     }
     const int tx_i = bid % ntx, ty_i = (bid / ntx) % nty, tz_i = bid / (ntx * nty);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: role tests become scalar branches
     const int x0 = tx_i * TX, y0 = ty_i * TY;
     const int zs = a.lz_lo + tz_i * a.zchunk;
     const int ze = min(zs + a.zchunk, a.lz_hi);
@@ -102,11 +103,10 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
 
     // ---- row slots of the main and halo-row waves ---------------------------------
     const int xl = lane * VEC, xi = x0 + xl;
-    const int wlim = g.pitch - g.xoff - R;        // aligned VEC group inside the row allocation
-    const bool xin = xi < wlim;
+    // Loads carry no bounds predicates: rows y0-2R .. y0+TY+2R, planes zs-2R .. ze+2R and whole
+    // tiles of x lie inside the allocation's zero guard zone (wafer_geom.h).
     int yrow[RY];          // work y of slot r
-    bool rowld[RY];        // the row exists in memory (frame rows included) and the group is in the row
-    bool rowwk[RY];        // the row is a work row
+    bool rowwk[RY];        // the row is a work row (wave-uniform)
     long long rowoff[RY];
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
@@ -118,35 +118,31 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
             y = y0 + wave * RY + r;                                   // main (unused for hcol)
         }
         yrow[r] = y;
-        rowld[r] = !is_hcol && xin && (y >= -R) && (y < g.ny + R);
         rowwk[r] = (y >= 0) && (y < g.ny);
         rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + xi;
     }
     // ---- outermost phi0 halo rows, fetched by the main waves -------------------------
-    bool orow_ld[Cfg::OPW];
     long long orow_off[Cfg::OPW];
     int orow_lds[Cfg::OPW];
 #pragma unroll
     for (int q = 0; q < Cfg::OPW; ++q) {
         const int o = wave + q * Cfg::NW2;                            // 0..2R-1 valid
         const int y = (o < R) ? (y0 - 2 * R + o) : (y0 + TY + R + (o - R));
-        orow_ld[q] = is_main && (o < Cfg::OUTER) && xin && (y >= -R) && (y < g.ny + R);
         orow_off[q] = (long long)(y + R) * g.pitch + g.xoff + R + xi;
         orow_lds[q] = (y - (y0 - 2 * R)) * LP0 + HX0 + xl;
     }
     // ---- halo-column cells of the last wave ------------------------------------------------
-    bool c_ld[Cfg::CPL], c_p1[Cfg::CPL];
+    bool c_p1[Cfg::CPL];
     long long c_off[Cfg::CPL];
     int c_lds0[Cfg::CPL], c_lds1[Cfg::CPL];
 #pragma unroll
     for (int q = 0; q < Cfg::CPL; ++q) {
-        const int cidx = lane + q * 64;
+        const int cidx = min(lane + q * 64, Cfg::NCOL - 1);         // surplus lanes repeat the last cell
         const int row = cidx / (2 * Cfg::HC0), k = cidx % (2 * Cfg::HC0);
         const int kk = (k < Cfg::HC0) ? k : k - Cfg::HC0;             // distance-1 from the tile edge
         const int lc = (k < Cfg::HC0) ? (-1 - kk) : (TX + kk);        // column relative to x0
         const int xw = x0 + lc, y = y0 - 2 * R + row;
-        const bool valid = is_hcol && cidx < Cfg::NCOL;
-        c_ld[q] = valid && (y >= -R) && (y < g.ny + R) && (xw >= -R) && (xw < g.nx + R);
+        const bool valid = is_hcol && lane + q * 64 < Cfg::NCOL;
         // phi1 is produced on the inner R columns and rows y0-R .. y0+TY+R-1, work cells only
         c_p1[q] = valid && (kk < R) && (row >= R) && (row < Cfg::ROWS0 - R) && (y >= 0) && (y < g.ny) &&
                   (xw >= 0) && (xw < g.nx);
@@ -156,7 +152,6 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
     }
     const bool c_p1slot_valid = is_hcol;
 
-    auto plane_ok = [&](int p) { return p >= 0 && p < g.lz; };
     auto work_plane = [&](int p) {
         const int kg = g.z_begin + (p - g.G);
         return kg >= 0 && kg < g.nz;
@@ -174,13 +169,17 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
 #pragma unroll
     for (int m = 0; m <= 2 * R; ++m) {
         const int p = z1 - R + m;
-        const bool ok = plane_ok(p);
 #pragma unroll
-        for (int r = 0; r < RY; ++r)
-            q0[m][r] = (ok && rowld[r]) ? *reinterpret_cast<const VT *>(phi + (long long)p * g.plane + rowoff[r]) : zero;
+        for (int r = 0; r < RY; ++r) q0[m][r] = zero;
 #pragma unroll
-        for (int q = 0; q < Cfg::CPL; ++q)
-            cq[q][m] = (ok && c_ld[q]) ? phi[(long long)p * g.plane + c_off[q]] : T(0);
+        for (int q = 0; q < Cfg::CPL; ++q) cq[q][m] = T(0);
+        if (!is_hcol) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r) q0[m][r] = *reinterpret_cast<const VT *>(phi + (long long)p * g.plane + rowoff[r]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < Cfg::CPL; ++q) cq[q][m] = phi[(long long)p * g.plane + c_off[q]];
+        }
     }
 #pragma unroll
     for (int m = 0; m <= R; ++m)
@@ -189,20 +188,22 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
             vq[m][r] = zero;
             bq[m][r] = zero;
         }
-    {
-        const bool ok = plane_ok(z1);
 #pragma unroll
-        for (int r = 0; r < RY; ++r)
-        {
-            vq[R][r] = (ok && rowld[r]) ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pv + (long long)z1 * g.plane + rowoff[r])) : zero;
-            if constexpr (!ABV)
-                bq[R][r] = (ok && rowld[r]) ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + (long long)z1 * g.plane + rowoff[r])) : zero;
+    for (int q = 0; q < Cfg::CPL; ++q) {
+        cv[q] = T(0);
+        cb[q] = T(0);
+    }
+    if (!is_hcol) {
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            vq[R][r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pv + (long long)z1 * g.plane + rowoff[r]));
+            if constexpr (!ABV) bq[R][r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + (long long)z1 * g.plane + rowoff[r]));
         }
+    } else {
 #pragma unroll
         for (int q = 0; q < Cfg::CPL; ++q) {
-            cv[q] = (ok && c_ld[q]) ? pv[(long long)z1 * g.plane + c_off[q]] : T(0);
-            cb[q] = T(0);
-            if constexpr (!ABV) cb[q] = (ok && c_ld[q]) ? pb[(long long)z1 * g.plane + c_off[q]] : T(0);
+            cv[q] = pv[(long long)z1 * g.plane + c_off[q]];
+            if constexpr (!ABV) cb[q] = pb[(long long)z1 * g.plane + c_off[q]];
         }
     }
     // phi1 z-queue (main waves), planes z-2R .. z; starts empty (zeros never reach an output:
@@ -224,22 +225,20 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
             for (int r = 0; r < RY; ++r)
                 *reinterpret_cast<VT *>(t0 + (yrow[r] - (y0 - 2 * R)) * LP0 + HX0 + xl) = q0[R][r];
         }
-        const bool ok = plane_ok(z1);
 #pragma unroll
         for (int q = 0; q < Cfg::OPW; ++q)
             if (is_main && wave + q * Cfg::NW2 < Cfg::OUTER)
-                *reinterpret_cast<VT *>(t0 + orow_lds[q]) =
-                    (ok && orow_ld[q]) ? *reinterpret_cast<const VT *>(phi + (long long)z1 * g.plane + orow_off[q]) : zero;
+                *reinterpret_cast<VT *>(t0 + orow_lds[q]) = *reinterpret_cast<const VT *>(phi + (long long)z1 * g.plane + orow_off[q]);
 #pragma unroll
         for (int q = 0; q < Cfg::CPL; ++q)
             if (is_hcol && lane + q * 64 < Cfg::NCOL) t0[c_lds0[q]] = cq[q][R];
     }
     VT orow_nxt[Cfg::OPW];
-    {
-        const bool ok = plane_ok(z1 + 1);
 #pragma unroll
-        for (int q = 0; q < Cfg::OPW; ++q)
-            orow_nxt[q] = (ok && orow_ld[q]) ? *reinterpret_cast<const VT *>(phi + (long long)(z1 + 1) * g.plane + orow_off[q]) : zero;
+    for (int q = 0; q < Cfg::OPW; ++q) {
+        orow_nxt[q] = zero;
+        if (is_main && wave + q * Cfg::NW2 < Cfg::OUTER)
+            orow_nxt[q] = *reinterpret_cast<const VT *>(phi + (long long)(z1 + 1) * g.plane + orow_off[q]);
     }
     __syncthreads();
 
@@ -250,25 +249,31 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
         // ---- 1. prefetch: phi0 plane z+R+1, V plane z+1, outer halo rows of plane z+2 ---------------
         VT pre[RY], pre_v[RY], pre_b[RY], orow_pre[Cfg::OPW];
         T cpre[Cfg::CPL], cvpre[Cfg::CPL], cbpre[Cfg::CPL];
-        {
-            const bool okp = more && plane_ok(z + R + 1);
-            const bool okv = more && plane_ok(z + 1);
-            const bool oko = (z + 2 < zend) && plane_ok(z + 2);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) pre[r] = pre_v[r] = pre_b[r] = zero;
+#pragma unroll
+        for (int q = 0; q < Cfg::OPW; ++q) orow_pre[q] = zero;
+#pragma unroll
+        for (int q = 0; q < Cfg::CPL; ++q) cpre[q] = cvpre[q] = cbpre[q] = T(0);
+        // (no bounds tests: one plane past the last one needed still lies in the guard zone; the
+        //  role tests are wave-uniform)
+        if (!is_hcol) {
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
-                pre[r] = (okp && rowld[r]) ? *reinterpret_cast<const VT *>(phi + zo + (long long)(R + 1) * g.plane + rowoff[r]) : zero;
-                pre_v[r] = (okv && rowld[r]) ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pv + zo + g.plane + rowoff[r])) : zero;
-                if constexpr (!ABV)
-                    pre_b[r] = (okv && rowld[r]) ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + zo + g.plane + rowoff[r])) : zero;
+                pre[r] = *reinterpret_cast<const VT *>(phi + zo + (long long)(R + 1) * g.plane + rowoff[r]);
+                pre_v[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pv + zo + g.plane + rowoff[r]));
+                if constexpr (!ABV) pre_b[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + zo + g.plane + rowoff[r]));
             }
 #pragma unroll
             for (int q = 0; q < Cfg::OPW; ++q)
-                orow_pre[q] = (oko && orow_ld[q]) ? *reinterpret_cast<const VT *>(phi + zo + 2 * g.plane + orow_off[q]) : zero;
+                if (is_main && wave + q * Cfg::NW2 < Cfg::OUTER)
+                    orow_pre[q] = *reinterpret_cast<const VT *>(phi + zo + 2 * g.plane + orow_off[q]);
+        } else {
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q) {
-                cpre[q] = (okp && c_ld[q]) ? phi[zo + (long long)(R + 1) * g.plane + c_off[q]] : T(0);
-                cvpre[q] = (okv && c_ld[q]) ? pv[zo + g.plane + c_off[q]] : T(0);
-                if constexpr (!ABV) cbpre[q] = (okv && c_ld[q]) ? pb[zo + g.plane + c_off[q]] : T(0);
+                cpre[q] = phi[zo + (long long)(R + 1) * g.plane + c_off[q]];
+                cvpre[q] = pv[zo + g.plane + c_off[q]];
+                if constexpr (!ABV) cbpre[q] = pb[zo + g.plane + c_off[q]];
             }
         }
         // ---- 2. stage phi0 plane z+1 into the other buffer ------------------------------------------------
@@ -366,7 +371,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
                 const T *c1 = lds1 + (((zo2 % Cfg::NB1) + Cfg::NB1) % Cfg::NB1) * Cfg::TILE1;
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
-                    if (rowld[r] && rowwk[r]) {
+                    if (rowwk[r]) {
                         const int ly = yrow[r] - (y0 - R);
                         VT res;
 #pragma unroll
@@ -437,10 +442,10 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R>::NT_)) void wafer_k_step2_fused(
 }
 
 // planes per workgroup / launch size for the fused kernel
-template <typename T, int R>
+template <typename T, int R, int NW2>
 static inline int wafer_f2_zchunk(const WaferGeom &g, int nplanes, int target_blocks)
 {
-    using Cfg = WaferF2Cfg<T, R>;
+    using Cfg = WaferF2Cfg<T, R, NW2>;
     const char *f = getenv("WAFER_ZCHUNK");
     if (f && atoi(f) > 0) return atoi(f);
     const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY);
@@ -453,25 +458,21 @@ static inline int wafer_f2_zchunk(const WaferGeom &g, int nplanes, int target_bl
 }
 
 // Advances planes [lz_lo, lz_hi) by TWO steps: out = step(step(phi)).
-template <typename T, typename C, int R>
-static inline hipError_t wafer_launch_step2_fused(WaferStepArgs a, const T *phi, const T *pa, const T *pb,
-                                                  const T *pv, T *out, hipStream_t s)
+template <typename T, typename C, int R, int NW2>
+static inline hipError_t wafer_launch_step2_fused_nw(WaferStepArgs a, const WaferLdsOpts &o, const T *phi,
+                                                     const T *pa, const T *pb, const T *pv, T *out, hipStream_t s)
 {
-    using Cfg = WaferF2Cfg<T, R>;
-    WaferLdsOpts o = wafer_lds_opts();
-    // default: stream a and b.  The fused kernel is issue-bound, not HBM-bound, and forming a, b
-    // from V costs a second fp64 division per update (0.426 vs 0.449 ms/step at 512^3).
-    if (o.abv < 0) o.abv = 0;
+    using Cfg = WaferF2Cfg<T, R, NW2>;
     const WaferGeom &g = a.g;
-    a.zchunk = wafer_f2_zchunk<T, R>(g, a.lz_hi - a.lz_lo, a.target_blocks);
+    a.zchunk = wafer_f2_zchunk<T, R, NW2>(g, a.lz_hi - a.lz_lo, a.target_blocks);
     const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX;
     const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
     const dim3 grid((unsigned)((long long)ntx * nty * ntz)), block(Cfg::NT_);
 #define WAFER_F2_CASE(NT_, ABV_)                                                                          \
     if ((o.nt != 0) == NT_ && (o.abv != 0) == ABV_) {                                                     \
-        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, NT_, ABV_>), grid, block, (size_t)o.pad, s, a,   \
-                           ntx, nty, o.swz, phi, ABV_ ? pv : pa, pb, out);                                 \
+        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, NT_, ABV_, NW2>), grid, block, (size_t)o.pad, s, \
+                           a, ntx, nty, o.swz, phi, ABV_ ? pv : pa, pb, out);                              \
         return hipGetLastError();                                                                         \
     }
     WAFER_F2_CASE(true, true)
@@ -480,4 +481,27 @@ static inline hipError_t wafer_launch_step2_fused(WaferStepArgs a, const T *phi,
     WAFER_F2_CASE(false, false)
 #undef WAFER_F2_CASE
     return hipErrorInvalidValue;
+}
+
+template <typename T, typename C, int R>
+static inline hipError_t wafer_launch_step2_fused(WaferStepArgs a, const T *phi, const T *pa, const T *pb,
+                                                  const T *pv, T *out, hipStream_t s)
+{
+    WaferLdsOpts o = wafer_lds_opts();
+    // Defaults measured at 512^3 fp64 (profiles/r01_sweep_f_512_fused.jsonl):
+    //   ext 1: 128x16 tiles (8 main waves + halo-row + halo-column wave = 640 threads), a and b
+    //          formed from V -- 0.369 ms/step; the taller tile halves the halo-row overhead
+    //          (phi0 20/16, V 18/16 rows per 16) and 147 VGPRs still fit 10 waves per CU.
+    //          Streaming a, b instead needs 168+ VGPRs at that size and spills.
+    //   ext 2: 128x8 tiles, a and b streamed (the kernel is issue-bound there; a second division
+    //          per update costs more than the extra stream).
+    // Ordinary (cache-retaining) loads: the halo-row wave re-reads rows its neighbour tile streams.
+    const char *e = getenv("WAFER_F2_NW2");
+    int nw2 = (e && *e) ? atoi(e) : ((R == 1 && a.g.ny >= 16) ? 8 : 4);
+    if (o.abv < 0) o.abv = (nw2 == 8) ? 1 : 0;
+    e = getenv("WAFER_NT");
+    if (!(e && *e)) o.nt = 0;
+    if (nw2 == 8) return wafer_launch_step2_fused_nw<T, C, R, 8>(a, o, phi, pa, pb, pv, out, s);
+    if (nw2 == 6) return wafer_launch_step2_fused_nw<T, C, R, 6>(a, o, phi, pa, pb, pv, out, s);
+    return wafer_launch_step2_fused_nw<T, C, R, 4>(a, o, phi, pa, pb, pv, out, s);
 }

@@ -158,20 +158,18 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     const int zs = a.lz_lo + tz_i * a.zchunk;
     const int ze = min(zs + a.zchunk, a.lz_hi);
 
-    // a lane's aligned VEC group lies inside the row allocation iff xi < wlim
-    const int wlim = g.pitch - g.xoff - R;
-    const bool xin = xi < wlim;
-    bool rowin[RY];
+    // Loads carry no bounds predicates: whole tiles, R halo rows / columns and the planes just
+    // outside the slab lie in the allocation's zero guard zone (wafer_geom.h).
+    bool rowin[RY];       // the row is a work row (wave-uniform)
     long long rowoff[RY]; // element offset of (row r, lane's first cell) inside a plane
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
         const int y = y0 + yl + r;
-        rowin[r] = xin && (y < g.ny);
+        rowin[r] = y < g.ny;
         rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + xi;
     }
 
     // halo rows this wave fetches: halo row h in [0,2R): h<R is row y0-R+h, else row y0+TY+(h-R)
-    bool hrow_in[Cfg::HALO_ROWS_PER_WAVE];
     long long hrow_off[Cfg::HALO_ROWS_PER_WAVE];
     int hrow_lds[Cfg::HALO_ROWS_PER_WAVE];
 #pragma unroll
@@ -179,22 +177,19 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
         const int h = wave + q * Cfg::NW;
         const int ly = (h < R) ? h : TY + h;          // LDS row (0..R-1 above, TY+R.. below)
         const int yp = y0 + ly;                        // padded y (= work y - R + R)
-        hrow_in[q] = (h < 2 * R) && xin && (yp < g.py);
         hrow_off[q] = (long long)yp * g.pitch + g.xoff + R + xi;
         hrow_lds[q] = ly * LP + HX + xl;
     }
     // halo-column cells: cell c in [0, 2R*TY): row = c / (2R), k = c % (2R);
     // k<R: column x0-1-k, else column x0+TX+(k-R)
-    bool hcol_in[Cfg::HALO_X_ITERS];
     long long hcol_off[Cfg::HALO_X_ITERS];
     int hcol_lds[Cfg::HALO_X_ITERS];
 #pragma unroll
     for (int q = 0; q < Cfg::HALO_X_ITERS; ++q) {
-        const int cidx = tid + q * 256;
+        const int cidx = min(tid + q * 256, Cfg::NHALO_X - 1);     // surplus lanes repeat the last cell
         const int row = cidx / (2 * R), k = cidx % (2 * R);
         const int xw = (k < R) ? (x0 - 1 - k) : (x0 + TX + (k - R)); // work x, may be -R..nx+R-1
         const int y = y0 + row;
-        hcol_in[q] = (cidx < Cfg::NHALO_X) && (y < g.ny) && (xw + R >= 0) && (xw + R < g.px);
         hcol_off[q] = (long long)(y + R) * g.pitch + g.xoff + R + xw;
         hcol_lds[q] = (row + R) * LP + ((k < R) ? (HX - 1 - k) : (HX + TX + (k - R)));
     }
@@ -210,13 +205,13 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     for (int m = 0; m <= 2 * R; ++m)
 #pragma unroll
         for (int r = 0; r < RY; ++r)
-            q[m][r] = rowin[r] ? *reinterpret_cast<const VT *>(phi + (long long)(zs - R + m) * g.plane + rowoff[r]) : zero;
+            q[m][r] = *reinterpret_cast<const VT *>(phi + (long long)(zs - R + m) * g.plane + rowoff[r]);
     VT ab_a[RY], ab_b[RY];
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-        ab_a[r] = rowin[r] ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + (long long)zs * g.plane + rowoff[r])) : zero;
+        ab_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + (long long)zs * g.plane + rowoff[r]));
         if constexpr (!ABV)
-            ab_b[r] = rowin[r] ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + (long long)zs * g.plane + rowoff[r])) : zero;
+            ab_b[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + (long long)zs * g.plane + rowoff[r]));
     }
     {
         T *tile = lds + (zs & 1) * Cfg::TILE;
@@ -226,24 +221,22 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
             if (wave + qq * Cfg::NW < 2 * R)
-                *reinterpret_cast<VT *>(tile + hrow_lds[qq]) =
-                    hrow_in[qq] ? *reinterpret_cast<const VT *>(phi + (long long)zs * g.plane + hrow_off[qq]) : zero;
+                *reinterpret_cast<VT *>(tile + hrow_lds[qq]) = *reinterpret_cast<const VT *>(phi + (long long)zs * g.plane + hrow_off[qq]);
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
             if (tid + qq * 256 < Cfg::NHALO_X)
-                tile[hcol_lds[qq]] = hcol_in[qq] ? phi[(long long)zs * g.plane + hcol_off[qq]] : T(0);
+                tile[hcol_lds[qq]] = phi[(long long)zs * g.plane + hcol_off[qq]];
     }
     // halo of plane zs+1, held in registers until it is written at iteration zs
     VT hrow_nxt[Cfg::HALO_ROWS_PER_WAVE];
     T hcol_nxt[Cfg::HALO_X_ITERS];
     {
-        const bool more = zs + 1 < ze;
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
-            hrow_nxt[qq] = (more && hrow_in[qq]) ? *reinterpret_cast<const VT *>(phi + (long long)(zs + 1) * g.plane + hrow_off[qq]) : zero;
+            hrow_nxt[qq] = *reinterpret_cast<const VT *>(phi + (long long)(zs + 1) * g.plane + hrow_off[qq]);
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
-            hcol_nxt[qq] = (more && hcol_in[qq]) ? phi[(long long)(zs + 1) * g.plane + hcol_off[qq]] : T(0);
+            hcol_nxt[qq] = phi[(long long)(zs + 1) * g.plane + hcol_off[qq]];
     }
     __syncthreads();
 
@@ -253,7 +246,6 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     for (int j = 0; j < NL; ++j) acc_t[j] = 0.0;
     for (int z = zs; z < ze; ++z) {
         const bool more = z + 1 < ze;   // wave-uniform
-        const bool more2 = z + 2 < ze;
         const long long zo = (long long)z * g.plane;
         // ---- 1. prefetch: phi plane z+R+1, a/b plane z+1, halo of plane z+2
         VT pre[RY], pre_a[RY], pre_b[RY];
@@ -261,18 +253,16 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
         T hcol_pre[Cfg::HALO_X_ITERS];
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            const bool ld = more && rowin[r];
-            pre[r] = ld ? *reinterpret_cast<const VT *>(phi + zo + (long long)(R + 1) * g.plane + rowoff[r]) : zero;
-            pre_a[r] = ld ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r])) : zero;
-            if constexpr (!ABV)
-                pre_b[r] = ld ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + zo + g.plane + rowoff[r])) : zero;
+            pre[r] = *reinterpret_cast<const VT *>(phi + zo + (long long)(R + 1) * g.plane + rowoff[r]);
+            pre_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]));
+            if constexpr (!ABV) pre_b[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + zo + g.plane + rowoff[r]));
         }
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
-            hrow_pre[qq] = (more2 && hrow_in[qq]) ? *reinterpret_cast<const VT *>(phi + zo + 2 * g.plane + hrow_off[qq]) : zero;
+            hrow_pre[qq] = *reinterpret_cast<const VT *>(phi + zo + 2 * g.plane + hrow_off[qq]);
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
-            hcol_pre[qq] = (more2 && hcol_in[qq]) ? phi[zo + 2 * g.plane + hcol_off[qq]] : T(0);
+            hcol_pre[qq] = phi[zo + 2 * g.plane + hcol_off[qq]];
 
         // stored states at this plane (only the cells this lane updates)
         VT lw[NL > 0 ? NL : 1][RY];
@@ -280,7 +270,7 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
         for (int j = 0; j < NL; ++j)
 #pragma unroll
             for (int r = 0; r < RY; ++r)
-                lw[j][r] = rowin[r] ? wafer_ld_stream<NT>(reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + zo + rowoff[r])) : zero;
+                lw[j][r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + zo + rowoff[r]));
         // ---- 2. stage plane z+1 into the other LDS buffer
         if (more) {
             T *nt = lds + ((z + 1) & 1) * Cfg::TILE;
