@@ -1,0 +1,125 @@
+//! Raw FFI to `libwafer_hip.so` (`include/wafer_hip.h`, ABI version 1) plus a thin safe wrapper
+//! with the call shapes of Wafer's `grid.rs`.
+//!
+//! UNTESTED: no Rust toolchain exists in the image this engine was built in.  Struct layouts and
+//! signatures mirror the C header field for field; `tests/test_abi.py` checks the same layout from
+//! the Python side.
+#![allow(non_camel_case_types)]
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct wafer_params {
+    pub struct_size: u32,
+    pub nx: u32,
+    pub ny: u32,
+    pub nz: u32,
+    pub central_difference: i32, // CentralDifference::ext(): 1 | 2 | 3
+    pub dtype: i32,              // 0 = f64, 1 = f32 storage
+    pub dn: f64,
+    pub dt: f64,
+    pub mass: f64,
+    pub sig: f64,
+    pub max_states: u32,
+    pub device: i32,
+    pub z_begin: u32,
+    pub z_count: u32,
+    pub halo_depth: u32,
+    pub flags: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct wafer_observables_t {
+    pub energy: f64,
+    pub norm2: f64,
+    pub v_infinity: f64,
+    pub r2: f64,
+}
+
+pub enum wafer_ctx {}
+
+pub type wafer_halo_fn = extern "C" fn(*mut c_void, *mut c_void, *mut c_void, *mut c_void, *mut c_void, usize, *mut c_void) -> c_int;
+pub type wafer_allreduce_fn = extern "C" fn(*mut c_void, *mut c_void, usize, *mut c_void) -> c_int;
+
+extern "C" {
+    pub fn wafer_abi_version() -> c_int;
+    pub fn wafer_last_error() -> *const c_char;
+    pub fn wafer_ctx_create(p: *const wafer_params, out: *mut *mut wafer_ctx) -> c_int;
+    pub fn wafer_ctx_destroy(ctx: *mut wafer_ctx) -> c_int;
+    pub fn wafer_synchronize(ctx: *mut wafer_ctx) -> c_int;
+    pub fn wafer_set_potential_builtin(ctx: *mut wafer_ctx, potential: c_int) -> c_int;
+    pub fn wafer_set_potential_host(ctx: *mut wafer_ctx, v: *const f64, potsub_kind: c_int, potsub_scalar: f64, potsub: *const f64) -> c_int;
+    pub fn wafer_set_initial_condition(ctx: *mut wafer_ctx, ic: c_int, seed: u64) -> c_int;
+    pub fn wafer_upload_phi(ctx: *mut wafer_ctx, phi: *const f64) -> c_int;
+    pub fn wafer_download_phi(ctx: *mut wafer_ctx, phi: *mut f64) -> c_int;
+    pub fn wafer_upload_phi_resampled(ctx: *mut wafer_ctx, src: *const f64, sx: u32, sy: u32, sz: u32, basis: *const u32) -> c_int;
+    pub fn wafer_evolve(ctx: *mut wafer_ctx, wnum: u32, n_steps: u64) -> c_int;
+    pub fn wafer_observables(ctx: *mut wafer_ctx, out: *mut wafer_observables_t) -> c_int;
+    pub fn wafer_norm2(ctx: *mut wafer_ctx, out: *mut f64) -> c_int;
+    pub fn wafer_normalise(ctx: *mut wafer_ctx, norm2: f64) -> c_int;
+    pub fn wafer_orthogonalise(ctx: *mut wafer_ctx, wnum: u32) -> c_int;
+    pub fn wafer_push_state(ctx: *mut wafer_ctx) -> c_int;
+    pub fn wafer_load_state(ctx: *mut wafer_ctx, idx: u32, state: *const f64) -> c_int;
+    pub fn wafer_clone_state_to_phi(ctx: *mut wafer_ctx, idx: u32) -> c_int;
+    pub fn wafer_set_comm_hooks(ctx: *mut wafer_ctx, halo: wafer_halo_fn, allreduce: wafer_allreduce_fn, user: *mut c_void) -> c_int;
+}
+
+/// `Err(message)` for any non-zero status; a Wafer integration maps it to an `ErrorKind`.
+pub fn check(rc: c_int) -> Result<(), String> {
+    if rc == 0 {
+        return Ok(());
+    }
+    let msg = unsafe { CStr::from_ptr(wafer_last_error()) }.to_string_lossy().into_owned();
+    Err(format!("wafer_hip error {}: {}", rc, msg))
+}
+
+/// Device-resident solver state; method names follow `grid.rs`.
+pub struct Engine {
+    ctx: *mut wafer_ctx,
+}
+
+impl Engine {
+    pub fn new(mut p: wafer_params) -> Result<Engine, String> {
+        p.struct_size = std::mem::size_of::<wafer_params>() as u32;
+        let mut ctx: *mut wafer_ctx = std::ptr::null_mut();
+        check(unsafe { wafer_ctx_create(&p, &mut ctx) })?;
+        Ok(Engine { ctx })
+    }
+    /// grid.rs:544-687
+    pub fn evolve(&mut self, wnum: u8, steps: u64) -> Result<(), String> {
+        check(unsafe { wafer_evolve(self.ctx, wnum as u32, steps) })
+    }
+    /// grid.rs:303-445
+    pub fn compute_observables(&mut self) -> Result<wafer_observables_t, String> {
+        let mut o = wafer_observables_t::default();
+        check(unsafe { wafer_observables(self.ctx, &mut o) })?;
+        Ok(o)
+    }
+    /// grid.rs:465-468
+    pub fn normalise_wavefunction(&mut self, norm2: f64) -> Result<(), String> {
+        check(unsafe { wafer_normalise(self.ctx, norm2) })
+    }
+    /// grid.rs:477-492
+    pub fn orthogonalise_wavefunction(&mut self, wnum: u8) -> Result<(), String> {
+        check(unsafe { wafer_orthogonalise(self.ctx, wnum as u32) })
+    }
+    /// `phi` is ndarray's standard-layout `Array3<R64>` storage, `(nx+bb, ny+bb, nz+bb)`.
+    pub fn upload_phi(&mut self, phi: &[f64]) -> Result<(), String> {
+        check(unsafe { wafer_upload_phi(self.ctx, phi.as_ptr()) })
+    }
+    pub fn download_phi(&mut self, phi: &mut [f64]) -> Result<(), String> {
+        check(unsafe { wafer_download_phi(self.ctx, phi.as_mut_ptr()) })
+    }
+    /// grid.rs:241
+    pub fn push_state(&mut self) -> Result<(), String> {
+        check(unsafe { wafer_push_state(self.ctx) })
+    }
+}
+
+impl Drop for Engine {
+    fn drop(&mut self) {
+        unsafe { wafer_ctx_destroy(self.ctx) };
+    }
+}

@@ -1,0 +1,60 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/wafer_hip.h
+declares; struct layouts of the bindings (Python ctypes, and the Rust source in bindings/rust)
+match the header.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import wafer_amd
+    return wafer_amd.load_library()
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "wafer_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wafer_[a-z0-9_]+)\s*\(", text)) - {"wafer_halo_fn", "wafer_allreduce_fn"})
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = header_functions()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/wafer_hip.h but not exported"
+    import wafer_amd.engine as eng
+    assert sorted(eng.EXPORTS) == names   # the ctypes mirror binds exactly the header's surface
+
+
+def test_abi_version_and_struct_layout(lib):
+    from wafer_amd.engine import _Params, _Obs, _Record, _ObsOut, _SlabInfo
+    assert lib.wafer_abi_version() == 1
+    # wafer_params: 4 u32, 2 i32, 4 f64, u32, i32, 4 u32 -> 24 + 32 + 24 = 80 bytes, 8-byte aligned
+    assert C.sizeof(_Params) == 80 and _Params.dn.offset == 24 and _Params.max_states.offset == 56
+    assert C.sizeof(_Obs) == 32 and C.sizeof(_Record) == 56 and C.sizeof(_ObsOut) == 40 and C.sizeof(_SlabInfo) == 32
+    rust = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    fields = re.findall(r"pub (\w+): (u32|i32|f64),", rust.split("pub struct wafer_params")[1].split("}")[0])
+    assert [f for f, _ in fields] == [n for n, _ in _Params._fields_]
+    ctype = {"u32": C.c_uint32, "i32": C.c_int32, "f64": C.c_double}
+    assert [ctype[t] for _, t in fields] == [t for _, t in _Params._fields_]
+
+
+def test_context_creation_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import wafer_amd
+    with pytest.raises(wafer_amd.WaferError) as e:
+        wafer_amd.Context(wafer_amd.Params(8, 8, 8, dn=0.1, dt=1e-3))
+    assert e.value.code == -2   # WAFER_ERR_HIP: there is no CPU path
+    with pytest.raises(wafer_amd.WaferError):   # ABI guard
+        p = wafer_amd.Params(8, 8, 8, dn=0.1, dt=1e-3).c()
+        p.struct_size = 12
+        h = C.c_void_p()
+        rc = lib.wafer_ctx_create(C.byref(p), C.byref(h))
+        raise wafer_amd.WaferError(rc, lib.wafer_last_error().decode()) if rc else AssertionError("accepted")

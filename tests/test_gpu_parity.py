@@ -511,6 +511,24 @@ def test_f32_path_tracks_f64(wo, wa):
     assert res["f64"][1] == pytest.approx(1.0, abs=1e-12)
 
 
+def test_f32_excited_state_path(wa):
+    """fp32 storage through the fused excited-state step (raw overlaps + one apply pass)"""
+    res = {}
+    for dtype in ("f64", "f32"):
+        _, par = make_pair((40, 36, 44), ext=1, potential="Harmonic", dn=0.3, dt=0.018, dtype=dtype, max_states=2)
+        with wa.Context(par) as ctx:
+            ctx.set_potential("Harmonic")
+            ctx.set_initial_condition("Gaussian", seed=5)
+            _, f0, c0 = ctx.solve_state(0, 1e-7, 100, max_steps=40000)
+            ctx.set_initial_condition("Gaussian", seed=6)
+            _, f1, c1 = ctx.solve_state(1, 1e-7, 100, max_steps=40000)
+            assert c0 and c1
+            res[dtype] = (f0["energy"], f1["energy"])
+    assert res["f32"][0] == pytest.approx(res["f64"][0], rel=1e-5)
+    assert res["f32"][1] == pytest.approx(res["f64"][1], rel=2e-5)
+    assert res["f64"][1] == pytest.approx(2.5, abs=0.05)
+
+
 # ---------------------------------------------------------------- full BASELINE size
 @pytest.mark.skipif(os.environ.get("WAFER_SKIP_BIG") == "1", reason="WAFER_SKIP_BIG=1")
 def test_full_size_512_properties(wa):
