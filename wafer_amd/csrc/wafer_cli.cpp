@@ -560,9 +560,13 @@ int main(int argc, char **argv)
         CsvArray start;   // wavefunction_N, else wavefunction_N_partial (input.rs:513-523)
         const bool from_disk = read_csv_array(input_dir + "/wavefunction_" + std::to_string(wnum) + ".csv", start, err) ||
                                read_csv_array(input_dir + "/wavefunction_" + std::to_string(wnum) + "_partial.csv", start, err);
+        bool cloned = false;
         if (wnum > 0) {
             if (from_disk) CHECK(upload_field(ctx, cfg, start, 0));
-            else CHECK(wafer_clone_state_to_phi(ctx, wnum - 1));
+            else {
+                CHECK(wafer_clone_state_to_phi(ctx, wnum - 1));
+                cloned = true;
+            }
         } else if (cfg.init_condition == WAFER_IC_FROMFILE) {
             if (!from_disk) { fprintf(stderr, "Error: SetInitialConditions: LoadWavefunction(0): %s\n", err.c_str()); return 1; }
             CHECK(upload_field(ctx, cfg, start, 0));
@@ -583,6 +587,23 @@ int main(int argc, char **argv)
             const double tau = (double)step * cfg.dt;
             CHECK(wafer_normalise(ctx, obs.norm2));
             if (wnum > 0) CHECK(wafer_orthogonalise(ctx, wnum));
+            if (wnum > 0 && step == 0 && cloned) {
+                // The reference starts an excited state from a CLONE of the previous one (grid.rs:95)
+                // and lets Gram-Schmidt reduce it to rounding noise.  With this engine's deterministic
+                // sums the overlap can round to exactly 1 and the state to exactly 0 (then 0/0 = NaN on
+                // the next normalise; the reference's debug build would panic in R64).  Seed with noise
+                // instead of spinning on NaNs.
+                double n2 = 0.0;
+                CHECK(wafer_norm2(ctx, &n2));
+                if (!(n2 > 0.0) || !std::isfinite(n2)) {
+                    fprintf(stderr, "Warning: the clone of state %u was annihilated exactly by Gram-Schmidt; "
+                                    "starting state %u from Gaussian noise instead.\n", wnum - 1, wnum);
+                    CHECK(wafer_set_initial_condition(ctx, WAFER_IC_GAUSSIAN, 0x5eedULL + wnum));
+                    cloned = false;
+                    last_energy = 1.7976931348623157e308;
+                    continue;
+                }
+            }
             if (cfg.has_snap_update && step % cfg.snap_update == 0) { // grid.rs:137-158, WITHOUT its second, stale-norm2 normalise
                 host.resize(padded_len);
                 CHECK(wafer_download_phi(ctx, host.data()));

@@ -337,9 +337,13 @@ static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
         a.target_blocks = c->num_cus;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
-        if (wafer_launch_step2_fused<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->a), as<T>(c->b), as<T>(c->v), as<T>(c->phi[dst]), s) != hipSuccess)
-            return fail(WAFER_ERR_HIP, "fused stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
-        return (int)WAFER_OK;
+        if constexpr (R <= 2) { // ext 3 spills registers in this kernel and is never dispatched to it
+            if (wafer_launch_step2_fused<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->a), as<T>(c->b), as<T>(c->v), as<T>(c->phi[dst]), s) != hipSuccess)
+                return fail(WAFER_ERR_HIP, "fused stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return (int)WAFER_OK;
+        } else {
+            return fail(WAFER_ERR_INVALID, "the fused two-step kernel is not built for SevenPoint");
+        }
     });
 }
 

@@ -501,7 +501,8 @@ static inline hipError_t wafer_launch_step2_fused(WaferStepArgs a, const T *phi,
     if (o.abv < 0) o.abv = (nw2 == 8) ? 1 : 0;
     e = getenv("WAFER_NT");
     if (!(e && *e)) o.nt = 0;
-    if (nw2 == 8) return wafer_launch_step2_fused_nw<T, C, R, 8>(a, o, phi, pa, pb, pv, out, s);
-    if (nw2 == 6) return wafer_launch_step2_fused_nw<T, C, R, 6>(a, o, phi, pa, pb, pv, out, s);
+    if constexpr (R == 1) {
+        if (nw2 == 8) return wafer_launch_step2_fused_nw<T, C, R, 8>(a, o, phi, pa, pb, pv, out, s);
+    }
     return wafer_launch_step2_fused_nw<T, C, R, 4>(a, o, phi, pa, pb, pv, out, s);
 }
