@@ -413,6 +413,29 @@ def test_excited_state_evolve_nonorthogonal_store(wo, wa, wnum):
         assert ctx.norm2() == pytest.approx(wo.norm2(cfg, phi), rel=1e-11)
 
 
+@pytest.mark.parametrize("ext", [1, 2, 3])
+@pytest.mark.parametrize("wnum", [1, 3, 4])
+def test_one_pass_excited_step_equals_two_pass(wa, wnum, ext, monkeypatch):
+    """the one-pass excited-state step (previous raw result normalised and projected on load)
+    performs the two-pass scheme's operations on the same operands: identical bits"""
+    shape = (70, 21, 19)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("WAFER_ONE_PASS", mode)
+        par = wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, max_states=4)
+        with wa.Context(par) as ctx:
+            ctx.set_potential("Coulomb")
+            for i in range(wnum):
+                ctx.set_initial_condition("Gaussian", seed=80 + i)
+                ctx.normalise(ctx.norm2())
+                ctx.push_state()
+            ctx.set_initial_condition("Gaussian", seed=90)
+            ctx.evolve(wnum, 7)
+            ctx.evolve(wnum, 1)
+            out[mode] = (ctx.download_phi(), ctx.norm2())
+    assert np.array_equal(out["0"][0], out["1"][0]) and out["0"][1] == out["1"][1]
+
+
 def test_solve_matches_oracle(wo, wa):
     """grid.rs:50-246: same block table (step, tau, E, diff) and stop step for the
     ground state and two excited states.  Excited states start here from a fresh

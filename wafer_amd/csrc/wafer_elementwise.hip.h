@@ -215,6 +215,14 @@ __global__ __launch_bounds__(256) void wafer_k_gs_apply(WaferRowArgs a, T *__res
     }
 }
 
+// scal[0] = 1, scal[1..n) = 0: the scalars for which the load transform / wafer_k_gs_apply is the
+// identity (x/1 - l*0), i.e. "phi is already normalised and projected"
+__global__ void wafer_k_identity_scalars(double *__restrict__ scal, int n)
+{
+    const int i = threadIdx.x;
+    if (i < n) scal[i] = (i == 0) ? 1.0 : 0.0;
+}
+
 // ---------------------------------------------------------------------------
 // Diagnostics: flat streaming kernels over the same buffers, to measure the
 // HBM ceiling of this device for (a) a copy and (b) the stencil's stream mix

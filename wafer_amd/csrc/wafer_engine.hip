@@ -453,11 +453,12 @@ static int recompute_gram(wafer_ctx *c)
     return WAFER_OK;
 }
 
-// one excited-state step with everything fused that can be (wnum <= WAFER_MAX_LOW):
-//   pass 1  phi' = step(phi), sum phi'^2, t_j = sum l_j phi'        (reads phi, V, l_0..l_{k-1})
-//   reduce  1 + k scalars (one all-reduce when sharded)
-//   pass 2  phi = phi'/norm - sum_j l_j s_j                          (reads phi', l_0..l_{k-1})
-static int excited_step_fused(wafer_ctx *c, int src, int dst, uint32_t wnum, hipStream_t s)
+// Excited-state steps with everything fused that can be (wnum <= WAFER_MAX_LOW).
+//   step kernel  phi' = step(x), sum phi'^2, t_j = sum l_j phi'   with x = phi (two-pass mode) or
+//                x = raw/norm - sum_j l_j s_j formed on load from the previous raw step (one-pass mode)
+//   reduce       1 + k scalars (one all-reduce when sharded)
+//   apply        phi = phi'/norm - sum_j l_j s_j: after every step (two-pass), or once at the end
+static int excited_step_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bool transform_on_load, hipStream_t s)
 {
     const WaferGeom &g = c->g;
     const int lo = g.G, hi = g.G + g.nzl;
@@ -476,16 +477,27 @@ static int excited_step_fused(wafer_ctx *c, int src, int dst, uint32_t wnum, hip
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
         if (wafer_launch_step_lds_excited<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->v), as<T>(c->phi[dst]), c->partials,
-                                                   c->partials_stride, (int)wnum, low, s) != hipSuccess)
+                                                   c->partials_stride, (int)wnum, low, s,
+                                                   transform_on_load ? c->scal : nullptr, c->gram) != hipSuccess)
             return fail(WAFER_ERR_HIP, "excited-state stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
         const long long nb = wafer_step_lds_excited_blocks<T, R>(g, lo, hi, c->num_cus);
-        TRY(reduce_to_scal(c, 1 + (int)wnum, nb, 0, s));
+        return reduce_to_scal(c, 1 + (int)wnum, nb, 0, s);
+    });
+}
+
+static int excited_apply(wafer_ctx *c, int buf, uint32_t wnum, hipStream_t s)
+{
+    WaferLowPtrs low;
+    for (uint32_t j = 0; j < wnum; ++j) low.p[j] = c->states[j];
+    return dispatch(c, [&](auto t, auto cc, auto) {
+        using T = decltype(t);
+        using C = decltype(cc);
         WaferRowArgs ra;
-        ra.g = g;
-        ra.lz_lo = lo;
-        ra.lz_hi = hi;
+        ra.g = c->g;
+        ra.lz_lo = c->g.G;
+        ra.lz_hi = c->g.G + c->g.nzl;
         const dim3 grid(c->num_cus * 8), block(256);
-        T *p = as<T>(c->phi[dst]);
+        T *p = as<T>(c->phi[buf]);
         switch (wnum) {
         case 1: hipLaunchKernelGGL((wafer_k_gs_apply<T, C, 1>), grid, block, 0, s, ra, p, low, c->scal, c->gram); break;
         case 2: hipLaunchKernelGGL((wafer_k_gs_apply<T, C, 2>), grid, block, 0, s, ra, p, low, c->scal, c->gram); break;
@@ -948,9 +960,17 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
         } else {
             // step + sum phi'^2 (grid.rs:675-678), normalise (:679), Gram-Schmidt (:680)
             if (wnum <= WAFER_MAX_LOW && active_variant(c) >= 1) {
-                TRY(excited_step_fused(c, src, dst, wnum, c->s_main));
-                TRY(exchange_halo(c, dst, c->s_main, R));
-                c->halo_valid = R;
+                // one pass per step: the raw result travels to the next step, which normalises and
+                // projects it on load; phi is materialised once after the last step
+                const bool one_pass = env_int("WAFER_ONE_PASS", 1) != 0;
+                if (one_pass && s == 0) {
+                    hipLaunchKernelGGL(wafer_k_identity_scalars, dim3(1), dim3(64), 0, c->s_main, c->scal, 1 + (int)wnum);
+                    HIP_TRY(hipGetLastError());
+                }
+                TRY(excited_step_launch(c, src, dst, wnum, one_pass, c->s_main));
+                if (!one_pass || s + 1 == steps) TRY(excited_apply(c, dst, wnum, c->s_main));
+                if (s + 1 < steps || !one_pass) TRY(exchange_halo(c, dst, c->s_main, R));
+                c->halo_valid = (one_pass && s + 1 == steps) ? 0 : R;
                 c->cur = dst;
                 s += 1;
                 continue;
@@ -1099,6 +1119,7 @@ int wafer_push_state(wafer_ctx *c)
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
     if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
     HIP_TRY(hipSetDevice(c->P.device));
+    TRY(ensure_halo(c, c->g.R)); // the one-pass excited step reads stored states on ghost planes
     void *slot = nullptr;
     TRY(new_state_slot(c, &slot));
     HIP_TRY(hipMemcpyAsync(alloc_base(c, slot), alloc_base(c, c->phi[c->cur]), (size_t)c->g.total * c->esz, hipMemcpyDeviceToDevice, c->s_main));

@@ -117,16 +117,24 @@ __device__ __forceinline__ void wafer_st_stream(VT *p, VT v)
 // sum(phi'^2) (grid.rs:675-678) and the raw overlaps t_j = sum(l_j * phi') with
 // NLOW stored states in the same pass (partials[q * pstride + workgroup]),
 // from which wafer_k_gs_apply forms the modified Gram-Schmidt coefficients.
-template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV>
+// XF (excited states only): `phi` holds the RAW result of the previous step (un-normalised,
+// un-projected) and every cell is normalised and Gram-Schmidt-projected as it is loaded,
+//   x = phi/norm - sum_j l_j s_j        (grid.rs:467, 488-490; the operations of wafer_k_gs_apply)
+// with norm and s_j formed from the previous step's scalars xscal[0..NLOW] and the Gram matrix.
+// That folds the apply pass into the next step: (3+k)*8 B per update instead of (5+2k)*8 B.
+template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false>
 __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty, int swz,
                                                         const T *__restrict__ phi,
                                                         const T *__restrict__ pa,
                                                         const T *__restrict__ pb, T *__restrict__ out,
                                                         double *__restrict__ partials, long long pstride,
-                                                        WaferLowPtrs low)
+                                                        WaferLowPtrs low,
+                                                        const double *__restrict__ xscal = nullptr,
+                                                        const double *__restrict__ xgram = nullptr)
 {
     constexpr bool NORM = NLOW >= 0;
     constexpr int NL = NLOW > 0 ? NLOW : 0;
+    static_assert(!XF || NL > 0, "transform-on-load needs stored states");
     using Cfg = WaferLdsCfg<T, R, RY>;
     using VT = typename WaferVec<T>::type;
     constexpr int VEC = Cfg::VEC, TX = Cfg::TX, TY = Cfg::TY, HX = Cfg::HX, LP = Cfg::LP;
@@ -199,13 +207,69 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
 #pragma unroll
     for (int v = 0; v < VEC; ++v) zero[v] = T(0);
 
+    // ---- transform-on-load coefficients (XF) -------------------------------------------------
+    C xnorm = C(1);
+    C xsj[NL > 0 ? NL : 1];
+    if constexpr (XF) {
+        xnorm = (C)sqrt(xscal[0]);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            double sj = xscal[1 + j] / (double)xnorm;
+#pragma unroll
+            for (int i = 0; i < j; ++i) sj -= (double)xsj[i] * xgram[j * WAFER_MAX_LOW + i];
+            xsj[j] = (C)sj;
+        }
+    }
+    // loads one VEC group / one cell of phi at element offset `off`, transformed if XF;
+    // lkeep (may be null) receives the stored states' values at the same cells
+    auto load_vec = [&](long long off, VT *lkeep) -> VT {
+        VT w = *reinterpret_cast<const VT *>(phi + off);
+        if constexpr (XF) {
+            VT l[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) l[j] = *reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + off);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                C x = (C)w[v] / xnorm;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) x = x - (C)l[j][v] * xsj[j];
+                w[v] = (T)x;
+            }
+            if (lkeep) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) lkeep[j] = l[j];
+            }
+        }
+        return w;
+    };
+    auto load_cell = [&](long long off) -> T {
+        T w = phi[off];
+        if constexpr (XF) {
+            C x = (C)w / xnorm;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) x = x - (C)static_cast<const T *>(low.p[j])[off] * xsj[j];
+            w = (T)x;
+        }
+        return w;
+    };
+
     // ---- prologue: z-queue for plane zs, LDS tile of plane zs, prefetches
     VT q[2 * R + 1][RY];
+    // XF: stored states at the lane's own cells, planes z .. z+R (+ prefetch), for the overlaps
+    VT lq[XF ? R + 2 : 1][RY][NL > 0 ? NL : 1];
 #pragma unroll
     for (int m = 0; m <= 2 * R; ++m)
 #pragma unroll
-        for (int r = 0; r < RY; ++r)
-            q[m][r] = *reinterpret_cast<const VT *>(phi + (long long)(zs - R + m) * g.plane + rowoff[r]);
+        for (int r = 0; r < RY; ++r) {
+            VT keep[NL > 0 ? NL : 1];
+            q[m][r] = load_vec((long long)(zs - R + m) * g.plane + rowoff[r], (XF && m >= R) ? keep : nullptr);
+            if constexpr (XF) {
+                if (m >= R) {
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) lq[m - R][r][j] = keep[j];
+                }
+            }
+        }
     VT ab_a[RY], ab_b[RY];
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
@@ -221,11 +285,11 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
             if (wave + qq * Cfg::NW < 2 * R)
-                *reinterpret_cast<VT *>(tile + hrow_lds[qq]) = *reinterpret_cast<const VT *>(phi + (long long)zs * g.plane + hrow_off[qq]);
+                *reinterpret_cast<VT *>(tile + hrow_lds[qq]) = load_vec((long long)zs * g.plane + hrow_off[qq], nullptr);
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
             if (tid + qq * 256 < Cfg::NHALO_X)
-                tile[hcol_lds[qq]] = phi[(long long)zs * g.plane + hcol_off[qq]];
+                tile[hcol_lds[qq]] = load_cell((long long)zs * g.plane + hcol_off[qq]);
     }
     // halo of plane zs+1, held in registers until it is written at iteration zs
     VT hrow_nxt[Cfg::HALO_ROWS_PER_WAVE];
@@ -233,10 +297,10 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     {
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
-            hrow_nxt[qq] = *reinterpret_cast<const VT *>(phi + (long long)(zs + 1) * g.plane + hrow_off[qq]);
+            hrow_nxt[qq] = load_vec((long long)(zs + 1) * g.plane + hrow_off[qq], nullptr);
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
-            hcol_nxt[qq] = phi[(long long)(zs + 1) * g.plane + hcol_off[qq]];
+            hcol_nxt[qq] = load_cell((long long)(zs + 1) * g.plane + hcol_off[qq]);
     }
     __syncthreads();
 
@@ -253,24 +317,33 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
         T hcol_pre[Cfg::HALO_X_ITERS];
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            pre[r] = *reinterpret_cast<const VT *>(phi + zo + (long long)(R + 1) * g.plane + rowoff[r]);
+            {
+                VT keep[NL > 0 ? NL : 1];
+                pre[r] = load_vec(zo + (long long)(R + 1) * g.plane + rowoff[r], XF ? keep : nullptr);
+                if constexpr (XF) {
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) lq[R + 1][r][j] = keep[j];
+                }
+            }
             pre_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]));
             if constexpr (!ABV) pre_b[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + zo + g.plane + rowoff[r]));
         }
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
-            hrow_pre[qq] = *reinterpret_cast<const VT *>(phi + zo + 2 * g.plane + hrow_off[qq]);
+            hrow_pre[qq] = load_vec(zo + 2 * g.plane + hrow_off[qq], nullptr);
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
-            hcol_pre[qq] = phi[zo + 2 * g.plane + hcol_off[qq]];
+            hcol_pre[qq] = load_cell(zo + 2 * g.plane + hcol_off[qq]);
 
         // stored states at this plane (only the cells this lane updates)
         VT lw[NL > 0 ? NL : 1][RY];
 #pragma unroll
         for (int j = 0; j < NL; ++j)
 #pragma unroll
-            for (int r = 0; r < RY; ++r)
-                lw[j][r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + zo + rowoff[r]));
+            for (int r = 0; r < RY; ++r) {
+                if constexpr (XF) lw[j][r] = lq[0][r][j];   // already loaded when the plane entered the pipeline
+                else lw[j][r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + zo + rowoff[r]));
+            }
         // ---- 2. stage plane z+1 into the other LDS buffer
         if (more) {
             T *nt = lds + ((z + 1) & 1) * Cfg::TILE;
@@ -354,6 +427,14 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) hrow_nxt[qq] = hrow_pre[qq];
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq) hcol_nxt[qq] = hcol_pre[qq];
+        if constexpr (XF) {
+#pragma unroll
+            for (int m = 0; m <= R; ++m)
+#pragma unroll
+                for (int r = 0; r < RY; ++r)
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) lq[m][r][j] = lq[m + 1][r][j];
+        }
     }
     if constexpr (NORM) {
         const double s = wafer_block_sum<4>(acc, red, tid);
@@ -366,11 +447,12 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     }
 }
 
-template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV>
+template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false>
 static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLdsOpts &o, const T *phi,
                                                   const T *pa, const T *pb, T *out, double *partials,
                                                   size_t partials_cap, hipStream_t s,
-                                                  const WaferLowPtrs &low = WaferLowPtrs())
+                                                  const WaferLowPtrs &low = WaferLowPtrs(),
+                                                  const double *xscal = nullptr, const double *xgram = nullptr)
 {
     using Cfg = WaferLdsCfg<T, R, RY>;
     const WaferGeom &g = a.g;
@@ -380,8 +462,8 @@ static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLd
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
     const long long nblocks = (long long)ntx * nty * ntz;
     if (NLOW >= 0 && (size_t)nblocks > partials_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NLOW, NT, ABV>), dim3((unsigned)nblocks), dim3(256), (size_t)o.pad, s,
-                       a, ntx, nty, o.swz, phi, pa, pb, out, partials, (long long)partials_cap, low);
+    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NLOW, NT, ABV, XF>), dim3((unsigned)nblocks), dim3(256), (size_t)o.pad, s,
+                       a, ntx, nty, o.swz, phi, pa, pb, out, partials, (long long)partials_cap, low, xscal, xgram);
     return hipGetLastError();
 }
 
@@ -389,10 +471,20 @@ static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLd
 template <typename T, typename C, int R>
 static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T *phi, const T *pv, T *out,
                                                        double *partials, size_t partials_cap, int nlow,
-                                                       const WaferLowPtrs &low, hipStream_t s)
+                                                       const WaferLowPtrs &low, hipStream_t s,
+                                                       const double *xscal = nullptr, const double *xgram = nullptr)
 {
     WaferLdsOpts o = wafer_lds_opts();
     o.ry = 2;
+    if (xscal) { // transform-on-load: phi is the raw previous step
+        switch (nlow) {
+        case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+        case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+        case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+        case 4: return wafer_launch_step_lds_ry<T, C, R, 2, 4, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (nlow) {
     case 0: return wafer_launch_step_lds_ry<T, C, R, 2, 0, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
     case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
