@@ -534,6 +534,29 @@ def test_f32_path_tracks_f64(wo, wa):
     assert res["f64"][1] == pytest.approx(1.0, abs=1e-12)
 
 
+def test_config5_flow_file_potential_fp32_vs_fp64(wa):
+    """BASELINE config #5 in miniature: a user potential given at low resolution (as a file would
+    hold it), trilinearly upsampled on the device (input.rs:667-716), solved with fp32 storage and
+    cross-checked against fp64: relative energy error <= 1e-5, |norm2 - 1| <= 1e-5."""
+    n_src, n = 16, 64
+    ax = (np.arange(n_src) - (n_src - 1) / 2) * (12.8 / n_src)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    src = np.ascontiguousarray(-3.0 / np.cosh(0.6 * np.sqrt(X * X + Y * Y + 2.0 * Z * Z)) ** 2)  # anisotropic Poschl-Teller well
+    res = {}
+    for dtype in ("f64", "f32"):
+        par = wa.Params(n, n, n, dn=0.2, dt=0.008, mass=1.0, dtype=dtype, max_states=1)
+        with wa.Context(par) as ctx:
+            ctx.set_potential_resampled(src)
+            ctx.set_initial_condition("Boolean")
+            recs, final, conv = ctx.solve_state(0, 1e-7, 200, max_steps=60000)
+            assert conv
+            ctx.clone_state_to_phi(0)
+            res[dtype] = (final["energy"], ctx.norm2())
+    assert res["f64"][0] < -0.5                      # bound state of the well
+    assert res["f32"][0] == pytest.approx(res["f64"][0], rel=1e-5)
+    assert res["f32"][1] == pytest.approx(1.0, abs=1e-5) and res["f64"][1] == pytest.approx(1.0, abs=1e-12)
+
+
 def test_f32_excited_state_path(wa):
     """fp32 storage through the fused excited-state step (raw overlaps + one apply pass)"""
     res = {}
