@@ -241,6 +241,28 @@ def test_fused_thousand_steps_64cubed(wo, wa):
         assert ulp_diff(ctx.download_phi(), phi) == 0
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_extreme_potential_takes_the_full_division(wo, wa, variant):
+    """a, b are formed from V in registers with a shortened reciprocal that is exact only for
+    2^-400 < |1 + dt V/2| < 2^400; the engine checks the potential and otherwise keeps the full
+    fp64 division.  A potential with 1 + dt V/2 = 2^-500 and 2^+600 cells must still match the
+    oracle bit for bit."""
+    cfg, par = make_pair((34, 20, 18), ext=1, dn=0.2, dt=0.004)
+    v = np.random.default_rng(3).standard_normal(cfg.padded_shape)
+    v[5, 6, 7] = (2.0 ** -500 - 1.0) * 2 / cfg.dt      # 1 + dt V/2 = 2^-500 (after rounding: tiny)
+    v[9, 3, 4] = (2.0 ** 600) * 2 / cfg.dt
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=21)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(variant)
+        ctx.set_potential_host(v)
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 4)
+        wo.evolve(cfg, 0, a, b, phi, [], 4)
+        got = ctx.download_phi()
+        assert np.array_equal(got, phi, equal_nan=True)
+
+
 def test_evolve_zero_steps_takes_one(wo, wa):
     """grid.rs:682-685"""
     cfg, par = make_pair((8, 8, 8))

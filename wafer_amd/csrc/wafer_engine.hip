@@ -100,6 +100,7 @@ struct wafer_ctx {
     int potsub_kind = WAFER_POTSUB_NONE;
     double potsub_scalar = 0.0;
     bool have_pot = false, have_phi = false;
+    bool v_in_range = false; // 2^-400 < |1 + dt*V/2| < 2^400 everywhere (wafer_recip's short form is exact)
 
     double *partials = nullptr; // [1 + WAFER_MAX_LOW][partials_stride]
     size_t partials_stride = 0;
@@ -173,6 +174,26 @@ static int alloc_grid_array(wafer_ctx *c, void **logical, hipStream_t s)
 }
 template <typename T>
 static inline const T *as(const void *p) { return static_cast<const T *>(p); }
+
+// after V changed: may the kernels that form a, b from V use the short reciprocal?
+static int check_v_range(wafer_ctx *c)
+{
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(c->scal + 16);
+    unsigned long long init[2] = {~0ull, 0ull}, got[2];
+    HIP_TRY(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, c->s_main));
+    if (c->f32)
+        hipLaunchKernelGGL((wafer_k_v_range<float>), dim3(c->num_cus * 4), dim3(256), 0, c->s_main, as<float>(alloc_base(c, c->v)), c->g.total, c->P.dt, d);
+    else
+        hipLaunchKernelGGL((wafer_k_v_range<double>), dim3(c->num_cus * 4), dim3(256), 0, c->s_main, as<double>(alloc_base(c, c->v)), c->g.total, c->P.dt, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(got, d, sizeof got, hipMemcpyDeviceToHost, c->s_main));
+    HIP_TRY(hipStreamSynchronize(c->s_main));
+    double lo, hi;
+    memcpy(&lo, &got[0], 8);
+    memcpy(&hi, &got[1], 8);
+    c->v_in_range = (lo > 0x1p-400) && (hi < 0x1p400); // a NaN anywhere makes hi a NaN: false
+    return WAFER_OK;
+}
 
 // second-stage reduce of `nq` quantities of `n` partials each into scal[slot..slot+nq)
 static int reduce_to_scal(wafer_ctx *c, int nq, long long n, int slot, hipStream_t s)
@@ -260,6 +281,7 @@ static int launch_step_t(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, h
     a.lz_hi = lz_hi;
     a.dt = c->P.dt;
     a.target_blocks = c->num_cus;
+    a.v_in_range = c->v_in_range ? 1 : 0;
     const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
     a.den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:569 / 594 / 626
     const T *phi = as<T>(c->phi[src]);
@@ -335,6 +357,7 @@ static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
         a.lz_hi = lz_hi;
         a.dt = c->P.dt;
         a.target_blocks = c->num_cus;
+        a.v_in_range = c->v_in_range ? 1 : 0;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
         if constexpr (R <= 2) { // ext 3 spills registers in this kernel and is never dispatched to it
@@ -474,6 +497,7 @@ static int excited_step_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bo
         a.lz_hi = hi;
         a.dt = c->P.dt;
         a.target_blocks = c->num_cus;
+        a.v_in_range = c->v_in_range ? 1 : 0;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
         if (wafer_launch_step_lds_excited<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->v), as<T>(c->phi[dst]), c->partials,
@@ -749,7 +773,7 @@ int wafer_set_potential_builtin(wafer_ctx *c, int potential)
         }
     }
     c->have_pot = true;
-    return WAFER_OK;
+    return check_v_range(c);
 }
 
 int wafer_set_potential_host(wafer_ctx *c, const double *v, int potsub_kind, double potsub_scalar, const double *potsub)
@@ -773,7 +797,7 @@ int wafer_set_potential_host(wafer_ctx *c, const double *v, int potsub_kind, dou
         TRY((convert_host_array<true>(c, const_cast<double *>(potsub), c->g.nx, c->g.ny, c->g.nz, c->g.R, c->g.R, c->g.R, c->potsub)));
     }
     c->have_pot = true;
-    return WAFER_OK;
+    return check_v_range(c);
 }
 
 int wafer_download_array(wafer_ctx *c, int id, double *out)
@@ -887,7 +911,7 @@ int wafer_set_potential_resampled(wafer_ctx *c, const double *src, uint32_t sx, 
     c->potsub_kind = WAFER_POTSUB_NONE; // potential.rs:357-358: FromFile has no pot_sub of its own
     c->potsub_scalar = 0.0;
     c->have_pot = true;
-    return WAFER_OK;
+    return check_v_range(c);
 }
 
 int wafer_download_phi(wafer_ctx *c, double *phi)

@@ -342,3 +342,29 @@ __global__ __launch_bounds__(256) void wafer_k_trilerp(WaferResampleArgs a, cons
     const double c1 = op(c01, c11, yd);
     dst[g.at(lzp, j + g.R, i + g.R)] = (T)op(c0, c1, zd);
 }
+
+// min / max of |1 + dt*V/2| over a whole allocation (guard cells hold V = 0 -> 1), as the bit
+// patterns of the non-negative doubles (their unsigned order is their numeric order; NaN sorts
+// above +inf).  out[0] = min (start at ~0ull), out[1] = max (start at 0).
+template <typename T>
+__global__ __launch_bounds__(256) void wafer_k_v_range(const T *__restrict__ v, long long n, double dt,
+                                                       unsigned long long *__restrict__ out)
+{
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double x = fabs(1. + dt * (double)v[i] / 2.);
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        lo = b < lo ? b : lo;
+        hi = b > hi ? b : hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long l2 = __shfl_down(lo, off, 64), h2 = __shfl_down(hi, off, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&out[0], lo);
+        atomicMax(&out[1], hi);
+    }
+}

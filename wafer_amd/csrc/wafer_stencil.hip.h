@@ -53,6 +53,27 @@ __device__ __forceinline__ T wafer_stencil_sum(const T *xs, const T *ys, const T
     }
 }
 
+// 1 / x for the in-register a, b (potential.rs:104-110).  With `in_range` -- the engine has
+// checked 2^-400 < |1 + dt*V/2| < 2^400 over the whole potential -- hipcc's own expansion of the
+// fp64 division (v_div_scale x2, v_rcp, 4 fma, mul, fma, v_div_fmas, v_div_fixup) shortens to
+// v_rcp + 6 fma WITH THE SAME BITS: v_div_scale returns both operands unchanged for a numerator
+// of 1.0 and such a denominator, 1.0 * r is exact, and v_div_fixup passes a finite normal result
+// through.  `in_range` is a kernel argument, so the choice is a scalar branch.
+__device__ __forceinline__ double wafer_recip(double x, bool in_range)
+{
+    if (in_range) {
+        const double rcp = __builtin_amdgcn_rcp(x);
+        const double f0 = __builtin_fma(-x, rcp, 1.0);
+        const double f1 = __builtin_fma(rcp, f0, rcp);
+        const double f2 = __builtin_fma(-x, f1, 1.0);
+        const double r = __builtin_fma(f1, f2, f1);
+        const double f4 = __builtin_fma(-x, r, 1.0);
+        return __builtin_fma(f4, r, r);
+    }
+    return 1.0 / x;
+}
+__device__ __forceinline__ float wafer_recip(float x, bool) { return 1.0f / x; }
+
 // grid.rs:580-589: *work = w*pa + pb*dt*S/denominator
 template <typename T>
 __device__ __forceinline__ T wafer_update(T w, T pa, T pb, T dt, T S, T den)
@@ -70,6 +91,7 @@ struct WaferStepArgs {
     int lz_lo, lz_hi;   // local planes [lz_lo, lz_hi) to update
     int zchunk;         // planes marched by one workgroup
     int target_blocks;  // workgroups a launch should aim for (the device's CU count)
+    int v_in_range;     // 2^-400 < |1 + dt*V/2| < 2^400 everywhere: wafer_recip may take its short form
     double dt, den;
 };
 

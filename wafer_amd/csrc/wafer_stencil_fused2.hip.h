@@ -59,9 +59,9 @@ struct WaferF2Cfg {
 
 // a, b from V, then the update: potential.rs:104-110 + grid.rs:580-589
 template <typename C>
-__device__ __forceinline__ C wafer_update_v(C w, C vv, C dt, C S, C den)
+__device__ __forceinline__ C wafer_update_v(C w, C vv, C dt, C S, C den, bool v_in_range)
 {
-    const C cb = C(1) / (C(1) + dt * vv / C(2));
+    const C cb = wafer_recip(C(1) + dt * vv / C(2), v_in_range);
     const C ca = (C(1) - dt * vv / C(2)) * cb;
     return w * ca + cb * dt * S / den;
 }
@@ -93,6 +93,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
     const int zs = a.lz_lo + tz_i * a.zchunk;
     const int ze = min(zs + a.zchunk, a.lz_hi);
     const C dt = (C)a.dt, den = (C)a.den;
+    const bool vir = a.v_in_range != 0;
     const bool is_main = wave < Cfg::NW2;
     const bool is_hrow = wave >= Cfg::NW2 && wave < Cfg::NW2 + Cfg::NWH;
     const bool is_hcol = wave == Cfg::NW - 1;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                         }
                         const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
                         T rs;
-                        if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)vq[R][r][v], dt, S, den);
+                        if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)vq[R][r][v], dt, S, den, vir);
                         else rs = (T)wafer_update<C>(w, (C)vq[R][r][v], (C)bq[R][r][v], dt, S, den);
                         res[v] = (xi + v < g.nx) ? rs : T(0);
                     }
@@ -348,7 +349,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                                 ys[d + R] = (d == 0) ? w : (C)c0[o0 + d * LP0];
                             }
                             const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                            if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)cv[q], dt, S, den);
+                            if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)cv[q], dt, S, den, vir);
                             else rs = (T)wafer_update<C>(w, (C)cv[q], (C)cb[q], dt, S, den);
                         }
                         w1[c_lds1[q]] = rs;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                                 }
                             }
                             const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                            if constexpr (ABV) res[v] = (T)wafer_update_v<C>(w, (C)vq[0][r][v], dt, S, den);
+                            if constexpr (ABV) res[v] = (T)wafer_update_v<C>(w, (C)vq[0][r][v], dt, S, den, vir);
                             else res[v] = (T)wafer_update<C>(w, (C)vq[0][r][v], (C)bq[0][r][v], dt, S, den);
                         }
                         T *dst = out + (long long)zo2 * g.plane + rowoff[r];

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
                 C ca, cb;
                 if constexpr (ABV) { // potential.rs:104-110
                     const C vv = (C)ab_a[r][v];
-                    cb = C(1) / (C(1) + dt * vv / C(2));
+                    cb = wafer_recip(C(1) + dt * vv / C(2), a.v_in_range != 0);
                     ca = (C(1) - dt * vv / C(2)) * cb;
                 } else {
                     ca = (C)ab_a[r][v];
