@@ -114,13 +114,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # WAFER_BENCH_TRANSPORT=host: halo planes staged through pinned host memory over gloo, ranks
+    # folded onto the GPUs present -- only for exercising the N > 1 leg on a one-GPU box
+    # (tests/test_gpu_multiprocess.py); the default is RCCL, one GPU per rank
+    host_transport = os.environ.get("WAFER_BENCH_TRANSPORT", "rccl") == "host"
+    if host_transport:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if host_transport:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ext = args.cd
     if args.grid:
@@ -150,7 +159,8 @@ def main():
         ctx.set_stencil_variant(args.variant)
     comm = None
     if world > 1:
-        comm = slab.TorchSlabComm(ctx, rank, world, torch.device("cuda", local_rank))
+        comm_cls = slab.HostStagedSlabComm if host_transport else slab.TorchSlabComm
+        comm = comm_cls(ctx, rank, world, torch.device("cuda", local_rank))
     ctx.set_potential(potential)
     ctx.set_initial_condition("Boolean")   # deterministic, "good for benchmarks" (config.rs:168)
     ctx.synchronize()
@@ -170,7 +180,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, ksteps = ctx.last_evolve_ms()     # HIP events on the engine's own stream
     if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64,
+                         device="cpu" if host_transport else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
@@ -201,7 +212,8 @@ def main():
             "workload": f"{shape[0]}x{shape[1]}x{shape[2]} {potential} potential, "
                         f"{ {1: 'ThreePoint', 2: 'FivePoint', 3: 'SevenPoint'}[ext]} stencil, ground-state "
                         f"imaginary-time evolve (grid.rs:544-687), Boolean initial condition"
-                        + ("" if n_gpus == 1 else f", z-slabs of {shape[2] // n_gpus} planes per GPU, RCCL halo exchange"),
+                        + ("" if n_gpus == 1 else f", z-slabs of {shape[2] // n_gpus} planes per GPU, "
+                           + ("host-staged gloo halo exchange (test transport)" if host_transport else "RCCL halo exchange")),
             "grid": list(shape),
             "points_per_gpu": pts_rank,
             "parallelism": f"zslab{n_gpus}",
@@ -226,10 +238,11 @@ def main():
         except Exception as e:  # the baseline is reported, never required
             result["cpu_baseline"] = {"value": None, "unit": "updates/s", "cores": physical_cores(),
                                       "kind": "port", "sample": f"failed: {e!r}"}
-    ctx.close()
-    if dist is not None:
+    if dist is not None:   # the process group goes first: its work objects refer to the engine's streams
+        ctx.synchronize()
         dist.barrier()
         dist.destroy_process_group()
+    ctx.close()
     if rank == 0:
         print(json.dumps(result), flush=True)
 

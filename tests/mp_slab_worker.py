@@ -1,0 +1,98 @@
+"""One rank of the multi-process z-slab run (launched by tests/test_gpu_multiprocess.py through
+torch.distributed.run, gloo rendezvous on 127.0.0.1).  All ranks share the box's one GPU; halo
+planes and scalars travel through wafer_amd.slab.HostStagedSlabComm.  Rank 0 also runs the SAME
+problem in one undecomposed context and compares:
+
+  * ground-state evolve (fused two-step kernel, overlap on): bit for bit,
+  * all-reduced observables: 1e-12,
+  * solve of ground + first excited state from Gaussian starts: energies 5e-7.
+
+Prints "MP-OK <world>" on success."""
+import dataclasses
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import wafer_amd as wa
+    from wafer_amd.slab import HostStagedSlabComm, partition
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+
+    # ---- ground state: fused passes over slabs ----
+    shape, ext, steps = (72, 40, 50), 1, 11
+    whole = wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext)
+    zb, zc = partition(shape[2], world, rank)
+    mine = dataclasses.replace(whole, z_begin=zb, z_count=zc, halo_depth=2 * ext)
+    with wa.Context(mine) as ctx:
+        comm = HostStagedSlabComm(ctx, rank, world, dev)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 4)
+        got = ctx.download_phi()
+        obs = ctx.observables()
+    pieces = [None] * world if rank == 0 else None
+    dist.gather_object((zb, zc, got[:, :, zb + ext:zb + zc + ext]), pieces, dst=0)
+    all_obs = [None] * world if rank == 0 else None
+    dist.gather_object(obs, all_obs, dst=0)
+    if rank == 0:
+        with wa.Context(whole) as ctx:
+            ctx.set_potential("Coulomb")
+            ctx.set_initial_condition("Boolean")
+            ctx.evolve(0, steps)
+            ctx.evolve(0, 4)
+            want = ctx.download_phi()
+            want_obs = ctx.observables()
+        full = np.zeros_like(want)
+        for b, c, p in pieces:
+            full[:, :, b + ext:b + c + ext] = p
+        assert np.array_equal(full, want), "slab evolve differs from the undecomposed run"
+        for o in all_obs:
+            for k, v in want_obs.items():
+                assert abs(o[k] - v) <= 1e-12 * max(1.0, abs(v)), (k, o[k], v)
+
+    # ---- ground + first excited state solve ----
+    shape2 = (16, 16, 20)
+    whole2 = wa.Params(*shape2, dn=0.55, dt=0.05, central_difference=1, max_states=2)
+    zb, zc = partition(shape2[2], world, rank)
+
+    def solve_all(ctx):
+        ctx.set_potential("Harmonic")
+        out = []
+        for wnum in range(2):
+            ctx.set_initial_condition("Gaussian", seed=9 + wnum)
+            recs, final, conv = ctx.solve_state(wnum, 1e-7, 100, max_steps=20000)
+            assert conv
+            out.append((final["energy"], len(recs)))
+        return out
+
+    with wa.Context(dataclasses.replace(whole2, z_begin=zb, z_count=zc)) as ctx:
+        comm = HostStagedSlabComm(ctx, rank, world, dev)
+        mine_e = solve_all(ctx)
+    every = [None] * world if rank == 0 else None
+    dist.gather_object(mine_e, every, dst=0)
+    if rank == 0:
+        with wa.Context(whole2) as ctx:
+            want_e = solve_all(ctx)
+        for e in every:
+            for (ge, gn), (we, wn) in zip(e, want_e):
+                assert abs(ge - we) < 5e-7 and abs(gn - wn) <= 1, (e, want_e)
+        assert abs(want_e[0][0] - 1.5) < 0.06 and abs(want_e[1][0] - 2.5) < 0.1
+        print(f"MP-OK {world}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

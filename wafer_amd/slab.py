@@ -143,3 +143,57 @@ class TorchSlabComm(SlabComm):
         with self.torch.cuda.stream(self._stream(stream)):
             self.allreduce(self._doubles(ptr, count))
         return 0
+
+
+class HostStagedSlabComm(TorchSlabComm):
+    """The same hooks over a CPU process group (gloo): halo planes and scalars are
+    staged through host buffers (plain pageable tensors and blocking copies:
+    torch's pinned-memory cache would remember the engine's streams past the
+    context's lifetime).  For fabrics without device-aware
+    collectives, and for running the multi-process path with several ranks on
+    ONE GPU (tests/test_gpu_multiprocess.py) -- RCCL refuses two ranks per
+    device.  The engine's arithmetic is untouched: only bytes move differently.
+    """
+
+    def __init__(self, ctx, rank: int, world: int, device, group=None):
+        super().__init__(ctx, rank, world, device, group)
+        self._host = {}
+
+    def _staging(self, tag, nbytes, dtype):
+        key = (tag, int(nbytes), dtype)
+        t = self._host.get(key)
+        if t is None:
+            t = self.torch.empty(int(nbytes), dtype=dtype)
+            self._host[key] = t
+        return t
+
+    def _halo_hook(self, send_lo, send_hi, recv_lo, recv_hi, nbytes, stream):
+        torch = self.torch
+        st = self._stream(stream)
+        u8 = torch.uint8
+        host = {}
+        with torch.cuda.stream(st):
+            for tag, ptr in (("slo", send_lo), ("shi", send_hi)):
+                if ptr:
+                    host[tag] = self._staging(tag, nbytes, u8)
+                    host[tag].copy_(self._bytes(ptr, nbytes))  # ordered on st, blocks until on the host
+            for tag, ptr in (("rlo", recv_lo), ("rhi", recv_hi)):
+                if ptr:
+                    host[tag] = self._staging(tag, nbytes, u8)
+            self.exchange(host.get("slo"), host.get("shi"), host.get("rlo"), host.get("rhi"))
+            for tag, ptr in (("rlo", recv_lo), ("rhi", recv_hi)):
+                if ptr:
+                    self._bytes(ptr, nbytes).copy_(host[tag])
+            st.synchronize()
+        return 0
+
+    def _allreduce_hook(self, ptr, count, stream):
+        torch = self.torch
+        st = self._stream(stream)
+        with torch.cuda.stream(st):
+            h = self._staging("scal", count, torch.float64)
+            h.copy_(self._doubles(ptr, count))
+            self.allreduce(h)
+            self._doubles(ptr, count).copy_(h)
+            st.synchronize()
+        return 0
