@@ -33,8 +33,8 @@ BYTES_PER_UPDATE = {"f64": 32, "f32": 16}  # phi, a, b in + phi' out (SURVEY.md 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--grid", default=None, help="override: NX,NY,NZ (global work area)")
     ap.add_argument("--cd", type=int, default=1, help="central difference ext: 1/2/3")
@@ -161,6 +161,7 @@ def main():
     if world > 1:
         comm_cls = slab.HostStagedSlabComm if host_transport else slab.TorchSlabComm
         comm = comm_cls(ctx, rank, world, torch.device("cuda", local_rank))
+        comm.warm_up()   # RCCL channel set-up is not part of any step
     ctx.set_potential(potential)
     ctx.set_initial_condition("Boolean")   # deterministic, "good for benchmarks" (config.rs:168)
     ctx.synchronize()

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Compute-side cost of the z-slab decomposition on ONE GPU: a middle slab of the N-GPU bench
+grid (1024 x 1024 x 128 owned planes, 2*ext ghost planes, boundary-first overlap on the second
+stream) against the same 2^27 points as an undecomposed grid.  The halo hook is a loopback
+(device-to-device copy of the slab's own boundary planes on the hook's stream, same bytes as a
+neighbour would send), so what is measured is everything except the fabric: split launches,
+redundant ghost-plane updates, stream fork/join.
+
+    python tools/slab_overhead.py [--steps 100] [--planes 128] [--cd 1]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import wafer_amd  # noqa: E402
+
+
+def hip_runtime():
+    wafer_amd.load_library()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                return C.CDLL(line.split()[-1])
+    raise RuntimeError("no HIP runtime mapped")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--planes", type=int, default=128)
+    ap.add_argument("--xy", type=int, default=1024)
+    ap.add_argument("--cd", type=int, default=1)
+    ap.add_argument("--world", type=int, default=8)
+    args = ap.parse_args()
+    hip = hip_runtime()
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    n, pl, ext = args.xy, args.planes, args.cd
+    kw = dict(dn=0.02, dt=8e-5, mass=2.35, sig=0.223, central_difference=ext)
+    out = {}
+
+    def run(par, hooks, overlap=True):
+        with wafer_amd.Context(par) as ctx:
+            if hooks:
+                ctx.set_comm_hooks(*hooks)
+                ctx.set_overlap(overlap)
+            ctx.set_potential("SimpleCornell")
+            ctx.set_initial_condition("Boolean")
+            ctx.evolve(0, 10)
+            ctx.synchronize()
+            ctx.evolve(0, args.steps)
+            ms, k = ctx.last_evolve_ms()
+            return ms / k
+
+    out["undecomposed_ms_per_step"] = run(wafer_amd.Params(n, n, pl, **kw), None)
+    calls = {"halo": 0, "bytes": 0}
+
+    def halo(slo, shi, rlo, rhi, nbytes, stream):
+        # my own boundary planes stand in for the neighbours': same sizes, same stream ordering
+        if rlo:
+            assert hip.hipMemcpyAsync(rlo, shi, nbytes, 3, stream) == 0
+        if rhi:
+            assert hip.hipMemcpyAsync(rhi, slo, nbytes, 3, stream) == 0
+        calls["halo"] += 1
+        calls["bytes"] = nbytes
+        return 0
+
+    def allreduce(ptr, count, stream):
+        return 0
+
+    mid = wafer_amd.Params(n, n, pl * args.world, z_begin=pl * (args.world // 2), z_count=pl, halo_depth=2 * ext, **kw)
+    for overlap in (True, False):
+        calls["halo"] = 0
+        out[f"slab_ms_per_step_overlap_{int(overlap)}"] = run(mid, (halo, allreduce), overlap)
+    out["halo_calls_per_step"] = calls["halo"] / (args.steps)
+    out["halo_bytes_per_direction_per_call"] = calls["bytes"]
+    out["slab_over_undecomposed"] = out["slab_ms_per_step_overlap_1"] / out["undecomposed_ms_per_step"]
+    out["grid"] = [n, n, pl]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

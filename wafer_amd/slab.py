@@ -108,6 +108,16 @@ class TorchSlabComm(SlabComm):
         self._streams = {}
         ctx.set_comm_hooks(self._halo_hook, self._allreduce_hook)
 
+    def warm_up(self):
+        """Establish the neighbour connections and the all-reduce ring before anything is timed
+        (RCCL builds its point-to-point channels lazily, at the first send / receive)."""
+        torch = self.torch
+        mk = lambda: torch.zeros(256, dtype=torch.uint8, device=self.device)  # noqa: E731
+        self.exchange(mk() if self.lower is not None else None, mk() if self.upper is not None else None,
+                      mk() if self.lower is not None else None, mk() if self.upper is not None else None)
+        self.allreduce(torch.zeros(8, dtype=torch.float64, device=self.device))
+        torch.cuda.synchronize(self.device)
+
     def _stream(self, ptr):
         s = self._streams.get(ptr)
         if s is None:
@@ -158,6 +168,13 @@ class HostStagedSlabComm(TorchSlabComm):
     def __init__(self, ctx, rank: int, world: int, device, group=None):
         super().__init__(ctx, rank, world, device, group)
         self._host = {}
+
+    def warm_up(self):
+        torch = self.torch
+        mk = lambda: torch.zeros(256, dtype=torch.uint8)  # noqa: E731
+        self.exchange(mk() if self.lower is not None else None, mk() if self.upper is not None else None,
+                      mk() if self.lower is not None else None, mk() if self.upper is not None else None)
+        self.allreduce(torch.zeros(8, dtype=torch.float64))
 
     def _staging(self, tag, nbytes, dtype):
         key = (tag, int(nbytes), dtype)
