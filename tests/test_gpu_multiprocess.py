@@ -48,3 +48,15 @@ def test_bench_multi_rank_path():
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 64
     assert d["roofline"]["steps_per_launch"] == 2 and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("ext", [1, 2])
+def test_rccl_transport_self_neighbours(ext):
+    """RCCL send / recv / all-reduce on tensors aliasing the engine's HBM, under the engine's
+    streams: one rank that is its own z-neighbour (tests/rccl_selfloop_worker.py)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + ext + os.getpid() % 300),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", WAFER_TEST_EXT=str(ext), PYTHONUNBUFFERED="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_selfloop_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=420, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "RCCL-OK" in r.stdout
