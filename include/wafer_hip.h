@@ -234,6 +234,18 @@ typedef struct wafer_slab_info {
     uint64_t elem_bytes;
 } wafer_slab_info;
 int wafer_get_slab_info(wafer_ctx *ctx, wafer_slab_info *out);
+/* the device the context runs on, as its own properties describe it (printed by the benchmark
+ * next to the datasheet HBM peak; the reference has no counterpart) */
+typedef struct wafer_device_info {
+    char name[64];
+    char arch[64];
+    uint32_t compute_units;
+    uint32_t memory_clock_khz;
+    uint32_t memory_bus_bits;
+    uint32_t l2_bytes;
+    uint64_t total_bytes;
+} wafer_device_info;
+int wafer_get_device_info(wafer_ctx *ctx, wafer_device_info *out);
 
 #ifdef __cplusplus
 }

@@ -32,11 +32,12 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_struct_layout(lib):
-    from wafer_amd.engine import _Params, _Obs, _Record, _ObsOut, _SlabInfo
+    from wafer_amd.engine import _Params, _Obs, _Record, _ObsOut, _SlabInfo, _DeviceInfo
     assert lib.wafer_abi_version() == 1
     # wafer_params: 4 u32, 2 i32, 4 f64, u32, i32, 4 u32 -> 24 + 32 + 24 = 80 bytes, 8-byte aligned
     assert C.sizeof(_Params) == 80 and _Params.dn.offset == 24 and _Params.max_states.offset == 56
     assert C.sizeof(_Obs) == 32 and C.sizeof(_Record) == 56 and C.sizeof(_ObsOut) == 40 and C.sizeof(_SlabInfo) == 32
+    assert C.sizeof(_DeviceInfo) == 152
     rust = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
     fields = re.findall(r"pub (\w+): (u32|i32|f64),", rust.split("pub struct wafer_params")[1].split("}")[0])
     assert [f for f, _ in fields] == [n for n, _ in _Params._fields_]

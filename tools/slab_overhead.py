@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--xy", type=int, default=1024)
     ap.add_argument("--cd", type=int, default=1)
     ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rccl", action="store_true",
+                    help="also serve the hook with RCCL send/recv to this same rank (wafer_amd.slab.TorchSlabComm, "
+                         "world of one): adds the host cost of the Python hook + batch_isend_irecv per pass")
     args = ap.parse_args()
     hip = hip_runtime()
     hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
@@ -75,6 +78,35 @@ def main():
     for overlap in (True, False):
         calls["halo"] = 0
         out[f"slab_ms_per_step_overlap_{int(overlap)}"] = run(mid, (halo, allreduce), overlap)
+    if args.rccl:
+        import torch
+        import torch.distributed as dist
+        from wafer_amd.slab import TorchSlabComm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29455")
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+
+        class SelfNeighbours(TorchSlabComm):
+            lower = 0
+            upper = 0
+
+        for overlap in (True, False):
+            with wafer_amd.Context(mid) as ctx:
+                comm = SelfNeighbours(ctx, 0, 1, dev)
+                comm.warm_up()
+                ctx.set_overlap(overlap)
+                ctx.set_potential("SimpleCornell")
+                ctx.set_initial_condition("Boolean")
+                ctx.evolve(0, 10)
+                ctx.synchronize()
+                ctx.evolve(0, args.steps)
+                ms, k = ctx.last_evolve_ms()
+                out[f"slab_rccl_self_ms_per_step_overlap_{int(overlap)}"] = ms / k
+                del comm
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
     out["halo_calls_per_step"] = calls["halo"] / (args.steps)
     out["halo_bytes_per_direction_per_call"] = calls["bytes"]
     out["slab_over_undecomposed"] = out["slab_ms_per_step_overlap_1"] / out["undecomposed_ms_per_step"]

@@ -1324,4 +1324,22 @@ int wafer_get_slab_info(wafer_ctx *c, wafer_slab_info *out)
     return WAFER_OK;
 }
 
+int wafer_get_device_info(wafer_ctx *c, wafer_device_info *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    hipDeviceProp_t p;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess)
+        return fail(WAFER_ERR_HIP, "hipGetDeviceProperties failed");
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", p.name);
+    snprintf(out->arch, sizeof out->arch, "%s", p.gcnArchName);
+    out->compute_units = (uint32_t)p.multiProcessorCount;
+    out->memory_clock_khz = (uint32_t)p.memoryClockRate;
+    out->memory_bus_bits = (uint32_t)p.memoryBusWidth;
+    out->l2_bytes = (uint32_t)p.l2CacheSize;
+    out->total_bytes = (uint64_t)p.totalGlobalMem;
+    return WAFER_OK;
+}
+
 } // extern "C"

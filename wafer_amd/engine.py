@@ -37,6 +37,7 @@ EXPORTS = [
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_diag_stream_bw", "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
+    "wafer_get_device_info",
 ]
 
 
@@ -69,6 +70,12 @@ class _Record(C.Structure):
 class _ObsOut(C.Structure):
     _fields_ = [("state", C.c_uint32), ("energy", C.c_double), ("binding_energy", C.c_double),
                 ("r", C.c_double), ("l_r", C.c_double)]
+
+
+class _DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("arch", C.c_char * 64), ("compute_units", C.c_uint32),
+                ("memory_clock_khz", C.c_uint32), ("memory_bus_bits", C.c_uint32), ("l2_bytes", C.c_uint32),
+                ("total_bytes", C.c_uint64)]
 
 
 class _SlabInfo(C.Structure):
@@ -148,6 +155,7 @@ def load_library():
     L.wafer_set_overlap.argtypes = [vp, C.c_int]
     L.wafer_set_stream.argtypes = [vp, vp]
     L.wafer_get_slab_info.argtypes = [vp, C.POINTER(_SlabInfo)]
+    L.wafer_get_device_info.argtypes = [vp, C.POINTER(_DeviceInfo)]
     if L.wafer_abi_version() != 1:
         raise ImportError("libwafer_hip.so ABI version mismatch")
     _lib = L
@@ -405,6 +413,13 @@ class Context:
 
     def set_stream(self, stream_ptr: int | None) -> None:
         self._check(self._L.wafer_set_stream(self._h, stream_ptr))
+
+    def device_info(self) -> dict:
+        d = _DeviceInfo()
+        self._check(self._L.wafer_get_device_info(self._h, C.byref(d)))
+        out = {k: getattr(d, k) for k, _ in _DeviceInfo._fields_}
+        out["name"], out["arch"] = d.name.decode(), d.arch.decode()
+        return out
 
     def slab_info(self) -> dict:
         s = _SlabInfo()
