@@ -148,6 +148,10 @@ int wafer_set_potential_host(wafer_ctx *ctx, const double *v, int potsub_kind, d
 /* tests / output::potential: padded global array out (POTSUB: unpadded) */
 int wafer_download_array(wafer_ctx *ctx, int array_id, double *out);
 int wafer_get_potsub(wafer_ctx *ctx, int *kind, double *scalar);
+/* replaces pot_sub after the potential has been set: a potential_sub file in ./input takes
+ * precedence over the computed value for every potential type (potential.rs:113-131).  potsub is
+ * the UNPADDED nx*ny*nz array when kind == WAFER_POTSUB_ARRAY, else ignored. */
+int wafer_set_potsub(wafer_ctx *ctx, int kind, double scalar, const double *potsub);
 
 /* ---- phi: config::set_initial_conditions (config.rs:577-627), input::wavefunction, output::wavefunction */
 int wafer_set_initial_condition(wafer_ctx *ctx, int ic, uint64_t seed);

@@ -168,3 +168,61 @@ def test_restart_from_lower_resolution(cli, tmp_path):
     e = lambda out: float(re.search(r"Ground state energy = ([0-9.eE+-]+)", out).group(1))
     assert e(warm.stdout) == pytest.approx(e(cold.stdout), abs=1e-5)
     assert blocks(warm.stdout) > 1 and blocks(cold.stdout) > 1
+
+
+@pytest.mark.gpu
+def test_messagepack_run_and_restart(cli, tmp_path):
+    """file_type: Messagepack end to end (output.rs:172-181, 606-617; input.rs:113-147): outputs
+    decode with an independent msgpack reader, and the saved state restarts a run from ./input"""
+    import msgpack
+    from oracle import wafer_oracle as wo
+    text = open(CASE).read().replace("file_type: Csv", "file_type: Messagepack").replace("wavemax: 1", "wavemax: 0")
+    (tmp_path / "mpk.yaml").write_text(text)
+    r = run(cli, "-c", str(tmp_path / "mpk.yaml"), "--output-dir", str(tmp_path / "out"), "--input-dir", str(tmp_path / "none"))
+    assert r.returncode == 0, r.stderr
+    od = tmp_path / "out" / os.listdir(tmp_path / "out")[0]
+    assert sorted(os.listdir(od)) == ["mpk.yaml", "observables_0.mpk", "potential.mpk", "wavefunction_0.mpk"]
+    state, energy, binding, r_rms, l_r = msgpack.unpackb(open(od / "observables_0.mpk", "rb").read())
+    e0 = float(re.search(r"Ground state energy = ([0-9.eE+-]+)", r.stdout).group(1))
+    assert state == 0 and energy == pytest.approx(e0, abs=1e-9) and l_r == pytest.approx(24 / r_rms, rel=1e-12)
+    assert binding == energy                                     # Harmonic: pot_sub is zero
+    v, dim, data = msgpack.unpackb(open(od / "potential.mpk", "rb").read())
+    wo.set_threads(4)
+    cfg = wo.Config(24, 20, 28, ext=1, potential="Harmonic", dn=0.5, dt=0.04, mass=1.0)
+    assert v == 1 and dim == [24, 20, 28]
+    assert np.array_equal(np.array(data).reshape(24, 20, 28), wo.potential_generate(cfg)[1:-1, 1:-1, 1:-1])
+    v, dim, data = msgpack.unpackb(open(od / "wavefunction_0.mpk", "rb").read())
+    assert dim == [24, 20, 28] and np.sum(np.square(data)) == pytest.approx(1.0, abs=1e-12)
+
+    # restart from the .mpk state: already converged, so the second observation ends the run
+    (tmp_path / "in").mkdir()
+    os.replace(od / "wavefunction_0.mpk", tmp_path / "in" / "wavefunction_0.mpk")
+    (tmp_path / "warm.yaml").write_text(text.replace("init_condition: Boolean", "init_condition: FromFile"))
+    r2 = run(cli, "-c", str(tmp_path / "warm.yaml"), "--progress", "--output-dir", str(tmp_path / "out2"), "--input-dir", str(tmp_path / "in"))
+    assert r2.returncode == 0, r2.stderr
+    rows = [l for l in r2.stdout.splitlines() if re.match(r"^\s+│\s*[0-9.]+ │", l)]
+    assert len(rows) == 2
+    assert float(re.search(r"Ground state energy = ([0-9.eE+-]+)", r2.stdout).group(1)) == pytest.approx(e0, abs=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,body", [("json", '{"pot_sub": 2.0}'), ("yaml", "---\npot_sub: 2.0\n"), ("csv", "2\n")])
+def test_potential_sub_file_overrides_the_computed_value(cli, tmp_path, fmt, body):
+    """potential.rs:113-131: ./input/potential_sub.* wins for every potential type; a singular
+    value shifts binding_energy = (energy - v_infinity) / norm2 by exactly that value"""
+    (tmp_path / "in").mkdir()
+    (tmp_path / "in" / f"potential_sub.{fmt}").write_text(body)
+    text = open(CASE).read().replace("wavemax: 1", "wavemax: 0").replace("save_wavefns: true", "save_wavefns: false")
+    (tmp_path / "c.yaml").write_text(text)
+    r = run(cli, "-c", str(tmp_path / "c.yaml"), "--output-dir", str(tmp_path / "out"), "--input-dir", str(tmp_path / "in"))
+    assert r.returncode == 0, r.stderr
+    assert "Potential_sub loaded from disk" in r.stderr
+    od = tmp_path / "out" / os.listdir(tmp_path / "out")[0]
+    rec = open(od / "observables_0.csv").read().splitlines()[1].split(",")
+    assert float(rec[2]) == pytest.approx(float(rec[1]) - 2.0, abs=1e-12)
+    assert open(od / "potential_sub.csv").read().strip() == "2"          # output::potential_sub, singular value
+    # an ARRAY for a potential whose pot_sub is singular is the reference's WrongPotentialSubDims error
+    (tmp_path / "in" / f"potential_sub.{fmt}").unlink()
+    (tmp_path / "in" / "potential_sub.json").write_text('{"v":1,"dim":[1,1,2],"data":[1.0,2.0]}')
+    r = run(cli, "-c", str(tmp_path / "c.yaml"), "--output-dir", str(tmp_path / "out3"), "--input-dir", str(tmp_path / "in"))
+    assert r.returncode == 1 and "WrongPotentialSubDims" in r.stderr

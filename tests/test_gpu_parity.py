@@ -353,6 +353,29 @@ def test_observables(wo, wa, ext, pot):
             assert got[k] == pytest.approx(want[k], rel=REL_SUM, abs=1e-300), k
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_potsub_override(wo, wa, kind):
+    """wafer_set_potsub: a potential_sub file replaces the computed pot_sub for any potential
+    (potential.rs:113-131); v_infinity follows grid.rs:408-427"""
+    cfg, par = make_pair((20, 17, 22), ext=2, potential="SimpleCornell", dn=0.15, dt=0.003, mass=1.4, sig=0.223)
+    v = wo.potential_generate(cfg)
+    phi = random_phi(cfg, seed=4)
+    arr = np.random.default_rng(12).standard_normal(cfg.work_shape) if kind == 2 else None
+    want = wo.observables(cfg, v, phi, (kind, 0.75 if kind == 1 else 0.0, arr))
+    with wa.Context(par) as ctx:
+        with pytest.raises(wa.WaferError):
+            ctx.set_potsub(1, 0.75)          # no potential yet
+        ctx.set_potential("SimpleCornell")
+        assert ctx.potsub()[0] == 1          # computed: the singular 4m term
+        ctx.set_potsub(kind, 0.75, arr)
+        assert ctx.potsub() == (kind, 0.75 if kind == 1 else 0.0)
+        ctx.upload_phi(phi)
+        got = ctx.observables()
+    for k in want:
+        assert got[k] == pytest.approx(want[k], rel=REL_SUM, abs=1e-300), k
+    assert (want["v_infinity"] == 0.0) == (kind == 0)
+
+
 def test_norm_normalise_orthogonalise(wo, wa):
     cfg, par = make_pair((19, 22, 17), ext=2)
     phi = random_phi(cfg, seed=8)

@@ -7,11 +7,13 @@
 // (output.rs:559-603) and observables_N / wavefunction_N / potential outputs
 // (output.rs:32-45, 85-165, 379-400, 533-677).
 //
+// Input and output files in all five of the reference's formats (wafer_files.h).
+//
 // Out of scope: clap's -s script potentials, slog file
-// logging, the progress bar, messagepack, symmetry constraints
-// (config.rs:691-728 hard-codes SevenPoint offsets).
+// logging, the progress bar.
 //
 //   wafer-hip [-c wafer.yaml] [--check-config] [--progress] [--output-dir DIR] [--input-dir DIR]
+//   wafer-hip --convert IN OUT      (array / potential_sub file from one format to another, by extension)
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -27,6 +29,7 @@
 #include <vector>
 
 #include "../../include/wafer_hip.h"
+#include "wafer_files.h"
 
 // ---------------------------------------------------------------------------
 // A reader for the YAML subset wafer.yaml uses: nested maps by indentation,
@@ -95,8 +98,6 @@ static const char *kPotentials[] = {"NoPotential", "Cube", "QuadWell", "Periodic
                                     "ElipticalCoulomb", "SimpleCornell", "FullCornell", "Harmonic",
                                     "ComplexHarmonic", "Dodecahedron", "FromFile", "FromScript"};
 static const char *kInitialConditions[] = {"FromFile", "Gaussian", "Coulomb", "Constant", "Boolean"};
-static const char *kFileTypes[] = {"Messagepack", "Csv", "Json", "Yaml", "Ron"};
-static const char *kFileExt[] = {".mpk", ".csv", ".json", ".yaml", ".ron"};
 
 struct Config {
     std::string project_name = "wafer";
@@ -195,15 +196,6 @@ static bool load_config(const std::string &path, Config &c, std::string &err)
 // ---------------------------------------------------------------------------
 // number formatting the way Rust's std::fmt does it
 // ---------------------------------------------------------------------------
-// `{}` on f64: shortest digits that round-trip, never scientific
-static std::string rust_display(double v)
-{
-    if (std::isnan(v)) return "NaN";
-    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
-    char buf[512];
-    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
-    return std::string(buf, r.ptr);
-}
 // `{:.Ne}` on f64: d.ddd…e<exp> with a bare exponent ("1.5000000000e0", "3.2e-5")
 static std::string rust_lower_exp(double v, int prec)
 {
@@ -298,85 +290,8 @@ static void print_summary(const wafer_observables_output &o)
 // ---------------------------------------------------------------------------
 // files
 // ---------------------------------------------------------------------------
-// shortest round-trip text of a double ("1.0"-style for integral values, like serde's writers)
-static std::string num_text(double v)
-{
-    if (std::isnan(v)) return "NaN";
-    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
-    char buf[64];
-    auto r = std::to_chars(buf, buf + sizeof buf, v);
-    std::string s(buf, r.ptr);
-    if (s.find_first_of(".e") == std::string::npos) s += ".0";
-    return s;
-}
-
-// output.rs:148-165: one `i,j,k,data` record per cell of the WORK area, no header
-static bool write_array(const std::string &path, int file_type, const double *padded, uint32_t nx, uint32_t ny,
-                        uint32_t nz, uint32_t e, std::string &err)
-{
-    FILE *f = fopen(path.c_str(), "w");
-    if (!f) { err = "CreateFile: " + path; return false; }
-    const size_t py = ny + 2 * e, pz = nz + 2 * e;
-    auto at = [&](uint32_t i, uint32_t j, uint32_t k) { return padded[((size_t)(i + e) * py + (j + e)) * pz + (k + e)]; };
-    if (file_type == 1) {
-        for (uint32_t i = 0; i < nx; ++i)
-            for (uint32_t j = 0; j < ny; ++j)
-                for (uint32_t k = 0; k < nz; ++k) fprintf(f, "%u,%u,%u,%s\n", i, j, k, num_text(at(i, j, k)).c_str());
-    } else { // ndarray's serde layout {v, dim, data} as JSON / YAML / RON text
-        const bool ron = file_type == 4, yaml = file_type == 3;
-        if (yaml) fprintf(f, "---\nv: 1\ndim:\n  - %u\n  - %u\n  - %u\ndata:\n", nx, ny, nz);
-        else if (ron) fprintf(f, "(v:1,dim:(%u,%u,%u),data:[", nx, ny, nz);
-        else fprintf(f, "{\"v\":1,\"dim\":[%u,%u,%u],\"data\":[", nx, ny, nz);
-        bool first = true;
-        for (uint32_t i = 0; i < nx; ++i)
-            for (uint32_t j = 0; j < ny; ++j)
-                for (uint32_t k = 0; k < nz; ++k) {
-                    if (yaml) fprintf(f, "  - %s\n", num_text(at(i, j, k)).c_str());
-                    else fprintf(f, "%s%s", first ? "" : ",", num_text(at(i, j, k)).c_str());
-                    first = false;
-                }
-        if (ron) fprintf(f, "])");
-        else if (!yaml) fprintf(f, "]}");
-    }
-    fclose(f);
-    return true;
-}
-
-// input.rs:607-662 (CSV branch): `i,j,k,data` records, dims = max index + 1, C order
-struct CsvArray {
-    uint32_t nx = 0, ny = 0, nz = 0;
-    std::vector<double> data; // unpadded [nx][ny][nz]
-};
-
-static bool read_csv_array(const std::string &path, CsvArray &out, std::string &err)
-{
-    std::ifstream f(path);
-    if (!f) { err = "missing " + path; return false; }
-    std::vector<double> vals;
-    unsigned mi = 0, mj = 0, mk = 0;
-    std::string line;
-    while (std::getline(f, line)) {
-        if (trim(line).empty()) continue;
-        unsigned i, j, k;
-        double d;
-        if (sscanf(line.c_str(), "%u,%u,%u,%lf", &i, &j, &k, &d) != 4) { err = "ParsePlainRecord: " + path; return false; }
-        if (i > mi) mi = i;
-        if (j > mj) mj = j;
-        if (k > mk) mk = k;
-        vals.push_back(d);
-    }
-    out.nx = mi + 1; out.ny = mj + 1; out.nz = mk + 1;
-    if (vals.size() != (size_t)out.nx * out.ny * out.nz) { // Array3::from_shape_vec fails: ErrorKind::ArrayShape
-        err = "ArrayShape: " + path + ": " + std::to_string(vals.size()) + " records do not fill " +
-              std::to_string(out.nx) + "x" + std::to_string(out.ny) + "x" + std::to_string(out.nz);
-        return false;
-    }
-    out.data.swap(vals);
-    return true;
-}
-
 // embeds an unpadded array of the configured size into the zero frame (input.rs:644-650)
-static std::vector<double> embed(const CsvArray &a, uint32_t e)
+static std::vector<double> embed(const FieldFile &a, uint32_t e)
 {
     const size_t py = a.ny + 2 * e, pz = a.nz + 2 * e;
     std::vector<double> p((size_t)(a.nx + 2 * e) * py * pz, 0.0);
@@ -386,9 +301,21 @@ static std::vector<double> embed(const CsvArray &a, uint32_t e)
     return p;
 }
 
+// <input_dir>/<stem>.* in whichever format is present (wafer_files.h find_input)
+static bool load_input(const std::string &dir, const std::string &stem, int configured, FieldFile &out, std::string &err)
+{
+    std::string path;
+    bool several = false;
+    const int t = find_input(dir, stem, configured, path, &several);
+    if (t < 0) { err = "FileNotFound: " + dir + "/" + stem + ".*"; return false; }
+    if (several)
+        fprintf(stderr, "Warning: multiple %s files found in input directory. Choosing '%s'.\n", stem.c_str(), path.c_str());
+    return read_field(path, t, out, err);
+}
+
 // what=0: phi, 1: potential.  Same size -> copied; otherwise trilinearly resampled on the
 // device with the reference's basis (input.rs:651-655, 667-716).
-static int upload_field(wafer_ctx *ctx, const Config &cfg, const CsvArray &a, int what)
+static int upload_field(wafer_ctx *ctx, const Config &cfg, const FieldFile &a, int what)
 {
     const uint32_t e = (uint32_t)cfg.central_difference;
     if (a.nx == cfg.nx && a.ny == cfg.ny && a.nz == cfg.nz) {
@@ -406,6 +333,14 @@ static int upload_field(wafer_ctx *ctx, const Config &cfg, const CsvArray &a, in
 static bool write_observables(const std::string &dir, int file_type, const wafer_observables_output &o, std::string &err)
 {
     const std::string path = dir + "/observables_" + std::to_string(o.state) + kFileExt[file_type];
+    if (file_type == WF_MPK) { // ObservablesOutput as a 5-array (output.rs:606-617)
+        MpkOut m;
+        m.array_len(5);
+        m.uint(o.state);
+        m.f64(o.energy); m.f64(o.binding_energy); m.f64(o.r); m.f64(o.l_r);
+        if (!m.save(path)) { err = "CreateFile: " + path; return false; }
+        return true;
+    }
     FILE *f = fopen(path.c_str(), "w");
     if (!f) { err = "CreateFile: " + path; return false; }
     const std::string e = num_text(o.energy), b = num_text(o.binding_energy), r = num_text(o.r), l = num_text(o.l_r);
@@ -457,9 +392,22 @@ int main(int argc, char **argv)
             printf("%s\n", sanitize(argv[++i]).c_str());
             return 0;
         }
+        else if (a == "--convert" && i + 2 < argc) { // any of the five formats to any other (wafer_files.h)
+            const std::string in = argv[i + 1], out = argv[i + 2];
+            const int ti = type_of_path(in), to = type_of_path(out);
+            FieldFile f;
+            std::string e;
+            if (ti < 0 || to < 0) { fprintf(stderr, "Error: unknown file extension\n"); return 2; }
+            if (!read_field(in, ti, f, e)) { fprintf(stderr, "Error: %s\n", e.c_str()); return 1; }
+            const bool ok = f.scalar ? write_scalar_sub(out, to, f.value, e)
+                                     : write_array(out, to, f.data.data(), f.nx, f.ny, f.nz, 0, e);
+            if (!ok) { fprintf(stderr, "Error: %s\n", e.c_str()); return 1; }
+            return 0;
+        }
         else if (a == "--progress") progress = true;
         else if (a == "-h" || a == "--help") {
-            printf("wafer-hip [-c wafer.yaml] [--check-config] [--progress] [--output-dir DIR] [--input-dir DIR]\n");
+            printf("wafer-hip [-c wafer.yaml] [--check-config] [--progress] [--output-dir DIR] [--input-dir DIR]\n"
+                   "wafer-hip --convert IN OUT   (.mpk .csv .json .yaml .ron)\n");
             return 0;
         } else {
             fprintf(stderr, "unknown argument %s\n", a.c_str());
@@ -491,7 +439,6 @@ int main(int argc, char **argv)
         return 1;
     }
     if (cfg.potential == WAFER_POT_FROMSCRIPT) { fprintf(stderr, "Error: FromScript potentials are not supported\n"); return 1; }
-    if (cfg.file_type == 0) { fprintf(stderr, "Error: Messagepack output is not supported; use Csv, Json, Yaml or Ron\n"); return 1; }
 
     // output directory ./output/<project>_<timestamp> (output.rs:680-699)
     char stamp[64];
@@ -525,25 +472,64 @@ int main(int argc, char **argv)
 
     // potential::load_arrays (potential.rs:75-175)
     if (cfg.potential == WAFER_POT_FROMFILE) {
-        CsvArray pot;
-        if (!read_csv_array(input_dir + "/potential.csv", pot, err)) {
-            fprintf(stderr, "Error: LoadPotential: %s\n", err.c_str());
+        FieldFile pot;
+        if (!load_input(input_dir, "potential", cfg.file_type, pot, err) || pot.scalar) {
+            fprintf(stderr, "Error: LoadPotential: %s\n", pot.scalar ? "potential file holds a single value" : err.c_str());
             return 1;
         }
         CHECK(upload_field(ctx, cfg, pot, 1));
     } else {
         CHECK(wafer_set_potential_builtin(ctx, cfg.potential));
     }
+    { // a potential_sub file in ./input overrides the computed one (potential.rs:113-131)
+        FieldFile sub;
+        std::string sub_err;
+        if (load_input(input_dir, "potential_sub", cfg.file_type, sub, sub_err)) {
+            const bool variable = cfg.potential == WAFER_POT_FULLCORNELL; // PotentialType::variable_pot_sub
+            if (sub.scalar && variable) {
+                fprintf(stderr, "Error: WrongPotentialSubDims: potential_sub input file contains a singular value, but potential type is FullCornell.\n");
+                return 1;
+            }
+            if (!sub.scalar && !variable) {
+                fprintf(stderr, "Error: WrongPotentialSubDims: potential_sub input file contains an array, but potential type is not FullCornell.\n");
+                return 1;
+            }
+            if (sub.scalar) {
+                CHECK(wafer_set_potsub(ctx, WAFER_POTSUB_SCALAR, sub.value, nullptr));
+            } else {
+                if (sub.nx != cfg.nx || sub.ny != cfg.ny || sub.nz != cfg.nz) {
+                    fprintf(stderr, "Error: potential_sub array is %ux%ux%u, the grid %ux%ux%u: resampling potential_sub (input.rs:437-470) is not supported\n",
+                            sub.nx, sub.ny, sub.nz, cfg.nx, cfg.ny, cfg.nz);
+                    return 1;
+                }
+                CHECK(wafer_set_potsub(ctx, WAFER_POTSUB_ARRAY, 0.0, sub.data.data()));
+            }
+            fprintf(stderr, "Potential_sub loaded from disk\n");
+        }
+    }
     if (cfg.save_potential) {
         host.resize(padded_len);
         CHECK(wafer_download_array(ctx, WAFER_ARRAY_V, host.data()));
         if (!write_array(out_dir + "/potential" + ext, cfg.file_type, host.data(), cfg.nx, cfg.ny, cfg.nz, e, err))
             fprintf(stderr, "Warning: could not write potential to disk: %s\n", err.c_str());
+        // output::potential_sub (output.rs:103-141): the array for FullCornell, a positive scalar, else nothing
+        int kind = 0;
+        double scalar = 0.0;
+        CHECK(wafer_get_potsub(ctx, &kind, &scalar));
+        bool ok = true;
+        if (kind == WAFER_POTSUB_ARRAY) {
+            std::vector<double> sub((size_t)cfg.nx * cfg.ny * cfg.nz);
+            CHECK(wafer_download_array(ctx, WAFER_ARRAY_POTSUB, sub.data()));
+            ok = write_array(out_dir + "/potential_sub" + ext, cfg.file_type, sub.data(), cfg.nx, cfg.ny, cfg.nz, 0, err);
+        } else if (kind == WAFER_POTSUB_SCALAR && scalar > 0.0) {
+            ok = write_scalar_sub(out_dir + "/potential_sub" + ext, cfg.file_type, scalar, err);
+        }
+        if (!ok) fprintf(stderr, "Warning: could not write potential_sub to disk: %s\n", err.c_str());
     }
     // grid.rs:35-39: converged lower states must come from disk when wavenum > 0
     for (uint32_t w = 0; w < cfg.wavenum; ++w) {
-        CsvArray st;
-        if (!read_csv_array(input_dir + "/wavefunction_" + std::to_string(w) + ".csv", st, err)) {
+        FieldFile st;
+        if (!load_input(input_dir, "wavefunction_" + std::to_string(w), cfg.file_type, st, err) || st.scalar) {
             fprintf(stderr, "Error: LoadWavefunction(%u): %s\n", w, err.c_str());
             return 1;
         }
@@ -557,9 +543,10 @@ int main(int argc, char **argv)
     int exit_code = 0;
     for (uint32_t wnum = cfg.wavenum; wnum <= cfg.wavemax; ++wnum) { // grid.rs:43-45
         // starting wavefunction, grid.rs:60-100
-        CsvArray start;   // wavefunction_N, else wavefunction_N_partial (input.rs:513-523)
-        const bool from_disk = read_csv_array(input_dir + "/wavefunction_" + std::to_string(wnum) + ".csv", start, err) ||
-                               read_csv_array(input_dir + "/wavefunction_" + std::to_string(wnum) + "_partial.csv", start, err);
+        FieldFile start;   // wavefunction_N, else wavefunction_N_partial (input.rs:513-523)
+        const bool from_disk = (load_input(input_dir, "wavefunction_" + std::to_string(wnum), cfg.file_type, start, err) ||
+                                load_input(input_dir, "wavefunction_" + std::to_string(wnum) + "_partial", cfg.file_type, start, err)) &&
+                               !start.scalar;
         bool cloned = false;
         if (wnum > 0) {
             if (from_disk) CHECK(upload_field(ctx, cfg, start, 0));

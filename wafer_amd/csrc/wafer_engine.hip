@@ -815,6 +815,22 @@ int wafer_download_array(wafer_ctx *c, int id, double *out)
     }
 }
 
+int wafer_set_potsub(wafer_ctx *c, int kind, double scalar, const double *potsub)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (!c->have_pot) return fail(WAFER_ERR_STATE, "set the potential first");
+    if (kind < 0 || kind > 2) return fail(WAFER_ERR_INVALID, "bad potsub kind");
+    if (kind == WAFER_POTSUB_ARRAY && !potsub) return fail(WAFER_ERR_INVALID, "potsub array missing");
+    HIP_TRY(hipSetDevice(c->P.device));
+    c->potsub_kind = kind;
+    c->potsub_scalar = (kind == WAFER_POTSUB_SCALAR) ? scalar : 0.0;
+    if (kind == WAFER_POTSUB_ARRAY) {
+        TRY(ensure_potsub_array(c));
+        TRY((convert_host_array<true>(c, const_cast<double *>(potsub), c->g.nx, c->g.ny, c->g.nz, c->g.R, c->g.R, c->g.R, c->potsub)));
+    }
+    return WAFER_OK;
+}
+
 int wafer_get_potsub(wafer_ctx *c, int *kind, double *scalar)
 {
     if (!c || !kind || !scalar) return fail(WAFER_ERR_INVALID, "null argument");

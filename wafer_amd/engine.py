@@ -37,7 +37,7 @@ EXPORTS = [
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_diag_stream_bw", "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
-    "wafer_get_device_info",
+    "wafer_get_device_info", "wafer_set_potsub",
 ]
 
 
@@ -125,6 +125,7 @@ def load_library():
     L.wafer_set_potential_host.argtypes = [vp, dp, C.c_int, C.c_double, dp]
     L.wafer_download_array.argtypes = [vp, C.c_int, dp]
     L.wafer_get_potsub.argtypes = [vp, C.POINTER(C.c_int), dp]
+    L.wafer_set_potsub.argtypes = [vp, C.c_int, C.c_double, dp]
     L.wafer_set_initial_condition.argtypes = [vp, C.c_int, C.c_uint64]
     L.wafer_upload_phi.argtypes = [vp, dp]
     L.wafer_download_phi.argtypes = [vp, dp]
@@ -263,6 +264,12 @@ class Context:
         out = np.zeros(self.params.work_shape if which == "potsub" else self.params.padded_shape)
         self._check(self._L.wafer_download_array(self._h, idx, _dp(out)))
         return out
+
+    def set_potsub(self, kind: int, scalar: float = 0.0, potsub: np.ndarray | None = None) -> None:
+        """override pot_sub (a potential_sub file in ./input, potential.rs:113-131)"""
+        if potsub is not None:
+            assert potsub.shape == self.params.work_shape
+        self._check(self._L.wafer_set_potsub(self._h, kind, scalar, _dp(potsub) if potsub is not None else None))
 
     def potsub(self):
         kind, scalar = C.c_int(0), C.c_double(0.0)
