@@ -166,6 +166,22 @@ int wafer_upload_phi_resampled(wafer_ctx *ctx, const double *src, uint32_t sx, u
 int wafer_set_potential_resampled(wafer_ctx *ctx, const double *src, uint32_t sx, uint32_t sy, uint32_t sz,
                                   const uint32_t *basis);
 
+/* config::symmetrise_wavefunction (config.rs:691-728), applied by the reference to the initial
+ * condition (config.rs:625) and to snapshots (grid.rs:138).  Constraint in the order of
+ * SymmetryConstraint (config.rs:184-197).  The reference indexes the SevenPoint frame literally
+ * (offset 3, extent n + 6) and would run out of bounds on a narrower one: any constraint other
+ * than NOT_CONSTRAINED returns WAFER_ERR_INVALID unless central_difference is SevenPoint.  Its
+ * quirks are kept: the mirror plane sits half a cell below the centre of the work area and the
+ * last work cell along the axis takes the frame's zero.  About z is not available on z-slabs. */
+typedef enum wafer_symmetry {
+    WAFER_SYM_NOT_CONSTRAINED = 0,
+    WAFER_SYM_ABOUT_Z,
+    WAFER_SYM_ANTISYM_ABOUT_Z,
+    WAFER_SYM_ABOUT_Y,
+    WAFER_SYM_ANTISYM_ABOUT_Y
+} wafer_symmetry;
+int wafer_symmetrise(wafer_ctx *ctx, int constraint);
+
 /* ---- the hot path -------------------------------------------------------- */
 /* evolve (grid.rs:544-687): n_steps = config.output.screen_update; like the
  * reference, n_steps == 0 still takes one step.  wnum > 0 renormalises and

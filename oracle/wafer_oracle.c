@@ -409,6 +409,32 @@ void wo_normalise(double *phi, size_t n, double norm2)
     for (size_t p = 0; p < n; ++p) phi[p] /= norm;
 }
 
+/* config.rs:691-728, the loops as written (sequential: later cells read cells this
+ * pass has already overwritten) */
+int wo_symmetrise(const wo_config *c, int kind, double *phi)
+{
+    if (kind == 0) return 0;
+    if (kind < 0 || kind > 4) return 1;
+    if (c->ext != 3) return 2; /* w[[sx, 3 + ny, 3 + nz]] is out of bounds for ext < 3 */
+    const int64_t nx = c->nx, ny = c->ny, nz = c->nz;
+    const int64_t py = ny + 6, pz = nz + 6;
+    const double sign = (kind == 2 || kind == 4) ? -1.0 : 1.0;
+    const int about_z = (kind == 1 || kind == 2);
+#define W(i, j, k) phi[((i) * py + (j)) * pz + (k)]
+    for (int64_t sx = 0; sx < nx + 6; ++sx)
+        for (int64_t sy = 3; sy < 3 + ny + 1; ++sy) {
+            int64_t y = sy;
+            if (!about_z && y > (3 + ny) / 2) y = (3 + ny) + 1 - y;
+            for (int64_t sz = 3; sz < 3 + nz + 1; ++sz) {
+                int64_t z = sz;
+                if (about_z && z > (3 + nz) / 2) z = (3 + nz) + 1 - z;
+                W(sx, sy, sz) = sign * W(sx, y, z);
+            }
+        }
+#undef W
+    return 0;
+}
+
 /* grid.rs:477-492: modified Gram-Schmidt, lower states in storage order,
  * with the reference's temporary product array and separate sum pass */
 void wo_orthogonalise(int wnum, double *phi, const double *const *w_store, size_t n)

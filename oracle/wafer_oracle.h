@@ -14,7 +14,7 @@
  *   PARITY UNPINNED by any reference test or reference-binary output (the
  *   Rust reference cannot be built here: no cargo/rustc, 27 unvendored crates):
  *     wo_evolve, wo_observables, wo_ab, wo_potential (other than r2/alphas/mu),
- *     initial conditions, wo_solve.  These follow the source text line by
+ *     initial conditions, wo_solve, wo_symmetrise.  These follow the source text line by
  *     line and are cross-checked against discrete analytic eigenpairs and a
  *     dense-matrix construction in tests/test_oracle_physics.py.
  *
@@ -99,6 +99,12 @@ double wo_norm2(const wo_config *c, const double *phi);
 void wo_normalise(double *phi, size_t n, double norm2);
 /* grid.rs:477-492; w_store = wnum padded arrays of n elements each */
 void wo_orthogonalise(int wnum, double *phi, const double *const *w_store, size_t n);
+/* config::symmetrise_wavefunction (config.rs:691-728), loop for loop: kind in the order of
+ * SymmetryConstraint (config.rs:184-197): 0 NotConstrained (nothing), 1 AboutZ, 2 AntisymAboutZ,
+ * 3 AboutY, 4 AntisymAboutY.  The reference hard-codes
+ * the SevenPoint frame (offset 3, extent n+6) and would index out of bounds on a narrower one:
+ * returns non-zero unless c->ext == 3. */
+int wo_symmetrise(const wo_config *c, int kind, double *phi);
 /* grid.rs:303-445; potsub_kind/scalar/array as wo_potential_sub */
 void wo_observables(const wo_config *c, const double *v, int potsub_kind, double potsub_scalar,
                     const double *potsub, const double *phi, wo_observables_t *out);

@@ -86,6 +86,8 @@ def lib():
         L.wo_normalise.argtypes = [dp, C.c_size_t, C.c_double]
         L.wo_orthogonalise.restype = None
         L.wo_orthogonalise.argtypes = [C.c_int, dp, C.POINTER(dp), C.c_size_t]
+        L.wo_symmetrise.restype = C.c_int
+        L.wo_symmetrise.argtypes = [cp, C.c_int, dp]
         L.wo_observables.restype = None
         L.wo_observables.argtypes = [cp, dp, C.c_int, C.c_double, dp, dp, C.POINTER(_Obs)]
         L.wo_evolve.restype = None
@@ -215,6 +217,16 @@ def normalise(phi: np.ndarray, n2: float) -> None:
 
 def orthogonalise(wnum: int, phi: np.ndarray, w_store) -> None:
     lib().wo_orthogonalise(wnum, _dp(phi), _store_ptrs(w_store), phi.size)
+
+
+SYMMETRY = ["NotConstrained", "AboutZ", "AntisymAboutZ", "AboutY", "AntisymAboutY"]  # config.rs:184-197
+
+
+def symmetrise(cfg: Config, kind: str, phi: np.ndarray) -> None:
+    """config::symmetrise_wavefunction (config.rs:691-728), in place"""
+    rc = lib().wo_symmetrise(C.byref(cfg.c()), SYMMETRY.index(kind), _dp(phi))
+    if rc:
+        raise ValueError("symmetry constraints index the SevenPoint frame (config.rs:702-725): ext must be 3")
 
 
 def observables(cfg: Config, v, phi, potsub=(0, 0.0, None)):

@@ -48,6 +48,7 @@ def test_config_echo(cli):
     (("potential: Harmonic", "potential: Yukawa"), "unknown potential"),
     (("mass: 1.0\n", ""), "missing field `mass`"),
     (("central_difference: ThreePoint", "central_difference: NinePoint"), "central_difference"),
+    (("init_symmetry: NotConstrained", "init_symmetry: Sideways"), "init_symmetry"),
 ])
 def test_config_errors(cli, tmp_path, edit, msg):
     text = open(CASE).read()
@@ -226,3 +227,42 @@ def test_potential_sub_file_overrides_the_computed_value(cli, tmp_path, fmt, bod
     (tmp_path / "in" / "potential_sub.json").write_text('{"v":1,"dim":[1,1,2],"data":[1.0,2.0]}')
     r = run(cli, "-c", str(tmp_path / "c.yaml"), "--output-dir", str(tmp_path / "out3"), "--input-dir", str(tmp_path / "in"))
     assert r.returncode == 1 and "WrongPotentialSubDims" in r.stderr
+
+
+def test_symmetry_needs_seven_point(cli, tmp_path):
+    """config.rs:702-725 walks n + 6 cells: with a narrower frame the reference panics on an
+    out-of-bounds index; the driver says so before touching the GPU"""
+    bad = tmp_path / "sym.yaml"
+    bad.write_text(open(CASE).read().replace("init_symmetry: NotConstrained", "init_symmetry: AboutZ"))
+    r = run(cli, "-c", str(bad), "--output-dir", str(tmp_path / "o"))
+    assert r.returncode == 1 and "SevenPoint" in r.stderr
+
+
+@pytest.mark.gpu
+def test_symmetry_constraint_is_applied_to_the_start(cli, tmp_path):
+    """init_symmetry: AntisymAboutZ on a Constant start (config.rs:625).  The first table row is
+    the energy of the constrained start -- the oracle's, to the last digits of the sums.  (The
+    reference's mirror plane sits half a cell off the potential's centre and it constrains only
+    the start and the snapshots, so the run still relaxes to the even ground state: 1.5.)"""
+    from oracle import wafer_oracle as wo
+    text = open(CASE).read().replace("central_difference: ThreePoint", "central_difference: SevenPoint") \
+        .replace("init_symmetry: NotConstrained", "init_symmetry: AntisymAboutZ") \
+        .replace("init_condition: Boolean", "init_condition: Constant") \
+        .replace("wavemax: 1", "wavemax: 0").replace("dt: 0.04", "dt: 0.02").replace("tolerance: 1e-7", "tolerance: 1e-5") \
+        .replace("x: 24", "x: 20").replace("z: 28", "z: 25")
+    (tmp_path / "sym.yaml").write_text(text)
+    r = run(cli, "-c", str(tmp_path / "sym.yaml"), "--progress", "--output-dir", str(tmp_path / "out"), "--input-dir", str(tmp_path / "none"))
+    assert r.returncode == 0, r.stderr
+    wo.set_threads(4)
+    cfg = wo.Config(20, 20, 25, ext=3, potential="Harmonic", dn=0.5, dt=0.02, mass=1.0)
+    v = wo.potential_generate(cfg)
+    phi = wo.initial_condition(cfg, "Constant")
+    plain = wo.observables(cfg, v, phi)
+    wo.symmetrise(cfg, "AntisymAboutZ", phi)
+    o = wo.observables(cfg, v, phi)
+    rows = [l for l in r.stdout.splitlines() if re.match(r"^\s+│\s*[0-9.]+ │", l)]
+    first = [c.strip() for c in rows[0].split("│")[1:5]]
+    assert float(first[0]) == 0.0 and float(first[1]) == pytest.approx(o["energy"] / o["norm2"], rel=1e-9)
+    assert abs(o["energy"] / o["norm2"] - plain["energy"] / plain["norm2"]) > 0.1     # the constraint did something
+    e = float(re.search(r"Ground state energy = ([0-9.eE+-]+)", r.stdout).group(1))
+    assert e == pytest.approx(1.5, abs=0.05)

@@ -353,6 +353,47 @@ def test_observables(wo, wa, ext, pot):
             assert got[k] == pytest.approx(want[k], rel=REL_SUM, abs=1e-300), k
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("kind", ["AboutZ", "AntisymAboutZ", "AboutY", "AntisymAboutY"])
+@pytest.mark.parametrize("shape", [(70, 9, 12), (12, 16, 7)])
+def test_symmetrise(wo, wa, kind, shape, dtype):
+    """wafer_symmetrise against config::symmetrise_wavefunction's loops (config.rs:691-728)"""
+    cfg, par = make_pair(shape, ext=3, dtype=dtype)
+    phi = random_phi(cfg, seed=21)
+    if dtype == "f32":
+        phi = phi.astype(np.float32).astype(np.float64)
+    want = phi.copy()
+    wo.symmetrise(cfg, kind, want)
+    with wa.Context(par) as ctx:
+        ctx.upload_phi(phi)
+        ctx.symmetrise("NotConstrained")
+        assert np.array_equal(ctx.download_phi(), phi)
+        ctx.symmetrise(kind)
+        got = ctx.download_phi()
+        assert np.array_equal(got, want)
+        n2 = ctx.norm2()                      # the engine keeps working on the swapped buffer
+        assert n2 == pytest.approx(wo.norm2(cfg, want), rel=1e-6 if dtype == "f32" else REL_SUM)
+        ctx.set_potential("Harmonic")
+        ctx.evolve(0, 2)                      # and the frame of that buffer is a frame
+        a, b = wo.ab(cfg, wo.potential_generate(cfg))
+        if dtype == "f64":
+            wo.evolve(cfg, 0, a, b, want, [], 2)
+            assert np.array_equal(ctx.download_phi(), want)
+
+
+def test_symmetrise_refuses_what_the_reference_cannot_index(wa):
+    with wa.Context(wa.Params(8, 8, 8, dn=0.1, dt=0.001, central_difference=2)) as ctx:
+        ctx.set_initial_condition("Boolean")
+        ctx.symmetrise("NotConstrained")
+        with pytest.raises(wa.WaferError, match="SevenPoint"):
+            ctx.symmetrise("AboutY")
+    with wa.Context(wa.Params(8, 8, 16, dn=0.1, dt=0.001, central_difference=3, z_begin=0, z_count=8)) as ctx:
+        ctx.set_initial_condition("Boolean")
+        ctx.symmetrise("AntisymAboutY")       # local to every z-plane
+        with pytest.raises(wa.WaferError, match="z-slabs"):
+            ctx.symmetrise("AboutZ")
+
+
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_potsub_override(wo, wa, kind):
     """wafer_set_potsub: a potential_sub file replaces the computed pot_sub for any potential

@@ -175,3 +175,52 @@ def test_wafer_yaml_ground_state(oracle):
     assert np.sqrt(recs[-1]["r2"] / recs[-1]["norm2"]) == pytest.approx(16.09, abs=5e-3)
     # analytic: 3(1-cos(pi/51))/(m dn^2) + <V>
     assert recs[-1]["energy"] / recs[-1]["norm2"] == pytest.approx(3.55639 + 0.01275, abs=2e-4)
+
+
+@pytest.mark.parametrize("kind", ["AboutZ", "AntisymAboutZ", "AboutY", "AntisymAboutY"])
+@pytest.mark.parametrize("shape", [(5, 6, 7), (4, 7, 6)])
+def test_symmetrise_follows_the_reference_loops(oracle, kind, shape):
+    wo = oracle
+    """config.rs:691-728 restated twice: the oracle's literal loops against an independent numpy
+    evaluation of what those loops do -- cells up to h = (3+n)/2 times sign, cells above mirrored
+    about n+4 (half a cell below the centre), the last work cell takes the frame's zero."""
+    cfg = wo.Config(*shape, ext=3, potential="Harmonic", dn=0.1, dt=0.001, mass=1.0)
+    rng = np.random.default_rng(3)
+    phi = np.zeros(cfg.padded_shape)
+    phi[3:-3, 3:-3, 3:-3] = rng.standard_normal(shape)
+    got = phi.copy()
+    wo.symmetrise(cfg, kind, got)
+    sign = -1.0 if kind.startswith("Antisym") else 1.0
+    axis = 2 if kind.endswith("Z") else 1
+    n = shape[axis]
+    h = (3 + n) // 2
+    want = phi.copy()
+    src = np.moveaxis(phi, axis, 0)
+    dst = np.moveaxis(want, axis, 0)      # a view: writes land in `want`
+    for s_ in range(3, 3 + n + 1):
+        t = s_ if s_ <= h else n + 4 - s_
+        if t == s_:
+            dst[s_] = sign * src[s_]
+        elif t >= 3:
+            dst[s_] = sign * (sign * src[t])
+        else:
+            dst[s_] = sign * src[t]
+    assert np.array_equal(got, want)
+    work = np.moveaxis(got, axis, 0)[3:3 + n]
+    assert not work[-1].any()                                  # last work cell along the axis: zero
+    assert np.array_equal(work[n - 2], sign * sign * np.moveaxis(phi, axis, 0)[3])   # s = n+1 mirrors s = 3
+    # applying it twice changes nothing more for the symmetric kinds
+    again = got.copy()
+    wo.symmetrise(cfg, kind, again)
+    if sign > 0:
+        assert np.array_equal(again, got)
+
+
+def test_symmetrise_needs_the_seven_point_frame(oracle):
+    wo = oracle
+    cfg = wo.Config(5, 5, 5, ext=1, potential="Harmonic", dn=0.1, dt=0.001, mass=1.0)
+    with pytest.raises(ValueError):
+        wo.symmetrise(cfg, "AboutZ", np.zeros(cfg.padded_shape))
+    phi = np.ones(cfg.padded_shape)
+    wo.symmetrise(cfg, "NotConstrained", phi)                  # does nothing, any frame
+    assert (phi == 1).all()

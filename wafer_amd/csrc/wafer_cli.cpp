@@ -97,6 +97,7 @@ static bool parse_yaml(const std::string &path, std::map<std::string, std::strin
 static const char *kPotentials[] = {"NoPotential", "Cube", "QuadWell", "Periodic", "Coulomb", "ComplexCoulomb",
                                     "ElipticalCoulomb", "SimpleCornell", "FullCornell", "Harmonic",
                                     "ComplexHarmonic", "Dodecahedron", "FromFile", "FromScript"};
+static const char *kSymmetry[] = {"NotConstrained", "AboutZ", "AntisymAboutZ", "AboutY", "AntisymAboutY"}; // config.rs:184-197
 static const char *kInitialConditions[] = {"FromFile", "Gaussian", "Coulomb", "Constant", "Boolean"};
 
 struct Config {
@@ -179,6 +180,7 @@ static bool load_config(const std::string &path, Config &c, std::string &err)
     if ((c.init_condition = index_of(kInitialConditions, 5, s)) < 0) { err = "Deserialize: unknown init_condition `" + s + "`"; return false; }
     if (!num("sig", c.sig)) return false;
     if (!need("init_symmetry", c.init_symmetry)) return false;
+    if (index_of(kSymmetry, 5, c.init_symmetry) < 0) { err = "init_symmetry: unknown variant `" + c.init_symmetry + "`"; return false; }
     if (!num("output.screen_update", d)) return false; c.screen_update = (uint64_t)d;
     if (kv.count("output.snap_update")) { if (!num("output.snap_update", d)) return false; c.has_snap_update = true; c.snap_update = (uint64_t)d; }
     if (!need("output.file_type", s)) return false;
@@ -434,8 +436,11 @@ int main(int argc, char **argv)
                cfg.save_wavefns ? "true" : "false", cfg.save_potential ? "true" : "false", cfg.dtype.c_str());
         return 0;
     }
-    if (cfg.init_symmetry != "NotConstrained") {
-        fprintf(stderr, "Error: init_symmetry %s is not supported (config.rs:691-728 hard-codes SevenPoint offsets)\n", cfg.init_symmetry.c_str());
+    const int symmetry = index_of(kSymmetry, 5, cfg.init_symmetry);
+    if (symmetry != WAFER_SYM_NOT_CONSTRAINED && cfg.central_difference != WAFER_CD_SEVENPOINT) {
+        // the reference would panic with an out-of-bounds index here (config.rs:702-725 walks n + 6 cells)
+        fprintf(stderr, "Error: init_symmetry %s needs central_difference: SevenPoint (config.rs:702-725 indexes the 3-cell frame)\n",
+                cfg.init_symmetry.c_str());
         return 1;
     }
     if (cfg.potential == WAFER_POT_FROMSCRIPT) { fprintf(stderr, "Error: FromScript potentials are not supported\n"); return 1; }
@@ -560,6 +565,7 @@ int main(int argc, char **argv)
         } else {
             CHECK(wafer_set_initial_condition(ctx, cfg.init_condition, (uint64_t)now));
         }
+        if (wnum == 0) CHECK(wafer_symmetrise(ctx, symmetry)); // config::set_initial_conditions, config.rs:625
         print_observable_header(wnum);
         // solve, grid.rs:122-246 (the loop itself: wafer_solve_state == grid.rs:126-221)
         std::vector<wafer_block_record> recs(progress ? 1u << 20 : 4);
@@ -592,6 +598,7 @@ int main(int argc, char **argv)
                 }
             }
             if (cfg.has_snap_update && step % cfg.snap_update == 0) { // grid.rs:137-158, WITHOUT its second, stale-norm2 normalise
+                CHECK(wafer_symmetrise(ctx, symmetry)); // grid.rs:138
                 host.resize(padded_len);
                 CHECK(wafer_download_phi(ctx, host.data()));
                 if (!write_array(out_dir + "/wavefunction_" + std::to_string(wnum) + "_partial" + ext, cfg.file_type, host.data(), cfg.nx, cfg.ny, cfg.nz, e, err))

@@ -870,6 +870,36 @@ int wafer_upload_phi(wafer_ctx *c, const double *phi)
     return WAFER_OK;
 }
 
+// config::symmetrise_wavefunction (config.rs:691-728)
+int wafer_symmetrise(wafer_ctx *c, int constraint)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (constraint < WAFER_SYM_NOT_CONSTRAINED || constraint > WAFER_SYM_ANTISYM_ABOUT_Y)
+        return fail(WAFER_ERR_INVALID, "unknown symmetry constraint %d", constraint);
+    if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
+    if (constraint == WAFER_SYM_NOT_CONSTRAINED) return WAFER_OK;
+    if (c->g.R != 3)
+        return fail(WAFER_ERR_INVALID, "symmetry constraints index the SevenPoint frame (config.rs:702-725); "
+                                       "the reference runs out of bounds with central_difference ext %d", c->g.R);
+    const int axis = (constraint == WAFER_SYM_ABOUT_Z || constraint == WAFER_SYM_ANTISYM_ABOUT_Z) ? 0 : 1;
+    if (axis == 0 && c->g.nzl != c->g.nz)
+        return fail(WAFER_ERR_NOT_AVAILABLE, "a mirror about z crosses z-slabs");
+    const double sign = (constraint == WAFER_SYM_ANTISYM_ABOUT_Z || constraint == WAFER_SYM_ANTISYM_ABOUT_Y) ? -1.0 : 1.0;
+    HIP_TRY(hipSetDevice(c->P.device));
+    const int src = c->cur, dst = c->cur ^ 1;
+    // the other buffer is scratch between steps: start from zeros so that the frame is the frame
+    HIP_TRY(hipMemsetAsync(alloc_base(c, c->phi[dst]), 0, (size_t)c->g.total * c->esz, c->s_main));
+    const dim3 grid(c->bx, c->by, c->g.lz), block(64, 4);
+    if (c->f32)
+        hipLaunchKernelGGL((wafer_k_symmetrise<float>), grid, block, 0, c->s_main, c->g, axis, sign, as<float>(c->phi[src]), as<float>(c->phi[dst]));
+    else
+        hipLaunchKernelGGL((wafer_k_symmetrise<double>), grid, block, 0, c->s_main, c->g, axis, sign, as<double>(c->phi[src]), as<double>(c->phi[dst]));
+    HIP_TRY(hipGetLastError());
+    c->cur = dst;
+    c->halo_valid = 0;
+    return WAFER_OK;
+}
+
 // fill_data / read_csv's resampling branch (input.rs:149-176, 640-656, 667-716): `src` is an
 // UNPADDED array of another resolution; the work area is filled by trilinear interpolation with
 // the reference's basis (the padded target size), the frame is zero.

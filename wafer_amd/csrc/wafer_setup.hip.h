@@ -236,6 +236,38 @@ __global__ __launch_bounds__(256) void wafer_k_initial_condition(WaferIcArgs a, 
     phi[g.at(lzp, yp, xp)] = (T)val;
 }
 
+// ---- symmetry constraints (config.rs:691-728) ---------------------------------------------------
+// The reference walks the SevenPoint frame in place and in ascending order, so cells above the
+// mirror plane read cells the same pass has already multiplied by `sign`.  Restated per cell from
+// the OLD values (out != in, no ordering between threads): along the constrained axis, padded
+// coordinate s in [3, 3 + n), h = (3 + n) / 2, t = n + 4 - s,
+//   s <= h or t == s : sign * old[s]
+//   t >= 3           : sign * (sign * old[t])
+//   t <  3           : sign * old[t]            (t is a frame cell: zero)
+// The other cells the reference touches (x frame, the frame row / plane at 3 + n) hold zeros and
+// are left alone.  axis 0: z (device plane index), 1: y.
+template <typename T>
+__global__ __launch_bounds__(256) void wafer_k_symmetrise(WaferGeom g, int axis, double sign, const T *__restrict__ in,
+                                                          T *__restrict__ out)
+{
+    const int xp = blockIdx.x * 64 + threadIdx.x;
+    const int yp = blockIdx.y * 4 + threadIdx.y;
+    const int lzp = blockIdx.z;
+    const int zp = g.zp_of(lzp);
+    if (xp < g.R || xp >= g.px - g.R || yp < g.R || yp >= g.py - g.R || zp < g.R || zp >= g.pzg - g.R) return;
+    const int n = axis == 0 ? g.nz : g.ny;
+    const int s = axis == 0 ? zp : yp;
+    const int h = (3 + n) / 2, t = n + 4 - s;
+    double v;
+    if (s <= h || t == s) {
+        v = sign * (double)in[g.at(lzp, yp, xp)];
+    } else {
+        const double src = axis == 0 ? (double)in[g.at(lzp + (t - s), yp, xp)] : (double)in[g.at(lzp, t, xp)];
+        v = t >= 3 ? sign * (sign * src) : sign * src;
+    }
+    out[g.at(lzp, yp, xp)] = (T)v;
+}
+
 // ---- layout transposes ----------------------------------------------------------
 // `dense` is a double array in the reference's C-order [sx][sy][sz]; its element
 // (x,y,z) corresponds to device cell (lzp0+z, yp0+y, xp0+x).

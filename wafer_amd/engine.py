@@ -21,6 +21,7 @@ POTENTIALS = [
     "ElipticalCoulomb", "SimpleCornell", "FullCornell", "Harmonic", "ComplexHarmonic",
     "Dodecahedron", "FromFile", "FromScript",
 ]  # config.rs:73-104
+SYMMETRY = ["NotConstrained", "AboutZ", "AntisymAboutZ", "AboutY", "AntisymAboutY"]  # config.rs:184-197
 INITIAL_CONDITIONS = ["FromFile", "Gaussian", "Coulomb", "Constant", "Boolean"]  # config.rs:151-170
 CENTRAL_DIFFERENCE = {"ThreePoint": 1, "FivePoint": 2, "SevenPoint": 3}  # config.rs:224-238
 
@@ -37,7 +38,7 @@ EXPORTS = [
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_diag_stream_bw", "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
-    "wafer_get_device_info", "wafer_set_potsub",
+    "wafer_get_device_info", "wafer_set_potsub", "wafer_symmetrise",
 ]
 
 
@@ -126,6 +127,7 @@ def load_library():
     L.wafer_download_array.argtypes = [vp, C.c_int, dp]
     L.wafer_get_potsub.argtypes = [vp, C.POINTER(C.c_int), dp]
     L.wafer_set_potsub.argtypes = [vp, C.c_int, C.c_double, dp]
+    L.wafer_symmetrise.argtypes = [vp, C.c_int]
     L.wafer_set_initial_condition.argtypes = [vp, C.c_int, C.c_uint64]
     L.wafer_upload_phi.argtypes = [vp, dp]
     L.wafer_download_phi.argtypes = [vp, dp]
@@ -279,6 +281,10 @@ class Context:
     # -- phi ----------------------------------------------------------------------------
     def set_initial_condition(self, name: str, seed: int = 0) -> None:
         self._check(self._L.wafer_set_initial_condition(self._h, INITIAL_CONDITIONS.index(name), seed))
+
+    def symmetrise(self, constraint: str) -> None:
+        """config::symmetrise_wavefunction (config.rs:691-728); SevenPoint only, like the reference"""
+        self._check(self._L.wafer_symmetrise(self._h, SYMMETRY.index(constraint)))
 
     def upload_phi(self, phi: np.ndarray) -> None:
         assert phi.shape == self.params.padded_shape
