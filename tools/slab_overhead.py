@@ -52,11 +52,14 @@ def main():
                 ctx.set_overlap(overlap)
             ctx.set_potential("SimpleCornell")
             ctx.set_initial_condition("Boolean")
-            ctx.evolve(0, 10)
+            ctx.evolve(0, 100)
             ctx.synchronize()
-            ctx.evolve(0, args.steps)
-            ms, k = ctx.last_evolve_ms()
-            return ms / k
+            best = None
+            for _ in range(5):   # median of 5 (clock ramp, other tenants)
+                ctx.evolve(0, args.steps)
+                ms, k = ctx.last_evolve_ms()
+                best = sorted((best or []) + [ms / k])
+            return best[len(best) // 2]
 
     out["undecomposed_ms_per_step"] = run(wafer_amd.Params(n, n, pl, **kw), None)
     calls = {"halo": 0, "bytes": 0}
@@ -99,15 +102,18 @@ def main():
                 ctx.set_overlap(overlap)
                 ctx.set_potential("SimpleCornell")
                 ctx.set_initial_condition("Boolean")
-                ctx.evolve(0, 10)
+                ctx.evolve(0, 100)
                 ctx.synchronize()
-                ctx.evolve(0, args.steps)
-                ms, k = ctx.last_evolve_ms()
-                out[f"slab_rccl_self_ms_per_step_overlap_{int(overlap)}"] = ms / k
+                ts = []
+                for _ in range(5):
+                    ctx.evolve(0, args.steps)
+                    ms, k = ctx.last_evolve_ms()
+                    ts.append(ms / k)
+                out[f"slab_rccl_self_ms_per_step_overlap_{int(overlap)}"] = sorted(ts)[2]
                 del comm
         torch.cuda.synchronize()
         dist.destroy_process_group()
-    out["halo_calls_per_step"] = calls["halo"] / (args.steps)
+    out["halo_calls_per_step"] = calls["halo"] / (100 + 5 * args.steps)
     out["halo_bytes_per_direction_per_call"] = calls["bytes"]
     out["slab_over_undecomposed"] = out["slab_ms_per_step_overlap_1"] / out["undecomposed_ms_per_step"]
     out["grid"] = [n, n, pl]

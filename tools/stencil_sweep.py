@@ -45,13 +45,18 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--configs", nargs="+", default=["v=0", "v=1"])
+    ap.add_argument("--potential", default="Coulomb")
+    ap.add_argument("--dn", type=float, default=0.05)
+    ap.add_argument("--dt", type=float, default=5e-4)
+    ap.add_argument("--mass", type=float, default=1.0)
+    ap.add_argument("--sig", type=float, default=0.223)
     args = ap.parse_args()
     nx, ny, nz = (int(s) for s in args.grid.split(","))
-    par = wafer_amd.Params(nx, ny, nz, dn=0.05, dt=5e-4, central_difference=args.cd, dtype=args.dtype,
-                           max_states=max(1, args.wnum))
+    par = wafer_amd.Params(nx, ny, nz, dn=args.dn, dt=args.dt, mass=args.mass, sig=args.sig,
+                           central_difference=args.cd, dtype=args.dtype, max_states=max(1, args.wnum))
     bpu = {"f64": 32, "f32": 16}[args.dtype]
     with wafer_amd.Context(par) as ctx:
-        ctx.set_potential("Coulomb")
+        ctx.set_potential(args.potential)
         ctx.set_initial_condition("Boolean")
         for i in range(args.wnum):
             ctx.set_initial_condition("Gaussian", seed=i + 1)

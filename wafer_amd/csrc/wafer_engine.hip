@@ -594,7 +594,11 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
 
     HIP_TRYC(hipStreamCreateWithFlags(&c->s_own, hipStreamNonBlocking));
     c->s_main = c->s_own;
-    HIP_TRYC(hipStreamCreateWithFlags(&c->s_aux, hipStreamNonBlocking));
+    { // boundary planes and their exchange go ahead of the interior update: highest priority
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRYC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_TRYC(hipStreamCreateWithPriority(&c->s_aux, hipStreamNonBlocking, prio_hi));
+    }
     HIP_TRYC(hipEventCreate(&c->ev_start));
     HIP_TRYC(hipEventCreate(&c->ev_stop));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -997,9 +1001,12 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
                 if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + 2 * R, c->s_aux));
                 if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - 2 * R, hi, c->s_aux));
+                // the interior is queued before the hook runs: whatever host time the hook takes
+                // (Python, RCCL enqueue) the GPU already has the bulk of the pass to work on.
+                // (Both boundaries in one launch, or the interior queued first: measured, no better.)
+                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + 2 * R : lo, c->has_hi() ? hi - 2 * R : hi, c->s_main));
                 TRY(exchange_halo(c, dst, c->s_aux, 2 * R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
-                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + 2 * R : lo, c->has_hi() ? hi - 2 * R : hi, c->s_main));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
             } else {
                 TRY(launch_step2(c, src, dst, lo, hi, c->s_main));
@@ -1019,9 +1026,9 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
                 if (c->has_lo()) TRY(launch_step(c, src, dst, lo, lo + R, false, c->s_aux));
                 if (c->has_hi()) TRY(launch_step(c, src, dst, hi - R, hi, false, c->s_aux));
+                TRY(launch_step(c, src, dst, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi, false, c->s_main));
                 TRY(exchange_halo(c, dst, c->s_aux, R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
-                TRY(launch_step(c, src, dst, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi, false, c->s_main));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
             } else {
                 TRY(launch_step(c, src, dst, lo, hi, false, c->s_main));
