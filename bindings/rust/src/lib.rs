@@ -60,6 +60,8 @@ extern "C" {
     pub fn wafer_norm2(ctx: *mut wafer_ctx, out: *mut f64) -> c_int;
     pub fn wafer_normalise(ctx: *mut wafer_ctx, norm2: f64) -> c_int;
     pub fn wafer_orthogonalise(ctx: *mut wafer_ctx, wnum: u32) -> c_int;
+    pub fn wafer_set_potsub(ctx: *mut wafer_ctx, kind: c_int, scalar: f64, potsub: *const f64) -> c_int;
+    pub fn wafer_symmetrise(ctx: *mut wafer_ctx, constraint: c_int) -> c_int;
     pub fn wafer_push_state(ctx: *mut wafer_ctx) -> c_int;
     pub fn wafer_load_state(ctx: *mut wafer_ctx, idx: u32, state: *const f64) -> c_int;
     pub fn wafer_clone_state_to_phi(ctx: *mut wafer_ctx, idx: u32) -> c_int;
