@@ -146,3 +146,22 @@ def test_malformed_files_fail_loudly(cli, tmp_path):
     assert r.returncode == 1 and "ParsePlainRecord" in r.stderr
     r = subprocess.run([cli, "--convert", str(tmp_path / "missing.mpk"), str(tmp_path / "x.json")], capture_output=True, text=True)
     assert r.returncode == 1 and "FileNotFound" in r.stderr
+
+
+def test_reference_output_potential_sub_cases(cli, tmp_path):
+    """the inputs of the reference's own `output_potential_sub` test (output.rs:799-821: it only
+    asserts is_ok): singular values 213.0 / 21.0 / 24.8 / 29.1 / 94.32 and a zeros((2, 2, 2)) array,
+    in every format -- written, read back, identical"""
+    import msgpack
+    for ext, val in zip(EXT, [213.0, 21.0, 24.8, 29.1, 94.32]):
+        (tmp_path / "v.json").write_text('{"pot_sub": %r}' % val)
+        out = convert(cli, tmp_path / "v.json", tmp_path / f"test.{ext}")
+        back = json.load(open(convert(cli, out, tmp_path / f"back_{ext}.json")))
+        assert back == {"pot_sub": val}
+    assert msgpack.unpackb(open(tmp_path / "test.mpk", "rb").read()) == [213.0]
+    assert open(tmp_path / "test.csv").read() == "21\n"                 # R64::to_string(): Display, no ".0"
+    write_csv(tmp_path / "z.csv", np.zeros((2, 2, 2)))
+    for ext in EXT:
+        out = convert(cli, tmp_path / "z.csv", tmp_path / f"zeros.{ext}")
+        back = np.loadtxt(convert(cli, out, tmp_path / f"zeros_back_{ext}.csv"), delimiter=",")
+        assert back.shape == (8, 4) and not back[:, 3].any()
