@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def launch(nproc, script, *args, timeout=420):
+    """script: a path, or "-m" followed by a module name in args"""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(29000 + 17 * nproc + os.getpid() % 500),
@@ -60,3 +61,48 @@ def test_rccl_transport_self_neighbours(ext):
                        capture_output=True, text=True, env=env, timeout=420, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "RCCL-OK" in r.stdout
+
+
+def test_multi_rank_solve_driver_matches_the_native_driver(tmp_path):
+    """python -m wafer_amd.run on 2 ranks (z-slabs, host-staged transport on the one GPU) against
+    wafer-hip on the whole grid: same table rows, same energies, the saved planes tile the state"""
+    import re
+    import numpy as np
+    case = os.path.join(ROOT, "tests", "golden", "cli_case.yaml")
+    cli = os.path.join(ROOT, "wafer_amd", "wafer-hip")
+    one = subprocess.run([cli, "-c", case, "--progress", "--output-dir", str(tmp_path / "one"), "--input-dir", str(tmp_path / "none")],
+                         capture_output=True, text=True)
+    assert one.returncode == 0, one.stderr
+    os.environ["WAFER_TRANSPORT"] = "host"
+    try:
+        two = launch(2, "-m", "wafer_amd.run", "-c", case, "--progress", "--output-dir", str(tmp_path / "two"))
+    finally:
+        os.environ.pop("WAFER_TRANSPORT", None)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+
+    def rows(text):
+        return [l for l in text.splitlines() if re.match(r"^\s+│\s*[0-9.]+ │", l)]
+
+    def ground_rows(text):
+        return rows(text.split("1st excited state caclulation")[0])
+
+    a, b = ground_rows(one.stdout), ground_rows(two.stdout)
+    assert len(a) == len(b) > 3
+    for la, lb in zip(a, b):
+        ca, cb = [c.strip() for c in la.split("│")[1:5]], [c.strip() for c in lb.split("│")[1:5]]
+        assert ca[0] == cb[0] and ca[2] == cb[2] and len(la) == len(lb)          # tau, r_rms, geometry
+        assert float(ca[1]) == pytest.approx(float(cb[1]), abs=2e-9)             # energy: sums associate differently
+    header = [l for l in two.stdout.splitlines() if "Ground state caclulation" in l]
+    assert header and header[0] in one.stdout                                    # the same header line, character for character
+    e1 = float(re.search(r"Ground state energy = ([0-9.eE+-]+)", one.stdout).group(1))
+    e2 = float(re.search(r"Ground state energy = ([0-9.eE+-]+)", two.stdout).group(1))
+    assert e2 == pytest.approx(e1, abs=2e-9)
+    od = tmp_path / "two" / os.listdir(tmp_path / "two")[0]
+    names = sorted(os.listdir(od))
+    assert "observables_0.csv" in names and "observables_1.json" in names
+    lo, hi = np.load(od / "wavefunction_0_z0-14.npy"), np.load(od / "wavefunction_0_z14-28.npy")
+    state = np.concatenate([lo, hi], axis=2)
+    assert state.shape == (24, 20, 28) and np.sum(state * state) == pytest.approx(1.0, abs=1e-12)
+    one_dir = tmp_path / "one" / os.listdir(tmp_path / "one")[0]
+    want = np.loadtxt(one_dir / "wavefunction_0.csv", delimiter=",")[:, 3].reshape(24, 20, 28)
+    assert np.allclose(state, want, rtol=0, atol=1e-12)
