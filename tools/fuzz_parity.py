@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the HIP path against the oracle (a development aid next to the
+fixed cases of tests/test_gpu_parity.py): random shapes incl. 1-cell axes, stencil orders,
+potentials, step counts and kernel variants; ground state bit for bit, excited states (random
+stored states, Gram-Schmidt every step) to 1e-10.   N=200 SEED=3 python tools/fuzz_parity.py"""
+import os, sys, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import wafer_amd as wa
+from oracle import wafer_oracle as wo
+from gpu_common import make_pair, random_phi
+wo.set_threads(8)
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+bad = 0
+for it in range(int(os.environ.get("N", "60"))):
+    ext = int(rng.integers(1, 4))
+    shape = tuple(int(x) for x in rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 64, 65, 127, 129, 130, 200, 257], size=3))
+    if rng.random() < 0.5:
+        shape = (shape[0], int(rng.integers(1, 40)), int(rng.integers(1, 40)))
+    pot = str(rng.choice(["Harmonic", "Coulomb", "SimpleCornell", "NoPotential", "Cube"]))
+    steps = int(rng.integers(1, 6))
+    variant = int(rng.choice([-1, 0, 1, 2]))
+    dtype = "f64"
+    try:
+        cfg, par = make_pair(shape, ext=ext, potential=pot, dn=0.2, dt=0.004, mass=1.3, sig=0.3, dtype=dtype)
+        v = wo.potential_generate(cfg); a, b = wo.ab(cfg, v)
+        phi = random_phi(cfg, seed=it)
+        want = phi.copy(); wo.evolve(cfg, 0, a, b, want, [], steps)
+        with wa.Context(par) as ctx:
+            ctx.set_stencil_variant(variant)
+            ctx.set_potential(pot); ctx.upload_phi(phi); ctx.evolve(0, steps)
+            got = ctx.download_phi()
+            ok = np.array_equal(got, want, equal_nan=True)
+            o1, o2 = ctx.observables(), wo.observables(cfg, v, want, wo.potential_sub(cfg))
+            ok2 = all(abs(o1[k]-o2[k]) <= 1e-11*max(1.0, abs(o2[k])) or (np.isnan(o1[k]) and np.isnan(o2[k])) for k in o2)
+        if not (ok and ok2):
+            bad += 1
+            print("MISMATCH", shape, ext, pot, steps, variant, ok, ok2, flush=True)
+    except Exception as e:
+        bad += 1
+        print("ERROR", shape, ext, pot, steps, variant, repr(e)[:200], flush=True)
+# excited states: normalise + modified Gram-Schmidt after every step (grid.rs:674-681)
+for it in range(int(os.environ.get("N", "60")) // 2):
+    ext = int(rng.integers(1, 4))
+    shape = tuple(int(x) for x in rng.choice([2, 3, 5, 8, 15, 16, 17, 31, 33, 64, 65, 129], size=3))
+    wnum = int(rng.integers(1, 6))
+    steps = int(rng.integers(1, 5))
+    pot = str(rng.choice(["Harmonic", "Coulomb", "NoPotential"]))
+    one_pass = int(rng.integers(0, 2))
+    os.environ["WAFER_ONE_PASS"] = str(one_pass)
+    try:
+        cfg, par = make_pair(shape, ext=ext, potential=pot, dn=0.2, dt=0.004, mass=1.3, sig=0.3, max_states=wnum)
+        v = wo.potential_generate(cfg); a, b = wo.ab(cfg, v)
+        lowers = []
+        for j in range(wnum):   # orthonormalised random states, as a converged w_store would be
+            l = random_phi(cfg, seed=1000 + 10 * it + j)
+            wo.normalise(l, wo.norm2(cfg, l)); wo.orthogonalise(j, l, lowers); wo.normalise(l, wo.norm2(cfg, l))
+            lowers.append(l)
+        phi = random_phi(cfg, seed=it)
+        want = phi.copy(); wo.evolve(cfg, wnum, a, b, want, lowers, steps)
+        with wa.Context(par) as ctx:
+            ctx.set_potential(pot)
+            for l in lowers:
+                ctx.upload_phi(l); ctx.push_state()
+            ctx.upload_phi(phi); ctx.evolve(wnum, steps)
+            got = ctx.download_phi()
+        scale = max(1e-300, float(np.max(np.abs(want))))
+        if not np.allclose(got, want, rtol=0, atol=1e-10 * scale):
+            bad += 1
+            print("MISMATCH excited", shape, ext, pot, wnum, steps, one_pass, float(np.max(np.abs(got - want))) / scale, flush=True)
+    except Exception as e:
+        bad += 1
+        print("ERROR excited", shape, ext, pot, wnum, steps, one_pass, repr(e)[:200], flush=True)
+os.environ.pop("WAFER_ONE_PASS", None)
+print("fuzz done, bad =", bad)
