@@ -494,12 +494,12 @@ static inline hipError_t wafer_launch_step2_fused(WaferStepArgs a, const T *phi,
     //          formed from V -- 0.369 ms/step; the taller tile halves the halo-row overhead
     //          (phi0 20/16, V 18/16 rows per 16) and 147 VGPRs still fit 10 waves per CU.
     //          Streaming a, b instead needs 168+ VGPRs at that size and spills.
-    //   ext 2: 128x8 tiles, a and b streamed (the kernel is issue-bound there; a second division
-    //          per update costs more than the extra stream).
+    //   ext 2: 128x8 tiles, a and b formed from V as well (0.53 ms/step against 0.66 with a, b
+    //          streamed and 0.58 for the single-step kernel, since wafer_recip shortened b's reciprocal).
     // Ordinary (cache-retaining) loads: the halo-row wave re-reads rows its neighbour tile streams.
     const char *e = getenv("WAFER_F2_NW2");
     int nw2 = (e && *e) ? atoi(e) : ((R == 1 && a.g.ny >= 16) ? 8 : 4);
-    if (o.abv < 0) o.abv = (nw2 == 8) ? 1 : 0;
+    if (o.abv < 0) o.abv = 1;
     e = getenv("WAFER_NT");
     if (!(e && *e)) o.nt = 0;
     if constexpr (R == 1) {
