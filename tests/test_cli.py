@@ -266,3 +266,37 @@ def test_symmetry_constraint_is_applied_to_the_start(cli, tmp_path):
     assert abs(o["energy"] / o["norm2"] - plain["energy"] / plain["norm2"]) > 0.1     # the constraint did something
     e = float(re.search(r"Ground state energy = ([0-9.eE+-]+)", r.stdout).group(1))
     assert e == pytest.approx(1.5, abs=0.05)
+
+
+@pytest.mark.gpu
+def test_snapshots_and_resume_from_partial(cli, tmp_path):
+    """snap_update (grid.rs:137-158): a `_partial` file per snapshot, written by a writer thread
+    while evolve continues; it is what is left when max_steps ends the run (grid.rs:223-245), is
+    removed on convergence, and restarts the state from ./input (input.rs:513-523)"""
+    text = open(CASE).read().replace("wavemax: 1", "wavemax: 0").replace("# snap_update: 1000", "snap_update: 100")
+    short = text.replace("max_steps: 200000", "max_steps: 150")
+    (tmp_path / "short.yaml").write_text(short)
+    r = run(cli, "-c", str(tmp_path / "short.yaml"), "--output-dir", str(tmp_path / "o1"), "--input-dir", str(tmp_path / "none"))
+    assert r.returncode == 1 and "MaxStep" in r.stderr
+    od = tmp_path / "o1" / os.listdir(tmp_path / "o1")[0]
+    assert "wavefunction_0_partial.csv" in os.listdir(od) and "wavefunction_0.csv" not in os.listdir(od)
+    assert not [n for n in os.listdir(od) if n.endswith(".tmp")]
+    part = np.loadtxt(od / "wavefunction_0_partial.csv", delimiter=",")[:, 3]
+    assert np.sum(part * part) == pytest.approx(1.0, abs=1e-12)          # normalised ONCE (not the reference's twice)
+
+    # resume: the partial state in ./input starts wavefunction 0 (FromFile), converges, and the
+    # run's own partial file is removed at the end
+    (tmp_path / "in").mkdir()
+    os.replace(od / "wavefunction_0_partial.csv", tmp_path / "in" / "wavefunction_0_partial.csv")
+    (tmp_path / "resume.yaml").write_text(text.replace("init_condition: Boolean", "init_condition: FromFile"))
+    r2 = run(cli, "-c", str(tmp_path / "resume.yaml"), "--progress", "--output-dir", str(tmp_path / "o2"), "--input-dir", str(tmp_path / "in"))
+    assert r2.returncode == 0, r2.stderr
+    od2 = tmp_path / "o2" / os.listdir(tmp_path / "o2")[0]
+    assert "wavefunction_0.csv" in os.listdir(od2) and "wavefunction_0_partial.csv" not in os.listdir(od2)
+    rows2 = [l for l in r2.stdout.splitlines() if re.match(r"^\s+│\s*[0-9.]+ │", l)]
+    (tmp_path / "full.yaml").write_text(text)
+    r3 = run(cli, "-c", str(tmp_path / "full.yaml"), "--progress", "--output-dir", str(tmp_path / "o3"), "--input-dir", str(tmp_path / "none"))
+    rows3 = [l for l in r3.stdout.splitlines() if re.match(r"^\s+│\s*[0-9.]+ │", l)]
+    assert r3.returncode == 0 and 1 < len(rows2) < len(rows3)            # the resumed run had a head start
+    e = lambda out: float(re.search(r"Ground state energy = ([0-9.eE+-]+)", out).group(1))
+    assert e(r2.stdout) == pytest.approx(e(r3.stdout), abs=1e-6)

@@ -44,7 +44,7 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
     src = os.path.join(CSRC, "wafer_cli.cpp")
     if not force and os.path.exists(CLI) and os.path.getmtime(CLI) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
         return CLI
-    cmd = ["g++", "-O2", "-std=c++17", src, "-o", CLI, "-L", HERE, "-lwafer_hip", "-Wl,-rpath,$ORIGIN"]
+    cmd = ["g++", "-O2", "-std=c++17", "-pthread", src, "-o", CLI, "-L", HERE, "-lwafer_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

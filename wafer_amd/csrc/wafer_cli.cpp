@@ -26,6 +26,7 @@
 #include <sstream>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/wafer_hip.h"
@@ -542,6 +543,11 @@ int main(int argc, char **argv)
         CHECK(wafer_push_state(ctx));
     }
 
+    struct Joined { // joins on every way out of main
+        std::thread t;
+        ~Joined() { if (t.joinable()) t.join(); }
+    } writer; // at most one snapshot is being written at a time
+    std::thread &snapshot_writer = writer.t;
     const clock_t t_start = clock();
     struct timespec ts0;
     clock_gettime(CLOCK_MONOTONIC, &ts0);
@@ -599,10 +605,18 @@ int main(int argc, char **argv)
             }
             if (cfg.has_snap_update && step % cfg.snap_update == 0) { // grid.rs:137-158, WITHOUT its second, stale-norm2 normalise
                 CHECK(wafer_symmetrise(ctx, symmetry)); // grid.rs:138
-                host.resize(padded_len);
-                CHECK(wafer_download_phi(ctx, host.data()));
-                if (!write_array(out_dir + "/wavefunction_" + std::to_string(wnum) + "_partial" + ext, cfg.file_type, host.data(), cfg.nx, cfg.ny, cfg.nz, e, err))
-                    fprintf(stderr, "Warning: could not output partial wavefunction: %s\n", err.c_str());
+                // the copy to the host is the only part the GPU waits for; formatting and writing
+                // the file (minutes for a 512^3 csv) go to a writer thread while evolve continues
+                if (snapshot_writer.joinable()) snapshot_writer.join();
+                std::vector<double> snap(padded_len);
+                CHECK(wafer_download_phi(ctx, snap.data()));
+                const std::string name = out_dir + "/wavefunction_" + std::to_string(wnum) + "_partial" + ext;
+                snapshot_writer = std::thread([snap = std::move(snap), name, &cfg, e]() {
+                    std::string werr;
+                    if (!write_array(name + ".tmp", cfg.file_type, snap.data(), cfg.nx, cfg.ny, cfg.nz, e, werr) ||
+                        rename((name + ".tmp").c_str(), name.c_str()) != 0)
+                        fprintf(stderr, "Warning: could not output partial wavefunction: %s\n", werr.c_str());
+                });
             }
             const double diff = std::fabs(norm_energy - last_energy);
             if (!std::isfinite(norm_energy)) { fprintf(stderr, "Error: state %u: energy is not finite at step %llu\n", wnum, (unsigned long long)step); return 1; }
@@ -617,6 +631,7 @@ int main(int argc, char **argv)
             CHECK(wafer_evolve(ctx, wnum, cfg.screen_update));
             step += cfg.screen_update;
         }
+        if (snapshot_writer.joinable()) snapshot_writer.join();
         wafer_observables_output fin;
         const double r_norm = std::sqrt(obs.r2 / obs.norm2);
         fin.state = wnum;
