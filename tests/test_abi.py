@@ -13,6 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def lib():
     import wafer_amd
+    from wafer_amd import build
+    if not os.path.exists(build.LIB):      # a clean checkout: the test harness builds, the product never does
+        build.build()
     return wafer_amd.load_library()
 
 
