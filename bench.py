@@ -27,7 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-BYTES_PER_UPDATE = {"f64": 32, "f32": 16}  # phi, a, b in + phi' out
+BYTES_PER_UPDATE = {"f64": 32, "f32": 16, "f32fast": 16}  # phi, a, b in + phi' out
 
 
 def parse_args():
@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "f32fast"])
     ap.add_argument("--grid", default=None, help="override: NX,NY,NZ (global work area)")
     ap.add_argument("--cd", type=int, default=1, help="central difference ext: 1/2/3")
     ap.add_argument("--potential", default="Coulomb")

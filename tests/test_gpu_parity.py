@@ -606,7 +606,7 @@ def test_f32_path_tracks_f64(wo, wa):
     fp64 and fp32 storage, relative energy error <= 1e-5, |norm2 - 1| <= 1e-5"""
     shape = (48, 48, 48)
     res = {}
-    for dtype in ("f64", "f32"):
+    for dtype in ("f64", "f32", "f32fast"):
         _, par = make_pair(shape, ext=1, potential="Harmonic", dn=0.27, dt=0.0145, dtype=dtype)
         with wa.Context(par) as ctx:
             ctx.set_potential("Harmonic")
@@ -618,6 +618,9 @@ def test_f32_path_tracks_f64(wo, wa):
     assert res["f32"][0] == pytest.approx(res["f64"][0], rel=1e-5)
     assert res["f32"][1] == pytest.approx(1.0, abs=1e-5)
     assert res["f64"][1] == pytest.approx(1.0, abs=1e-12)
+    # fp32 arithmetic in the stencil steps as well (WAFER_F32_FAST): same bars
+    assert res["f32fast"][0] == pytest.approx(res["f64"][0], rel=1e-5)
+    assert res["f32fast"][1] == pytest.approx(1.0, abs=1e-5)
 
 
 def test_config5_flow_file_potential_fp32_vs_fp64(wa):
@@ -629,7 +632,7 @@ def test_config5_flow_file_potential_fp32_vs_fp64(wa):
     X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
     src = np.ascontiguousarray(-3.0 / np.cosh(0.6 * np.sqrt(X * X + Y * Y + 2.0 * Z * Z)) ** 2)  # anisotropic Poschl-Teller well
     res = {}
-    for dtype in ("f64", "f32"):
+    for dtype in ("f64", "f32", "f32fast"):
         par = wa.Params(n, n, n, dn=0.2, dt=0.008, mass=1.0, dtype=dtype, max_states=1)
         with wa.Context(par) as ctx:
             ctx.set_potential_resampled(src)
@@ -641,6 +644,28 @@ def test_config5_flow_file_potential_fp32_vs_fp64(wa):
     assert res["f64"][0] < -0.5                      # bound state of the well
     assert res["f32"][0] == pytest.approx(res["f64"][0], rel=1e-5)
     assert res["f32"][1] == pytest.approx(1.0, abs=1e-5) and res["f64"][1] == pytest.approx(1.0, abs=1e-12)
+    assert res["f32fast"][0] == pytest.approx(res["f64"][0], rel=1e-5)
+    assert res["f32fast"][1] == pytest.approx(1.0, abs=1e-5)
+
+
+@pytest.mark.parametrize("ext", [1, 2, 3])
+def test_f32fast_steps_track_fp64(wo, wa, ext):
+    """WAFER_F32_FAST: 40 ground-state steps with fp32 stencil arithmetic stay within fp32 rounding
+    of the fp64 oracle (per cell 2e-5 of the largest value), on every stencil order"""
+    cfg, par = make_pair((70, 33, 40), ext=ext, potential="Coulomb", dn=0.2, dt=0.004, dtype="f32fast")
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=5).astype(np.float32).astype(np.float64)
+    want = phi.copy()
+    wo.evolve(cfg, 0, a, b, want, [], 40)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 40)
+        got = ctx.download_phi()
+        n2 = ctx.norm2()
+    assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want))
+    assert n2 == pytest.approx(wo.norm2(cfg, want), rel=1e-5)
 
 
 def test_f32_excited_state_path(wa):

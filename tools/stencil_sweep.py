@@ -54,7 +54,7 @@ def main():
     nx, ny, nz = (int(s) for s in args.grid.split(","))
     par = wafer_amd.Params(nx, ny, nz, dn=args.dn, dt=args.dt, mass=args.mass, sig=args.sig,
                            central_difference=args.cd, dtype=args.dtype, max_states=max(1, args.wnum))
-    bpu = {"f64": 32, "f32": 16}[args.dtype]
+    bpu = {"f64": 32, "f32": 16, "f32fast": 16}[args.dtype]
     with wafer_amd.Context(par) as ctx:
         ctx.set_potential(args.potential)
         ctx.set_initial_condition("Boolean")

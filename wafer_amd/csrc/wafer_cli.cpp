@@ -192,7 +192,7 @@ static bool load_config(const std::string &path, Config &c, std::string &err)
     // Config::parse, config.rs:362-370
     if (c.dt > c.dn * c.dn / 3.) { err = "ConfigParse: LargeDt: dt must be <= dn^2/3"; return false; }
     if (c.wavenum > c.wavemax) { err = "ConfigParse: LargeWavenum: wavenum must be <= wavemax"; return false; }
-    if (c.dtype != "f64" && c.dtype != "f32") { err = "gpu.dtype must be f64 or f32"; return false; }
+    if (c.dtype != "f64" && c.dtype != "f32" && c.dtype != "f32fast") { err = "gpu.dtype must be f64, f32 or f32fast"; return false; }
     return true;
 }
 
@@ -465,7 +465,7 @@ int main(int argc, char **argv)
     p.struct_size = sizeof p;
     p.nx = cfg.nx; p.ny = cfg.ny; p.nz = cfg.nz;
     p.central_difference = cfg.central_difference;
-    p.dtype = cfg.dtype == "f32" ? WAFER_F32 : WAFER_F64;
+    p.dtype = cfg.dtype == "f32" ? WAFER_F32 : cfg.dtype == "f32fast" ? WAFER_F32_FAST : WAFER_F64;
     p.dn = cfg.dn; p.dt = cfg.dt; p.mass = cfg.mass; p.sig = cfg.sig;
     p.max_states = cfg.wavemax + 1;
     p.device = cfg.device;

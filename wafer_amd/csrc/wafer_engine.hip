@@ -87,7 +87,8 @@ enum { SCAL_SLOTS = 32 };
 struct wafer_ctx {
     wafer_params P;
     WaferGeom g;
-    bool f32 = false;
+    bool f32 = false;       // fp32 storage
+    bool f32_arith = false; // ... and fp32 arithmetic in the ground-state stencil steps (WAFER_F32_FAST)
     size_t esz = 8;
 
     hipStream_t s_main = nullptr, s_aux = nullptr, s_own = nullptr;
@@ -317,10 +318,17 @@ static long long step_partials_count(wafer_ctx *c, int lz_lo, int lz_hi)
 }
 
 template <typename F>
-static int dispatch(wafer_ctx *c, F &&f)
+static int dispatch(wafer_ctx *c, F &&f, bool step_kernel = false)
 {
     // f(T storage tag, C compute tag, R tag)
     const int R = c->g.R;
+    if (c->f32 && c->f32_arith && step_kernel) {
+        // WAFER_F32_FAST: the ground-state stencil steps also COMPUTE in fp32 (sums, projections
+        // and observables stay fp64)
+        if (R == 1) return f(float{}, float{}, std::integral_constant<int, 1>{});
+        if (R == 2) return f(float{}, float{}, std::integral_constant<int, 2>{});
+        return f(float{}, float{}, std::integral_constant<int, 3>{});
+    }
     if (!c->f32) {
         if (R == 1) return f(double{}, double{}, std::integral_constant<int, 1>{});
         if (R == 2) return f(double{}, double{}, std::integral_constant<int, 2>{});
@@ -340,7 +348,7 @@ static int launch_step(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, boo
         constexpr int R = decltype(r)::value;
         return norm ? launch_step_t<T, C, R, true>(c, src, dst, lz_lo, lz_hi, s)
                     : launch_step_t<T, C, R, false>(c, src, dst, lz_lo, lz_hi, s);
-    });
+    }, !norm);
 }
 
 // two fused steps over planes [lz_lo, lz_hi): phi[dst] = step(step(phi[src]))
@@ -367,7 +375,7 @@ static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
         } else {
             return fail(WAFER_ERR_INVALID, "the fused two-step kernel is not built for SevenPoint");
         }
-    });
+    }, true);
 }
 
 
@@ -550,7 +558,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     if (p->nx < 1 || p->ny < 1 || p->nz < 1) return fail(WAFER_ERR_INVALID, "grid size must be >= 1");
     if (p->central_difference < 1 || p->central_difference > 3)
         return fail(WAFER_ERR_INVALID, "central_difference must be 1 (Three), 2 (Five) or 3 (SevenPoint)");
-    if (p->dtype != WAFER_F64 && p->dtype != WAFER_F32) return fail(WAFER_ERR_INVALID, "bad dtype");
+    if (p->dtype != WAFER_F64 && p->dtype != WAFER_F32 && p->dtype != WAFER_F32_FAST) return fail(WAFER_ERR_INVALID, "bad dtype");
     if (!(p->dn > 0) || !(p->dt > 0) || !(p->mass > 0)) return fail(WAFER_ERR_INVALID, "dn, dt, mass must be > 0");
     // config.rs:362-365 (ErrorKind::LargeDt)
     if (!(p->flags & WAFER_FLAG_SKIP_DT_CHECK) && p->dt > p->dn * p->dn / 3.)
@@ -574,7 +582,8 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     wafer_ctx *c = new wafer_ctx();
     c->num_cus = cus > 0 ? cus : 256;
     c->P = *p;
-    c->f32 = (p->dtype == WAFER_F32);
+    c->f32 = (p->dtype == WAFER_F32 || p->dtype == WAFER_F32_FAST);
+    c->f32_arith = (p->dtype == WAFER_F32_FAST);
     c->esz = c->f32 ? 4 : 8;
     c->g = wafer_make_geom((int)p->nx, (int)p->ny, (int)p->nz, R, G, (int)zb, (int)zc, (int)c->esz);
     c->bx = (c->g.px + 63) / 64; // covers both the work area and the padded extent

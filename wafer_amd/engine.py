@@ -176,7 +176,7 @@ class Params:
     mass: float = 1.0
     sig: float = 1.0
     central_difference: int = 1      # 1/2/3 or "ThreePoint"/"FivePoint"/"SevenPoint"
-    dtype: str = "f64"               # "f64" | "f32"
+    dtype: str = "f64"               # "f64" | "f32" (fp32 storage, fp64 arithmetic) | "f32fast" (+ fp32 step arithmetic)
     max_states: int = 4
     device: int = 0
     z_begin: int = 0
@@ -200,7 +200,7 @@ class Params:
 
     def c(self) -> _Params:
         return _Params(C.sizeof(_Params), self.nx, self.ny, self.nz, self.ext,
-                       {"f64": 0, "f32": 1}[self.dtype], self.dn, self.dt, self.mass, self.sig,
+                       {"f64": 0, "f32": 1, "f32fast": 2}[self.dtype], self.dn, self.dt, self.mass, self.sig,
                        self.max_states, self.device, self.z_begin, self.z_count, self.halo_depth,
                        FLAG_SKIP_DT_CHECK if self.skip_dt_check else 0)
 
