@@ -102,6 +102,11 @@ def pmc_traffic(kernel_name: str):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON result: native libraries that write to the C stdout
+    # (RCCL prints a version banner there, flushed at exit) are sent to stderr instead
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -266,7 +271,8 @@ def main():
         dist.destroy_process_group()
     ctx.close()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        result_out.write(json.dumps(result) + "\n")
+        result_out.flush()
 
 
 if __name__ == "__main__":
