@@ -68,7 +68,10 @@ __device__ __forceinline__ C wafer_update_v(C w, C vv, C dt, C S, C den, bool v_
 
 // ABV: pv is V and a, b are formed in registers (24 B per two updates);
 // !ABV: pv is a, pb is b, streamed (32 B per two updates, ~14 fp64 ops fewer per update).
-template <typename T, typename C, int R, bool NT, bool ABV, int NW2 = 4>
+// VIR: the potential passed check_v_range, so b's reciprocal takes its short form -- a template
+// parameter rather than a kernel argument so that the updates of a plane form one basic block and
+// their division chains interleave.
+template <typename T, typename C, int R, bool NT, bool ABV, int NW2 = 4, bool VIR = false>
 __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fused(
     WaferStepArgs a, int ntx, int nty, int swz, const T *__restrict__ phi, const T *__restrict__ pv,
     const T *__restrict__ pb, T *__restrict__ out)
@@ -93,7 +96,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
     const int zs = a.lz_lo + tz_i * a.zchunk;
     const int ze = min(zs + a.zchunk, a.lz_hi);
     const C dt = (C)a.dt, den = (C)a.den;
-    const bool vir = a.v_in_range != 0;
+    constexpr bool vir = VIR;
     const bool is_main = wave < Cfg::NW2;
     const bool is_hrow = wave >= Cfg::NW2 && wave < Cfg::NW2 + Cfg::NWH;
     const bool is_hcol = wave == Cfg::NW - 1;
@@ -301,7 +304,10 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
                 VT res = zero;
-                if (wplane && rowwk[r]) {
+                // computed unconditionally (rows and planes outside the work area read the zero
+                // guard zone) and selected afterwards: one basic block for all RY x VEC updates, so
+                // their division chains interleave
+                {
                     const int ly = yrow[r] - (y0 - 2 * R);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
@@ -323,7 +329,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                         T rs;
                         if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)vq[R][r][v], dt, S, den, vir);
                         else rs = (T)wafer_update<C>(w, (C)vq[R][r][v], (C)bq[R][r][v], dt, S, den);
-                        res[v] = (xi + v < g.nx) ? rs : T(0);
+                        res[v] = (wplane && rowwk[r] && xi + v < g.nx) ? rs : T(0);
                     }
                 }
                 p1new[r] = res;
@@ -370,9 +376,10 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
             const int zo2 = z - R;
             if (zo2 >= zs) {
                 const T *c1 = lds1 + (((zo2 % Cfg::NB1) + Cfg::NB1) % Cfg::NB1) * Cfg::TILE1;
+                VT res2[RY];
 #pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    if (rowwk[r]) {
+                for (int r = 0; r < RY; ++r) { // all rows first (one basic block), stores afterwards
+                    {
                         const int ly = yrow[r] - (y0 - R);
                         VT res;
 #pragma unroll
@@ -396,13 +403,19 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                             if constexpr (ABV) res[v] = (T)wafer_update_v<C>(w, (C)vq[0][r][v], dt, S, den, vir);
                             else res[v] = (T)wafer_update<C>(w, (C)vq[0][r][v], (C)bq[0][r][v], dt, S, den);
                         }
+                        res2[r] = res;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    if (rowwk[r]) {
                         T *dst = out + (long long)zo2 * g.plane + rowoff[r];
                         if (xi + VEC <= g.nx) {
-                            wafer_st_stream<NT>(reinterpret_cast<VT *>(dst), res);
+                            wafer_st_stream<NT>(reinterpret_cast<VT *>(dst), res2[r]);
                         } else {
 #pragma unroll
                             for (int v = 0; v < VEC; ++v)
-                                if (xi + v < g.nx) dst[v] = res[v];
+                                if (xi + v < g.nx) dst[v] = res2[r][v];
                         }
                     }
                 }
@@ -470,16 +483,19 @@ static inline hipError_t wafer_launch_step2_fused_nw(WaferStepArgs a, const Wafe
     const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
     const dim3 grid((unsigned)((long long)ntx * nty * ntz)), block(Cfg::NT_);
-#define WAFER_F2_CASE(NT_, ABV_)                                                                          \
-    if ((o.nt != 0) == NT_ && (o.abv != 0) == ABV_) {                                                     \
-        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, NT_, ABV_, NW2>), grid, block, (size_t)o.pad, s, \
-                           a, ntx, nty, o.swz, phi, ABV_ ? pv : pa, pb, out);                              \
-        return hipGetLastError();                                                                         \
+    const bool vir = a.v_in_range != 0;
+#define WAFER_F2_CASE(NT_, ABV_, VIR_)                                                                          \
+    if ((o.nt != 0) == NT_ && (o.abv != 0) == ABV_ && (!ABV_ || vir == VIR_)) {                                 \
+        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, NT_, ABV_, NW2, VIR_>), grid, block, (size_t)o.pad, s, \
+                           a, ntx, nty, o.swz, phi, ABV_ ? pv : pa, pb, out);                                    \
+        return hipGetLastError();                                                                               \
     }
-    WAFER_F2_CASE(true, true)
-    WAFER_F2_CASE(false, true)
-    WAFER_F2_CASE(true, false)
-    WAFER_F2_CASE(false, false)
+    WAFER_F2_CASE(true, true, true)
+    WAFER_F2_CASE(true, true, false)
+    WAFER_F2_CASE(false, true, true)
+    WAFER_F2_CASE(false, true, false)
+    WAFER_F2_CASE(true, false, false)
+    WAFER_F2_CASE(false, false, false)
 #undef WAFER_F2_CASE
     return hipErrorInvalidValue;
 }
