@@ -31,6 +31,7 @@
 // side; slabs of a sharded grid need 2R valid ghost planes of phi0.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "wafer_geom.h"
 #include "wafer_stencil.hip.h"
 #include "wafer_stencil_lds.hip.h"
@@ -301,40 +302,48 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
         const bool wplane = work_plane(z);
         VT p1new[RY];
         if (!is_hcol) {
+            // INTERIOR: the plane and every row of this wave are work cells (the common case) -- no
+            // wave-uniform tests are left inside, so the RY x VEC updates form ONE basic block and
+            // their division chains interleave; the general form tests per row.
+            auto step1 = [&](auto interior_tag) {
+                constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                VT res = zero;
-                // computed unconditionally (rows and planes outside the work area read the zero
-                // guard zone) and selected afterwards: one basic block for all RY x VEC updates, so
-                // their division chains interleave
-                {
-                    const int ly = yrow[r] - (y0 - 2 * R);
+                for (int r = 0; r < RY; ++r) {
+                    VT res = zero;
+                    if (INTERIOR || (wplane && rowwk[r])) {
+                        const int ly = yrow[r] - (y0 - 2 * R);
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
-                        const C w = (C)q0[R][r][v];
+                        for (int v = 0; v < VEC; ++v) {
+                            C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
+                            const C w = (C)q0[R][r][v];
 #pragma unroll
-                        for (int d = -R; d <= R; ++d) {
-                            zz[d + R] = (C)q0[R + d][r][v];
-                            if (d == 0) {
-                                xs[R] = w;
-                                ys[R] = w;
-                            } else {
-                                xs[d + R] = (v + d >= 0 && v + d < VEC) ? (C)q0[R][r][(v + d + VEC) % VEC]
-                                                                       : (C)c0[ly * LP0 + HX0 + xl + v + d];
-                                ys[d + R] = (C)c0[(ly + d) * LP0 + HX0 + xl + v];
+                            for (int d = -R; d <= R; ++d) {
+                                zz[d + R] = (C)q0[R + d][r][v];
+                                if (d == 0) {
+                                    xs[R] = w;
+                                    ys[R] = w;
+                                } else {
+                                    xs[d + R] = (v + d >= 0 && v + d < VEC) ? (C)q0[R][r][(v + d + VEC) % VEC]
+                                                                           : (C)c0[ly * LP0 + HX0 + xl + v + d];
+                                    ys[d + R] = (C)c0[(ly + d) * LP0 + HX0 + xl + v];
+                                }
                             }
+                            const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
+                            T rs;
+                            if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)vq[R][r][v], dt, S, den, vir);
+                            else rs = (T)wafer_update<C>(w, (C)vq[R][r][v], (C)bq[R][r][v], dt, S, den);
+                            res[v] = (xi + v < g.nx) ? rs : T(0);
                         }
-                        const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                        T rs;
-                        if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)vq[R][r][v], dt, S, den, vir);
-                        else rs = (T)wafer_update<C>(w, (C)vq[R][r][v], (C)bq[R][r][v], dt, S, den);
-                        res[v] = (wplane && rowwk[r] && xi + v < g.nx) ? rs : T(0);
                     }
+                    p1new[r] = res;
+                    *reinterpret_cast<VT *>(w1 + (yrow[r] - (y0 - R)) * LP1 + HX1 + xl) = res;
                 }
-                p1new[r] = res;
-                *reinterpret_cast<VT *>(w1 + (yrow[r] - (y0 - R)) * LP1 + HX1 + xl) = res;
-            }
+            };
+            bool all_rows = wplane;
+#pragma unroll
+            for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];
+            if (all_rows) step1(std::true_type{});
+            else step1(std::false_type{});
         } else {
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q) {
@@ -376,49 +385,56 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
             const int zo2 = z - R;
             if (zo2 >= zs) {
                 const T *c1 = lds1 + (((zo2 % Cfg::NB1) + Cfg::NB1) % Cfg::NB1) * Cfg::TILE1;
-                VT res2[RY];
+                auto step2 = [&](auto interior_tag) {
+                    constexpr bool INTERIOR = decltype(interior_tag)::value;
+                    VT res2[RY];
 #pragma unroll
-                for (int r = 0; r < RY; ++r) { // all rows first (one basic block), stores afterwards
-                    {
-                        const int ly = yrow[r] - (y0 - R);
-                        VT res;
+                    for (int r = 0; r < RY; ++r) {
+                        res2[r] = zero;
+                        if (INTERIOR || rowwk[r]) {
+                            const int ly = yrow[r] - (y0 - R);
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
-                            const C w = (C)q1[R][r][v];
+                            for (int v = 0; v < VEC; ++v) {
+                                C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
+                                const C w = (C)q1[R][r][v];
 #pragma unroll
-                            for (int d = -R; d <= R; ++d) {
-                                zz[d + R] = (C)q1[R + d][r][v];
-                                if (d == 0) {
-                                    xs[R] = w;
-                                    ys[R] = w;
-                                } else {
-                                    xs[d + R] = (v + d >= 0 && v + d < VEC) ? (C)q1[R][r][(v + d + VEC) % VEC]
-                                                                           : (C)c1[ly * LP1 + HX1 + xl + v + d];
-                                    ys[d + R] = (r + d >= 0 && r + d < RY) ? (C)q1[R][(r + d + RY) % RY][v]
-                                                                         : (C)c1[(ly + d) * LP1 + HX1 + xl + v];
+                                for (int d = -R; d <= R; ++d) {
+                                    zz[d + R] = (C)q1[R + d][r][v];
+                                    if (d == 0) {
+                                        xs[R] = w;
+                                        ys[R] = w;
+                                    } else {
+                                        xs[d + R] = (v + d >= 0 && v + d < VEC) ? (C)q1[R][r][(v + d + VEC) % VEC]
+                                                                               : (C)c1[ly * LP1 + HX1 + xl + v + d];
+                                        ys[d + R] = (r + d >= 0 && r + d < RY) ? (C)q1[R][(r + d + RY) % RY][v]
+                                                                             : (C)c1[(ly + d) * LP1 + HX1 + xl + v];
+                                    }
                                 }
+                                const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
+                                if constexpr (ABV) res2[r][v] = (T)wafer_update_v<C>(w, (C)vq[0][r][v], dt, S, den, vir);
+                                else res2[r][v] = (T)wafer_update<C>(w, (C)vq[0][r][v], (C)bq[0][r][v], dt, S, den);
                             }
-                            const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                            if constexpr (ABV) res[v] = (T)wafer_update_v<C>(w, (C)vq[0][r][v], dt, S, den, vir);
-                            else res[v] = (T)wafer_update<C>(w, (C)vq[0][r][v], (C)bq[0][r][v], dt, S, den);
-                        }
-                        res2[r] = res;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    if (rowwk[r]) {
-                        T *dst = out + (long long)zo2 * g.plane + rowoff[r];
-                        if (xi + VEC <= g.nx) {
-                            wafer_st_stream<NT>(reinterpret_cast<VT *>(dst), res2[r]);
-                        } else {
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v)
-                                if (xi + v < g.nx) dst[v] = res2[r][v];
                         }
                     }
-                }
+#pragma unroll
+                    for (int r = 0; r < RY; ++r) {
+                        if (INTERIOR || rowwk[r]) {
+                            T *dst = out + (long long)zo2 * g.plane + rowoff[r];
+                            if (xi + VEC <= g.nx) {
+                                wafer_st_stream<NT>(reinterpret_cast<VT *>(dst), res2[r]);
+                            } else {
+#pragma unroll
+                                for (int v = 0; v < VEC; ++v)
+                                    if (xi + v < g.nx) dst[v] = res2[r][v];
+                            }
+                        }
+                    }
+                };
+                bool all_rows2 = true;
+#pragma unroll
+                for (int r = 0; r < RY; ++r) all_rows2 = all_rows2 && rowwk[r];
+                if (all_rows2) step2(std::true_type{});
+                else step2(std::false_type{});
             }
         }
         __syncthreads();
