@@ -106,3 +106,23 @@ def test_multi_rank_solve_driver_matches_the_native_driver(tmp_path):
     one_dir = tmp_path / "one" / os.listdir(tmp_path / "one")[0]
     want = np.loadtxt(one_dir / "wavefunction_0.csv", delimiter=",")[:, 3].reshape(24, 20, 28)
     assert np.allclose(state, want, rtol=0, atol=1e-12)
+
+
+def test_native_rccl_host_self_neighbours():
+    """wafer-hip-slabs --self: the hooks served by RCCL's C API directly from a native host
+    (no Python, no torch in that process), one rank that is its own z-neighbour, bit for bit
+    against device copies (wafer_amd/csrc/wafer_rccl_host.cpp)"""
+    exe = os.path.join(ROOT, "wafer_amd", "wafer-hip-slabs")
+    if not os.path.exists(exe):
+        from wafer_amd import build
+        build.build_rccl_host()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "--self", "136", "40", "96", "9"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "SELF-OK" in r.stdout and "halo_calls=" in r.stdout
+    # the same binary as an ordinary single-rank run prints one JSON record
+    import json
+    r = subprocess.run([exe, "64", "48", "40", "10"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 10 and rec["norm2"] > 0

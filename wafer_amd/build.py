@@ -51,6 +51,22 @@ def build_cli(force: bool = False, verbose: bool = False) -> str:
     return CLI
 
 
+SLABS = os.path.join(HERE, "wafer-hip-slabs")
+
+
+def build_rccl_host(force: bool = False, verbose: bool = False) -> str:
+    """The native multi-GPU host (hooks served by RCCL's C API directly; wafer_rccl_host.cpp)."""
+    src = os.path.join(CSRC, "wafer_rccl_host.cpp")
+    if not force and os.path.exists(SLABS) and os.path.getmtime(SLABS) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return SLABS
+    cmd = [hipcc(), "-O2", "-std=c++17", "-pthread", src, "-o", SLABS, "-L", HERE, "-lwafer_hip", "-lrccl",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return SLABS
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
         cmd = [hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
@@ -58,6 +74,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
     build_cli(force=force, verbose=verbose)
+    build_rccl_host(force=force, verbose=verbose)
     return LIB
 
 

@@ -1,0 +1,224 @@
+// wafer-hip-slabs -- a native (no Python, no torch) multi-GPU host above the C ABI: one process
+// per GPU, the grid z-slab decomposed over the ranks, the engine's two communication hooks served by
+// RCCL called directly (ncclSend / ncclRecv in a group, ncclAllReduce) on the stream the engine
+// passes.  This is the shape of the Rust host INTEGRATION.md section 3 describes; the tested
+// production path for multi-GPU runs is wafer_amd/slab.py + wafer_amd/run.py (same hooks over
+// torch.distributed).
+//
+//   RANK=r WORLD_SIZE=n LOCAL_RANK=r WAFER_NCCL_ID_FILE=/tmp/id  wafer-hip-slabs NX NY NZ STEPS [potential]
+//       every rank runs this; rank 0 writes the ncclUniqueId to the file, the others wait for it.
+//       Ground-state evolve of a Boolean start; rank 0 prints one JSON line.
+//   wafer-hip-slabs --self NX NY NZ STEPS
+//       ONE process, one GPU: the slab is a middle slab of an 8-rank world whose neighbours are this
+//       same rank, so halo planes really travel through ncclSend / ncclRecv (and scalars through
+//       ncclAllReduce); the run is repeated with plain device copies as hooks and must agree bit for
+//       bit.  Prints SELF-OK.  (tests/test_gpu_multiprocess.py)
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include "../../include/wafer_hip.h"
+
+#define HIPCHECK(x)                                                                         \
+    do {                                                                                    \
+        hipError_t e_ = (x);                                                                \
+        if (e_ != hipSuccess) {                                                             \
+            fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_));                  \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while (0)
+#define NCCLCHECK(x)                                                                        \
+    do {                                                                                    \
+        ncclResult_t r_ = (x);                                                              \
+        if (r_ != ncclSuccess) {                                                            \
+            fprintf(stderr, "%s failed: %s\n", #x, ncclGetErrorString(r_));                 \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while (0)
+#define WCHECK(x)                                                                           \
+    do {                                                                                    \
+        if ((x) != WAFER_OK) {                                                              \
+            fprintf(stderr, "%s failed: %s\n", #x, wafer_last_error());                     \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while (0)
+
+struct Fabric {
+    ncclComm_t comm = nullptr;
+    int lower = -1, upper = -1; // neighbour ranks, -1 = none
+    long halo_calls = 0, reduce_calls = 0;
+};
+
+// hooks: enqueue on the engine's stream, never block the host
+static int rccl_halo(void *user, void *send_lo, void *send_hi, void *recv_lo, void *recv_hi, size_t bytes, void *stream)
+{
+    Fabric *f = static_cast<Fabric *>(user);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ncclGroupStart() != ncclSuccess) return 1;
+    // receives first, then sends: between one pair of ranks they match in posting order
+    if (recv_lo && ncclRecv(recv_lo, bytes, ncclChar, f->lower, f->comm, s) != ncclSuccess) return 1;
+    if (recv_hi && ncclRecv(recv_hi, bytes, ncclChar, f->upper, f->comm, s) != ncclSuccess) return 1;
+    if (send_lo && ncclSend(send_lo, bytes, ncclChar, f->lower, f->comm, s) != ncclSuccess) return 1;
+    if (send_hi && ncclSend(send_hi, bytes, ncclChar, f->upper, f->comm, s) != ncclSuccess) return 1;
+    if (ncclGroupEnd() != ncclSuccess) return 1;
+    ++f->halo_calls;
+    return 0;
+}
+static int rccl_allreduce(void *user, void *dev_ptr, size_t count, void *stream)
+{
+    Fabric *f = static_cast<Fabric *>(user);
+    ++f->reduce_calls;
+    return ncclAllReduce(dev_ptr, dev_ptr, count, ncclDouble, ncclSum, f->comm, static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : 1;
+}
+// the same exchange with itself as both neighbours, by device copies (what the self test expects
+// RCCL to deliver: first receive posted <- first send posted)
+static int copy_halo(void *, void *send_lo, void *send_hi, void *recv_lo, void *recv_hi, size_t bytes, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(recv_lo, send_lo, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+    if (hipMemcpyAsync(recv_hi, send_hi, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+    return 0;
+}
+static int copy_allreduce(void *, void *, size_t, void *) { return 0; }
+
+static int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+struct RunResult {
+    std::vector<double> phi;
+    wafer_observables_t obs;
+    float ms = 0.f;
+    uint64_t steps = 0;
+};
+
+static int run_slab(const wafer_params &p, int potential, uint64_t steps, wafer_halo_fn halo, wafer_allreduce_fn allreduce,
+                    void *user, bool download, RunResult &out)
+{
+    wafer_ctx *ctx = nullptr;
+    WCHECK(wafer_ctx_create(&p, &ctx));
+    WCHECK(wafer_set_comm_hooks(ctx, halo, allreduce, user));
+    WCHECK(wafer_set_potential_builtin(ctx, potential));
+    WCHECK(wafer_set_initial_condition(ctx, WAFER_IC_BOOLEAN, 0));
+    WCHECK(wafer_evolve(ctx, 0, steps < 20 ? steps : 20)); // warm-up (and channel set-up) outside the timing
+    WCHECK(wafer_evolve(ctx, 0, steps));
+    WCHECK(wafer_last_evolve_ms(ctx, &out.ms, &out.steps));
+    WCHECK(wafer_observables(ctx, &out.obs));
+    if (download) {
+        const uint32_t e = (uint32_t)p.central_difference;
+        out.phi.assign((size_t)(p.nx + 2 * e) * (p.ny + 2 * e) * (p.nz + 2 * e), 0.0);
+        WCHECK(wafer_download_phi(ctx, out.phi.data()));
+    }
+    WCHECK(wafer_ctx_destroy(ctx));
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    bool self = false;
+    int a0 = 1;
+    if (argc > 1 && std::string(argv[1]) == "--self") { self = true; a0 = 2; }
+    if (argc < a0 + 4) {
+        fprintf(stderr, "usage: wafer-hip-slabs [--self] NX NY NZ STEPS [potential index, default SimpleCornell]\n");
+        return 2;
+    }
+    const uint32_t nx = (uint32_t)atoi(argv[a0]), ny = (uint32_t)atoi(argv[a0 + 1]), nz = (uint32_t)atoi(argv[a0 + 2]);
+    const uint64_t steps = (uint64_t)atoll(argv[a0 + 3]);
+    const int potential = argc > a0 + 4 ? atoi(argv[a0 + 4]) : (int)WAFER_POT_SIMPLECORNELL;
+    const int rank = self ? 0 : env_int("RANK", 0), world = self ? 1 : env_int("WORLD_SIZE", 1);
+    const int device = env_int("LOCAL_RANK", rank);
+    HIPCHECK(hipSetDevice(device));
+
+    // ---- communicator: rank 0 publishes the unique id through a file ------------------------------
+    Fabric fab;
+    ncclUniqueId id;
+    if (world > 1) {
+        const char *path = getenv("WAFER_NCCL_ID_FILE");
+        if (!path) { fprintf(stderr, "WAFER_NCCL_ID_FILE must name a file all ranks can reach\n"); return 2; }
+        if (rank == 0) {
+            NCCLCHECK(ncclGetUniqueId(&id));
+            const std::string tmp = std::string(path) + ".tmp";
+            FILE *f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(&id, sizeof id, 1, f) != 1) { fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
+            fclose(f);
+            rename(tmp.c_str(), path);
+        } else {
+            FILE *f = nullptr;
+            for (int tries = 0; tries < 6000 && !(f = fopen(path, "rb")); ++tries)
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            if (!f || fread(&id, sizeof id, 1, f) != 1) { fprintf(stderr, "cannot read %s\n", path); return 1; }
+            fclose(f);
+        }
+    } else {
+        NCCLCHECK(ncclGetUniqueId(&id));
+    }
+    NCCLCHECK(ncclCommInitRank(&fab.comm, world, id, rank));
+
+    // ---- slab of this rank ----------------------------------------------------------------------------
+    wafer_params p;
+    memset(&p, 0, sizeof p);
+    p.struct_size = sizeof p;
+    p.nx = nx; p.ny = ny; p.nz = nz;
+    p.central_difference = WAFER_CD_THREEPOINT;
+    p.dtype = WAFER_F64;
+    p.dn = 0.02; p.dt = 8e-5; p.mass = 2.35; p.sig = 0.223; // BASELINE config #4
+    p.max_states = 1;
+    p.device = device;
+    p.halo_depth = 2; // two fused steps per exchange
+    int rc = 0;
+    if (self) {
+        const uint32_t parts = 8, per = nz / parts;
+        if (per < 4) { fprintf(stderr, "--self needs NZ >= 32\n"); return 2; }
+        p.z_begin = 4 * per; p.z_count = per; // a middle slab: neighbours on both sides
+        fab.lower = fab.upper = 0;
+        RunResult via_rccl, via_copies;
+        if ((rc = run_slab(p, potential, steps, rccl_halo, rccl_allreduce, &fab, true, via_rccl))) return rc;
+        if ((rc = run_slab(p, potential, steps, copy_halo, copy_allreduce, nullptr, true, via_copies))) return rc;
+        const bool same = via_rccl.phi.size() == via_copies.phi.size() &&
+                          memcmp(via_rccl.phi.data(), via_copies.phi.data(), via_rccl.phi.size() * sizeof(double)) == 0 &&
+                          memcmp(&via_rccl.obs, &via_copies.obs, sizeof(wafer_observables_t)) == 0;
+        double sum = 0.0;
+        for (double v : via_rccl.phi) sum += v * v;
+        if (!same || !(sum > 0.0) || fab.halo_calls == 0 || fab.reduce_calls == 0) {
+            fprintf(stderr, "SELF-FAIL same=%d sum=%g halo_calls=%ld reduce_calls=%ld\n", (int)same, sum, fab.halo_calls, fab.reduce_calls);
+            return 1;
+        }
+        printf("SELF-OK halo_calls=%ld reduce_calls=%ld ms_per_step_rccl=%.4f ms_per_step_copies=%.4f\n", fab.halo_calls,
+               fab.reduce_calls, via_rccl.ms / (double)via_rccl.steps, via_copies.ms / (double)via_copies.steps);
+    } else {
+        // contiguous balanced z-ranges, the rule of wafer_amd.slab.partition
+        const uint32_t base = nz / (uint32_t)world, extra = nz % (uint32_t)world;
+        p.z_count = world > 1 ? base + ((uint32_t)rank < extra ? 1u : 0u) : 0;
+        p.z_begin = world > 1 ? (uint32_t)rank * base + ((uint32_t)rank < extra ? (uint32_t)rank : extra) : 0;
+        if (world == 1) p.halo_depth = 0;
+        fab.lower = rank > 0 ? rank - 1 : -1;
+        fab.upper = rank + 1 < world ? rank + 1 : -1;
+        RunResult r;
+        if ((rc = run_slab(p, potential, steps, rccl_halo, rccl_allreduce, &fab, false, r))) return rc;
+        // slowest rank's kernel time decides
+        float *dms = nullptr;
+        HIPCHECK(hipMalloc((void **)&dms, sizeof(float)));
+        HIPCHECK(hipMemcpy(dms, &r.ms, sizeof(float), hipMemcpyHostToDevice));
+        NCCLCHECK(ncclAllReduce(dms, dms, 1, ncclFloat, ncclMax, fab.comm, nullptr));
+        HIPCHECK(hipDeviceSynchronize());
+        HIPCHECK(hipMemcpy(&r.ms, dms, sizeof(float), hipMemcpyDeviceToHost));
+        (void)hipFree(dms);
+        if (rank == 0)
+            printf("{\"n_gpus\": %d, \"grid\": [%u, %u, %u], \"steps\": %llu, \"ms_per_step\": %.5f, \"updates_per_s\": %.6e, "
+                   "\"energy_per_norm2\": %.12e, \"norm2\": %.12e, \"halo_calls\": %ld}\n",
+                   world, nx, ny, nz, (unsigned long long)r.steps, r.ms / (double)r.steps,
+                   (double)nx * ny * nz * (double)r.steps / (r.ms * 1e-3), r.obs.energy / r.obs.norm2, r.obs.norm2, fab.halo_calls);
+    }
+    ncclCommDestroy(fab.comm);
+    return 0;
+}
