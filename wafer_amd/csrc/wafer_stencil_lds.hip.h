@@ -55,12 +55,12 @@ static inline WaferLdsOpts wafer_lds_opts()
     if ((e = getenv("WAFER_NT")) && *e) o.nt = atoi(e);
     if ((e = getenv("WAFER_LDS_PAD")) && *e) o.pad = atoi(e);
     if ((e = getenv("WAFER_ABV")) && *e) o.abv = atoi(e);
-    else o.abv = -1; // kernel default: single-step forms a, b from V; the fused kernel streams them
+    else o.abv = -1; // kernel default (both the single-step and the fused kernel form a, b from V)
     if (o.ry != 2 && o.ry != 4) o.ry = 2;
     return o;
 }
 
-// Planes per workgroup.  Measured on MI355X (profiles/r01_sweep.md): the step
+// Planes per workgroup.  Measured on MI355X (profiles/r01_sweep_*.jsonl): the step
 // kernel streams fastest with ONE workgroup per CU marching a long z-column
 // (256 workgroups at 512^3: 0.73 ms/step) and loses 5-12 % when the same work
 // is cut into 2-8x more, shorter columns -- more concurrent streams than CUs
