@@ -76,7 +76,7 @@ static inline int wafer_lds_zchunk(const WaferGeom &g, int nplanes, int ry, int 
     const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + TY - 1) / TY);
     const char *t = getenv("WAFER_TARGET_BLOCKS");
     // two workgroups per CU: with a, b formed from V the kernel does more arithmetic per byte and
-    // a second resident workgroup hides it (0.539 vs 0.574 ms at 512^3, profiles/r01_sweep_d_512.jsonl)
+    // a second resident workgroup hides it (0.539 vs 0.574 ms at 512^3, profiles/r01_sweep_e_512.jsonl)
     const long long target = (t && atoi(t) > 0) ? atoi(t) : 2 * (target_blocks > 0 ? target_blocks : 256);
     long long nch = (target + per_layer / 2) / per_layer; // nearest
     if (nch < 1) nch = 1;
