@@ -168,22 +168,21 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
     VT q0[2 * R + 1][RY];
     VT vq[R + 1][RY];     // V (or a) of planes z-R .. z (oldest first); only vq[R] is used by step 1
     VT bq[R + 1][RY];     // b of the same planes (!ABV only)
-    T cq[Cfg::CPL][2 * R + 1];
-    T cv[Cfg::CPL];       // V (or a) at the halo-column cells, plane z
-    T cb[Cfg::CPL];       // b there (!ABV only)
+    // The halo-column wave keeps ITS state in the same registers: cell q of its CPL cells lives in
+    // component q of row slot 0 (q0[m][0][q], vq[R][0][q], ...), so the roles do not add up in the
+    // kernel's register budget.
+    static_assert(Cfg::CPL <= VEC, "halo-column cells per lane must fit one row slot");
 #pragma unroll
     for (int m = 0; m <= 2 * R; ++m) {
         const int p = z1 - R + m;
 #pragma unroll
         for (int r = 0; r < RY; ++r) q0[m][r] = zero;
-#pragma unroll
-        for (int q = 0; q < Cfg::CPL; ++q) cq[q][m] = T(0);
         if (!is_hcol) {
 #pragma unroll
             for (int r = 0; r < RY; ++r) q0[m][r] = *reinterpret_cast<const VT *>(phi + (long long)p * g.plane + rowoff[r]);
         } else {
 #pragma unroll
-            for (int q = 0; q < Cfg::CPL; ++q) cq[q][m] = phi[(long long)p * g.plane + c_off[q]];
+            for (int q = 0; q < Cfg::CPL; ++q) q0[m][0][q] = phi[(long long)p * g.plane + c_off[q]];
         }
     }
 #pragma unroll
@@ -193,11 +192,6 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
             vq[m][r] = zero;
             bq[m][r] = zero;
         }
-#pragma unroll
-    for (int q = 0; q < Cfg::CPL; ++q) {
-        cv[q] = T(0);
-        cb[q] = T(0);
-    }
     if (!is_hcol) {
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
@@ -207,8 +201,8 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
     } else {
 #pragma unroll
         for (int q = 0; q < Cfg::CPL; ++q) {
-            cv[q] = pv[(long long)z1 * g.plane + c_off[q]];
-            if constexpr (!ABV) cb[q] = pb[(long long)z1 * g.plane + c_off[q]];
+            vq[R][0][q] = pv[(long long)z1 * g.plane + c_off[q]];
+            if constexpr (!ABV) bq[R][0][q] = pb[(long long)z1 * g.plane + c_off[q]];
         }
     }
     // phi1 z-queue (main waves), planes z-2R .. z; starts empty (zeros never reach an output:
@@ -236,7 +230,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                 *reinterpret_cast<VT *>(t0 + orow_lds[q]) = *reinterpret_cast<const VT *>(phi + (long long)z1 * g.plane + orow_off[q]);
 #pragma unroll
         for (int q = 0; q < Cfg::CPL; ++q)
-            if (is_hcol && lane + q * 64 < Cfg::NCOL) t0[c_lds0[q]] = cq[q][R];
+            if (is_hcol && lane + q * 64 < Cfg::NCOL) t0[c_lds0[q]] = q0[R][0][q];
     }
     VT orow_nxt[Cfg::OPW];
 #pragma unroll
@@ -253,13 +247,10 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
         const long long zo = (long long)z * g.plane;
         // ---- 1. prefetch: phi0 plane z+R+1, V plane z+1, outer halo rows of plane z+2 ---------------
         VT pre[RY], pre_v[RY], pre_b[RY], orow_pre[Cfg::OPW];
-        T cpre[Cfg::CPL], cvpre[Cfg::CPL], cbpre[Cfg::CPL];
 #pragma unroll
         for (int r = 0; r < RY; ++r) pre[r] = pre_v[r] = pre_b[r] = zero;
 #pragma unroll
         for (int q = 0; q < Cfg::OPW; ++q) orow_pre[q] = zero;
-#pragma unroll
-        for (int q = 0; q < Cfg::CPL; ++q) cpre[q] = cvpre[q] = cbpre[q] = T(0);
         // (no bounds tests: one plane past the last one needed still lies in the guard zone; the
         //  role tests are wave-uniform)
         if (!is_hcol) {
@@ -276,9 +267,9 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
         } else {
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q) {
-                cpre[q] = phi[zo + (long long)(R + 1) * g.plane + c_off[q]];
-                cvpre[q] = pv[zo + g.plane + c_off[q]];
-                if constexpr (!ABV) cbpre[q] = pb[zo + g.plane + c_off[q]];
+                pre[0][q] = phi[zo + (long long)(R + 1) * g.plane + c_off[q]];
+                pre_v[0][q] = pv[zo + g.plane + c_off[q]];
+                if constexpr (!ABV) pre_b[0][q] = pb[zo + g.plane + c_off[q]];
             }
         }
         // ---- 2. stage phi0 plane z+1 into the other buffer ------------------------------------------------
@@ -294,7 +285,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                 if (is_main && wave + q * Cfg::NW2 < Cfg::OUTER) *reinterpret_cast<VT *>(nt + orow_lds[q]) = orow_nxt[q];
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q)
-                if (is_hcol && lane + q * 64 < Cfg::NCOL) nt[c_lds0[q]] = cq[q][R + 1];
+                if (is_hcol && lane + q * 64 < Cfg::NCOL) nt[c_lds0[q]] = q0[R + 1][0][q];
         }
         // ---- 3. step 1: phi1 plane z ---------------------------------------------------------------------------
         const T *c0 = lds0 + (z & 1) * Cfg::TILE0;
@@ -356,16 +347,16 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                         if (wplane && c_p1[q]) {
                             const int o0 = c_lds0[q];
                             C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
-                            const C w = (C)cq[q][R];
+                            const C w = (C)q0[R][0][q];
 #pragma unroll
                             for (int d = -R; d <= R; ++d) {
-                                zz[d + R] = (C)cq[q][R + d];
+                                zz[d + R] = (C)q0[R + d][0][q];
                                 xs[d + R] = (d == 0) ? w : (C)c0[o0 + d];
                                 ys[d + R] = (d == 0) ? w : (C)c0[o0 + d * LP0];
                             }
                             const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                            if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)cv[q], dt, S, den, vir);
-                            else rs = (T)wafer_update<C>(w, (C)cv[q], (C)cb[q], dt, S, den);
+                            if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)vq[R][0][q], dt, S, den, vir);
+                            else rs = (T)wafer_update<C>(w, (C)vq[R][0][q], (C)bq[R][0][q], dt, S, den);
                         }
                         w1[c_lds1[q]] = rs;
                     }
@@ -443,17 +434,9 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
         for (int m = 0; m < 2 * R; ++m) {
 #pragma unroll
             for (int r = 0; r < RY; ++r) q0[m][r] = q0[m + 1][r];
-#pragma unroll
-            for (int q = 0; q < Cfg::CPL; ++q) cq[q][m] = cq[q][m + 1];
         }
 #pragma unroll
         for (int r = 0; r < RY; ++r) q0[2 * R][r] = pre[r];
-#pragma unroll
-        for (int q = 0; q < Cfg::CPL; ++q) {
-            cq[q][2 * R] = cpre[q];
-            cv[q] = cvpre[q];
-            if constexpr (!ABV) cb[q] = cbpre[q];
-        }
 #pragma unroll
         for (int m = 0; m < R; ++m)
 #pragma unroll
