@@ -67,6 +67,14 @@ __device__ __forceinline__ C wafer_update_v(C w, C vv, C dt, C S, C den, bool v_
     return w * ca + cb * dt * S / den;
 }
 
+// a, b of one cell from V (potential.rs:104-110)
+template <typename C>
+__device__ __forceinline__ void wafer_ab_from_v(C vv, C dt, bool v_in_range, C &ca, C &cb)
+{
+    cb = wafer_recip(C(1) + dt * vv / C(2), v_in_range);
+    ca = (C(1) - dt * vv / C(2)) * cb;
+}
+
 // ABV: pv is V and a, b are formed in registers (24 B per two updates);
 // !ABV: pv is a, pb is b, streamed (32 B per two updates, ~14 fp64 ops fewer per update).
 // VIR: the potential passed check_v_range, so b's reciprocal takes its short form -- a template
@@ -212,6 +220,12 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
     for (int m = 0; m <= 2 * R; ++m)
 #pragma unroll
         for (int r = 0; r < RY; ++r) q1[m][r] = zero;
+    // ABV: the a, b formed for step 1 at plane z serve step 2 at the same plane R iterations later
+    VT caq[R + 1][RY], cbq[R + 1][RY];
+#pragma unroll
+    for (int m = 0; m <= R; ++m)
+#pragma unroll
+        for (int r = 0; r < RY; ++r) caq[m][r] = cbq[m][r] = zero;
 
     // LDS: zero the phi0 pad columns once (they stay zero), stage the centre plane z1
     for (int i = tid; i < 2 * Cfg::TILE0; i += Cfg::NT_) lds0[i] = T(0);
@@ -321,8 +335,13 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                             }
                             const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
                             T rs;
-                            if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)vq[R][r][v], dt, S, den, vir);
-                            else rs = (T)wafer_update<C>(w, (C)vq[R][r][v], (C)bq[R][r][v], dt, S, den);
+                            if constexpr (ABV) {
+                                C ca, cb;
+                                wafer_ab_from_v<C>((C)vq[R][r][v], dt, vir, ca, cb);
+                                caq[R][r][v] = (T)ca;
+                                cbq[R][r][v] = (T)cb;
+                                rs = (T)wafer_update<C>(w, ca, cb, dt, S, den);
+                            } else rs = (T)wafer_update<C>(w, (C)vq[R][r][v], (C)bq[R][r][v], dt, S, den);
                             res[v] = (xi + v < g.nx) ? rs : T(0);
                         }
                     }
@@ -402,7 +421,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                                     }
                                 }
                                 const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                                if constexpr (ABV) res2[r][v] = (T)wafer_update_v<C>(w, (C)vq[0][r][v], dt, S, den, vir);
+                                if constexpr (ABV) res2[r][v] = (T)wafer_update<C>(w, (C)caq[0][r][v], (C)cbq[0][r][v], dt, S, den);
                                 else res2[r][v] = (T)wafer_update<C>(w, (C)vq[0][r][v], (C)bq[0][r][v], dt, S, den);
                             }
                         }
@@ -448,6 +467,15 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
         for (int r = 0; r < RY; ++r) {
             vq[R][r] = pre_v[r];
             if constexpr (!ABV) bq[R][r] = pre_b[r];
+        }
+        if constexpr (ABV) {
+#pragma unroll
+            for (int m = 0; m < R; ++m)
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    caq[m][r] = caq[m + 1][r];
+                    cbq[m][r] = cbq[m + 1][r];
+                }
         }
 #pragma unroll
         for (int q = 0; q < Cfg::OPW; ++q) orow_nxt[q] = orow_pre[q];
