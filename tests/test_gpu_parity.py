@@ -585,6 +585,21 @@ def test_solve_max_steps(wa):
         assert ctx.num_states() == 0
 
 
+def test_out_of_memory_fails_loudly_and_leaves_the_device_usable(wa):
+    """a grid no device holds: wafer_ctx_create reports the HIP error, frees what it had taken,
+    and the stale error does not resurface in the next context"""
+    import torch
+    free0 = torch.cuda.mem_get_info(0)[0]
+    with pytest.raises(wa.WaferError, match="memory"):
+        wa.Context(wa.Params(4096, 4096, 4096, dn=0.05, dt=5e-4))
+    assert torch.cuda.mem_get_info(0)[0] >= free0 - (1 << 30)
+    with wa.Context(wa.Params(40, 40, 40, dn=0.2, dt=0.004)) as ctx:
+        ctx.set_potential("Harmonic")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 4)
+        assert np.isfinite(ctx.norm2())
+
+
 def test_config_validation(wa):
     with pytest.raises(wa.WaferError):  # ErrorKind::LargeDt, config.rs:362-365
         wa.Context(wa.Params(8, 8, 8, dn=0.1, dt=0.1))

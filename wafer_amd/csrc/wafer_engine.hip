@@ -37,6 +37,9 @@ static int fail(int code, const char *fmt, ...)
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_last_error = buf;
+    // HIP keeps the last error per thread until it is read: a failed hipMalloc would otherwise
+    // resurface at the next hipGetLastError() after a perfectly good kernel launch
+    if (code == WAFER_ERR_HIP) (void)hipGetLastError();
     return code;
 }
 
