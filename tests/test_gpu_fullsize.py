@@ -40,6 +40,7 @@ def closed_forms(n, dn, dt, mass, store):
 
 
 def run_case(wa, n, dtype, dn, dt, mass):
+    """(the single-step kernel run here is the LDS one with a, b from V: no stored a, b arrays)"""
     store = np.float32 if dtype == "f32" else np.float64
     k, n0, n1, r2, e0 = closed_forms(n, dn, dt, mass, store)
     par = wa.Params(n, n, n, dn=dn, dt=dt, mass=mass, dtype=dtype, max_states=1)
@@ -86,6 +87,16 @@ def test_config5_grid_2048_cubed_fp32(wa_mod):
     if free_gib() < 200:
         pytest.skip("needs 200 GiB of free device memory")
     ms = run_case(wa_mod, 2048, "f32", 0.01, 2e-5, 1.0)
+    assert ms < 200.0
+
+
+def test_config5_grid_2048_cubed_fp64_cross_check_size(wa_mod):
+    """2048^3 in fp64 on ONE device (config #5's fp64 cross-check size: 71 GB per array).  It fits
+    because the default kernels form a, b from V in registers and the stored a, b arrays are only
+    allocated on demand: phi x 2 + V = 214 GB of the 288 GB."""
+    if free_gib() < 235:
+        pytest.skip("needs 235 GiB of free device memory")
+    ms = run_case(wa_mod, 2048, "f64", 0.01, 2e-5, 1.0)
     assert ms < 200.0
 
 

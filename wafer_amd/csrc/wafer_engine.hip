@@ -179,6 +179,38 @@ static int alloc_grid_array(wafer_ctx *c, void **logical, hipStream_t s)
 template <typename T>
 static inline const T *as(const void *p) { return static_cast<const T *>(p); }
 
+// The stored a, b arrays (potential.rs:101-110) are needed by the kernels that stream them (variant 0,
+// WAFER_ABV=0) and by wafer_download_array; everything else forms a, b from V in registers.  They
+// are allocated and filled on first use and kept in step with V from then on.
+static int ensure_ab(wafer_ctx *c)
+{
+    if (c->a && c->b) return WAFER_OK;
+    TRY(alloc_grid_array(c, &c->a, c->s_main));
+    TRY(alloc_grid_array(c, &c->b, c->s_main));
+    if (c->have_pot) {
+        const dim3 grid(c->bx, c->by, c->g.lz), block(64, 4);
+        if (c->f32)
+            hipLaunchKernelGGL((wafer_k_ab<float>), grid, block, 0, c->s_main, c->g, c->P.dt, as<float>(c->v), as<float>(c->a), as<float>(c->b));
+        else
+            hipLaunchKernelGGL((wafer_k_ab<double>), grid, block, 0, c->s_main, c->g, c->P.dt, as<double>(c->v), as<double>(c->a), as<double>(c->b));
+        HIP_TRY(hipGetLastError());
+    }
+    return WAFER_OK;
+}
+// V changed: bring a, b (if they exist) back in step
+static int refresh_ab(wafer_ctx *c)
+{
+    if (!c->a || !c->b) return WAFER_OK;
+    const dim3 grid(c->bx, c->by, c->g.lz), block(64, 4);
+    if (c->f32)
+        hipLaunchKernelGGL((wafer_k_ab<float>), grid, block, 0, c->s_main, c->g, c->P.dt, as<float>(c->v), as<float>(c->a), as<float>(c->b));
+    else
+        hipLaunchKernelGGL((wafer_k_ab<double>), grid, block, 0, c->s_main, c->g, c->P.dt, as<double>(c->v), as<double>(c->a), as<double>(c->b));
+    HIP_TRY(hipGetLastError());
+    return WAFER_OK;
+}
+static bool kernels_stream_ab(int variant) { return variant == 0 || env_int("WAFER_ABV", 1) == 0; }
+
 // after V changed: may the kernels that form a, b from V use the short reciprocal?
 static int check_v_range(wafer_ctx *c)
 {
@@ -279,6 +311,7 @@ static int launch_step_t(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, h
 {
     if (lz_hi <= lz_lo) return WAFER_OK;
     const int variant = active_variant(c);
+    if (kernels_stream_ab(variant)) TRY(ensure_ab(c));
     WaferStepArgs a;
     a.g = c->g;
     a.lz_lo = lz_lo;
@@ -371,6 +404,7 @@ static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
         a.v_in_range = c->v_in_range ? 1 : 0;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
+        if (kernels_stream_ab(2)) TRY(ensure_ab(c));
         if constexpr (R <= 2) { // ext 3 spills registers in this kernel and is never dispatched to it
             if (wafer_launch_step2_fused<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->a), as<T>(c->b), as<T>(c->v), as<T>(c->phi[dst]), s) != hipSuccess)
                 return fail(WAFER_ERR_HIP, "fused stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -616,7 +650,8 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 
-    void **arrays[] = {&c->phi[0], &c->phi[1], &c->v, &c->a, &c->b};
+    // a and b are allocated on first use (ensure_ab): the default kernels form them from V in registers
+    void **arrays[] = {&c->phi[0], &c->phi[1], &c->v};
     for (void **arr : arrays)
         if (alloc_grid_array(c, arr, c->s_main) != WAFER_OK) return cleanup_fail(WAFER_ERR_HIP);
     c->partials_stride = (size_t)c->bx * c->by * 64 + 1024;
@@ -799,12 +834,7 @@ int wafer_set_potential_host(wafer_ctx *c, const double *v, int potsub_kind, dou
     if (potsub_kind == WAFER_POTSUB_ARRAY && !potsub) return fail(WAFER_ERR_INVALID, "potsub array missing");
     HIP_TRY(hipSetDevice(c->P.device));
     TRY(upload_padded(c, v, c->v));
-    const dim3 grid(c->bx, c->by, c->g.lz), block(64, 4);
-    if (c->f32)
-        hipLaunchKernelGGL((wafer_k_ab<float>), grid, block, 0, c->s_main, c->g, c->P.dt, as<float>(c->v), as<float>(c->a), as<float>(c->b));
-    else
-        hipLaunchKernelGGL((wafer_k_ab<double>), grid, block, 0, c->s_main, c->g, c->P.dt, as<double>(c->v), as<double>(c->a), as<double>(c->b));
-    HIP_TRY(hipGetLastError());
+    TRY(refresh_ab(c));
     c->potsub_kind = potsub_kind;
     c->potsub_scalar = (potsub_kind == WAFER_POTSUB_SCALAR) ? potsub_scalar : 0.0;
     if (potsub_kind == WAFER_POTSUB_ARRAY) {
@@ -822,8 +852,8 @@ int wafer_download_array(wafer_ctx *c, int id, double *out)
     HIP_TRY(hipSetDevice(c->P.device));
     switch (id) {
     case WAFER_ARRAY_V: return download_padded(c, out, c->v);
-    case WAFER_ARRAY_A: return download_padded(c, out, c->a);
-    case WAFER_ARRAY_B: return download_padded(c, out, c->b);
+    case WAFER_ARRAY_A: TRY(ensure_ab(c)); return download_padded(c, out, c->a);
+    case WAFER_ARRAY_B: TRY(ensure_ab(c)); return download_padded(c, out, c->b);
     case WAFER_ARRAY_POTSUB:
         if (c->potsub_kind != WAFER_POTSUB_ARRAY) return fail(WAFER_ERR_STATE, "pot_sub is not an array");
         return convert_host_array<false>(c, out, c->g.nx, c->g.ny, c->g.nz, c->g.R, c->g.R, c->g.R, c->potsub);
@@ -964,12 +994,7 @@ int wafer_set_potential_resampled(wafer_ctx *c, const double *src, uint32_t sx, 
     if (!c || !src) return fail(WAFER_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->P.device));
     TRY(resample_into(c, src, sx, sy, sz, basis, c->v));
-    const dim3 grid(c->bx, c->by, c->g.lz), block(64, 4);
-    if (c->f32)
-        hipLaunchKernelGGL((wafer_k_ab<float>), grid, block, 0, c->s_main, c->g, c->P.dt, as<float>(c->v), as<float>(c->a), as<float>(c->b));
-    else
-        hipLaunchKernelGGL((wafer_k_ab<double>), grid, block, 0, c->s_main, c->g, c->P.dt, as<double>(c->v), as<double>(c->a), as<double>(c->b));
-    HIP_TRY(hipGetLastError());
+    TRY(refresh_ab(c));
     c->potsub_kind = WAFER_POTSUB_NONE; // potential.rs:357-358: FromFile has no pot_sub of its own
     c->potsub_scalar = 0.0;
     c->have_pot = true;
@@ -1325,9 +1350,10 @@ int wafer_diag_stream_bw(wafer_ctx *c, int n_reads, int iters, double *gbps)
     if (!c || !gbps) return fail(WAFER_ERR_INVALID, "null argument");
     if (n_reads < 1 || n_reads > 3 || iters < 1) return fail(WAFER_ERR_INVALID, "n_reads in 1..3, iters >= 1");
     HIP_TRY(hipSetDevice(c->P.device));
+    if (n_reads > 1) TRY(ensure_ab(c)); // the second and third read streams
     const long long n16 = (long long)c->g.total * (long long)c->esz / 16;
-    const wafer_f4 *r0 = as<const wafer_f4>(alloc_base(c, c->a)), *r1 = as<const wafer_f4>(alloc_base(c, c->b)),
-                   *r2 = as<const wafer_f4>(alloc_base(c, c->v));
+    const wafer_f4 *r0 = as<const wafer_f4>(alloc_base(c, c->v)), *r1 = as<const wafer_f4>(alloc_base(c, c->a)),
+                   *r2 = as<const wafer_f4>(alloc_base(c, c->b));
     wafer_f4 *w = as<wafer_f4>(alloc_base(c, c->phi[c->cur ^ 1])); // scratch between steps
     const dim3 grid(256 * 8), block(256);
     hipEvent_t e0, e1;

@@ -130,8 +130,10 @@ __global__ __launch_bounds__(256) void wafer_k_potential(WaferPotArgs a, T *__re
     const double aa = (1. - a.dt * vv / 2.) * bb;
     const long long p = g.at(lzp, yp, xp);
     v[p] = (T)vv;
-    pa[p] = (T)aa;
-    pb[p] = (T)bb;
+    if (pa) { // the a, b arrays exist only once a kernel that streams them has been asked for
+        pa[p] = (T)aa;
+        pb[p] = (T)bb;
+    }
 }
 
 // a, b from an uploaded V (potential.rs:101-110)
