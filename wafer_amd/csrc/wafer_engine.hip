@@ -541,11 +541,11 @@ static int excited_step_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bo
         a.lz_lo = lo;
         a.lz_hi = hi;
         a.dt = c->P.dt;
-        // workgroups per CU: two with one stored state, ONE with more -- every workgroup streams
-        // 3 + k arrays a plane ahead, and beyond ~5 streams two per CU overflow the XCD's 4 MB L2, so
-        // the halo rows a neighbour just loaded are gone again (512^3: k = 2 1.24 -> 1.13 ms, k = 3
-        // 1.45 -> 1.39; k = 1 the other way, 0.89 vs 0.96).  The launcher doubles target_blocks.
-        const int target = wnum >= 2 ? (c->num_cus + 1) / 2 : c->num_cus;
+        // ONE workgroup per CU (8 waves on a 128x16 tile for k <= 3): every workgroup streams 3 + k
+        // arrays a plane ahead, and two per CU overflow the XCD's 4 MB L2, so the halo rows a
+        // neighbour just loaded are gone again (512^3, 128x8 tiles: k = 2 1.24 -> 1.13 ms, k = 3
+        // 1.45 -> 1.39).  The launcher doubles target_blocks.
+        const int target = (wnum >= 2 || wafer_excited_nw((int)wnum) == 8) ? (c->num_cus + 1) / 2 : c->num_cus;
         a.target_blocks = target;
         a.v_in_range = c->v_in_range ? 1 : 0;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
@@ -554,7 +554,7 @@ static int excited_step_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bo
                                                    c->partials_stride, (int)wnum, low, s,
                                                    transform_on_load ? c->scal : nullptr, c->gram) != hipSuccess)
             return fail(WAFER_ERR_HIP, "excited-state stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
-        const long long nb = wafer_step_lds_excited_blocks<T, R>(g, lo, hi, target);
+        const long long nb = wafer_step_lds_excited_blocks<T, R>(g, lo, hi, target, (int)wnum, transform_on_load);
         return reduce_to_scal(c, 1 + (int)wnum, nb, 0, s);
     });
 }

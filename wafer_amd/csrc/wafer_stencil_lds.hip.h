@@ -22,10 +22,11 @@ template <typename T> struct WaferVec;
 template <> struct WaferVec<double> { static constexpr int N = 2; typedef double __attribute__((ext_vector_type(2))) type; };
 template <> struct WaferVec<float> { static constexpr int N = 4; typedef float __attribute__((ext_vector_type(4))) type; };
 
-template <typename T, int R, int RY_>
+template <typename T, int R, int RY_, int NW_ = 4>
 struct WaferLdsCfg {
     static constexpr int VEC = WaferVec<T>::N;
-    static constexpr int NW = 4;                  // wavefronts per workgroup, stacked along y
+    static constexpr int NW = NW_;                // wavefronts per workgroup, stacked along y (4, or 8: 16-row tiles)
+    static constexpr int NT = NW * 64;            // threads per workgroup
     static constexpr int RY = RY_;                // rows per lane
     static constexpr int TX = 64 * VEC;           // tile width  (one wave-wide 1 KiB row segment)
     static constexpr int TY = NW * RY;            // tile height
@@ -34,7 +35,7 @@ struct WaferLdsCfg {
     static constexpr int LROWS = TY + 2 * R;
     static constexpr int TILE = LROWS * LP;       // elements per LDS buffer
     static constexpr int NHALO_X = 2 * R * TY;    // halo-column cells per plane
-    static constexpr int HALO_X_ITERS = (NHALO_X + 255) / 256; // cells are dealt over all 256 lanes
+    static constexpr int HALO_X_ITERS = (NHALO_X + NT - 1) / NT; // cells are dealt over all lanes of the workgroup
     static constexpr int HALO_ROWS_PER_WAVE = (2 * R + NW - 1) / NW;
 };
 
@@ -124,8 +125,8 @@ __device__ __forceinline__ void wafer_st_stream(VT *p, VT v)
 //   x = phi/norm - sum_j l_j s_j        (grid.rs:467, 488-490; the operations of wafer_k_gs_apply)
 // with norm and s_j formed from the previous step's scalars xscal[0..NLOW] and the Gram matrix.
 // That folds the apply pass into the next step: (3+k)*8 B per update instead of (5+2k)*8 B.
-template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false>
-__global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty, int swz,
+template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty, int swz,
                                                         const T *__restrict__ phi,
                                                         const T *__restrict__ pa,
                                                         const T *__restrict__ pb, T *__restrict__ out,
@@ -137,11 +138,11 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     constexpr bool NORM = NLOW >= 0;
     constexpr int NL = NLOW > 0 ? NLOW : 0;
     static_assert(!XF || NL > 0, "transform-on-load needs stored states");
-    using Cfg = WaferLdsCfg<T, R, RY>;
+    using Cfg = WaferLdsCfg<T, R, RY, NW>;
     using VT = typename WaferVec<T>::type;
     constexpr int VEC = Cfg::VEC, TX = Cfg::TX, TY = Cfg::TY, HX = Cfg::HX, LP = Cfg::LP;
     __shared__ __attribute__((aligned(16))) T lds[2 * Cfg::TILE];
-    __shared__ double red[4];
+    __shared__ double red[NW];
 
     const WaferGeom &g = a.g;
     // tile coordinates: x fastest, then y, then z-chunk
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
     int hcol_lds[Cfg::HALO_X_ITERS];
 #pragma unroll
     for (int q = 0; q < Cfg::HALO_X_ITERS; ++q) {
-        const int cidx = min(tid + q * 256, Cfg::NHALO_X - 1);     // surplus lanes repeat the last cell
+        const int cidx = min(tid + q * Cfg::NT, Cfg::NHALO_X - 1);     // surplus lanes repeat the last cell
         const int row = cidx / (2 * R), k = cidx % (2 * R);
         const int xw = (k < R) ? (x0 - 1 - k) : (x0 + TX + (k - R)); // work x, may be -R..nx+R-1
         const int y = y0 + row;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
                 *reinterpret_cast<VT *>(tile + hrow_lds[qq]) = load_vec((long long)zs * g.plane + hrow_off[qq], nullptr);
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
-            if (tid + qq * 256 < Cfg::NHALO_X)
+            if (tid + qq * Cfg::NT < Cfg::NHALO_X)
                 tile[hcol_lds[qq]] = load_cell((long long)zs * g.plane + hcol_off[qq]);
     }
     // halo of plane zs+1, held in registers until it is written at iteration zs
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
                 if (wave + qq * Cfg::NW < 2 * R) *reinterpret_cast<VT *>(nt + hrow_lds[qq]) = hrow_nxt[qq];
 #pragma unroll
             for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
-                if (tid + qq * 256 < Cfg::NHALO_X) nt[hcol_lds[qq]] = hcol_nxt[qq];
+                if (tid + qq * Cfg::NT < Cfg::NHALO_X) nt[hcol_lds[qq]] = hcol_nxt[qq];
         }
 
         // ---- 3. update plane z
@@ -439,34 +440,44 @@ __global__ __launch_bounds__(256) void wafer_k_step_lds(WaferStepArgs a, int ntx
         }
     }
     if constexpr (NORM) {
-        const double s = wafer_block_sum<4>(acc, red, tid);
+        const double s = wafer_block_sum<NW>(acc, red, tid);
         if (tid == 0) partials[blockIdx.x] = s;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const double t = wafer_block_sum<4>(acc_t[j], red, tid);
+            const double t = wafer_block_sum<NW>(acc_t[j], red, tid);
             if (tid == 0) partials[(size_t)(1 + j) * pstride + blockIdx.x] = t;
         }
     }
 }
 
-template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false>
+template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false, int NW = 4>
 static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLdsOpts &o, const T *phi,
                                                   const T *pa, const T *pb, T *out, double *partials,
                                                   size_t partials_cap, hipStream_t s,
                                                   const WaferLowPtrs &low = WaferLowPtrs(),
                                                   const double *xscal = nullptr, const double *xgram = nullptr)
 {
-    using Cfg = WaferLdsCfg<T, R, RY>;
+    using Cfg = WaferLdsCfg<T, R, RY, NW>;
     const WaferGeom &g = a.g;
-    a.zchunk = wafer_lds_zchunk<T, R>(g, a.lz_hi - a.lz_lo, RY, a.target_blocks);
+    a.zchunk = wafer_lds_zchunk<T, R>(g, a.lz_hi - a.lz_lo, RY * (NW / 4), a.target_blocks); // tile height NW * RY
     const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX;
     const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
     const long long nblocks = (long long)ntx * nty * ntz;
     if (NLOW >= 0 && (size_t)nblocks > partials_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NLOW, NT, ABV, XF>), dim3((unsigned)nblocks), dim3(256), (size_t)o.pad, s,
+    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NLOW, NT, ABV, XF, NW>), dim3((unsigned)nblocks), dim3(Cfg::NT), (size_t)o.pad, s,
                        a, ntx, nty, o.swz, phi, pa, pb, out, partials, (long long)partials_cap, low, xscal, xgram);
     return hipGetLastError();
+}
+
+// Waves per workgroup of the excited-state step kernels: with one to three stored states 8 waves on a
+// 128x16 tile, one workgroup per CU (half the halo rows of phi and of every stored state per tile: at
+// 512^3 k = 1 0.87 -> 0.83 ms, k = 2 1.13 -> 1.09, k = 3 1.40 -> 1.31); WAFER_XF_NW=4 restores the 128x8 tile.
+static inline int wafer_excited_nw(int nlow)
+{
+    const char *e = getenv("WAFER_XF_NW");
+    const int want = (e && *e) ? atoi(e) : 8;
+    return (want == 8 && nlow >= 1 && nlow <= 3) ? 8 : 4;
 }
 
 // excited-state step with `nlow` raw overlaps fused in (fixed tuning: RY 2, NT, a/b from V)
@@ -479,11 +490,27 @@ static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T 
     WaferLdsOpts o = wafer_lds_opts();
     o.ry = 2;
     if (xscal) { // transform-on-load: phi is the raw previous step
+        if (wafer_excited_nw(nlow) == 8) { // 128x16 tiles, 8 waves: half the halo rows per array
+            switch (nlow) {
+            case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+            case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+            case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, true, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+            default: return hipErrorInvalidValue;
+            }
+        }
         switch (nlow) {
         case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
         case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
         case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
         case 4: return wafer_launch_step_lds_ry<T, C, R, 2, 4, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (wafer_excited_nw(nlow) == 8) { // the same tiles as the transform-on-load kernel: same partial sums, same bits
+        switch (nlow) {
+        case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, false, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+        case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, false, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+        case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, false, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
         default: return hipErrorInvalidValue;
         }
     }
@@ -498,12 +525,15 @@ static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T 
 }
 
 template <typename T, int R>
-static inline long long wafer_step_lds_excited_blocks(const WaferGeom &g, int lz_lo, int lz_hi, int target_blocks)
+static inline long long wafer_step_lds_excited_blocks(const WaferGeom &g, int lz_lo, int lz_hi, int target_blocks,
+                                                      int nlow = 0, bool xf = false)
 {
     using Cfg = WaferLdsCfg<T, R, 2>;
-    const int zc = wafer_lds_zchunk<T, R>(g, lz_hi - lz_lo, 2, target_blocks);
-    return (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY) *
-           ((lz_hi - lz_lo + zc - 1) / zc);
+    (void)xf;
+    const int mul = (wafer_excited_nw(nlow) == 8) ? 2 : 1;
+    const int TY = Cfg::TY * mul;
+    const int zc = wafer_lds_zchunk<T, R>(g, lz_hi - lz_lo, 2 * mul, target_blocks);
+    return (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + TY - 1) / TY) * ((lz_hi - lz_lo + zc - 1) / zc);
 }
 
 template <typename T, typename C, int R>
