@@ -544,6 +544,18 @@ static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, co
     if (o.abv < 0) o.abv = 1;
     double *partials = nullptr;
     const size_t partials_cap = 0;
+    { // ThreePoint / FivePoint with a, b from V: 8 waves on a 128x16 tile, one workgroup per CU (half the
+      // halo rows per tile: 0.56 -> 0.54 ms/step at 512^3); WAFER_LDS_NW=4 or an explicit WAFER_LDS_RY
+      // select the 4-wave kernels
+        const char *e = getenv("WAFER_LDS_NW");
+        const char *ry = getenv("WAFER_LDS_RY");
+        const bool eight = (e && *e) ? atoi(e) == 8 : (R <= 2 && !(ry && *ry));
+        if (eight && o.abv != 0) {
+            a.target_blocks = (a.target_blocks + 1) / 2; // one workgroup per CU
+            if (o.nt != 0) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8>(a, o, phi, pv, pb, out, partials, partials_cap, s);
+            return wafer_launch_step_lds_ry<T, C, R, 2, -1, false, true, false, 8>(a, o, phi, pv, pb, out, partials, partials_cap, s);
+        }
+    }
     // with ABV, V takes a's slot and b is not read
 #define WAFER_LDS_CASE(RY_, NT_, ABV_)                                                               \
     if (o.ry == RY_ && (o.nt != 0) == NT_ && (o.abv != 0) == ABV_)                                   \
