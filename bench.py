@@ -192,8 +192,8 @@ def main():
                 # HBM3E moves 4 bits per pin per reported memory clock (2 GHz -> 8 Gb/s/pin):
                 # 8192 pins x 8 Gb/s = 8.19 TB/s, the datasheet's "8 TB/s"
                 "hbm_GBps_from_props": 4.0 * mclk_khz * 1e3 * width / 8 / 1e9,
-                "measured_stream_GBps_1r1w": round(ctx.stream_bandwidth(1, 60), 1),
-                "measured_stream_GBps_3r1w": round(ctx.stream_bandwidth(3, 60), 1),
+                "measured_stream_GBps_1r1w": round(ctx.stream_bandwidth(1, 300), 1),
+                "measured_stream_GBps_3r1w": round(ctx.stream_bandwidth(3, 300), 1),
             }
         except Exception as e:  # informational
             device_info = {"error": repr(e)}
