@@ -62,3 +62,12 @@ def test_context_creation_fails_loudly_without_gpu(lib):
         h = C.c_void_p()
         rc = lib.wafer_ctx_create(C.byref(p), C.byref(h))
         raise wafer_amd.WaferError(rc, lib.wafer_last_error().decode()) if rc else AssertionError("accepted")
+
+
+def test_tools_and_entry_points_compile():
+    """every script of the repo at least parses (they need a GPU to run)"""
+    import glob
+    import py_compile
+    for path in sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "wafer_amd", "*.py")) +
+                       [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]):
+        py_compile.compile(path, doraise=True)
