@@ -119,9 +119,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    # WAFER_BENCH_TRANSPORT=host: halo planes staged through pinned host memory over gloo, ranks
-    # folded onto the GPUs present -- only for exercising the N > 1 leg on a one-GPU box
-    # (tests/test_gpu_multiprocess.py); the default is RCCL, one GPU per rank
+    # WAFER_BENCH_TRANSPORT=host: halo planes staged through host memory over gloo, ranks folded
+    # onto the GPUs present -- only for exercising the N > 1 leg on a one-GPU box
+    # (tests/test_gpu_multiprocess.py); the default is RCCL, one GPU per rank, the hooks served by
+    # RCCL's C API directly (WAFER_TRANSPORT=torch: through torch.distributed)
     host_transport = os.environ.get("WAFER_BENCH_TRANSPORT", "rccl") == "host"
     if host_transport:
         local_rank %= torch.cuda.device_count()
@@ -162,10 +163,10 @@ def main():
     ctx = wafer_amd.Context(par)
     if args.variant >= 0:
         ctx.set_stencil_variant(args.variant)
-    comm = None
+    comm, transport_name = None, None
     if world > 1:
-        comm_cls = slab.HostStagedSlabComm if host_transport else slab.TorchSlabComm
-        comm = comm_cls(ctx, rank, world, torch.device("cuda", local_rank))
+        comm, transport_name = slab.make_slab_comm(ctx, rank, world, torch.device("cuda", local_rank),
+                                                   "host" if host_transport else None)
         comm.warm_up()   # RCCL channel set-up is not part of any step
     ctx.set_potential(potential)
     ctx.set_initial_condition("Boolean")   # deterministic, "good for benchmarks" (config.rs:168)
@@ -241,7 +242,7 @@ def main():
                         f"{ {1: 'ThreePoint', 2: 'FivePoint', 3: 'SevenPoint'}[ext]} stencil, ground-state "
                         f"imaginary-time evolve (grid.rs:544-687), Boolean initial condition"
                         + ("" if n_gpus == 1 else f", z-slabs of {shape[2] // n_gpus} planes per GPU, "
-                           + ("host-staged gloo halo exchange (test transport)" if host_transport else "RCCL halo exchange")),
+                           + f"halo exchange: {transport_name}"),
             "grid": list(shape),
             "points_per_gpu": pts_rank,
             "parallelism": f"zslab{n_gpus}",
@@ -269,6 +270,8 @@ def main():
                                       "kind": "port", "sample": f"failed: {e!r}"}
     if dist is not None:   # the process group goes first: its work objects refer to the engine's streams
         ctx.synchronize()
+        if hasattr(comm, "close"):
+            comm.close()       # the native hooks' communicator
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -126,3 +126,25 @@ def test_native_rccl_host_self_neighbours():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert rec["n_gpus"] == 1 and rec["steps"] == 10 and rec["norm2"] > 0
+
+
+def test_native_rccl_hooks_from_python_self_neighbours():
+    """wafer_amd.slab.NativeRcclSlabComm (libwafer_rccl.so: RCCL's C API, torch's RCCL library in
+    the process) with the rank as its own z-neighbour, bit for bit against device copies"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_native_selfloop_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=420, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "NATIVE-OK" in r.stdout
+
+
+def test_transport_selection_and_fallback():
+    """make_slab_comm: native RCCL hooks by default, all ranks fall back to the torch.distributed
+    hooks together when they cannot be installed (tests/make_comm_worker.py)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1")
+    env.pop("WAFER_TRANSPORT", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "make_comm_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=420, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "COMM-OK" in r.stdout and "falling back to torch.distributed" in r.stderr

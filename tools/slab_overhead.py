@@ -111,6 +111,23 @@ def main():
                     ts.append(ms / k)
                 out[f"slab_rccl_self_ms_per_step_overlap_{int(overlap)}"] = sorted(ts)[2]
                 del comm
+        from wafer_amd.slab import NativeRcclSlabComm
+        for overlap in (True, False):
+            with wafer_amd.Context(mid) as ctx:
+                comm = NativeRcclSlabComm(ctx, 0, 1, dev, self_neighbours=True)
+                comm.warm_up()
+                ctx.set_overlap(overlap)
+                ctx.set_potential("SimpleCornell")
+                ctx.set_initial_condition("Boolean")
+                ctx.evolve(0, 100)
+                ctx.synchronize()
+                ts = []
+                for _ in range(5):
+                    ctx.evolve(0, args.steps)
+                    ms, k = ctx.last_evolve_ms()
+                    ts.append(ms / k)
+                out[f"slab_native_rccl_self_ms_per_step_overlap_{int(overlap)}"] = sorted(ts)[2]
+                comm.close()
         torch.cuda.synchronize()
         dist.destroy_process_group()
     out["halo_calls_per_step"] = calls["halo"] / (100 + 5 * args.steps)

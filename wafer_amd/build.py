@@ -67,6 +67,22 @@ def build_rccl_host(force: bool = False, verbose: bool = False) -> str:
     return SLABS
 
 
+RCCL_LIB = os.path.join(HERE, "libwafer_rccl.so")
+
+
+def build_rccl_lib(force: bool = False, verbose: bool = False) -> str:
+    """libwafer_rccl.so: the RCCL hooks for hosts that are not C++ (wafer_rccl_lib.cpp)."""
+    srcs = [os.path.join(CSRC, "wafer_rccl_lib.cpp"), os.path.join(CSRC, "wafer_rccl_hooks.h")]
+    if not force and os.path.exists(RCCL_LIB) and os.path.getmtime(RCCL_LIB) > max([os.path.getmtime(x) for x in srcs] + [os.path.getmtime(LIB)]):
+        return RCCL_LIB
+    cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", srcs[0], "-o", RCCL_LIB, "-L", HERE, "-lwafer_hip", "-lrccl",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return RCCL_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
         cmd = [hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
@@ -75,6 +91,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.check_call(cmd, cwd=CSRC)
     build_cli(force=force, verbose=verbose)
     build_rccl_host(force=force, verbose=verbose)
+    build_rccl_lib(force=force, verbose=verbose)
     return LIB
 
 

@@ -1,0 +1,40 @@
+// The engine's two communication hooks (include/wafer_hip.h) served by RCCL's C API: grouped
+// ncclSend / ncclRecv of the boundary planes to the z-neighbours and an in-place ncclAllReduce of
+// the reduction scalars, both enqueued on the hipStream_t the engine passes (nothing blocks the
+// host).  Shared by the native host (wafer_rccl_host.cpp) and by libwafer_rccl.so, which lets a
+// Python host install the same hooks (wafer_amd.slab.NativeRcclSlabComm).
+#pragma once
+#include <cstddef>
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+struct WaferRcclFabric {
+    ncclComm_t comm = nullptr;
+    int lower = -1, upper = -1; // z-neighbour ranks, -1 = the global Dirichlet frame
+    long halo_calls = 0, reduce_calls = 0;
+};
+
+static inline int wafer_rccl_halo(void *user, void *send_lo, void *send_hi, void *recv_lo, void *recv_hi, size_t bytes,
+                                  void *stream)
+{
+    WaferRcclFabric *f = static_cast<WaferRcclFabric *>(user);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ncclGroupStart() != ncclSuccess) return 1;
+    // receives first, then sends: between one pair of ranks they match in posting order
+    bool ok = true;
+    if (recv_lo) ok = ok && ncclRecv(recv_lo, bytes, ncclChar, f->lower, f->comm, s) == ncclSuccess;
+    if (recv_hi) ok = ok && ncclRecv(recv_hi, bytes, ncclChar, f->upper, f->comm, s) == ncclSuccess;
+    if (send_lo) ok = ok && ncclSend(send_lo, bytes, ncclChar, f->lower, f->comm, s) == ncclSuccess;
+    if (send_hi) ok = ok && ncclSend(send_hi, bytes, ncclChar, f->upper, f->comm, s) == ncclSuccess;
+    if (ncclGroupEnd() != ncclSuccess || !ok) return 1;
+    ++f->halo_calls;
+    return 0;
+}
+
+static inline int wafer_rccl_allreduce(void *user, void *dev_ptr, size_t count, void *stream)
+{
+    WaferRcclFabric *f = static_cast<WaferRcclFabric *>(user);
+    ++f->reduce_calls;
+    return ncclAllReduce(dev_ptr, dev_ptr, count, ncclDouble, ncclSum, f->comm, static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : 1;
+}

@@ -26,6 +26,7 @@
 #include <rccl/rccl.h>
 
 #include "../../include/wafer_hip.h"
+#include "wafer_rccl_hooks.h"
 
 #define HIPCHECK(x)                                                                         \
     do {                                                                                    \
@@ -51,33 +52,10 @@
         }                                                                                   \
     } while (0)
 
-struct Fabric {
-    ncclComm_t comm = nullptr;
-    int lower = -1, upper = -1; // neighbour ranks, -1 = none
-    long halo_calls = 0, reduce_calls = 0;
-};
+using Fabric = WaferRcclFabric;
+static auto &rccl_halo = wafer_rccl_halo;
+static auto &rccl_allreduce = wafer_rccl_allreduce;
 
-// hooks: enqueue on the engine's stream, never block the host
-static int rccl_halo(void *user, void *send_lo, void *send_hi, void *recv_lo, void *recv_hi, size_t bytes, void *stream)
-{
-    Fabric *f = static_cast<Fabric *>(user);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ncclGroupStart() != ncclSuccess) return 1;
-    // receives first, then sends: between one pair of ranks they match in posting order
-    if (recv_lo && ncclRecv(recv_lo, bytes, ncclChar, f->lower, f->comm, s) != ncclSuccess) return 1;
-    if (recv_hi && ncclRecv(recv_hi, bytes, ncclChar, f->upper, f->comm, s) != ncclSuccess) return 1;
-    if (send_lo && ncclSend(send_lo, bytes, ncclChar, f->lower, f->comm, s) != ncclSuccess) return 1;
-    if (send_hi && ncclSend(send_hi, bytes, ncclChar, f->upper, f->comm, s) != ncclSuccess) return 1;
-    if (ncclGroupEnd() != ncclSuccess) return 1;
-    ++f->halo_calls;
-    return 0;
-}
-static int rccl_allreduce(void *user, void *dev_ptr, size_t count, void *stream)
-{
-    Fabric *f = static_cast<Fabric *>(user);
-    ++f->reduce_calls;
-    return ncclAllReduce(dev_ptr, dev_ptr, count, ncclDouble, ncclSum, f->comm, static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : 1;
-}
 // the same exchange with itself as both neighbours, by device copies (what the self test expects
 // RCCL to deliver: first receive posted <- first send posted)
 static int copy_halo(void *, void *send_lo, void *send_hi, void *recv_lo, void *recv_hi, size_t bytes, void *stream)

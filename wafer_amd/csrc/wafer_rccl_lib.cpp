@@ -1,0 +1,81 @@
+// libwafer_rccl.so -- installs the RCCL hooks of wafer_rccl_hooks.h on a context from any host
+// language (Python: wafer_amd.slab.NativeRcclSlabComm).  The ranks share one ncclUniqueId, made by
+// rank 0 with wafer_rccl_unique_id and distributed by whatever the host uses for rendezvous.
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/wafer_hip.h"
+#include "wafer_rccl_hooks.h"
+
+static thread_local std::string g_err;
+static int fail(const char *what, ncclResult_t r)
+{
+    g_err = std::string(what) + ": " + ncclGetErrorString(r);
+    return 1;
+}
+
+extern "C" {
+
+const char *wafer_rccl_last_error(void) { return g_err.c_str(); }
+int wafer_rccl_unique_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
+
+int wafer_rccl_unique_id(void *out)
+{
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail("ncclGetUniqueId", r);
+    memcpy(out, &id, sizeof id);
+    return 0;
+}
+
+// rank's z-neighbours are rank - 1 and rank + 1 (lower_override / upper_override >= 0 replace them:
+// a single rank that is its own neighbour, for tests)
+int wafer_rccl_attach(wafer_ctx *ctx, int rank, int world, const void *unique_id, int lower_override, int upper_override,
+                      void **handle)
+{
+    if (!ctx || !unique_id || !handle || world < 1 || rank < 0 || rank >= world) { g_err = "bad argument"; return 1; }
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    WaferRcclFabric *f = new WaferRcclFabric();
+    ncclResult_t r = ncclCommInitRank(&f->comm, world, id, rank);
+    if (r != ncclSuccess) { delete f; return fail("ncclCommInitRank", r); }
+    f->lower = lower_override >= 0 ? lower_override : (rank > 0 ? rank - 1 : -1);
+    f->upper = upper_override >= 0 ? upper_override : (rank + 1 < world ? rank + 1 : -1);
+    if (wafer_set_comm_hooks(ctx, wafer_rccl_halo, wafer_rccl_allreduce, f) != WAFER_OK) {
+        g_err = wafer_last_error();
+        ncclCommDestroy(f->comm);
+        delete f;
+        return 1;
+    }
+    *handle = f;
+    return 0;
+}
+
+// one small exchange with the neighbours and one all-reduce, so that channel set-up is not part of
+// any timed step; `scratch` is >= 4 KiB of device memory, `stream` any stream of the device
+int wafer_rccl_warm_up(void *handle, void *scratch, void *stream)
+{
+    WaferRcclFabric *f = static_cast<WaferRcclFabric *>(handle);
+    char *p = static_cast<char *>(scratch);
+    if (wafer_rccl_halo(f, f->lower >= 0 ? p : nullptr, f->upper >= 0 ? p + 1024 : nullptr, f->lower >= 0 ? p + 2048 : nullptr,
+                        f->upper >= 0 ? p + 3072 : nullptr, 256, stream) != 0) { g_err = "warm-up exchange failed"; return 1; }
+    if (wafer_rccl_allreduce(f, p, 8, stream) != 0) { g_err = "warm-up all-reduce failed"; return 1; }
+    f->halo_calls = f->reduce_calls = 0;
+    return hipStreamSynchronize(static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : 1;
+}
+
+long wafer_rccl_halo_calls(void *handle) { return static_cast<WaferRcclFabric *>(handle)->halo_calls; }
+
+int wafer_rccl_detach(wafer_ctx *ctx, void *handle)
+{
+    WaferRcclFabric *f = static_cast<WaferRcclFabric *>(handle);
+    if (ctx) (void)wafer_set_comm_hooks(ctx, nullptr, nullptr, nullptr);
+    if (f) {
+        ncclCommDestroy(f->comm);
+        delete f;
+    }
+    return 0;
+}
+
+} // extern "C"

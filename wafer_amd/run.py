@@ -177,8 +177,8 @@ def main(argv=None) -> int:
     with wafer_amd.Context(par) as ctx:
         comm = None
         if world > 1:
-            comm = (slab.HostStagedSlabComm if host_transport else slab.TorchSlabComm)(
-                ctx, rank, world, torch.device("cuda", local_rank))
+            comm, _name = slab.make_slab_comm(ctx, rank, world, torch.device("cuda", local_rank),
+                                              "host" if host_transport else None)
             comm.warm_up()
         ctx.set_potential(cfg["potential"])
         for wnum in range(cfg["wavenum"], cfg["wavemax"] + 1):          # grid.rs:43-45
@@ -241,6 +241,8 @@ def main(argv=None) -> int:
                 break
             ctx.push_state()                                             # grid.rs:241
         ctx.synchronize()
+        if hasattr(comm, "close"):
+            comm.close()
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
