@@ -202,6 +202,39 @@ def test_excited_state_and_solve_on_slabs(wa):
     assert np.allclose(ground, want_states[0], rtol=0, atol=1e-8)
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("world,shape,ext,wnum", [(2, (40, 24, 32), 1, 1), (3, (33, 17, 30), 2, 2), (4, (130, 20, 40), 1, 3)])
+def test_excited_state_steps_on_slabs(wa, world, shape, ext, wnum, overlap):
+    """excited-state evolve (renormalise + Gram-Schmidt every step) on z-slabs against one context:
+    with overlap the R boundary planes of each side are stepped first and their raw halo exchange
+    runs behind the interior launch; the sums then associate per launch, so cells agree to 1e-13"""
+    import sys
+    sys.setswitchinterval(1e-4)
+    base = wa.Params(*shape, dn=0.25, dt=0.006, mass=1.0, central_difference=ext, max_states=wnum)
+
+    def body(ctx, rank=0):
+        ctx.set_overlap(overlap)
+        ctx.set_potential("Harmonic")
+        for j in range(wnum):      # orthonormalised random stored states, identical on every slab
+            ctx.set_initial_condition("Gaussian", seed=40 + j)
+            ctx.normalise(ctx.norm2())
+            ctx.orthogonalise(j)
+            ctx.normalise(ctx.norm2())
+            ctx.push_state()
+        ctx.set_initial_condition("Gaussian", seed=7)
+        ctx.evolve(wnum, 5)
+        ctx.evolve(wnum, 2)
+        return ctx.download_phi(), ctx.norm2()
+
+    with wa.Context(base) as ctx:
+        want, want_n2 = body(ctx)
+    res, fabric = run_slabs(wa, base, world, body)
+    got = assemble(base, world, [r[0] for r in res])
+    assert np.allclose(got, want, rtol=0, atol=1e-13 * max(1.0, float(np.max(np.abs(want)))))
+    for _, n2 in res:
+        assert n2 == pytest.approx(want_n2, rel=1e-12)
+
+
 def test_slab_without_hooks_fails_loudly(wa):
     par = wa.Params(16, 16, 16, dn=0.2, dt=0.004, z_begin=0, z_count=8)
     with wa.Context(par) as ctx:

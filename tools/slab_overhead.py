@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--xy", type=int, default=1024)
     ap.add_argument("--cd", type=int, default=1)
     ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--wnum", type=int, default=0, help="excited-state steps against this many stored states")
     ap.add_argument("--rccl", action="store_true",
                     help="also serve the hook with RCCL send/recv to this same rank (wafer_amd.slab.TorchSlabComm, "
                          "world of one): adds the host cost of the Python hook + batch_isend_irecv per pass")
@@ -42,7 +43,7 @@ def main():
     hip = hip_runtime()
     hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     n, pl, ext = args.xy, args.planes, args.cd
-    kw = dict(dn=0.02, dt=8e-5, mass=2.35, sig=0.223, central_difference=ext)
+    kw = dict(dn=0.02, dt=8e-5, mass=2.35, sig=0.223, central_difference=ext, max_states=max(1, args.wnum))
     out = {}
 
     def run(par, hooks, overlap=True):
@@ -51,12 +52,16 @@ def main():
                 ctx.set_comm_hooks(*hooks)
                 ctx.set_overlap(overlap)
             ctx.set_potential("SimpleCornell")
+            for j in range(args.wnum):
+                ctx.set_initial_condition("Gaussian", seed=j + 1)
+                ctx.normalise(ctx.norm2())
+                ctx.push_state()
             ctx.set_initial_condition("Boolean")
-            ctx.evolve(0, 100)
+            ctx.evolve(args.wnum, 100)
             ctx.synchronize()
             best = None
             for _ in range(5):   # median of 5 (clock ramp, other tenants)
-                ctx.evolve(0, args.steps)
+                ctx.evolve(args.wnum, args.steps)
                 ms, k = ctx.last_evolve_ms()
                 best = sorted((best or []) + [ms / k])
             return best[len(best) // 2]
@@ -118,12 +123,16 @@ def main():
                 comm.warm_up()
                 ctx.set_overlap(overlap)
                 ctx.set_potential("SimpleCornell")
+                for j in range(args.wnum):
+                    ctx.set_initial_condition("Gaussian", seed=j + 1)
+                    ctx.normalise(ctx.norm2())
+                    ctx.push_state()
                 ctx.set_initial_condition("Boolean")
-                ctx.evolve(0, 100)
+                ctx.evolve(args.wnum, 100)
                 ctx.synchronize()
                 ts = []
                 for _ in range(5):
-                    ctx.evolve(0, args.steps)
+                    ctx.evolve(args.wnum, args.steps)
                     ms, k = ctx.last_evolve_ms()
                     ts.append(ms / k)
                 out[f"slab_native_rccl_self_ms_per_step_overlap_{int(overlap)}"] = sorted(ts)[2]

@@ -526,20 +526,25 @@ static int recompute_gram(wafer_ctx *c)
 //                x = raw/norm - sum_j l_j s_j formed on load from the previous raw step (one-pass mode)
 //   reduce       1 + k scalars (one all-reduce when sharded)
 //   apply        phi = phi'/norm - sum_j l_j s_j: after every step (two-pass), or once at the end
-static int excited_step_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bool transform_on_load, hipStream_t s)
+// One excited-state stencil launch over local planes [lz_lo, lz_hi): the step, sum phi'^2 and the
+// raw overlaps with the stored states; the workgroups' partial sums go to partials[pbase + ...].
+// Returns the number of partials written through *nb_out.
+static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bool transform_on_load, int lz_lo, int lz_hi,
+                                  long long pbase, hipStream_t s, long long *nb_out)
 {
     const WaferGeom &g = c->g;
-    const int lo = g.G, hi = g.G + g.nzl;
+    *nb_out = 0;
+    if (lz_hi <= lz_lo) return WAFER_OK;
     WaferLowPtrs low;
     for (uint32_t j = 0; j < wnum; ++j) low.p[j] = c->states[j];
     return dispatch(c, [&](auto t, auto cc, auto r) {
         using T = decltype(t);
         using C = decltype(cc);
         constexpr int R = decltype(r)::value;
-        WaferStepArgs a;
+        WaferStepArgs a{};
         a.g = g;
-        a.lz_lo = lo;
-        a.lz_hi = hi;
+        a.lz_lo = lz_lo;
+        a.lz_hi = lz_hi;
         a.dt = c->P.dt;
         // ONE workgroup per CU (8 waves on a 128x16 tile for k <= 3): every workgroup streams 3 + k
         // arrays a plane ahead, and two per CU overflow the XCD's 4 MB L2, so the halo rows a
@@ -550,13 +555,42 @@ static int excited_step_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bo
         a.v_in_range = c->v_in_range ? 1 : 0;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
-        if (wafer_launch_step_lds_excited<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->v), as<T>(c->phi[dst]), c->partials,
-                                                   c->partials_stride, (int)wnum, low, s,
+        const long long nb = wafer_step_lds_excited_blocks<T, R>(g, lz_lo, lz_hi, target, (int)wnum, transform_on_load);
+        if (pbase + nb > (long long)c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
+        if (wafer_launch_step_lds_excited<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->v), as<T>(c->phi[dst]), c->partials + pbase,
+                                                   c->partials_stride /* the row stride of the partials, too */, (int)wnum, low, s,
                                                    transform_on_load ? c->scal : nullptr, c->gram) != hipSuccess)
             return fail(WAFER_ERR_HIP, "excited-state stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
-        const long long nb = wafer_step_lds_excited_blocks<T, R>(g, lo, hi, target, (int)wnum, transform_on_load);
-        return reduce_to_scal(c, 1 + (int)wnum, nb, 0, s);
+        *nb_out = nb;
+        return (int)WAFER_OK;
     });
+}
+
+// the whole slab in one launch, then the 1 + wnum sums (all-reduced when sharded)
+static int excited_step_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bool transform_on_load, hipStream_t s)
+{
+    long long nb = 0;
+    TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, c->g.G, c->g.G + c->g.nzl, 0, s, &nb));
+    return reduce_to_scal(c, 1 + (int)wnum, nb, 0, s);
+}
+
+// z-slabs: the R boundary planes of each side first, on the second stream, their (raw) halo exchange
+// behind the interior launch; the sums wait for all three launches
+static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32_t wnum, bool transform_on_load)
+{
+    const WaferGeom &g = c->g;
+    const int R = g.R, lo = g.G, hi = g.G + g.nzl;
+    long long nb_lo = 0, nb_hi = 0, nb_in = 0;
+    HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
+    HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
+    if (c->has_lo()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, lo, lo + R, 0, c->s_aux, &nb_lo));
+    if (c->has_hi()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, hi - R, hi, nb_lo, c->s_aux, &nb_hi));
+    TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi,
+                               nb_lo + nb_hi, c->s_main, &nb_in));
+    TRY(exchange_halo(c, dst, c->s_aux, R));
+    HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
+    HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
+    return reduce_to_scal(c, 1 + (int)wnum, nb_lo + nb_hi + nb_in, 0, c->s_main);
 }
 
 static int excited_apply(wafer_ctx *c, int buf, uint32_t wnum, hipStream_t s)
@@ -1086,9 +1120,16 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                     hipLaunchKernelGGL(wafer_k_identity_scalars, dim3(1), dim3(64), 0, c->s_main, c->scal, 1 + (int)wnum);
                     HIP_TRY(hipGetLastError());
                 }
-                TRY(excited_step_launch(c, src, dst, wnum, one_pass, c->s_main));
-                if (!one_pass || s + 1 == steps) TRY(excited_apply(c, dst, wnum, c->s_main));
-                if (s + 1 < steps || !one_pass) TRY(exchange_halo(c, dst, c->s_main, R));
+                // z-slabs, one-pass scheme, not the last step: the raw result's halo exchange hides behind
+                // the interior launch (the last step's phi is materialised first and exchanged on demand)
+                const bool split = one_pass && s + 1 < steps && c->sharded() && c->overlap && g.nzl > 2 * R;
+                if (split) {
+                    TRY(excited_step_launch_overlapped(c, src, dst, wnum, one_pass));
+                } else {
+                    TRY(excited_step_launch(c, src, dst, wnum, one_pass, c->s_main));
+                    if (!one_pass || s + 1 == steps) TRY(excited_apply(c, dst, wnum, c->s_main));
+                    if (s + 1 < steps || !one_pass) TRY(exchange_halo(c, dst, c->s_main, R));
+                }
                 c->halo_valid = (one_pass && s + 1 == steps) ? 0 : R;
                 c->cur = dst;
                 s += 1;
