@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""A few overlapped fused passes on the bench slab with a loopback hook, for `rocprofv3 --kernel-trace`:
+    rocprofv3 --kernel-trace --output-format csv -d out -o t -- python3 tools/slab_trace.py
+tools/slab_trace.py --parse out/.../t_kernel_trace.csv   prints the per-pass timeline."""
+import ctypes as C
+import csv
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def parse(path):
+    rows = [r for r in csv.DictReader(open(path)) if "step2_fused" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    rows = rows[-30:]
+    t0 = int(rows[0]["Start_Timestamp"])
+    for r in rows:
+        s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+        print(f"{s / 1e3:10.1f} us -> {e / 1e3:10.1f} us  ({(e - s) / 1e3:7.1f} us)  grid {r.get('Grid_Size', r.get('Grid_Size_X', '?'))}")
+
+
+def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--parse":
+        return parse(sys.argv[2])
+    import wafer_amd
+    wafer_amd.load_library()
+    hip = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                hip = C.CDLL(line.split()[-1])
+                break
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+
+    def halo(slo, shi, rlo, rhi, nbytes, stream):
+        hip.hipMemcpyAsync(rlo, shi, nbytes, 3, stream)
+        hip.hipMemcpyAsync(rhi, slo, nbytes, 3, stream)
+        return 0
+    par = wafer_amd.Params(1024, 1024, 1024, dn=0.02, dt=8e-5, mass=2.35, sig=0.223, z_begin=512, z_count=128, halo_depth=2)
+    with wafer_amd.Context(par) as ctx:
+        ctx.set_comm_hooks(halo, lambda p, n, s: 0)
+        ctx.set_potential("SimpleCornell")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 40)
+        ctx.synchronize()
+
+
+if __name__ == "__main__":
+    main()

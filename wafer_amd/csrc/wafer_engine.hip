@@ -95,7 +95,7 @@ struct wafer_ctx {
     size_t esz = 8;
 
     hipStream_t s_main = nullptr, s_aux = nullptr, s_own = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_bdry = nullptr;
 
     void *phi[2] = {nullptr, nullptr};
     int cur = 0;
@@ -585,6 +585,8 @@ static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32
     HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
     if (c->has_lo()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, lo, lo + R, 0, c->s_aux, &nb_lo));
     if (c->has_hi()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, hi - R, hi, nb_lo, c->s_aux, &nb_hi));
+    HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux)); // the interior must not crowd the boundary launches out (see wafer_evolve)
+    HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
     TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi,
                                nb_lo + nb_hi, c->s_main, &nb_in));
     TRY(exchange_halo(c, dst, c->s_aux, R));
@@ -688,6 +690,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     HIP_TRYC(hipEventCreate(&c->ev_stop));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRYC(hipEventCreateWithFlags(&c->ev_bdry, hipEventDisableTiming));
 
     // a and b are allocated on first use (ensure_ab): the default kernels form them from V in registers
     void **arrays[] = {&c->phi[0], &c->phi[1], &c->v};
@@ -721,7 +724,7 @@ int wafer_ctx_destroy(wafer_ctx *c)
     if (c->scal) (void)hipFree(c->scal);
     if (c->gram) (void)hipFree(c->gram);
     if (c->scal_host) (void)hipHostFree(c->scal_host);
-    for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join})
+    for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join, c->ev_bdry})
         if (e) (void)hipEventDestroy(e);
     if (c->s_own) (void)hipStreamDestroy(c->s_own);
     if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
@@ -1077,9 +1080,13 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
                 if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + 2 * R, c->s_aux));
                 if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - 2 * R, hi, c->s_aux));
-                // the interior is queued before the hook runs: whatever host time the hook takes
-                // (Python, RCCL enqueue) the GPU already has the bulk of the pass to work on.
-                // (Both boundaries in one launch, or the interior queued first: measured, no better.)
+                // The interior waits for the boundary kernels: left to themselves both streams start
+                // together, the interior's workgroups take every CU for a full round and the thin
+                // boundary launches -- and with them the exchange -- finish only when the pass does
+                // (kernel trace: 0.68 of 0.72 ms).  It is queued before the hook runs, so whatever host
+                // time the hook takes the GPU already has the bulk of the pass to work on.
+                HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux));
+                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
                 TRY(launch_step2(c, src, dst, c->has_lo() ? lo + 2 * R : lo, c->has_hi() ? hi - 2 * R : hi, c->s_main));
                 TRY(exchange_halo(c, dst, c->s_aux, 2 * R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
@@ -1102,6 +1109,8 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
                 if (c->has_lo()) TRY(launch_step(c, src, dst, lo, lo + R, false, c->s_aux));
                 if (c->has_hi()) TRY(launch_step(c, src, dst, hi - R, hi, false, c->s_aux));
+                HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux));
+                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
                 TRY(launch_step(c, src, dst, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi, false, c->s_main));
                 TRY(exchange_halo(c, dst, c->s_aux, R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
