@@ -12,13 +12,14 @@ sys.path.insert(0, ROOT)
 
 
 def parse(path):
-    rows = [r for r in csv.DictReader(open(path)) if "step2_fused" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "step2_fused" in r["Kernel_Name"] or "ccl" in r["Kernel_Name"].lower()
+            or "copyBuffer" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    rows = rows[-30:]
+    rows = rows[-24:]
     t0 = int(rows[0]["Start_Timestamp"])
     for r in rows:
         s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-        print(f"{s / 1e3:10.1f} us -> {e / 1e3:10.1f} us  ({(e - s) / 1e3:7.1f} us)  grid {r.get('Grid_Size', r.get('Grid_Size_X', '?'))}")
+        print(f"{s / 1e3:10.1f} us -> {e / 1e3:10.1f} us  ({(e - s) / 1e3:7.1f} us)  {r['Kernel_Name'][:48]}")
 
 
 def main():
@@ -40,11 +41,20 @@ def main():
         return 0
     par = wafer_amd.Params(1024, 1024, 1024, dn=0.02, dt=8e-5, mass=2.35, sig=0.223, z_begin=512, z_count=128, halo_depth=2)
     with wafer_amd.Context(par) as ctx:
-        ctx.set_comm_hooks(halo, lambda p, n, s: 0)
+        comm = None
+        if "--rccl" in sys.argv:
+            import torch
+            from wafer_amd.slab import NativeRcclSlabComm
+            comm = NativeRcclSlabComm(ctx, 0, 1, torch.device("cuda", 0), self_neighbours=True)
+            comm.warm_up()
+        else:
+            ctx.set_comm_hooks(halo, lambda p, n, s: 0)
         ctx.set_potential("SimpleCornell")
         ctx.set_initial_condition("Boolean")
         ctx.evolve(0, 40)
         ctx.synchronize()
+        if comm is not None:
+            comm.close()
 
 
 if __name__ == "__main__":
