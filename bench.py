@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--cd", type=int, default=1, help="central difference ext: 1/2/3")
     ap.add_argument("--potential", default="Coulomb")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle sample")
     ap.add_argument("--variant", type=int, default=-1, help="stencil kernel variant (-1 = default)")
     return ap.parse_args()
 
