@@ -2,7 +2,7 @@
 """Randomised parity sweep of the HIP path against the oracle (a development aid next to the
 fixed cases of tests/test_gpu_parity.py): random shapes incl. 1-cell axes, stencil orders,
 potentials, step counts and kernel variants; ground state bit for bit, excited states (random
-stored states, Gram-Schmidt every step) to 1e-10.   N=200 SEED=3 python tools/fuzz_parity.py"""
+stored states, Gram-Schmidt every step) to 1e-10.   N=200 SEED=3 python tests/fuzz_parity.py   (it lives under tests/ because it drives the oracle)"""
 import os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -73,3 +73,4 @@ for it in range(int(os.environ.get("N", "60")) // 2):
         print("ERROR excited", shape, ext, pot, wnum, steps, one_pass, repr(e)[:200], flush=True)
 os.environ.pop("WAFER_ONE_PASS", None)
 print("fuzz done, bad =", bad)
+sys.exit(1 if bad else 0)

@@ -753,3 +753,15 @@ def test_full_size_512_coulomb_three_steps_bit_exact(wo, wa):
         obs, want = ctx.observables(), wo.observables(cfg, v, phi)
         for k in ("energy", "norm2", "r2"):
             assert obs[k] == pytest.approx(want[k], rel=REL_SUM)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_randomised_parity_sweep(seed):
+    """tests/fuzz_parity.py: random shapes (1-cell axes included), stencil orders, potentials, kernel
+    variants and step counts; ground state bit for bit, excited states with random stores to 1e-10"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py")], capture_output=True, text=True,
+                       env=dict(os.environ, N="80", SEED=str(seed)), timeout=600)
+    assert r.returncode == 0 and "bad = 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
