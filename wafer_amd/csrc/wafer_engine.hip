@@ -585,12 +585,12 @@ static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32
     HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
     if (c->has_lo()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, lo, lo + R, 0, c->s_aux, &nb_lo));
     if (c->has_hi()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, hi - R, hi, nb_lo, c->s_aux, &nb_hi));
-    HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux)); // the interior must not crowd the boundary launches out (see wafer_evolve)
+    HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux));
+    TRY(exchange_halo(c, dst, c->s_aux, R));        // enqueued before the interior: its kernels reach the CUs first
+    HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
     HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
     TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi,
                                nb_lo + nb_hi, c->s_main, &nb_in));
-    TRY(exchange_halo(c, dst, c->s_aux, R));
-    HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
     HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
     return reduce_to_scal(c, 1 + (int)wnum, nb_lo + nb_hi + nb_in, 0, c->s_main);
 }
@@ -1076,20 +1076,22 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             TRY(ensure_halo(c, 2 * R));
             const bool split = c->sharded() && c->overlap && g.nzl > 4 * R;
             if (split) {
+                // Second stream: boundary planes, then their exchange.  Main stream: the interior, released
+                // by an event recorded after the boundary kernels.  The exchange is enqueued BEFORE the
+                // interior launch and needs no event hop, so its kernels reach the CUs first; the interior
+                // then fills what is left.  (Without the dependency the interior started first, filled
+                // every CU for a whole round, and the boundary kernels -- and the exchange behind them --
+                // finished only with the pass; with the exchange merely enqueued second, RCCL's
+                // workgroups waited 0.35 ms for CUs: profiles/r01_slab_overlap_timeline.txt.)
                 HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
                 HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
                 if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + 2 * R, c->s_aux));
                 if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - 2 * R, hi, c->s_aux));
-                // The interior waits for the boundary kernels: left to themselves both streams start
-                // together, the interior's workgroups take every CU for a full round and the thin
-                // boundary launches -- and with them the exchange -- finish only when the pass does
-                // (kernel trace: 0.68 of 0.72 ms).  It is queued before the hook runs, so whatever host
-                // time the hook takes the GPU already has the bulk of the pass to work on.
                 HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux));
-                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
-                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + 2 * R : lo, c->has_hi() ? hi - 2 * R : hi, c->s_main));
                 TRY(exchange_halo(c, dst, c->s_aux, 2 * R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
+                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
+                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + 2 * R : lo, c->has_hi() ? hi - 2 * R : hi, c->s_main));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
             } else {
                 TRY(launch_step2(c, src, dst, lo, hi, c->s_main));
@@ -1104,16 +1106,16 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
         if (wnum == 0) {
             const bool split = c->sharded() && c->overlap && g.nzl > 2 * R;
             if (split) {
-                // boundary planes first on the aux stream, their exchange overlaps the interior
+                // boundary planes and their exchange on the second stream, the interior behind an event (as above)
                 HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
                 HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
                 if (c->has_lo()) TRY(launch_step(c, src, dst, lo, lo + R, false, c->s_aux));
                 if (c->has_hi()) TRY(launch_step(c, src, dst, hi - R, hi, false, c->s_aux));
                 HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux));
-                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
-                TRY(launch_step(c, src, dst, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi, false, c->s_main));
                 TRY(exchange_halo(c, dst, c->s_aux, R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
+                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
+                TRY(launch_step(c, src, dst, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi, false, c->s_main));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
             } else {
                 TRY(launch_step(c, src, dst, lo, hi, false, c->s_main));
