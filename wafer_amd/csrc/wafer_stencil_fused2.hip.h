@@ -489,6 +489,7 @@ static inline int wafer_f2_zchunk(const WaferGeom &g, int nplanes, int target_bl
     using Cfg = WaferF2Cfg<T, R, NW2>;
     const char *f = getenv("WAFER_ZCHUNK");
     if (f && atoi(f) > 0) return atoi(f);
+    if (target_blocks < 0) return -target_blocks < nplanes ? -target_blocks : nplanes; // the caller fixed the chunk length
     const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY);
     const char *t = getenv("WAFER_TARGET_BLOCKS");
     const long long target = (t && atoi(t) > 0) ? atoi(t) : (target_blocks > 0 ? target_blocks : 256);

@@ -231,6 +231,12 @@ class NativeRcclSlabComm:
         import os
         import torch  # before librccl: the process-wide RCCL / HIP runtime are torch's (same sonames)
         self.torch, self.ctx, self.rank, self.world, self.device = torch, ctx, rank, world, device
+        # RCCL's send / recv kernels take whole CUs away from the stencil for as long as the links are
+        # busy (their workgroups cannot share a CU with a stencil workgroup); left alone RCCL launches
+        # 64 of them for the four transfers of a pass.  8 channels still move the 2 x 17.7 MB of a
+        # 1024^2 plane pair faster than a link can (215 GB/s to the same GPU) and leave the CUs to the
+        # interior launch.  Respected only if the user has not chosen otherwise.
+        os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "8")
         here = os.path.dirname(os.path.abspath(__file__))
         path = os.path.join(here, "libwafer_rccl.so")
         if not os.path.exists(path):
