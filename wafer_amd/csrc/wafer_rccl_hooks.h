@@ -5,9 +5,17 @@
 // Python host install the same hooks (wafer_amd.slab.NativeRcclSlabComm).
 #pragma once
 #include <cstddef>
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+
+// RCCL's send / recv kernels take whole CUs away from the stencil for as long as the links are busy
+// (their workgroups cannot share a CU with a stencil workgroup) and RCCL launches 64 of them by
+// default for the four transfers of a pass.  Eight channels still move two 1024^2 planes faster than
+// a link can and leave the CUs to the interior launch.  Call before the communicator is created;
+// a value chosen by the user wins.
+static inline void wafer_rccl_default_env() { setenv("NCCL_MAX_P2P_NCHANNELS", "8", 0); }
 
 struct WaferRcclFabric {
     ncclComm_t comm = nullptr;

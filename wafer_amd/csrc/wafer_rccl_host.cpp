@@ -140,6 +140,7 @@ int main(int argc, char **argv)
     } else {
         NCCLCHECK(ncclGetUniqueId(&id));
     }
+    wafer_rccl_default_env();
     NCCLCHECK(ncclCommInitRank(&fab.comm, world, id, rank));
 
     // ---- slab of this rank ----------------------------------------------------------------------------

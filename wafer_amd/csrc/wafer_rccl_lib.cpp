@@ -37,6 +37,7 @@ int wafer_rccl_attach(wafer_ctx *ctx, int rank, int world, const void *unique_id
     if (!ctx || !unique_id || !handle || world < 1 || rank < 0 || rank >= world) { g_err = "bad argument"; return 1; }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
+    wafer_rccl_default_env();
     WaferRcclFabric *f = new WaferRcclFabric();
     ncclResult_t r = ncclCommInitRank(&f->comm, world, id, rank);
     if (r != ncclSuccess) { delete f; return fail("ncclCommInitRank", r); }
