@@ -531,7 +531,7 @@ static int recompute_gram(wafer_ctx *c)
 // raw overlaps with the stored states; the workgroups' partial sums go to partials[pbase + ...].
 // Returns the number of partials written through *nb_out.
 static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bool transform_on_load, int lz_lo, int lz_hi,
-                                  long long pbase, hipStream_t s, long long *nb_out)
+                                  long long pbase, hipStream_t s, long long *nb_out, int zchunk = 0)
 {
     const WaferGeom &g = c->g;
     *nb_out = 0;
@@ -551,7 +551,8 @@ static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum,
         // arrays a plane ahead, and two per CU overflow the XCD's 4 MB L2, so the halo rows a
         // neighbour just loaded are gone again (512^3, 128x8 tiles: k = 2 1.24 -> 1.13 ms, k = 3
         // 1.45 -> 1.39).  The launcher doubles target_blocks.
-        const int target = (wnum >= 2 || wafer_excited_nw((int)wnum) == 8) ? (c->num_cus + 1) / 2 : c->num_cus;
+        const int target = zchunk > 0 ? -zchunk  // planes per workgroup fixed by the caller (slab interior)
+                                      : (wnum >= 2 || wafer_excited_nw((int)wnum) == 8) ? (c->num_cus + 1) / 2 : c->num_cus;
         a.target_blocks = target;
         a.v_in_range = c->v_in_range ? 1 : 0;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
@@ -590,6 +591,9 @@ static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32
     TRY(exchange_halo(c, dst, c->s_aux, R));        // enqueued before the interior: its kernels reach the CUs first
     HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
     HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
+    // (one long workgroup per tile here: shorter ones -- the fused ground-state split's answer to CUs
+    //  held by the exchange -- cost this kernel more in pipeline refills than the tail they avoid:
+    //  k = 1 0.98 vs 1.01 ms, k = 3 1.57 vs 1.53 under an 8-channel RCCL kernel)
     TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi,
                                nb_lo + nb_hi, c->s_main, &nb_in));
     HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));

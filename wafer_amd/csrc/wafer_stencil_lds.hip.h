@@ -76,6 +76,7 @@ static inline int wafer_lds_zchunk(const WaferGeom &g, int nplanes, int ry, int 
     const int TY = Cfg::NW * ry;
     const char *f = getenv("WAFER_ZCHUNK");
     if (f && atoi(f) > 0) return atoi(f);
+    if (target_blocks < 0) return -target_blocks < nplanes ? -target_blocks : nplanes; // the caller fixed the chunk length
     const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + TY - 1) / TY);
     const char *t = getenv("WAFER_TARGET_BLOCKS");
     // two workgroups per CU: with a, b formed from V the kernel does more arithmetic per byte and
