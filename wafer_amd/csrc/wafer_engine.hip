@@ -388,8 +388,9 @@ static int launch_step(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, boo
 }
 
 // two fused steps over planes [lz_lo, lz_hi): phi[dst] = step(step(phi[src]))
-// zchunk > 0 fixes the planes per workgroup (the interior launch of a slab, see wafer_evolve)
-static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s, int zchunk = 0)
+// short_tail: the interior launch of a slab -- one long workgroup per tile, except the last 1/16 of
+// the tiles, which go as four short workgroups each (see wafer_evolve)
+static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s, bool short_tail = false)
 {
     if (lz_hi <= lz_lo) return WAFER_OK;
     return dispatch(c, [&](auto t, auto cc, auto r) {
@@ -401,7 +402,9 @@ static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
         a.lz_lo = lz_lo;
         a.lz_hi = lz_hi;
         a.dt = c->P.dt;
-        a.target_blocks = zchunk > 0 ? -zchunk : c->num_cus;
+        a.target_blocks = c->num_cus;
+        a.n_long = 0;
+        a.nsub = short_tail ? 4 : 0;
         a.v_in_range = c->v_in_range ? 1 : 0;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
@@ -1096,18 +1099,14 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 TRY(exchange_halo(c, dst, c->s_aux, 2 * R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
-                {
-                    // The exchange's kernels hold a few CUs for as long as the links need (RCCL's
-                    // workgroups cannot share a CU with a stencil workgroup).  With one long workgroup
-                    // per tile every displaced workgroup would add a whole extra round at the end of the
-                    // pass (measured with an 8-channel RCCL kernel of realistic length: 0.465 ms/step,
-                    // worse than no overlap); about four workgroups per tile keep that tail short at
-                    // 3 extra planes of pipeline fill per workgroup (0.406).
-                    const int i_lo = c->has_lo() ? lo + 2 * R : lo, i_hi = c->has_hi() ? hi - 2 * R : hi;
-                    int zc = (i_hi - i_lo + 3) / 4;
-                    zc = zc < 24 ? 24 : (zc > 48 ? 48 : zc);
-                    TRY(launch_step2(c, src, dst, i_lo, i_hi, c->s_main, zc));
-                }
+                // The exchange's kernels hold a few CUs for as long as the links need (RCCL's workgroups
+                // cannot share a CU with a stencil workgroup).  With one long workgroup per tile every
+                // displaced workgroup would add a whole extra round at the end of the pass (measured with
+                // an 8-channel RCCL kernel of realistic length: 0.465 ms/step, worse than no overlap).
+                // Cutting EVERY tile into four workgroups fixes that at 3 planes of pipeline fill per
+                // workgroup (0.396); cutting only the last 1/16 of the tiles -- dispatched last, they
+                // fill the holes -- keeps the long workgroups' efficiency.
+                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + 2 * R : lo, c->has_hi() ? hi - 2 * R : hi, c->s_main, true));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
             } else {
                 TRY(launch_step2(c, src, dst, lo, hi, c->s_main));

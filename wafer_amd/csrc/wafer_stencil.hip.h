@@ -92,6 +92,10 @@ struct WaferStepArgs {
     int zchunk;         // planes marched by one workgroup
     int target_blocks;  // workgroups a launch should aim for (the device's CU count)
     int v_in_range;     // 2^-400 < |1 + dt*V/2| < 2^400 everywhere: wafer_recip may take its short form
+    // fused kernel, mixed launch (slab interiors): the first n_long workgroups march all of
+    // [lz_lo, lz_hi) for one tile each, the remaining tiles are cut into nsub workgroups of zchunk
+    // planes; nsub <= 1: every tile is cut into workgroups of zchunk planes
+    int n_long, nsub;
     double dt, den;
 };
 

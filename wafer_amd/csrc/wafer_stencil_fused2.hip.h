@@ -98,12 +98,29 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
         const int n = gridDim.x, q = n >> 3, r = n & 7, k = bid & 7;
         bid = k * q + min(k, r) + (bid >> 3);
     }
-    const int tx_i = bid % ntx, ty_i = (bid / ntx) % nty, tz_i = bid / (ntx * nty);
+    int tx_i, ty_i, zs, ze;
+    if (a.nsub > 1) { // mixed launch: long workgroups first (dispatched first), the last tiles as short ones
+        int tile, sub = 0;
+        if (bid < a.n_long) {
+            tile = bid;
+        } else {
+            tile = a.n_long + (bid - a.n_long) / a.nsub;
+            sub = (bid - a.n_long) % a.nsub;
+        }
+        tx_i = tile % ntx;
+        ty_i = tile / ntx;
+        zs = bid < a.n_long ? a.lz_lo : a.lz_lo + sub * a.zchunk;
+        ze = bid < a.n_long ? a.lz_hi : min(zs + a.zchunk, a.lz_hi);
+    } else {
+        const int tz_i = bid / (ntx * nty);
+        tx_i = bid % ntx;
+        ty_i = (bid / ntx) % nty;
+        zs = a.lz_lo + tz_i * a.zchunk;
+        ze = min(zs + a.zchunk, a.lz_hi);
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: role tests become scalar branches
     const int x0 = tx_i * TX, y0 = ty_i * TY;
-    const int zs = a.lz_lo + tz_i * a.zchunk;
-    const int ze = min(zs + a.zchunk, a.lz_hi);
     const C dt = (C)a.dt, den = (C)a.den;
     constexpr bool vir = VIR;
     const bool is_main = wave < Cfg::NW2;
@@ -506,16 +523,28 @@ static inline hipError_t wafer_launch_step2_fused_nw(WaferStepArgs a, const Wafe
 {
     using Cfg = WaferF2Cfg<T, R, NW2>;
     const WaferGeom &g = a.g;
-    a.zchunk = wafer_f2_zchunk<T, R, NW2>(g, a.lz_hi - a.lz_lo, a.target_blocks);
     const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX;
     const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
-    const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
-    const dim3 grid((unsigned)((long long)ntx * nty * ntz)), block(Cfg::NT_);
+    int swz = o.swz;
+    long long nblocks;
+    if (a.nsub > 1 && a.lz_hi - a.lz_lo < 8 * a.nsub) a.nsub = 0; // too thin to cut
+    if (a.nsub > 1) { // mixed launch (see WaferStepArgs)
+        const int nplanes = a.lz_hi - a.lz_lo, ntiles = ntx * nty;
+        const int nshort_tiles = ntiles / 16 > 0 ? ntiles / 16 : 1;
+        a.n_long = ntiles - nshort_tiles;
+        a.zchunk = (nplanes + a.nsub - 1) / a.nsub;
+        nblocks = a.n_long + (long long)nshort_tiles * a.nsub;
+        swz = 0; // the hardware's dispatch order is the point
+    } else {
+        a.zchunk = wafer_f2_zchunk<T, R, NW2>(g, a.lz_hi - a.lz_lo, a.target_blocks);
+        nblocks = (long long)ntx * nty * ((a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk);
+    }
+    const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
     const bool vir = a.v_in_range != 0;
 #define WAFER_F2_CASE(NT_, ABV_, VIR_)                                                                          \
     if ((o.nt != 0) == NT_ && (o.abv != 0) == ABV_ && (!ABV_ || vir == VIR_)) {                                 \
         hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, NT_, ABV_, NW2, VIR_>), grid, block, (size_t)o.pad, s, \
-                           a, ntx, nty, o.swz, phi, ABV_ ? pv : pa, pb, out);                                    \
+                           a, ntx, nty, swz, phi, ABV_ ? pv : pa, pb, out);                                      \
         return hipGetLastError();                                                                               \
     }
     WAFER_F2_CASE(true, true, true)
