@@ -50,6 +50,9 @@ class FakeFabric:
             if rhi:
                 assert hip.hipMemcpy(rhi, self.send[rank + 1]["lo"], nbytes, 3) == 0
             assert (rlo is None) == (rank == 0) and (rhi is None) == (rank == self.world - 1)
+            # a device-to-device hipMemcpy may return before the copy is done (no host-side
+            # synchronisation for that kind), and the engine's streams are non-blocking: wait here
+            assert hip.hipStreamSynchronize(None) == 0
             self.halo_calls[rank] += 1
             self.bar.wait()
             return 0
