@@ -147,7 +147,8 @@ def test_ground_state_slabs_bit_exact(wa, world, shape, ext, overlap):
 
 
 @pytest.mark.parametrize("overlap", [True, False])
-@pytest.mark.parametrize("world,shape,ext,steps", [(2, (40, 24, 32), 1, 12), (3, (33, 17, 31), 2, 7), (4, (130, 12, 40), 1, 9)])
+@pytest.mark.parametrize("world,shape,ext,steps", [(2, (40, 24, 32), 1, 12), (3, (33, 17, 31), 2, 7), (4, (130, 12, 40), 1, 9),
+                                                  (2, (300, 70, 96), 1, 6), (2, (130, 40, 100), 2, 5)])   # thick slabs: the mixed long / short interior launch
 def test_fused_kernel_on_slabs_bit_exact(wa, world, shape, ext, steps, overlap):
     """two fused steps per pass on z-slabs: 2*ext ghost planes, one exchange of
     2*ext planes per pass (plus ext planes after an odd trailing step)"""
