@@ -101,6 +101,9 @@ def pmc_traffic(kernel_name: str):
 
 
 def main():
+    # RCCL caches its parameters at first use, which is torch's own communicator: the channel limit the
+    # slab transport wants (wafer_rccl_hooks.h) has to be in the environment before that
+    os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "8")
     args = parse_args()
     # stdout carries exactly ONE line, the JSON result: native libraries that write to the C stdout
     # (RCCL prints a version banner there, flushed at exit) are sent to stderr instead

@@ -125,6 +125,8 @@ def main(argv=None) -> int:
     ap.add_argument("--progress", action="store_true", help="print a table row per screen_update block")
     args = ap.parse_args(argv)
 
+    # RCCL caches its parameters at first use (torch's own communicator): see wafer_rccl_hooks.h
+    os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "8")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
