@@ -173,6 +173,31 @@ def test_fused_kernel_on_slabs_bit_exact(wa, world, shape, ext, steps, overlap):
     assert np.array_equal(assemble(base, world, res), want)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f32fast"])
+def test_fp32_storage_on_slabs_bit_exact(wa, dtype):
+    """fp32 storage (and fp32 step arithmetic) on z-slabs: the same bits as one context"""
+    shape, world, steps = (264, 40, 72), 3, 9
+    base = wa.Params(*shape, dn=0.2, dt=0.004, central_difference=1, dtype=dtype, halo_depth=2)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=1, dtype=dtype)) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        want = ctx.download_phi()
+        want_obs = ctx.observables()
+
+    def body(ctx, rank):
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        return ctx.download_phi(), ctx.observables()
+
+    res, _ = run_slabs(wa, base, world, body)
+    assert np.array_equal(assemble(base, world, [r[0] for r in res]), want)
+    for _, obs in res:
+        for k in want_obs:
+            assert obs[k] == pytest.approx(want_obs[k], rel=1e-12, abs=1e-300)
+
+
 def test_excited_state_and_solve_on_slabs(wa):
     import sys
     sys.setswitchinterval(1e-4)   # three lock-step threads hand the GIL over at every hook
