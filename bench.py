@@ -262,6 +262,8 @@ def main():
             "avg_launch_ms": launch_s * 1e3,
             "steps_per_launch": spl,
             "algorithmic_bytes_per_launch": pts_rank * bpu * spl,
+            # what the kernel really moved per second (PMC traffic / launch time), next to the accounting figure
+            "traffic_GBps": (traffic / launch_s / 1e9) if traffic else None,
         },
         "device": device_info,
     }
