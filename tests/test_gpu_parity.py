@@ -585,6 +585,42 @@ def test_solve_max_steps(wa):
         assert ctx.num_states() == 0
 
 
+def test_caller_stream_state_store_and_slab_info(wo, wa):
+    """wafer_set_stream (the engine runs on a caller-owned hipStream_t), wafer_clear_states,
+    wafer_get_slab_info, wafer_get_device_info"""
+    import torch
+    cfg, par = make_pair((70, 30, 41), ext=1, potential="Coulomb", max_states=2)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    want = random_phi(cfg, seed=2)
+    phi = want.copy()
+    wo.evolve(cfg, 0, a, b, want, [], 7)
+    with wa.Context(par) as ctx:
+        mine = torch.cuda.Stream()
+        ctx.set_stream(mine.cuda_stream)
+        ctx.set_potential("Coulomb")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 7)
+        mine.synchronize()                       # everything was enqueued on the caller's stream
+        assert np.array_equal(ctx.download_phi(), want)
+        ctx.set_stream(None)                     # back to the context's own stream
+        ctx.evolve(0, 1)
+        info = ctx.slab_info()
+        assert (info["z_begin"], info["z_count"], info["halo_depth"], info["ext"], info["elem_bytes"]) == (0, 41, 1, 1, 8)
+        assert info["plane_elems"] >= (30 + 2) * (70 + 2)
+        dev = ctx.device_info()
+        assert dev["compute_units"] > 0 and dev["total_bytes"] > 0 and dev["arch"].startswith("gfx")
+        ctx.push_state()
+        ctx.push_state()
+        assert ctx.num_states() == 2
+        with pytest.raises(wa.WaferError):
+            ctx.push_state()                     # max_states = 2
+        ctx.clear_states()
+        assert ctx.num_states() == 0
+        ctx.push_state()
+        assert ctx.num_states() == 1
+
+
 def test_out_of_memory_fails_loudly_and_leaves_the_device_usable(wa):
     """a grid no device holds: wafer_ctx_create reports the HIP error, frees what it had taken,
     and the stale error does not resurface in the next context"""
