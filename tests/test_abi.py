@@ -71,3 +71,19 @@ def test_tools_and_entry_points_compile():
     for path in sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "wafer_amd", "*.py")) +
                        [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]):
         py_compile.compile(path, doraise=True)
+
+
+def test_rccl_hook_library_exports_its_header():
+    """include/wafer_rccl.h <-> libwafer_rccl.so (loads without a GPU: RCCL and HIP are only linked)"""
+    from wafer_amd import build
+    build.build()
+    import wafer_amd
+    wafer_amd.load_library()            # libwafer_hip.so first (libwafer_rccl.so links it)
+    lib = C.CDLL(build.RCCL_LIB)
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "wafer_rccl.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(wafer_rccl_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) == 7
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/wafer_rccl.h but not exported"
+    lib.wafer_rccl_unique_id_bytes.restype = C.c_int
+    assert lib.wafer_rccl_unique_id_bytes() == 128

@@ -5,7 +5,7 @@
 #include <cstring>
 #include <string>
 
-#include "../../include/wafer_hip.h"
+#include "../../include/wafer_rccl.h"
 #include "wafer_rccl_hooks.h"
 
 static thread_local std::string g_err;
