@@ -42,7 +42,8 @@ CLI = os.path.join(HERE, "wafer-hip")
 def build_cli(force: bool = False, verbose: bool = False) -> str:
     """The host driver (wafer.yaml -> table + observables/wavefunction files), plain g++."""
     src = os.path.join(CSRC, "wafer_cli.cpp")
-    if not force and os.path.exists(CLI) and os.path.getmtime(CLI) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+    deps = [src, os.path.join(CSRC, "wafer_files.h"), LIB]
+    if not force and os.path.exists(CLI) and os.path.getmtime(CLI) > max(os.path.getmtime(d) for d in deps):
         return CLI
     cmd = ["g++", "-O2", "-std=c++17", "-pthread", src, "-o", CLI, "-L", HERE, "-lwafer_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
@@ -57,7 +58,8 @@ SLABS = os.path.join(HERE, "wafer-hip-slabs")
 def build_rccl_host(force: bool = False, verbose: bool = False) -> str:
     """The native multi-GPU host (hooks served by RCCL's C API directly; wafer_rccl_host.cpp)."""
     src = os.path.join(CSRC, "wafer_rccl_host.cpp")
-    if not force and os.path.exists(SLABS) and os.path.getmtime(SLABS) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+    deps = [src, os.path.join(CSRC, "wafer_rccl_hooks.h"), LIB]
+    if not force and os.path.exists(SLABS) and os.path.getmtime(SLABS) > max(os.path.getmtime(d) for d in deps):
         return SLABS
     cmd = [hipcc(), "-O2", "-std=c++17", "-pthread", src, "-o", SLABS, "-L", HERE, "-lwafer_hip", "-lrccl",
            "-Wl,-rpath,$ORIGIN"]
@@ -72,7 +74,8 @@ RCCL_LIB = os.path.join(HERE, "libwafer_rccl.so")
 
 def build_rccl_lib(force: bool = False, verbose: bool = False) -> str:
     """libwafer_rccl.so: the RCCL hooks for hosts that are not C++ (wafer_rccl_lib.cpp)."""
-    srcs = [os.path.join(CSRC, "wafer_rccl_lib.cpp"), os.path.join(CSRC, "wafer_rccl_hooks.h")]
+    srcs = [os.path.join(CSRC, "wafer_rccl_lib.cpp"), os.path.join(CSRC, "wafer_rccl_hooks.h"),
+            os.path.join(os.path.dirname(HERE), "include", "wafer_rccl.h")]
     if not force and os.path.exists(RCCL_LIB) and os.path.getmtime(RCCL_LIB) > max([os.path.getmtime(x) for x in srcs] + [os.path.getmtime(LIB)]):
         return RCCL_LIB
     cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", srcs[0], "-o", RCCL_LIB, "-L", HERE, "-lwafer_hip", "-lrccl",

@@ -1,9 +1,9 @@
 // wafer-hip-slabs -- a native (no Python, no torch) multi-GPU host above the C ABI: one process
 // per GPU, the grid z-slab decomposed over the ranks, the engine's two communication hooks served by
 // RCCL called directly (ncclSend / ncclRecv in a group, ncclAllReduce) on the stream the engine
-// passes.  This is the shape of the Rust host INTEGRATION.md section 3 describes; the tested
-// production path for multi-GPU runs is wafer_amd/slab.py + wafer_amd/run.py (same hooks over
-// torch.distributed).
+// passes.  This is the shape of the Rust host INTEGRATION.md section 3 describes; the hooks are the
+// ones libwafer_rccl.so ships (wafer_rccl_hooks.h), which wafer_amd/slab.py + wafer_amd/run.py and
+// bench.py install by default.
 //
 //   RANK=r WORLD_SIZE=n LOCAL_RANK=r WAFER_NCCL_ID_FILE=/tmp/id  wafer-hip-slabs NX NY NZ STEPS [potential]
 //       every rank runs this; rank 0 writes the ncclUniqueId to the file, the others wait for it.
