@@ -61,6 +61,7 @@ extern "C" {
     pub fn wafer_normalise(ctx: *mut wafer_ctx, norm2: f64) -> c_int;
     pub fn wafer_orthogonalise(ctx: *mut wafer_ctx, wnum: u32) -> c_int;
     pub fn wafer_set_potsub(ctx: *mut wafer_ctx, kind: c_int, scalar: f64, potsub: *const f64) -> c_int;
+    pub fn wafer_set_potsub_resampled(ctx: *mut wafer_ctx, src: *const f64, sx: u32, sy: u32, sz: u32) -> c_int;
     pub fn wafer_symmetrise(ctx: *mut wafer_ctx, constraint: c_int) -> c_int;
     pub fn wafer_push_state(ctx: *mut wafer_ctx) -> c_int;
     pub fn wafer_load_state(ctx: *mut wafer_ctx, idx: u32, state: *const f64) -> c_int;

@@ -157,6 +157,10 @@ int wafer_get_potsub(wafer_ctx *ctx, int *kind, double *scalar);
  * precedence over the computed value for every potential type (potential.rs:113-131).  potsub is
  * the UNPADDED nx*ny*nz array when kind == WAFER_POTSUB_ARRAY, else ignored. */
 int wafer_set_potsub(wafer_ctx *ctx, int kind, double scalar, const double *potsub);
+/* the same override from a potential_sub array of another resolution: input::fill_sub_data
+ * (input.rs:453-478) resamples it with trilerp_resize onto the work area, basis = (nx, ny, nz).
+ * src is an UNPADDED [sx][sy][sz] array. */
+int wafer_set_potsub_resampled(wafer_ctx *ctx, const double *src, uint32_t sx, uint32_t sy, uint32_t sz);
 
 /* ---- phi: config::set_initial_conditions (config.rs:577-627), input::wavefunction, output::wavefunction */
 int wafer_set_initial_condition(wafer_ctx *ctx, int ic, uint64_t seed);

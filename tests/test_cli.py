@@ -229,6 +229,25 @@ def test_potential_sub_file_overrides_the_computed_value(cli, tmp_path, fmt, bod
     assert r.returncode == 1 and "WrongPotentialSubDims" in r.stderr
 
 
+@pytest.mark.gpu
+def test_potential_sub_array_is_resampled_to_the_grid(cli, tmp_path, oracle):
+    """input::fill_sub_data (input.rs:453-478): a potential_sub ARRAY of another size is
+    interpolated to (nx, ny, nz) with trilerp_resize; the driver writes back what the run used
+    (output::potential_sub), which must be the oracle's resample of the file, digit for digit"""
+    (tmp_path / "in").mkdir()
+    src = np.random.default_rng(8).uniform(0.5, 2.0, (5, 4, 6))
+    (tmp_path / "in" / "potential_sub.json").write_text(json.dumps({"v": 1, "dim": list(src.shape), "data": src.ravel().tolist()}))
+    text = (open(CASE).read().replace("wavemax: 1", "wavemax: 0").replace("save_wavefns: true", "save_wavefns: false")
+            .replace("potential: Harmonic", "potential: FullCornell").replace("tolerance: 1e-7", "tolerance: 1e-3"))
+    (tmp_path / "c.yaml").write_text(text)
+    r = run(cli, "-c", str(tmp_path / "c.yaml"), "--output-dir", str(tmp_path / "out"), "--input-dir", str(tmp_path / "in"))
+    assert r.returncode == 0, r.stderr
+    assert "Interpolating potential_sub from [5, 4, 6] to requested size of [24, 20, 28]." in r.stderr
+    od = tmp_path / "out" / os.listdir(tmp_path / "out")[0]
+    got = np.loadtxt(od / "potential_sub.csv", delimiter=",")[:, 3].reshape(24, 20, 28)
+    assert np.array_equal(got, oracle.trilerp_resize(src, (24, 20, 28)))
+
+
 def test_symmetry_needs_seven_point(cli, tmp_path):
     """config.rs:702-725 walks n + 6 cells: with a narrower frame the reference panics on an
     out-of-bounds index; the driver says so before touching the GPU"""

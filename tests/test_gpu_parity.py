@@ -417,6 +417,35 @@ def test_potsub_override(wo, wa, kind):
     assert (want["v_infinity"] == 0.0) == (kind == 0)
 
 
+def test_potsub_array_of_another_resolution(wo, wa):
+    """input::fill_sub_data (input.rs:453-478): a potential_sub array whose dims differ from the
+    grid is resampled with trilerp_resize onto (nx, ny, nz) -- basis = that target size, no frame --
+    bit exact against the oracle, on one context and on z-slabs"""
+    cfg, par = make_pair((18, 21, 24), ext=2, potential="FullCornell", dn=0.15, dt=0.003, mass=1.4, sig=0.223)
+    src = np.random.default_rng(5).standard_normal((7, 9, 5))
+    want = wo.trilerp_resize(src, cfg.work_shape)
+    v = wo.potential_generate(cfg)
+    phi = random_phi(cfg, seed=4)
+    obs = wo.observables(cfg, v, phi, (2, 0.0, want))
+    with wa.Context(par) as ctx:
+        with pytest.raises(wa.WaferError):
+            ctx.set_potsub_resampled(src)   # no potential yet
+        ctx.set_potential("FullCornell")
+        ctx.set_potsub_resampled(src)
+        assert ctx.potsub() == (2, 0.0)
+        assert np.array_equal(ctx.download_array("potsub"), want)
+        ctx.upload_phi(phi)
+        got = ctx.observables()
+    for k in obs:
+        assert got[k] == pytest.approx(obs[k], rel=REL_SUM, abs=1e-300), k
+    import dataclasses
+    for z0, zc in ((0, 10), (10, 14)):
+        with wa.Context(dataclasses.replace(par, z_begin=z0, z_count=zc)) as ctx:
+            ctx.set_potential("FullCornell")
+            ctx.set_potsub_resampled(src)
+            assert np.array_equal(ctx.download_array("potsub")[:, :, z0:z0 + zc], want[:, :, z0:z0 + zc])
+
+
 def test_norm_normalise_orthogonalise(wo, wa):
     cfg, par = make_pair((19, 22, 17), ext=2)
     phi = random_phi(cfg, seed=8)

@@ -503,12 +503,13 @@ int main(int argc, char **argv)
             if (sub.scalar) {
                 CHECK(wafer_set_potsub(ctx, WAFER_POTSUB_SCALAR, sub.value, nullptr));
             } else {
-                if (sub.nx != cfg.nx || sub.ny != cfg.ny || sub.nz != cfg.nz) {
-                    fprintf(stderr, "Error: potential_sub array is %ux%ux%u, the grid %ux%ux%u: resampling potential_sub (input.rs:437-470) is not supported\n",
-                            sub.nx, sub.ny, sub.nz, cfg.nx, cfg.ny, cfg.nz);
-                    return 1;
+                if (sub.nx != cfg.nx || sub.ny != cfg.ny || sub.nz != cfg.nz) { // input::fill_sub_data (input.rs:453-478)
+                    fprintf(stderr, "Interpolating potential_sub from [%u, %u, %u] to requested size of [%u, %u, %u].\n", sub.nx,
+                            sub.ny, sub.nz, cfg.nx, cfg.ny, cfg.nz);
+                    CHECK(wafer_set_potsub_resampled(ctx, sub.data.data(), sub.nx, sub.ny, sub.nz));
+                } else {
+                    CHECK(wafer_set_potsub(ctx, WAFER_POTSUB_ARRAY, 0.0, sub.data.data()));
                 }
-                CHECK(wafer_set_potsub(ctx, WAFER_POTSUB_ARRAY, 0.0, sub.data.data()));
             }
             fprintf(stderr, "Potential_sub loaded from disk\n");
         }

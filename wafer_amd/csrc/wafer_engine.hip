@@ -1051,6 +1051,19 @@ int wafer_set_potential_resampled(wafer_ctx *c, const double *src, uint32_t sx, 
     return check_v_range(c);
 }
 
+int wafer_set_potsub_resampled(wafer_ctx *c, const double *src, uint32_t sx, uint32_t sy, uint32_t sz)
+{
+    if (!c || !src) return fail(WAFER_ERR_INVALID, "null argument");
+    if (!c->have_pot) return fail(WAFER_ERR_STATE, "set the potential first");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(ensure_potsub_array(c));
+    const uint32_t basis[3] = {(uint32_t)c->g.nx, (uint32_t)c->g.ny, (uint32_t)c->g.nz}; // input.rs:472: target_size
+    TRY(resample_into(c, src, sx, sy, sz, basis, c->potsub));
+    c->potsub_kind = WAFER_POTSUB_ARRAY;
+    c->potsub_scalar = 0.0;
+    return WAFER_OK;
+}
+
 int wafer_download_phi(wafer_ctx *c, double *phi)
 {
     if (!c || !phi) return fail(WAFER_ERR_INVALID, "null argument");

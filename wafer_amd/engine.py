@@ -38,7 +38,7 @@ EXPORTS = [
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_diag_stream_bw", "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
-    "wafer_get_device_info", "wafer_set_potsub", "wafer_symmetrise",
+    "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise",
 ]
 
 
@@ -127,6 +127,7 @@ def load_library():
     L.wafer_download_array.argtypes = [vp, C.c_int, dp]
     L.wafer_get_potsub.argtypes = [vp, C.POINTER(C.c_int), dp]
     L.wafer_set_potsub.argtypes = [vp, C.c_int, C.c_double, dp]
+    L.wafer_set_potsub_resampled.argtypes = [vp, dp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.wafer_symmetrise.argtypes = [vp, C.c_int]
     L.wafer_set_initial_condition.argtypes = [vp, C.c_int, C.c_uint64]
     L.wafer_upload_phi.argtypes = [vp, dp]
@@ -272,6 +273,12 @@ class Context:
         if potsub is not None:
             assert potsub.shape == self.params.work_shape
         self._check(self._L.wafer_set_potsub(self._h, kind, scalar, _dp(potsub) if potsub is not None else None))
+
+    def set_potsub_resampled(self, src: np.ndarray) -> None:
+        """pot_sub from an array of another resolution (input::fill_sub_data, input.rs:453-478)"""
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        assert src.ndim == 3
+        self._check(self._L.wafer_set_potsub_resampled(self._h, _dp(src), *src.shape))
 
     def potsub(self):
         kind, scalar = C.c_int(0), C.c_double(0.0)
