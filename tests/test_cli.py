@@ -248,6 +248,74 @@ def test_potential_sub_array_is_resampled_to_the_grid(cli, tmp_path, oracle):
     assert np.array_equal(got, oracle.trilerp_resize(src, (24, 20, 28)))
 
 
+SCRIPT = """#!/usr/bin/env python3
+import json, sys
+g = json.load(sys.stdin)["grid"]
+assert list(g) == ["dn", "x", "y", "z"]          # serde_json's (sorted) key order
+for i in range(g["x"]):
+    for j in range(g["y"]):
+        for k in range(g["z"]):
+            r2 = sum(((q + 1) * g["dn"] - g["dn"] * (n + 1) / 2.) ** 2 for q, n in ((i, g["x"]), (j, g["y"]), (k, g["z"])))
+            print(%s)
+"""
+
+
+def write_script(path, expr):
+    path.write_text(SCRIPT % expr)
+    path.chmod(0o755)
+
+
+@pytest.mark.parametrize("expr,msg", [
+    ('"abc"', "ParseFloat"),                      # a line that is not a float (input.rs:224-227)
+    ('0.5 * r2 if i else ""', "ParseFloat"),      # empty lines do not parse either
+    ('*([0.5 * r2] if i else []), end=chr(10) if i else ""', "ArrayShape"),   # too few values (input.rs:229-231)
+])
+def test_script_potential_errors(cli, tmp_path, expr, msg):
+    """potential: FromScript (input.rs:186-246) fails like the reference does -- before any GPU work,
+    so these run on the CPU box"""
+    text = open(CASE).read().replace("potential: Harmonic", "potential: FromScript")
+    (tmp_path / "c.yaml").write_text(text)
+    r = run(cli, "-c", "c.yaml", cwd=tmp_path)
+    assert r.returncode == 1 and "SpawnPython" in r.stderr, r.stderr          # no ./gen_potential.py here
+    write_script(tmp_path / "pot.py", expr)
+    r = run(cli, "-c", "c.yaml", "-s", "pot.py", cwd=tmp_path)
+    assert r.returncode == 1 and "LoadPotential" in r.stderr and msg in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_script_potential_runs(cli, tmp_path):
+    """the script's values become the work area of V; the same numbers supplied as a
+    potential FILE give the same run, row for row"""
+    text = (open(CASE).read().replace("potential: Harmonic", "potential: FromScript").replace("wavemax: 1", "wavemax: 0")
+            .replace("save_wavefns: true", "save_wavefns: false"))
+    (tmp_path / "c.yaml").write_text(text)
+    write_script(tmp_path / "gen_potential.py", "repr(0.5 * r2)")
+    r = run(cli, "-c", "c.yaml", cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "Generating potential from script file: ./gen_potential.py" in r.stderr
+    od = tmp_path / "output" / os.listdir(tmp_path / "output")[0]
+    pot = np.loadtxt(od / "potential.csv", delimiter=",")[:, 3].reshape(24, 20, 28)   # output::potential: the work area
+    dn = 0.5
+    ax = [((np.arange(n) + 1) * dn - dn * (n + 1) / 2.) ** 2 for n in (24, 20, 28)]
+    want = np.zeros((24, 20, 28))
+    for i in range(24):       # the script's own summation order
+        for j in range(20):
+            want[i, j, :] = [0.5 * sum((ax[0][i], ax[1][j], ax[2][k])) for k in range(28)]
+    assert np.array_equal(pot, want)
+    # the same array as ./input/potential.csv with potential: FromFile
+    (tmp_path / "input").mkdir(exist_ok=True)
+    with open(tmp_path / "input" / "potential.csv", "w") as f:
+        for i in range(24):
+            for j in range(20):
+                for k in range(28):
+                    f.write(f"{i},{j},{k},{float(want[i, j, k])!r}\n")
+    (tmp_path / "f.yaml").write_text(text.replace("potential: FromScript", "potential: FromFile"))
+    r2 = run(cli, "-c", "f.yaml", "--output-dir", "out2", cwd=tmp_path)
+    assert r2.returncode == 0, r2.stderr
+    rows = lambda t: [l for l in t.splitlines() if "│" in l]
+    assert rows(r.stdout) == rows(r2.stdout) and len(rows(r.stdout)) >= 2
+
+
 def test_symmetry_needs_seven_point(cli, tmp_path):
     """config.rs:702-725 walks n + 6 cells: with a narrower frame the reference panics on an
     out-of-bounds index; the driver says so before touching the GPU"""

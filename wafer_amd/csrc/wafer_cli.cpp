@@ -9,10 +9,12 @@
 //
 // Input and output files in all five of the reference's formats (wafer_files.h).
 //
-// Out of scope: clap's -s script potentials, slog file
-// logging, the progress bar.
+// potential: FromScript runs ./<script> (-s, default gen_potential.py) with the reference's
+// stdin / stdout protocol (input.rs:186-246) before the GPU is touched.
 //
-//   wafer-hip [-c wafer.yaml] [--check-config] [--progress] [--output-dir DIR] [--input-dir DIR]
+// Out of scope: slog file logging, the progress bar.
+//
+//   wafer-hip [-c wafer.yaml] [-s SCRIPT] [--check-config] [--progress] [--output-dir DIR] [--input-dir DIR]
 //   wafer-hip --convert IN OUT      (array / potential_sub file from one format to another, by extension)
 #include <charconv>
 #include <cmath>
@@ -25,7 +27,10 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <csignal>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -316,6 +321,64 @@ static bool load_input(const std::string &dir, const std::string &stem, int conf
     return read_field(path, t, out, err);
 }
 
+// input::script_potential (input.rs:186-246): spawn ./<script>, write {"grid":{"dn":..,"x":..,"y":..,"z":..}}
+// (serde_json's key order) to its stdin, close it, parse one f64 per stdout line -- nx*ny*nz values of
+// the WORK area, x slowest.  Runs before the GPU is touched: a process that has initialised HIP must
+// not fork + exec on the GPU boxes.
+static bool run_potential_script(const std::string &file, const Config &cfg, FieldFile &out, std::string &err)
+{
+    int to_child[2], from_child[2];
+    if (pipe(to_child) != 0 || pipe(from_child) != 0) { err = "SpawnPython: pipe failed"; return false; }
+    const pid_t pid = fork();
+    if (pid < 0) { err = "SpawnPython: Unable to spawn a python script process"; return false; }
+    if (pid == 0) {
+        dup2(to_child[0], 0);
+        dup2(from_child[1], 1);
+        close(to_child[0]); close(to_child[1]); close(from_child[0]); close(from_child[1]);
+        execl(file.c_str(), file.c_str(), (char *)nullptr);
+        _exit(127);
+    }
+    close(to_child[0]);
+    close(from_child[1]);
+    const std::string input = "{\"grid\":{\"dn\":" + num_text(cfg.dn) + ",\"x\":" + std::to_string(cfg.nx) + ",\"y\":" +
+                              std::to_string(cfg.ny) + ",\"z\":" + std::to_string(cfg.nz) + "}}";
+    signal(SIGPIPE, SIG_IGN);
+    const bool wrote = write(to_child[1], input.data(), input.size()) == (ssize_t)input.size();
+    close(to_child[1]); // the script starts processing once its stdin is closed
+    std::string text;
+    char buf[1 << 16];
+    for (ssize_t n; (n = read(from_child[0], buf, sizeof buf)) > 0;) text.append(buf, (size_t)n);
+    close(from_child[0]);
+    int status = 0;
+    waitpid(pid, &status, 0);
+    if (WIFEXITED(status) && WEXITSTATUS(status) == 127 && text.empty()) { err = "SpawnPython: Unable to spawn a python script process (" + file + ")"; return false; }
+    if (!wrote) { err = "StdIn: Unable to write to stdin in of the python script process"; return false; }
+    out = FieldFile();
+    out.nx = cfg.nx; out.ny = cfg.ny; out.nz = cfg.nz;
+    size_t pos = 0;
+    while (pos < text.size()) { // str::lines + parse::<f64>: the whole line must be a float
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        std::string line = text.substr(pos, eol - pos);
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        pos = eol + 1;
+        char *endp = nullptr;
+        const double v = strtod(line.c_str(), &endp); // Rust's parse::<f64> takes no surrounding blanks
+        if (line.empty() || isspace((unsigned char)line[0]) || endp != line.c_str() + line.size()) {
+            err = "ParseFloat: Cannot parse float '" + line + "'";
+            return false;
+        }
+        out.data.push_back(v);
+    }
+    const size_t want = (size_t)cfg.nx * cfg.ny * cfg.nz;
+    if (out.data.size() != want) {
+        err = "ArrayShape: Cannot reshape " + std::to_string(out.data.size()) + " values into [" + std::to_string(cfg.nx) + ", " +
+              std::to_string(cfg.ny) + ", " + std::to_string(cfg.nz) + "]";
+        return false;
+    }
+    return true;
+}
+
 // what=0: phi, 1: potential.  Same size -> copied; otherwise trilinearly resampled on the
 // device with the reference's basis (input.rs:651-655, 667-716).
 static int upload_field(wafer_ctx *ctx, const Config &cfg, const FieldFile &a, int what)
@@ -383,7 +446,7 @@ static std::string sanitize(const std::string &s)
 
 int main(int argc, char **argv)
 {
-    std::string config_file = "wafer.yaml", output_root = "./output", input_dir = "./input";
+    std::string config_file = "wafer.yaml", output_root = "./output", input_dir = "./input", script_file = "gen_potential.py";
     bool check_only = false, progress = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -407,9 +470,10 @@ int main(int argc, char **argv)
             if (!ok) { fprintf(stderr, "Error: %s\n", e.c_str()); return 1; }
             return 0;
         }
+        else if ((a == "-s" || a == "--script") && i + 1 < argc) script_file = argv[++i];
         else if (a == "--progress") progress = true;
         else if (a == "-h" || a == "--help") {
-            printf("wafer-hip [-c wafer.yaml] [--check-config] [--progress] [--output-dir DIR] [--input-dir DIR]\n"
+            printf("wafer-hip [-c wafer.yaml] [-s gen_potential.py] [--check-config] [--progress] [--output-dir DIR] [--input-dir DIR]\n"
                    "wafer-hip --convert IN OUT   (.mpk .csv .json .yaml .ron)\n");
             return 0;
         } else {
@@ -444,7 +508,15 @@ int main(int argc, char **argv)
                 cfg.init_symmetry.c_str());
         return 1;
     }
-    if (cfg.potential == WAFER_POT_FROMSCRIPT) { fprintf(stderr, "Error: FromScript potentials are not supported\n"); return 1; }
+    FieldFile scripted; // potential.rs:87-94; config.rs:344-347: the script lives at ./<name>
+    if (cfg.potential == WAFER_POT_FROMSCRIPT) {
+        const std::string file = "./" + script_file;
+        fprintf(stderr, "Generating potential from script file: %s\n", file.c_str());
+        if (!run_potential_script(file, cfg, scripted, err)) {
+            fprintf(stderr, "Error: LoadPotential: %s\n", err.c_str());
+            return 1;
+        }
+    }
 
     // output directory ./output/<project>_<timestamp> (output.rs:680-699)
     char stamp[64];
@@ -484,6 +556,9 @@ int main(int argc, char **argv)
             return 1;
         }
         CHECK(upload_field(ctx, cfg, pot, 1));
+    } else if (cfg.potential == WAFER_POT_FROMSCRIPT) {
+        CHECK(upload_field(ctx, cfg, scripted, 1)); // "generated is the right size by definition: copy down"
+        scripted = FieldFile();
     } else {
         CHECK(wafer_set_potential_builtin(ctx, cfg.potential));
     }
