@@ -38,6 +38,50 @@ pub struct wafer_observables_t {
     pub r2: f64,
 }
 
+/// One row of the convergence table (grid.rs:126-221, output.rs:497-521).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct wafer_block_record {
+    pub step: u64,
+    pub tau: f64,
+    pub obs: wafer_observables_t,
+    pub diff: f64,
+}
+
+/// output.rs:32-45, 540-547
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct wafer_observables_output {
+    pub state: u32,
+    pub energy: f64,
+    pub binding_energy: f64,
+    pub r: f64,
+    pub l_r: f64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct wafer_slab_info {
+    pub z_begin: u32,
+    pub z_count: u32,
+    pub halo_depth: u32,
+    pub ext: u32,
+    pub plane_elems: u64,
+    pub elem_bytes: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct wafer_device_info {
+    pub name: [c_char; 64],
+    pub arch: [c_char; 64],
+    pub compute_units: u32,
+    pub memory_clock_khz: u32,
+    pub memory_bus_bits: u32,
+    pub l2_bytes: u32,
+    pub total_bytes: u64,
+}
+
 pub enum wafer_ctx {}
 
 pub type wafer_halo_fn = extern "C" fn(*mut c_void, *mut c_void, *mut c_void, *mut c_void, *mut c_void, usize, *mut c_void) -> c_int;
@@ -67,6 +111,25 @@ extern "C" {
     pub fn wafer_load_state(ctx: *mut wafer_ctx, idx: u32, state: *const f64) -> c_int;
     pub fn wafer_clone_state_to_phi(ctx: *mut wafer_ctx, idx: u32) -> c_int;
     pub fn wafer_set_comm_hooks(ctx: *mut wafer_ctx, halo: wafer_halo_fn, allreduce: wafer_allreduce_fn, user: *mut c_void) -> c_int;
+    pub fn wafer_set_overlap(ctx: *mut wafer_ctx, enabled: c_int) -> c_int;
+    pub fn wafer_set_stream(ctx: *mut wafer_ctx, hip_stream: *mut c_void) -> c_int;
+    pub fn wafer_get_slab_info(ctx: *mut wafer_ctx, out: *mut wafer_slab_info) -> c_int;
+    pub fn wafer_get_device_info(ctx: *mut wafer_ctx, out: *mut wafer_device_info) -> c_int;
+    pub fn wafer_set_potential_resampled(ctx: *mut wafer_ctx, src: *const f64, sx: u32, sy: u32, sz: u32, basis: *const u32) -> c_int;
+    pub fn wafer_download_array(ctx: *mut wafer_ctx, array_id: c_int, out: *mut f64) -> c_int;
+    pub fn wafer_get_potsub(ctx: *mut wafer_ctx, kind: *mut c_int, scalar: *mut f64) -> c_int;
+    pub fn wafer_download_state(ctx: *mut wafer_ctx, idx: u32, state: *mut f64) -> c_int;
+    pub fn wafer_num_states(ctx: *mut wafer_ctx, out: *mut u32) -> c_int;
+    pub fn wafer_clear_states(ctx: *mut wafer_ctx) -> c_int;
+    pub fn wafer_solve_state(
+        ctx: *mut wafer_ctx, wnum: u32, tolerance: f64, screen_update: u64, has_max_steps: c_int, max_steps: u64,
+        records: *mut wafer_block_record, max_records: usize, n_records: *mut usize, final_out: *mut wafer_observables_output,
+    ) -> c_int;
+    pub fn wafer_last_evolve_ms(ctx: *mut wafer_ctx, ms: *mut f32, steps: *mut u64) -> c_int;
+    pub fn wafer_stencil_kernel_name(ctx: *mut wafer_ctx) -> *const c_char;
+    pub fn wafer_stencil_steps_per_launch(ctx: *mut wafer_ctx) -> c_int;
+    pub fn wafer_set_stencil_variant(ctx: *mut wafer_ctx, variant: c_int) -> c_int;
+    pub fn wafer_diag_stream_bw(ctx: *mut wafer_ctx, n_reads: c_int, iters: c_int, gbps: *mut f64) -> c_int;
 }
 
 /// `Err(message)` for any non-zero status; a Wafer integration maps it to an `ErrorKind`.
@@ -114,6 +177,23 @@ impl Engine {
     }
     pub fn download_phi(&mut self, phi: &mut [f64]) -> Result<(), String> {
         check(unsafe { wafer_download_phi(self.ctx, phi.as_mut_ptr()) })
+    }
+    /// One state of grid::solve (grid.rs:50-246): the evolve / observables / convergence loop on the
+    /// device; `Ok(rows, summary)` when converged, the engine's MaxStep error otherwise.
+    pub fn solve_state(
+        &mut self, wnum: u8, tolerance: f64, screen_update: u64, max_steps: Option<u64>,
+    ) -> Result<(Vec<wafer_block_record>, wafer_observables_output), String> {
+        let mut rows = vec![wafer_block_record::default(); 4096];
+        let mut n: usize = 0;
+        let mut out = wafer_observables_output::default();
+        check(unsafe {
+            wafer_solve_state(
+                self.ctx, wnum as u32, tolerance, screen_update, max_steps.is_some() as c_int, max_steps.unwrap_or(0),
+                rows.as_mut_ptr(), rows.len(), &mut n, &mut out,
+            )
+        })?;
+        rows.truncate(n);
+        Ok((rows, out))
     }
     /// grid.rs:241
     pub fn push_state(&mut self) -> Result<(), String> {

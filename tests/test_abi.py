@@ -87,3 +87,21 @@ def test_rccl_hook_library_exports_its_header():
         assert hasattr(lib, n), f"{n} declared in include/wafer_rccl.h but not exported"
     lib.wafer_rccl_unique_id_bytes.restype = C.c_int
     assert lib.wafer_rccl_unique_id_bytes() == 128
+
+
+def test_rust_binding_declares_every_entry_point():
+    """bindings/rust/src/lib.rs cannot be compiled here (no Rust toolchain); at least its extern block
+    must name every function of include/wafer_hip.h, with as many arguments"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "wafer_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    rust = open(os.path.join(root, "bindings", "rust", "src", "lib.rs")).read()
+    decls = re.findall(r"\b(?:int|const char \*)\s*(wafer_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
+    assert len(decls) >= 39
+    for name, args in decls:
+        m = re.search(r"pub fn %s\s*\((.*?)\)\s*->" % name, rust, flags=re.S)
+        assert m, f"{name} missing from the Rust binding"
+        n_c = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        n_rs = len([a for a in m.group(1).split(",") if a.strip()])
+        assert n_c == n_rs, (name, n_c, n_rs)
