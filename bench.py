@@ -176,10 +176,12 @@ def main():
     ctx.synchronize()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        # this rank's queued work first, then every rank's, then whatever the barrier itself queued
         ctx.synchronize()
         torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
 
     # the box itself next to the 8 TB/s datasheet peak: the bandwidth its own
     # properties imply and what a flat streaming kernel reaches on the same buffers.  Measured
