@@ -108,6 +108,70 @@ def test_multi_rank_solve_driver_matches_the_native_driver(tmp_path):
     assert np.allclose(state, want, rtol=0, atol=1e-12)
 
 
+def test_multi_rank_driver_reads_input_files(tmp_path):
+    """potential: FromFile + a potential_sub override + a restart at wavenum 1 (grid.rs:35-39) on 2
+    ranks: rank 0 stages the reference-format files as framed .npy, every rank memory-maps them and
+    uploads only its own planes.  Same rows as wafer-hip reading the same ./input on one GPU."""
+    import re
+    import shutil
+    case = os.path.join(ROOT, "tests", "golden", "cli_case.yaml")
+    cli = os.path.join(ROOT, "wafer_amd", "wafer-hip")
+    first = subprocess.run([cli, "-c", case, "--output-dir", str(tmp_path / "first"), "--input-dir", str(tmp_path / "none")],
+                           capture_output=True, text=True)
+    assert first.returncode == 0, first.stderr
+    od = tmp_path / "first" / os.listdir(tmp_path / "first")[0]
+    inp = tmp_path / "input"
+    inp.mkdir()
+    shutil.copy(od / "potential.csv", inp / "potential.csv")
+    shutil.copy(od / "wavefunction_0.csv", inp / "wavefunction_0.csv")
+    (inp / "potential_sub.json").write_text('{"pot_sub": 2.0}')
+    # a deterministic start for state 1 (a clone of state 0 leaves rounding noise, which differs between
+    # one and two ranks): x times the ground state, as a snapshot file (input.rs:513-523)
+    import numpy as np
+    w0 = np.loadtxt(od / "wavefunction_0.csv", delimiter=",")
+    with open(inp / "wavefunction_1_partial.csv", "w") as f:
+        for i, j, k, v in w0:
+            f.write(f"{int(i)},{int(j)},{int(k)},{float(v * (i - 11.5))!r}\n")
+    text = (open(case).read().replace("potential: Harmonic", "potential: FromFile").replace("wavenum: 0", "wavenum: 1"))
+    (tmp_path / "restart.yaml").write_text(text)
+    one = subprocess.run([cli, "-c", str(tmp_path / "restart.yaml"), "--progress", "--output-dir", str(tmp_path / "one"),
+                          "--input-dir", str(inp)], capture_output=True, text=True)
+    assert one.returncode == 0, one.stderr
+    os.environ["WAFER_TRANSPORT"] = "host"
+    try:
+        two = launch(2, "-m", "wafer_amd.run", "-c", str(tmp_path / "restart.yaml"), "--progress",
+                     "--output-dir", str(tmp_path / "two"), "--input-dir", str(inp))
+    finally:
+        os.environ.pop("WAFER_TRANSPORT", None)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    assert sorted(os.listdir(inp / ".wafer_amd")) == ["potential.pad1.npy", "potential_sub.pad0.npy", "wavefunction_0.pad1.npy",
+                                                     "wavefunction_1_partial.pad1.npy"]
+    assert "Ground state" not in two.stdout and "1st excited state caclulation" in two.stdout
+
+    def rows(text):
+        return [l for l in text.splitlines() if re.match(r"^\s+│\s*[0-9.]+ │", l)]
+
+    a, b = rows(one.stdout), rows(two.stdout)
+    assert len(a) == len(b) > 3
+    for la, lb in zip(a, b):
+        ca, cb = [c.strip() for c in la.split("│")[1:5]], [c.strip() for c in lb.split("│")[1:5]]
+        assert ca[0] == cb[0] and ca[2] == cb[2]
+        assert float(ca[1]) == pytest.approx(float(cb[1]), abs=5e-9)
+    e = [float(re.search(r"1st excited state energy = ([0-9.eE+-]+)", t).group(1)) for t in (one.stdout, two.stdout)]
+    be = [float(re.search(r"1st excited state binding energy = ([0-9.eE+-]+)", t).group(1)) for t in (one.stdout, two.stdout)]
+    assert e[1] == pytest.approx(e[0], abs=5e-9)
+    assert be[0] == pytest.approx(e[0] - 2.0, abs=1e-12) and be[1] == pytest.approx(e[1] - 2.0, abs=1e-12)
+    # a wrong-sized array is refused with a pointer to the single-GPU driver, which resamples
+    (inp / "potential.csv").write_text("0,0,0,1.0\n0,0,1,1.0\n")
+    os.environ["WAFER_TRANSPORT"] = "host"
+    try:
+        bad = launch(2, "-m", "wafer_amd.run", "-c", str(tmp_path / "restart.yaml"), "--output-dir", str(tmp_path / "bad"),
+                     "--input-dir", str(inp))
+    finally:
+        os.environ.pop("WAFER_TRANSPORT", None)
+    assert bad.returncode != 0 and "resample it once with wafer-hip" in bad.stderr
+
+
 def test_native_rccl_host_self_neighbours():
     """wafer-hip-slabs --self: the hooks served by RCCL's C API directly from a native host
     (no Python, no torch in that process), one rank that is its own z-neighbour, bit for bit

@@ -16,6 +16,7 @@
 //
 //   wafer-hip [-c wafer.yaml] [-s SCRIPT] [--check-config] [--progress] [--output-dir DIR] [--input-dir DIR]
 //   wafer-hip --convert IN OUT      (array / potential_sub file from one format to another, by extension)
+//   wafer-hip --convert IN OUT.npy [--pad E]   (numpy's format, optionally framed: wafer_amd.run's input)
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -461,10 +462,18 @@ int main(int argc, char **argv)
         else if (a == "--convert" && i + 2 < argc) { // any of the five formats to any other (wafer_files.h)
             const std::string in = argv[i + 1], out = argv[i + 2];
             const int ti = type_of_path(in), to = type_of_path(out);
+            const bool to_npy = out.size() > 4 && out.compare(out.size() - 4, 4, ".npy") == 0;
             FieldFile f;
             std::string e;
-            if (ti < 0 || to < 0) { fprintf(stderr, "Error: unknown file extension\n"); return 2; }
+            if (ti < 0 || (to < 0 && !to_npy)) { fprintf(stderr, "Error: unknown file extension\n"); return 2; }
             if (!read_field(in, ti, f, e)) { fprintf(stderr, "Error: %s\n", e.c_str()); return 1; }
+            if (to_npy) { // numpy's format, optionally with the zero frame of `--pad E` cells: what
+                          // wafer_amd.run memory-maps so that each rank touches only its own planes
+                uint32_t pad = 0;
+                if (i + 4 < argc && std::string(argv[i + 3]) == "--pad") pad = (uint32_t)atoi(argv[i + 4]);
+                if (!write_npy(out, f, pad, e)) { fprintf(stderr, "Error: %s\n", e.c_str()); return 1; } // a single value: shape ()
+                return 0;
+            }
             const bool ok = f.scalar ? write_scalar_sub(out, to, f.value, e)
                                      : write_array(out, to, f.data.data(), f.nx, f.ny, f.nz, 0, e);
             if (!ok) { fprintf(stderr, "Error: %s\n", e.c_str()); return 1; }
@@ -474,7 +483,7 @@ int main(int argc, char **argv)
         else if (a == "--progress") progress = true;
         else if (a == "-h" || a == "--help") {
             printf("wafer-hip [-c wafer.yaml] [-s gen_potential.py] [--check-config] [--progress] [--output-dir DIR] [--input-dir DIR]\n"
-                   "wafer-hip --convert IN OUT   (.mpk .csv .json .yaml .ron)\n");
+                   "wafer-hip --convert IN OUT   (.mpk .csv .json .yaml .ron; OUT may be .npy, then [--pad E] adds the zero frame)\n");
             return 0;
         } else {
             fprintf(stderr, "unknown argument %s\n", a.c_str());

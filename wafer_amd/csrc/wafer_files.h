@@ -273,6 +273,35 @@ static bool write_array(const std::string &path, int file_type, const double *pa
                        [&](uint32_t i, uint32_t j, uint32_t k) { return padded[((size_t)(i + e) * py + (j + e)) * pz + (k + e)]; }, err);
 }
 
+// numpy .npy (version 1.0), C order float64, shape (nx + 2 pad, ny + 2 pad, nz + 2 pad): the work
+// area surrounded by `pad` zero cells.  Not one of the reference's formats: the hand-over to the
+// multi-rank driver, which memory-maps it (wafer_amd/run.py).
+static bool write_npy(const std::string &path, const FieldFile &a, uint32_t pad, std::string &err)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { err = "CreateFile: " + path; return false; }
+    const size_t px = a.nx + 2 * (size_t)pad, py = a.ny + 2 * (size_t)pad, pz = a.nz + 2 * (size_t)pad;
+    std::string head = "{'descr': '<f8', 'fortran_order': False, 'shape': (" +
+                       (a.scalar ? std::string() : std::to_string(px) + ", " + std::to_string(py) + ", " + std::to_string(pz)) + "), }";
+    while ((10 + head.size() + 1) % 64 != 0) head.push_back(' ');
+    head.push_back('\n');
+    const unsigned char magic[10] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0, (unsigned char)(head.size() & 0xff),
+                                     (unsigned char)(head.size() >> 8)};
+    bool ok = fwrite(magic, 1, 10, f) == 10 && fwrite(head.data(), 1, head.size(), f) == head.size();
+    if (a.scalar) ok = ok && fwrite(&a.value, sizeof(double), 1, f) == 1; // PotentialSubSingle: a 0-d array
+    const std::vector<double> zeros(pz, 0.0);
+    std::vector<double> row(pz, 0.0);
+    for (size_t i = 0; ok && !a.scalar && i < px; ++i)
+        for (size_t j = 0; ok && j < py; ++j) {
+            const bool inside = i >= pad && i < pad + a.nx && j >= pad && j < pad + a.ny;
+            if (inside) memcpy(&row[pad], &a.data[((i - pad) * a.ny + (j - pad)) * (size_t)a.nz], sizeof(double) * a.nz);
+            ok = fwrite(inside ? row.data() : zeros.data(), sizeof(double), pz, f) == pz;
+        }
+    if (fclose(f) != 0) ok = false;
+    if (!ok) err = "CreateFile: short write to " + path;
+    return ok;
+}
+
 // PotentialSubSingle { pot_sub } (output.rs:224-377)
 static bool write_scalar_sub(const std::string &path, int file_type, double v, std::string &err)
 {

@@ -11,10 +11,15 @@ executes the loop; the observables it sees are already all-reduced, so all ranks
 branches; rank 0 prints the table (output.rs:421-603) and writes the files.
 
 Configuration parsing and validation are the native driver's (`wafer-hip --check-config`), so both
-drivers accept exactly the same files.  Not available across ranks: FromFile potentials /
-wavefunctions and restarts from ./input (each rank would have to read the whole array), symmetry
-constraints about z.  WAFER_TRANSPORT=host selects the host-staged gloo transport (ranks folded
-onto the GPUs present; tests/test_gpu_multiprocess.py).
+drivers accept exactly the same files.  Arrays from ./input -- `potential: FromFile`, a
+`potential_sub` override, `wavefunction_N` restarts (grid.rs:35-39, 60-100) in any of the reference's
+five formats -- are staged once by rank 0 as a framed .npy next to the input (`wafer-hip --convert
+IN OUT.npy --pad E`) and memory-mapped by every rank: the engine copies only the planes of its own
+slab out of the mapping, so no rank ever holds the whole array (BASELINE config #5: a 2048^3
+potential from file over 8 GPUs).  A ready-made framed `<stem>.npy` in ./input is used as is.
+Not available across ranks: resampling an array of another resolution (do that once with
+`wafer-hip`), potentials from a script, symmetry constraints about z.  WAFER_TRANSPORT=host selects
+the host-staged gloo transport (ranks folded onto the GPUs present; tests/test_gpu_multiprocess.py).
 """
 from __future__ import annotations
 
@@ -114,6 +119,47 @@ def load_config(path: str) -> dict:
     return json.loads(r.stdout)
 
 
+FILE_EXT = {"Messagepack": ".mpk", "Csv": ".csv", "Json": ".json", "Yaml": ".yaml", "Ron": ".ron"}
+
+
+def find_input(input_dir: str, stem: str, file_type: str):
+    """input.rs:75-110, 264-300, 542-575: <dir>/<stem>.{mpk,csv,json,yaml,ron}; with several present
+    the configured type arbitrates, otherwise the first in that order (wafer_files.h find_input)"""
+    present = [e for e in FILE_EXT.values() if os.path.exists(os.path.join(input_dir, stem + e))]
+    if not present:
+        return None
+    pick = FILE_EXT[file_type] if len(present) > 1 and FILE_EXT[file_type] in present else present[0]
+    return os.path.join(input_dir, stem + pick)
+
+
+def staged_array(input_dir: str, stem: str, file_type: str, pad: int, rank: int, wait_s: float = 6 * 3600.0):
+    """The array of ./input/<stem>.* as a read-only memory map with `pad` zero cells around the work
+    area, or None if there is no such file.  Rank 0 converts (cached by modification time); the other
+    ranks wait for the file -- no collective, so that nothing times out under a long conversion."""
+    ready = os.path.join(input_dir, stem + ".npy")
+    if os.path.exists(ready):
+        return np.load(ready, mmap_mode="r")
+    src = find_input(input_dir, stem, file_type)
+    if src is None:
+        return None
+    cache = os.path.join(input_dir, ".wafer_amd")
+    dst = os.path.join(cache, f"{stem}.pad{pad}.npy")
+    fresh = lambda: os.path.exists(dst) and os.path.getmtime(dst) >= os.path.getmtime(src)  # noqa: E731
+    if rank == 0 and not fresh():
+        os.makedirs(cache, exist_ok=True)
+        tmp = os.path.join(cache, f"{stem}.pad{pad}.tmp.npy")
+        r = subprocess.run([CLI, "--convert", src, tmp, "--pad", str(pad)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise SystemExit(f"could not read {src}: {r.stderr.strip()}")
+        os.replace(tmp, dst)
+    t0 = time.time()
+    while not fresh():
+        if time.time() - t0 > wait_s:
+            raise SystemExit(f"rank {rank}: gave up waiting for rank 0 to stage {src}")
+        time.sleep(0.05)
+    return np.load(dst, mmap_mode="r")
+
+
 def sanitize(cli_arg: str) -> str:
     return subprocess.run([CLI, "--sanitize", cli_arg], capture_output=True, text=True).stdout.rstrip("\n")
 
@@ -122,6 +168,7 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="python -m wafer_amd.run")
     ap.add_argument("-c", "--config", default="wafer.yaml")
     ap.add_argument("--output-dir", default="./output")
+    ap.add_argument("--input-dir", default="./input")
     ap.add_argument("--progress", action="store_true", help="print a table row per screen_update block")
     args = ap.parse_args(argv)
 
@@ -131,8 +178,9 @@ def main(argv=None) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     cfg = load_config(args.config)
-    if cfg["potential"] in ("FromFile", "FromScript") or cfg["init_condition"] == "FromFile" or cfg["wavenum"] > 0:
-        raise SystemExit("wafer_amd.run: file potentials / wavefunctions and restarts are single-GPU features (wafer-hip)")
+    if cfg["potential"] == "FromScript":
+        raise SystemExit("wafer_amd.run: script potentials are a single-GPU feature (wafer-hip -s); "
+                         "save the potential there and use potential: FromFile")
 
     import torch
     import wafer_amd
@@ -182,15 +230,62 @@ def main(argv=None) -> int:
             comm, _name = slab.make_slab_comm(ctx, rank, world, torch.device("cuda", local_rank),
                                               "host" if host_transport else None)
             comm.warm_up()
-        ctx.set_potential(cfg["potential"])
+        def from_input(stem, pad, shape, what):
+            a = staged_array(args.input_dir, stem, cfg["file_type"], pad, rank)
+            if a is not None and (a.dtype != np.float64 or tuple(a.shape) != tuple(shape)):
+                raise SystemExit(f"{what}: {stem} holds {tuple(a.shape)} {a.dtype}, this run needs {tuple(shape)} float64 "
+                                 f"(the frame of {pad} cells included); resample it once with wafer-hip")
+            return a
+
+        if cfg["potential"] == "FromFile":                              # potential.rs:80-86
+            v = from_input("potential", ext, par.padded_shape, "LoadPotential")
+            if v is None:
+                raise SystemExit(f"Error: LoadPotential: FileNotFound: {args.input_dir}/potential.*")
+            say("Loading potential from file", file=sys.stderr)
+            ctx.set_potential_host(v)
+            del v
+        else:
+            ctx.set_potential(cfg["potential"])
+        sub = staged_array(args.input_dir, "potential_sub", cfg["file_type"], 0, rank)   # potential.rs:113-131
+        if sub is not None:
+            variable = cfg["potential"] == "FullCornell"
+            if (sub.ndim == 0) == variable:
+                raise SystemExit("Error: WrongPotentialSubDims: potential_sub input file does not suit the potential type")
+            if sub.ndim == 0:
+                ctx.set_potsub(1, float(sub))
+            else:
+                if tuple(sub.shape) != par.work_shape:
+                    raise SystemExit(f"potential_sub holds {tuple(sub.shape)}, the grid is {par.work_shape}; resample it once with wafer-hip")
+                ctx.set_potsub(2, 0.0, sub)
+            say("Potential_sub loaded from disk", file=sys.stderr)
+            del sub
+        for w in range(cfg["wavenum"]):                                  # grid.rs:35-39: converged lower states from disk
+            st = from_input(f"wavefunction_{w}", ext, par.padded_shape, f"LoadWavefunction({w})")
+            if st is None:
+                raise SystemExit(f"Error: LoadWavefunction({w}): FileNotFound: {args.input_dir}/wavefunction_{w}.*")
+            ctx.upload_phi(st)
+            ctx.push_state()
+            del st
         for wnum in range(cfg["wavenum"], cfg["wavemax"] + 1):          # grid.rs:43-45
             cloned = False
-            if wnum == 0:                                                # grid.rs:99, config.rs:577-627
+            start = from_input(f"wavefunction_{wnum}", ext, par.padded_shape, f"LoadWavefunction({wnum})")
+            if start is None:                                            # input.rs:513-523
+                start = from_input(f"wavefunction_{wnum}_partial", ext, par.padded_shape, f"LoadWavefunction({wnum})")
+            if wnum > 0:
+                if start is not None:
+                    ctx.upload_phi(start)
+                else:                                                    # grid.rs:95
+                    ctx.clone_state_to_phi(wnum - 1)
+                    cloned = True
+            elif cfg["init_condition"] == "FromFile":
+                if start is None:
+                    raise SystemExit(f"Error: SetInitialConditions: LoadWavefunction(0): FileNotFound: {args.input_dir}/wavefunction_0*.*")
+                ctx.upload_phi(start)
+            else:                                                        # grid.rs:99, config.rs:577-627
                 ctx.set_initial_condition(cfg["init_condition"], seed=seed)
-                ctx.symmetrise(symmetry)
-            else:                                                        # grid.rs:95
-                ctx.clone_state_to_phi(wnum - 1)
-                cloned = True
+            del start
+            if wnum == 0:
+                ctx.symmetrise(symmetry)                                 # config.rs:625
             say(observable_header(wnum))
             step, last_energy, converged = 0, sys.float_info.max, False
             while True:                                                  # grid.rs:126-221
