@@ -98,6 +98,7 @@ extern "C" {
     pub fn wafer_set_initial_condition(ctx: *mut wafer_ctx, ic: c_int, seed: u64) -> c_int;
     pub fn wafer_upload_phi(ctx: *mut wafer_ctx, phi: *const f64) -> c_int;
     pub fn wafer_download_phi(ctx: *mut wafer_ctx, phi: *mut f64) -> c_int;
+    pub fn wafer_download_phi_owned(ctx: *mut wafer_ctx, out: *mut f64) -> c_int;
     pub fn wafer_upload_phi_resampled(ctx: *mut wafer_ctx, src: *const f64, sx: u32, sy: u32, sz: u32, basis: *const u32) -> c_int;
     pub fn wafer_evolve(ctx: *mut wafer_ctx, wnum: u32, n_steps: u64) -> c_int;
     pub fn wafer_observables(ctx: *mut wafer_ctx, out: *mut wafer_observables_t) -> c_int;

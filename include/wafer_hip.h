@@ -166,6 +166,10 @@ int wafer_set_potsub_resampled(wafer_ctx *ctx, const double *src, uint32_t sx, u
 int wafer_set_initial_condition(wafer_ctx *ctx, int ic, uint64_t seed);
 int wafer_upload_phi(wafer_ctx *ctx, const double *phi);
 int wafer_download_phi(wafer_ctx *ctx, double *phi);
+/* the work cells of the planes this context OWNS, [nx][ny][z_count] in the reference's axis order
+ * (z_count = nz without a slab): what a rank of a decomposed run saves -- its host buffer is the size
+ * of its slab, not of the grid */
+int wafer_download_phi_owned(wafer_ctx *ctx, double *out);
 /* Restart from another resolution: input::fill_data / read_csv's resampling branch with
  * trilerp_resize (input.rs:149-176, 640-656, 667-716).  src is an UNPADDED [sx][sy][sz] array;
  * basis = the `size` the reference builds its linspace from (NULL = the padded target size, which

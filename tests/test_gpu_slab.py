@@ -274,6 +274,33 @@ def test_slab_without_hooks_fails_loudly(wa):
             ctx.evolve(0, 1)
 
 
+@pytest.mark.parametrize("ext,dtype", [(1, "f64"), (3, "f64"), (2, "f32")])
+def test_slab_host_transfers_touch_only_the_slab(wa, ext, dtype):
+    """uploads take the slab's z-range out of a GLOBAL host array (gathered through pinned chunks:
+    a memory-mapped file works as the source) and wafer_download_phi_owned returns exactly the owned
+    work planes, (nx, ny, z_count)"""
+    shape = (21, 18, 40)
+    rng = np.random.default_rng(3)
+    full = np.zeros(tuple(s + 2 * ext for s in shape))
+    full[ext:-ext, ext:-ext, ext:-ext] = rng.standard_normal(shape)
+    if dtype == "f32":
+        full = full.astype(np.float32).astype(np.float64)
+    for z0, zc in ((0, 13), (13, 17), (30, 10), (0, 0)):
+        par = wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, dtype=dtype, z_begin=z0, z_count=zc,
+                        halo_depth=2 * ext if zc else 0)
+        with wa.Context(par) as ctx:
+            ctx.upload_phi(full)
+            owned = ctx.download_phi_owned()
+            zc_ = zc if zc else shape[2]
+            assert owned.shape == (shape[0], shape[1], zc_)
+            assert np.array_equal(owned, full[ext:-ext, ext:-ext, ext + z0:ext + z0 + zc_])
+            back = ctx.download_phi()      # global-shaped: the slab's planes (ghosts included) and zeros elsewhere
+            g = 2 * ext if zc else 0
+            lo, hi = max(0, ext + z0 - g), min(full.shape[2], ext + z0 + zc_ + g)
+            assert np.array_equal(back[:, :, ext + z0:ext + z0 + zc_], full[:, :, ext + z0:ext + z0 + zc_])
+            assert not back[:, :, :lo].any() and not back[:, :, hi:].any()
+
+
 def test_torch_hooks_alias_engine_memory(wa):
     """wafer_amd.slab.TorchSlabComm's plumbing on one GPU: the tensors it builds from the
     hooks' raw device addresses (__cuda_array_interface__), the ExternalStream it issues

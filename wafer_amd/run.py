@@ -328,9 +328,8 @@ def main(argv=None) -> int:
                     f.write("state,energy,binding_energy,r,l_r\n%d,%r,%r,%r,%r\n" % (
                         wnum, fin["energy"], fin["binding_energy"], fin["r"], fin["l_r"]))
             if cfg["save_wavefns"]:      # each rank saves the planes it owns (work area, reference axis order)
-                e = ext
                 zb, zc = (0, cfg["nz"]) if world == 1 else (z_begin, z_count)
-                piece = ctx.download_phi()[e:-e, e:-e, zb + e:zb + zc + e]
+                piece = ctx.download_phi_owned()     # a host buffer the size of the slab, not of the grid
                 np.save(os.path.join(out_dir, f"wavefunction_{wnum}{'' if converged else '_partial'}_z{zb}-{zb + zc}.npy"), piece)
             if not converged:                                            # grid.rs:243-245
                 say(f"Error: MaxStep: maximum step limit reached for state {wnum}", file=sys.stderr)
