@@ -106,12 +106,16 @@ def main():
                 comm.warm_up()
                 ctx.set_overlap(overlap)
                 ctx.set_potential("SimpleCornell")
+                for j in range(args.wnum):
+                    ctx.set_initial_condition("Gaussian", seed=j + 1)
+                    ctx.normalise(ctx.norm2())
+                    ctx.push_state()
                 ctx.set_initial_condition("Boolean")
-                ctx.evolve(0, 100)
+                ctx.evolve(args.wnum, 100)
                 ctx.synchronize()
                 ts = []
                 for _ in range(5):
-                    ctx.evolve(0, args.steps)
+                    ctx.evolve(args.wnum, args.steps)
                     ms, k = ctx.last_evolve_ms()
                     ts.append(ms / k)
                 out[f"slab_rccl_self_ms_per_step_overlap_{int(overlap)}"] = sorted(ts)[2]
