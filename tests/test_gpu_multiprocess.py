@@ -161,6 +161,22 @@ def test_multi_rank_driver_reads_input_files(tmp_path):
     be = [float(re.search(r"1st excited state binding energy = ([0-9.eE+-]+)", t).group(1)) for t in (one.stdout, two.stdout)]
     assert e[1] == pytest.approx(e[0], abs=5e-9)
     assert be[0] == pytest.approx(e[0] - 2.0, abs=1e-12) and be[1] == pytest.approx(e[1] - 2.0, abs=1e-12)
+    # a ready-made framed .npy is used as it is (what one writes for grids too large for the text formats)
+    pot = np.zeros((26, 22, 30))
+    pot[1:-1, 1:-1, 1:-1] = np.loadtxt(od / "potential.csv", delimiter=",")[:, 3].reshape(24, 20, 28)
+    np.save(inp / "potential.npy", pot)
+    (inp / "potential.csv").unlink()
+    (inp / ".wafer_amd" / "potential.pad1.npy").unlink()
+    os.environ["WAFER_TRANSPORT"] = "host"
+    try:
+        again = launch(2, "-m", "wafer_amd.run", "-c", str(tmp_path / "restart.yaml"), "--output-dir", str(tmp_path / "again"),
+                       "--input-dir", str(inp))
+    finally:
+        os.environ.pop("WAFER_TRANSPORT", None)
+    assert again.returncode == 0, again.stdout[-2000:] + again.stderr[-4000:]
+    assert not (inp / ".wafer_amd" / "potential.pad1.npy").exists()
+    assert float(re.search(r"1st excited state energy = ([0-9.eE+-]+)", again.stdout).group(1)) == e[1]
+    (inp / "potential.npy").unlink()
     # a wrong-sized array is refused with a pointer to the single-GPU driver, which resamples
     (inp / "potential.csv").write_text("0,0,0,1.0\n0,0,1,1.0\n")
     os.environ["WAFER_TRANSPORT"] = "host"
