@@ -263,6 +263,34 @@ def test_extreme_potential_takes_the_full_division(wo, wa, variant):
         assert np.array_equal(got, phi, equal_nan=True)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("scale,exact", [(1e-280, True), (1.0, True), (1e150, True), (1e300, True),
+                                         (1e-295, False), (1e-303, False), (1e-306, False), (4e-320, False)])
+def test_division_by_the_invariant_denominator_over_the_exponent_range(wo, wa, variant, scale, exact):
+    """wafer_div_invariant: the hoisted-reciprocal division is the IEEE quotient, bit for bit, wherever
+    Markstein's theorem holds -- wavefunctions from 1e-280 to 1e300 -- and within one unit in the last
+    place per step below (|b dt S| < 2^-960, where the remainders become subnormal): after 4 steps
+    of a sign-alternating field the ABSOLUTE difference stays below 1e-319, a few thousand subnormal
+    quanta, down to subnormal wavefunctions.  Zero, infinite and NaN operands:
+    test_extreme_potential_takes_the_full_division."""
+    cfg, par = make_pair((37, 22, 19), ext=1, dn=0.2, dt=0.004)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=33) * scale
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(variant)
+        ctx.set_potential("Harmonic")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 4)
+        wo.evolve(cfg, 0, a, b, phi, [], 4)
+        got = ctx.download_phi()
+    assert np.isfinite(phi).all() and np.abs(phi).max() > 0
+    if exact:
+        assert ulp_diff(got, phi) == 0
+    else:
+        assert float(np.max(np.abs(got - phi))) <= 1e-319
+
+
 def test_evolve_zero_steps_takes_one(wo, wa):
     """grid.rs:682-685"""
     cfg, par = make_pair((8, 8, 8))

@@ -74,11 +74,39 @@ __device__ __forceinline__ double wafer_recip(double x, bool in_range)
 }
 __device__ __forceinline__ float wafer_recip(float x, bool) { return 1.0f / x; }
 
+// x / den for the loop-invariant denominator c*dn^2*m.  The fp64 form hoists y = RN(1/den) (the
+// compiler moves the one IEEE division out of the plane loop) and refines q = x*y with two exact
+// remainders: after the first, q is a faithful quotient; Markstein's theorem (correctly rounded
+// reciprocal + faithful quotient + exact remainder by FMA) makes the second RN(x/den) -- the bits of
+// the IEEE division, in 5 full-rate instructions instead of the 11 of the division sequence with its
+// quarter-rate v_rcp_f64.  v_div_fixup restores the IEEE results for zero / infinite / NaN operands.
+// Outside the theorem: |x| < 2^-960 (the remainder is no longer exact in the subnormal range; the
+// quotient is then within one ulp) -- wavefunction values below 1e-289.  -DWAFER_IEEE_DIV keeps the
+// division.
+template <typename T>
+__device__ __forceinline__ T wafer_div_invariant(T x, T den)
+{
+    return x / den;
+}
+#ifndef WAFER_IEEE_DIV
+template <>
+__device__ __forceinline__ double wafer_div_invariant<double>(double x, double den)
+{
+    const double y = 1.0 / den;
+    double q = x * y;
+    double r = __builtin_fma(-q, den, x);
+    q = __builtin_fma(r, y, q);
+    r = __builtin_fma(-q, den, x);
+    q = __builtin_fma(r, y, q);
+    return __builtin_amdgcn_div_fixup(q, den, x);
+}
+#endif
+
 // grid.rs:580-589: *work = w*pa + pb*dt*S/denominator
 template <typename T>
 __device__ __forceinline__ T wafer_update(T w, T pa, T pb, T dt, T S, T den)
 {
-    return w * pa + pb * dt * S / den;
+    return w * pa + wafer_div_invariant<T>(pb * dt * S, den);
 }
 
 #define WAFER_MAX_LOW 4 // stored states whose overlaps ride along with the excited-state step
