@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void wafer_k_normalise_dot(WaferEwArgs a, T *_
     if (active)
         for (int z = zs; z < ze; ++z) {
             const long long p = col + (long long)z * g.plane;
-            const T r = (T)((C)phi[p] / norm);
+            const T r = (T)wafer_div_invariant<C>((C)phi[p], norm);
             phi[p] = r;
             if (lower) acc += (double)((C)lower[p] * (C)r);
         }
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void wafer_k_gs_apply(WaferRowArgs a, T *__res
         VT r;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            C x = (C)w[v] / norm;                 // grid.rs:467
+            C x = wafer_div_invariant<C>((C)w[v], norm); // grid.rs:467
 #pragma unroll
             for (int j = 0; j < NLOW; ++j) x = x - (C)l[j][v] * sj[j]; // grid.rs:488-490
             r[v] = (T)x;

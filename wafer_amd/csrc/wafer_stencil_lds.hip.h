@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
             for (int j = 0; j < NL; ++j) l[j] = *reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + off);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                C x = (C)w[v] / xnorm;
+                C x = wafer_div_invariant<C>((C)w[v], xnorm);
 #pragma unroll
                 for (int j = 0; j < NL; ++j) x = x - (C)l[j][v] * xsj[j];
                 w[v] = (T)x;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
     auto load_cell = [&](long long off) -> T {
         T w = phi[off];
         if constexpr (XF) {
-            C x = (C)w / xnorm;
+            C x = wafer_div_invariant<C>((C)w, xnorm);
 #pragma unroll
             for (int j = 0; j < NL; ++j) x = x - (C)static_cast<const T *>(low.p[j])[off] * xsj[j];
             w = (T)x;
