@@ -88,7 +88,10 @@ def build_rccl_lib(force: bool = False, verbose: bool = False) -> str:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
-        cmd = [hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+        # WAFER_IEEE_DIV=1 at build time keeps hipcc's IEEE division sequence for the divisions by
+        # loop-invariant denominators (wafer_div_invariant, wafer_stencil.hip.h) -- for A/B runs
+        extra = ["-DWAFER_IEEE_DIV"] if os.environ.get("WAFER_IEEE_DIV", "") not in ("", "0") else []
+        cmd = [hipcc(), *FLAGS, *extra, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
