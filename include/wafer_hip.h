@@ -241,6 +241,14 @@ int wafer_set_stencil_variant(wafer_ctx *ctx, int variant);
  * measured HBM ceiling next to which the stencil's rate is reported. */
 int wafer_diag_stream_bw(wafer_ctx *ctx, int n_reads, int iters, double *gbps);
 
+/* Diagnostic: the divisions by loop-invariant denominators (c*dn^2*m in the stencil update, the norm in
+ * the excited-state transform) use a hoisted reciprocal with two exact remainders instead of the IEEE
+ * sequence (wafer_div_invariant, wafer_stencil.hip.h).  Draws n_operands (rounded up to 2^18) doubles
+ * with uniform sign / significand and biased exponent uniform in [lo_exp, hi_exp] and counts those
+ * whose quotient by `den` differs in any bit from the device's IEEE x / den. */
+int wafer_diag_div_check(wafer_ctx *ctx, double den, uint64_t seed, uint64_t n_operands, int lo_exp, int hi_exp,
+                         uint64_t *mismatches);
+
 /* ---- multi-GPU: communication hooks --------------------------------------- */
 /* The engine never links a communication library.  A host that z-slabs the
  * grid over several contexts installs two hooks (RCCL via torch.distributed in

@@ -291,6 +291,19 @@ def test_division_by_the_invariant_denominator_over_the_exponent_range(wo, wa, v
         assert float(np.max(np.abs(got - phi))) <= 1e-319
 
 
+def test_hoisted_division_equals_the_ieee_division_on_2e10_operands(wa):
+    """wafer_div_invariant against the device's own IEEE x / den, bit for bit: 2^31 random operands
+    (uniform significand and sign, exponents 2^-959 ... 2^+960) for each of ten denominators -- the
+    c dn^2 m of the configurations in use, norms, and awkward significands (all ones, 1 + ulp)."""
+    dens = [2 * 0.05 ** 2 * 1.0, 2 * 0.02 ** 2 * 2.35, 24 * 0.2 ** 2 * 1.3, 360 * 0.01 ** 2 * 0.7, 1.0,
+            float(np.nextafter(2.0, 0.0)), float(np.nextafter(1.0, 2.0)), 3.0, 0.9999999999999432, 1.7320508075688772e-3]
+    with wa.Context(wa.Params(8, 8, 8, dn=0.2, dt=0.004)) as ctx:
+        for i, den in enumerate(dens):
+            assert ctx.div_check(den, 1 << 31, lo_exp=64, hi_exp=1983, seed=100 + i) == 0, den
+        # the counter is live: below the theorem's range some quotients differ (by one ulp)
+        assert ctx.div_check(dens[0], 1 << 24, lo_exp=1, hi_exp=40, seed=7) > 0
+
+
 def test_evolve_zero_steps_takes_one(wo, wa):
     """grid.rs:682-685"""
     cfg, par = make_pair((8, 8, 8))

@@ -244,3 +244,27 @@ __global__ __launch_bounds__(256) void wafer_k_stream(const wafer_f4 *__restrict
         w[i] = v;
     }
 }
+
+// ---- diagnostic: wafer_div_invariant against the IEEE division ------------------------------------
+// Every thread draws `per_thread` operands x from a counter-based generator (splitmix64 of the global
+// operand index and the seed): uniform significand and sign, biased exponent uniform in [lo_exp, hi_exp].
+// Counts the operands for which wafer_div_invariant(x, den) and x / den differ in any bit.
+__global__ __launch_bounds__(256) void wafer_k_div_check(double den, unsigned long long seed, int per_thread, int lo_exp,
+                                                         int hi_exp, unsigned long long *__restrict__ mismatches)
+{
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad = 0;
+    for (int i = 0; i < per_thread; ++i) {
+        unsigned long long z = seed + (tid * (unsigned long long)per_thread + (unsigned long long)i) * 0x9e3779b97f4a7c15ull;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        const unsigned long long e = (unsigned long long)lo_exp + (z >> 53) % (unsigned long long)(hi_exp - lo_exp + 1);
+        const unsigned long long bits = (z & 0x800fffffffffffffull) | (e << 52);
+        const double x = __longlong_as_double((long long)bits);
+        const double q_fast = wafer_div_invariant<double>(x, den);
+        const double q_ieee = x / den;
+        bad += (unsigned long long)(__double_as_longlong(q_fast) != __double_as_longlong(q_ieee));
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}

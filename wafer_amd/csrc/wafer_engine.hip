@@ -1516,6 +1516,32 @@ int wafer_diag_stream_bw(wafer_ctx *c, int n_reads, int iters, double *gbps)
     return WAFER_OK;
 }
 
+int wafer_diag_div_check(wafer_ctx *c, double den, uint64_t seed, uint64_t n_operands, int lo_exp, int hi_exp,
+                         uint64_t *mismatches)
+{
+    if (!c || !mismatches) return fail(WAFER_ERR_INVALID, "null argument");
+    if (lo_exp < 0 || hi_exp > 2046 || lo_exp > hi_exp) return fail(WAFER_ERR_INVALID, "biased exponents in 0..2046");
+    HIP_TRY(hipSetDevice(c->P.device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof *d));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof *d, c->s_main);
+    const int per_thread = 1024, threads = 256;
+    const uint64_t blocks = (n_operands + (uint64_t)per_thread * threads - 1) / ((uint64_t)per_thread * threads);
+    if (e == hipSuccess && blocks > 0) {
+        hipLaunchKernelGGL(wafer_k_div_check, dim3((unsigned)std::min<uint64_t>(blocks, 1u << 30)), dim3(threads), 0, c->s_main, den,
+                           (unsigned long long)seed, per_thread, lo_exp, hi_exp, d);
+        e = hipGetLastError();
+    }
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, c->s_main);
+    hipError_t e2 = hipStreamSynchronize(c->s_main);
+    (void)hipFree(d);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(WAFER_ERR_HIP, "division check failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    *mismatches = h;
+    return WAFER_OK;
+}
+
 // ---- multi-GPU plumbing -----------------------------------------------------------------
 int wafer_set_comm_hooks(wafer_ctx *c, wafer_halo_fn halo, wafer_allreduce_fn allreduce, void *user)
 {

@@ -38,7 +38,7 @@ EXPORTS = [
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_diag_stream_bw", "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
-    "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned",
+    "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check",
 ]
 
 
@@ -130,6 +130,7 @@ def load_library():
     L.wafer_set_potsub_resampled.argtypes = [vp, dp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.wafer_symmetrise.argtypes = [vp, C.c_int]
     L.wafer_download_phi_owned.argtypes = [vp, dp]
+    L.wafer_diag_div_check.argtypes = [vp, C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.wafer_set_initial_condition.argtypes = [vp, C.c_int, C.c_uint64]
     L.wafer_upload_phi.argtypes = [vp, dp]
     L.wafer_download_phi.argtypes = [vp, dp]
@@ -293,6 +294,13 @@ class Context:
     def symmetrise(self, constraint: str) -> None:
         """config::symmetrise_wavefunction (config.rs:691-728); SevenPoint only, like the reference"""
         self._check(self._L.wafer_symmetrise(self._h, SYMMETRY.index(constraint)))
+
+    def div_check(self, den: float, n_operands: int, lo_exp: int = 64, hi_exp: int = 1983, seed: int = 1) -> int:
+        """operands (of n_operands random ones) whose hoisted-reciprocal quotient by `den` differs from the
+        IEEE division in any bit (wafer_diag_div_check)"""
+        bad = C.c_uint64(0)
+        self._check(self._L.wafer_diag_div_check(self._h, den, seed, n_operands, lo_exp, hi_exp, C.byref(bad)))
+        return int(bad.value)
 
     def download_phi_owned(self) -> np.ndarray:
         """the work cells of the planes this context owns, (nx, ny, z_count)"""
