@@ -572,6 +572,18 @@ static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum,
     });
 }
 
+// Where the boundary kernels of a split pass run.  Default: on the MAIN stream, in order before the
+// interior launch -- only the exchange hops to the second stream (it waits for ev_bdry, the next pass
+// waits for ev_join).  The interior, which is the critical path, then follows the boundary kernels
+// without a cross-stream event hop: 0.363 -> 0.355 ms/step at the bench slab with a loopback hook,
+// 0.371 -> 0.359 under the native RCCL hooks.  WAFER_BDRY_MAIN=0: boundary kernels on the second
+// stream too and the interior released by ev_bdry (the previous scheme).
+static bool bdry_on_main()
+{
+    static const bool v = [] { const char *e = getenv("WAFER_BDRY_MAIN"); return !(e && *e) || atoi(e) != 0; }();
+    return v;
+}
+
 // the whole slab in one launch, then the 1 + wnum sums (all-reduced when sharded)
 static int excited_step_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bool transform_on_load, hipStream_t s)
 {
@@ -587,14 +599,18 @@ static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32
     const WaferGeom &g = c->g;
     const int R = g.R, lo = g.G, hi = g.G + g.nzl;
     long long nb_lo = 0, nb_hi = 0, nb_in = 0;
-    HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
-    HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
-    if (c->has_lo()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, lo, lo + R, 0, c->s_aux, &nb_lo));
-    if (c->has_hi()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, hi - R, hi, nb_lo, c->s_aux, &nb_hi));
-    HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux));
+    const hipStream_t sb = bdry_on_main() ? c->s_main : c->s_aux;
+    if (sb == c->s_aux) {
+        HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
+        HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
+    }
+    if (c->has_lo()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, lo, lo + R, 0, sb, &nb_lo));
+    if (c->has_hi()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, hi - R, hi, nb_lo, sb, &nb_hi));
+    HIP_TRY(hipEventRecord(c->ev_bdry, sb));
+    if (sb == c->s_main) HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_bdry, 0));
     TRY(exchange_halo(c, dst, c->s_aux, R));        // enqueued before the interior: its kernels reach the CUs first
     HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
-    HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
+    if (sb == c->s_aux) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
     // (one long workgroup per tile here: shorter ones -- the fused ground-state split's answer to CUs
     //  held by the exchange -- cost this kernel more in pipeline refills than the tail they avoid:
     //  k = 1 0.98 vs 1.01 ms, k = 3 1.57 vs 1.53 under an 8-channel RCCL kernel)
@@ -1151,21 +1167,26 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             TRY(ensure_halo(c, 2 * R));
             const bool split = c->sharded() && c->overlap && g.nzl > 4 * R;
             if (split) {
-                // Second stream: boundary planes, then their exchange.  Main stream: the interior, released
-                // by an event recorded after the boundary kernels.  The exchange is enqueued BEFORE the
-                // interior launch and needs no event hop, so its kernels reach the CUs first; the interior
-                // then fills what is left.  (Without the dependency the interior started first, filled
-                // every CU for a whole round, and the boundary kernels -- and the exchange behind them --
-                // finished only with the pass; with the exchange merely enqueued second, RCCL's
-                // workgroups waited 0.35 ms for CUs: profiles/r01_slab_overlap_timeline.txt.)
-                HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
-                HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
-                if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + 2 * R, c->s_aux));
-                if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - 2 * R, hi, c->s_aux));
-                HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux));
+                // Boundary planes first (bdry_on_main(): in order on the main stream), their exchange on the
+                // second stream behind ev_bdry, then the interior.  The interior must not start before the
+                // boundary kernels have run, and the exchange is enqueued BEFORE the interior launch so
+                // that its kernels reach the CUs first; the interior then fills what is left.  (When the
+                // boundary kernels ran unordered beside the interior, the interior filled every CU for a
+                // whole round and they -- and the exchange behind them -- finished only with the pass; with
+                // the exchange merely enqueued second, RCCL's workgroups waited 0.35 ms for CUs:
+                // profiles/r01_slab_overlap_timeline.txt.)
+                const hipStream_t sb = bdry_on_main() ? c->s_main : c->s_aux;
+                if (sb == c->s_aux) {
+                    HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
+                    HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
+                }
+                if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + 2 * R, sb));
+                if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - 2 * R, hi, sb));
+                HIP_TRY(hipEventRecord(c->ev_bdry, sb));
+                if (sb == c->s_main) HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_bdry, 0));
                 TRY(exchange_halo(c, dst, c->s_aux, 2 * R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
-                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
+                if (sb == c->s_aux) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
                 // The exchange's kernels hold a few CUs for as long as the links need (RCCL's workgroups
                 // cannot share a CU with a stencil workgroup).  With one long workgroup per tile every
                 // displaced workgroup would add a whole extra round at the end of the pass (measured with
@@ -1189,14 +1210,18 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             const bool split = c->sharded() && c->overlap && g.nzl > 2 * R;
             if (split) {
                 // boundary planes and their exchange on the second stream, the interior behind an event (as above)
-                HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
-                HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
-                if (c->has_lo()) TRY(launch_step(c, src, dst, lo, lo + R, false, c->s_aux));
-                if (c->has_hi()) TRY(launch_step(c, src, dst, hi - R, hi, false, c->s_aux));
-                HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux));
+                const hipStream_t sb = bdry_on_main() ? c->s_main : c->s_aux;
+                if (sb == c->s_aux) {
+                    HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
+                    HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
+                }
+                if (c->has_lo()) TRY(launch_step(c, src, dst, lo, lo + R, false, sb));
+                if (c->has_hi()) TRY(launch_step(c, src, dst, hi - R, hi, false, sb));
+                HIP_TRY(hipEventRecord(c->ev_bdry, sb));
+                if (sb == c->s_main) HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_bdry, 0));
                 TRY(exchange_halo(c, dst, c->s_aux, R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
-                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
+                if (sb == c->s_aux) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
                 TRY(launch_step(c, src, dst, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi, false, c->s_main));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
             } else {
