@@ -572,15 +572,19 @@ static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum,
     });
 }
 
-// Where the boundary kernels of a split pass run.  Default: on the MAIN stream, in order before the
-// interior launch -- only the exchange hops to the second stream (it waits for ev_bdry, the next pass
-// waits for ev_join).  The interior, which is the critical path, then follows the boundary kernels
-// without a cross-stream event hop: 0.363 -> 0.355 ms/step at the bench slab with a loopback hook,
-// 0.371 -> 0.359 under the native RCCL hooks.  WAFER_BDRY_MAIN=0: boundary kernels on the second
-// stream too and the interior released by ev_bdry (the previous scheme).
+// Where the boundary kernels of a split pass run.  Default: on the SECOND stream, with the exchange
+// directly behind them in stream order and the interior released by ev_bdry -- the interior pays the
+// cross-stream event hop (a few microseconds), and that is the point: the exchange's kernels reach the
+// CUs before the interior launch fills them.  WAFER_BDRY_MAIN=1 runs the boundary kernels in order on
+// the main stream and lets only the exchange hop: the interior then wins the race for the CUs by ~6 us,
+// RCCL's workgroups (which cannot share a CU with a stencil workgroup) wait until the first long
+// workgroups retire, and the exchange gets the second half of the pass only (kernel trace: RCCL kernel
+// 0.60 ms long instead of 0.33, ending 60 us before the pass).  With a device-to-device loopback that
+// still hides and the saved hop shows as 0.371 -> 0.359 ms/step; on a real link, where the transfer
+// needs most of the pass, it would be exposed.  Kept as a switch for measurements on real fabric.
 static bool bdry_on_main()
 {
-    static const bool v = [] { const char *e = getenv("WAFER_BDRY_MAIN"); return !(e && *e) || atoi(e) != 0; }();
+    static const bool v = [] { const char *e = getenv("WAFER_BDRY_MAIN"); return e && *e && atoi(e) != 0; }();
     return v;
 }
 
@@ -1167,14 +1171,14 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             TRY(ensure_halo(c, 2 * R));
             const bool split = c->sharded() && c->overlap && g.nzl > 4 * R;
             if (split) {
-                // Boundary planes first (bdry_on_main(): in order on the main stream), their exchange on the
-                // second stream behind ev_bdry, then the interior.  The interior must not start before the
-                // boundary kernels have run, and the exchange is enqueued BEFORE the interior launch so
-                // that its kernels reach the CUs first; the interior then fills what is left.  (When the
-                // boundary kernels ran unordered beside the interior, the interior filled every CU for a
-                // whole round and they -- and the exchange behind them -- finished only with the pass; with
-                // the exchange merely enqueued second, RCCL's workgroups waited 0.35 ms for CUs:
-                // profiles/r01_slab_overlap_timeline.txt.)
+                // Second stream: boundary planes, then their exchange.  Main stream: the interior, released
+                // by an event recorded after the boundary kernels.  The exchange is enqueued BEFORE the
+                // interior launch and needs no event hop, so its kernels reach the CUs first; the interior
+                // then fills what is left.  (Without the dependency the interior started first, filled
+                // every CU for a whole round, and the boundary kernels -- and the exchange behind them --
+                // finished only with the pass; with the exchange merely enqueued second, RCCL's
+                // workgroups waited 0.35 ms for CUs: profiles/r01_slab_overlap_timeline.txt.  See
+                // bdry_on_main() for the in-stream variant.)
                 const hipStream_t sb = bdry_on_main() ? c->s_main : c->s_aux;
                 if (sb == c->s_aux) {
                     HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
