@@ -165,3 +165,44 @@ def test_reference_output_potential_sub_cases(cli, tmp_path):
         out = convert(cli, tmp_path / "z.csv", tmp_path / f"zeros.{ext}")
         back = np.loadtxt(convert(cli, out, tmp_path / f"zeros_back_{ext}.csv"), delimiter=",")
         assert back.shape == (8, 4) and not back[:, 3].any()
+
+
+def test_multi_rank_driver_stages_input_arrays(tmp_path):
+    """wafer_amd.run.staged_array: rank 0 converts ./input/<stem>.* once into a framed .npy (wafer-hip
+    --convert ... --pad E, no GPU involved), every rank memory-maps it; the cache follows the source's
+    modification time; the configured file type arbitrates between several files (input.rs:75-110)"""
+    import json
+    import time
+    from wafer_amd import run
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((5, 4, 6))
+    inp = tmp_path / "input"
+    inp.mkdir()
+    (inp / "potential.json").write_text(json.dumps({"v": 1, "dim": list(a.shape), "data": a.ravel().tolist()}))
+    assert run.staged_array(str(inp), "wavefunction_0", "Csv", 1, 0) is None
+    m = run.staged_array(str(inp), "potential", "Csv", 2, 0)
+    assert m.shape == (9, 8, 10) and np.array_equal(m[2:-2, 2:-2, 2:-2], a) and np.abs(m).sum() == np.abs(a).sum()
+    cache = inp / ".wafer_amd" / "potential.pad2.npy"
+    stamp = cache.stat().st_mtime_ns
+    again = run.staged_array(str(inp), "potential", "Csv", 2, 1, wait_s=5)     # another rank: waits, never converts
+    assert np.array_equal(again, m) and cache.stat().st_mtime_ns == stamp
+    # a second file: the configured type decides, and a newer source invalidates the cache
+    b = a + 1.0
+    time.sleep(0.05)
+    with open(inp / "potential.csv", "w") as f:
+        for i in range(5):
+            for j in range(4):
+                for k in range(6):
+                    f.write(f"{i},{j},{k},{float(b[i, j, k])!r}\n")
+    assert run.find_input(str(inp), "potential", "Csv").endswith("potential.csv")
+    assert run.find_input(str(inp), "potential", "Json").endswith("potential.json")
+    assert run.find_input(str(inp), "potential", "Yaml").endswith("potential.csv")     # neither is yaml: the first in mpk, csv, json, ... order
+    m2 = run.staged_array(str(inp), "potential", "Csv", 2, 0)
+    assert np.array_equal(m2[2:-2, 2:-2, 2:-2], b)
+    # a single value (potential_sub) becomes a 0-d array
+    (inp / "potential_sub.yaml").write_text("---\npot_sub: 2.5\n")
+    s = run.staged_array(str(inp), "potential_sub", "Csv", 0, 0)
+    assert s.ndim == 0 and float(s) == 2.5
+    # a ready-made .npy is used as it is
+    np.save(inp / "wavefunction_3.npy", np.ones((3, 3, 3)))
+    assert run.staged_array(str(inp), "wavefunction_3", "Csv", 1, 0).shape == (3, 3, 3)
