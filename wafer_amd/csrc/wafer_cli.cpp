@@ -658,6 +658,8 @@ int main(int argc, char **argv)
         }
         if (wnum == 0) CHECK(wafer_symmetrise(ctx, symmetry)); // config::set_initial_conditions, config.rs:625
         print_observable_header(wnum);
+        struct timespec ts_state;
+        clock_gettime(CLOCK_MONOTONIC, &ts_state);
         // solve, grid.rs:122-246 (the loop itself: wafer_solve_state == grid.rs:126-221)
         std::vector<wafer_block_record> recs(progress ? 1u << 20 : 4);
         // run block by block so rows can be shown as they are produced
@@ -717,6 +719,13 @@ int main(int argc, char **argv)
             step += cfg.screen_update;
         }
         if (snapshot_writer.joinable()) snapshot_writer.join();
+        { // per-state accounting on stderr (the reference prints the total only)
+            struct timespec ts_now;
+            clock_gettime(CLOCK_MONOTONIC, &ts_now);
+            const double st = (ts_now.tv_sec - ts_state.tv_sec) + 1e-9 * (ts_now.tv_nsec - ts_state.tv_nsec);
+            fprintf(stderr, "state %u: %llu steps in %.3f s (%.4f ms per step, evolve + observables + normalise)\n", wnum,
+                    (unsigned long long)step, st, step ? 1e3 * st / (double)step : 0.0);
+        }
         wafer_observables_output fin;
         const double r_norm = std::sqrt(obs.r2 / obs.norm2);
         fin.state = wnum;
