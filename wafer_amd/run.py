@@ -189,8 +189,10 @@ def main(argv=None) -> int:
     if not torch.cuda.is_available():
         raise SystemExit("wafer_amd.run needs a GPU: the engine has no CPU path")
     host_transport = os.environ.get("WAFER_TRANSPORT", "rccl") == "host"
-    if host_transport:
-        local_rank %= torch.cuda.device_count()
+    # a launcher that narrows each rank's view to its own GPU (ROCR_/HIP_VISIBLE_DEVICES per rank) leaves
+    # one visible device with index 0; the host-staged test transport folds ranks onto the GPUs present
+    if host_transport or local_rank >= torch.cuda.device_count():
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
