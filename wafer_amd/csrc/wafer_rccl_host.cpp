@@ -114,7 +114,9 @@ int main(int argc, char **argv)
     const uint64_t steps = (uint64_t)atoll(argv[a0 + 3]);
     const int potential = argc > a0 + 4 ? atoi(argv[a0 + 4]) : (int)WAFER_POT_SIMPLECORNELL;
     const int rank = self ? 0 : env_int("RANK", 0), world = self ? 1 : env_int("WORLD_SIZE", 1);
-    const int device = env_int("LOCAL_RANK", rank);
+    int device = env_int("LOCAL_RANK", rank), visible = 0;
+    HIPCHECK(hipGetDeviceCount(&visible));
+    if (visible > 0 && device >= visible) device %= visible; // a launcher that shows each rank only its own GPU
     HIPCHECK(hipSetDevice(device));
 
     // ---- communicator: rank 0 publishes the unique id through a file ------------------------------
