@@ -37,7 +37,7 @@ def test_bench_multi_rank_path():
     env_extra = {"WAFER_BENCH_TRANSPORT": "host"}
     os.environ.update(env_extra)
     try:
-        r = launch(2, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+        r = launch(2, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
                    "--grid", "256,256,128")
     finally:
         for k in env_extra:
@@ -46,7 +46,9 @@ def test_bench_multi_rank_path():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    ho = d["config"]["halo_overlap"]      # both exchange schedules were tried during set-up, one was chosen for all ranks
+    assert isinstance(ho["overlap"], bool) and ho["ms_per_step_overlap"] > 0 and ho["ms_per_step_no_overlap"] > 0
     assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 64
     assert d["roofline"]["steps_per_launch"] == 2 and "cpu_baseline" not in d
 
