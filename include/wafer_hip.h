@@ -264,7 +264,11 @@ typedef int (*wafer_halo_fn)(void *user, void *send_lo, void *send_hi, void *rec
                              size_t bytes, void *hip_stream);
 typedef int (*wafer_allreduce_fn)(void *user, void *dev_ptr, size_t count, void *hip_stream);
 int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn allreduce, void *user);
-/* overlap the halo exchange with interior updates on a second stream (default 1) */
+/* z-slabs, how the halo exchange is scheduled: 1 (default) = boundary planes first, then their exchange,
+ * both on a second stream, beside the interior update; 0 = the exchange after the whole slab's update;
+ * 2 = like 1 with the boundary kernels in order on the main stream and only the exchange on the second
+ * (saves a cross-stream hop, but the exchange's kernels then reach the CUs after the interior's: only for
+ * links fast enough to need less than half a pass).  All three give identical results. */
 int wafer_set_overlap(wafer_ctx *ctx, int enabled);
 /* run every kernel on a caller-owned hipStream_t (NULL = the context's own) */
 int wafer_set_stream(wafer_ctx *ctx, void *hip_stream);

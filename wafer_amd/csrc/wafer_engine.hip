@@ -122,6 +122,7 @@ struct wafer_ctx {
     wafer_allreduce_fn allreduce_hook = nullptr;
     void *hook_user = nullptr;
     bool overlap = true;
+    bool bdry_main = false; // split passes: boundary kernels in order on the main stream (see bdry_on_main)
     int halo_valid = 0; // ghost planes of phi[cur] (counted from the owned region) known to be current
 
     uint64_t last_steps = 0;
@@ -581,12 +582,9 @@ static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum,
 // workgroups retire, and the exchange gets the second half of the pass only (kernel trace: RCCL kernel
 // 0.60 ms long instead of 0.33, ending 60 us before the pass).  With a device-to-device loopback that
 // still hides and the saved hop shows as 0.371 -> 0.359 ms/step; on a real link, where the transfer
-// needs most of the pass, it would be exposed.  Kept as a switch for measurements on real fabric.
-static bool bdry_on_main()
-{
-    static const bool v = [] { const char *e = getenv("WAFER_BDRY_MAIN"); return e && *e && atoi(e) != 0; }();
-    return v;
-}
+// needs most of the pass, it would be exposed.  Kept as a mode (wafer_set_overlap(ctx, 2)) that a host
+// can time against the default on real fabric, as bench.py does during set-up.
+static bool bdry_on_main(const wafer_ctx *c) { return c->bdry_main; }
 
 // the whole slab in one launch, then the 1 + wnum sums (all-reduced when sharded)
 static int excited_step_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bool transform_on_load, hipStream_t s)
@@ -603,7 +601,7 @@ static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32
     const WaferGeom &g = c->g;
     const int R = g.R, lo = g.G, hi = g.G + g.nzl;
     long long nb_lo = 0, nb_hi = 0, nb_in = 0;
-    const hipStream_t sb = bdry_on_main() ? c->s_main : c->s_aux;
+    const hipStream_t sb = bdry_on_main(c) ? c->s_main : c->s_aux;
     if (sb == c->s_aux) {
         HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
         HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
@@ -696,6 +694,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->bx = (c->g.px + 63) / 64; // covers both the work area and the padded extent
     c->by = (c->g.py + 3) / 4;
     c->overlap = env_int("WAFER_OVERLAP", 1) != 0;
+    c->bdry_main = env_int("WAFER_BDRY_MAIN", 0) != 0;
 
     auto cleanup_fail = [&](int rc) {
         wafer_ctx_destroy(c);
@@ -1178,8 +1177,8 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 // every CU for a whole round, and the boundary kernels -- and the exchange behind them --
                 // finished only with the pass; with the exchange merely enqueued second, RCCL's
                 // workgroups waited 0.35 ms for CUs: profiles/r01_slab_overlap_timeline.txt.  See
-                // bdry_on_main() for the in-stream variant.)
-                const hipStream_t sb = bdry_on_main() ? c->s_main : c->s_aux;
+                // bdry_on_main for the in-stream variant.)
+                const hipStream_t sb = bdry_on_main(c) ? c->s_main : c->s_aux;
                 if (sb == c->s_aux) {
                     HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
                     HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
@@ -1214,7 +1213,7 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             const bool split = c->sharded() && c->overlap && g.nzl > 2 * R;
             if (split) {
                 // boundary planes and their exchange on the second stream, the interior behind an event (as above)
-                const hipStream_t sb = bdry_on_main() ? c->s_main : c->s_aux;
+                const hipStream_t sb = bdry_on_main(c) ? c->s_main : c->s_aux;
                 if (sb == c->s_aux) {
                     HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
                     HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
@@ -1584,7 +1583,9 @@ int wafer_set_comm_hooks(wafer_ctx *c, wafer_halo_fn halo, wafer_allreduce_fn al
 int wafer_set_overlap(wafer_ctx *c, int enabled)
 {
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (enabled < 0 || enabled > 2) return fail(WAFER_ERR_INVALID, "overlap mode 0, 1 or 2");
     c->overlap = enabled != 0;
+    c->bdry_main = enabled == 2;
     return WAFER_OK;
 }
 

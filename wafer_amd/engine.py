@@ -444,8 +444,9 @@ class Context:
         self._hooks = (HALO_FN(_halo), ALLREDUCE_FN(_allreduce))  # keep alive
         self._check(self._L.wafer_set_comm_hooks(self._h, self._hooks[0], self._hooks[1], None))
 
-    def set_overlap(self, enabled: bool) -> None:
-        self._check(self._L.wafer_set_overlap(self._h, 1 if enabled else 0))
+    def set_overlap(self, enabled) -> None:
+        """halo schedule of a z-slab: False / 0, True / 1 (default), or 2 (include/wafer_hip.h)"""
+        self._check(self._L.wafer_set_overlap(self._h, int(enabled)))
 
     def set_stream(self, stream_ptr: int | None) -> None:
         self._check(self._L.wafer_set_stream(self._h, stream_ptr))
