@@ -208,14 +208,15 @@ def main():
 
     ctx.set_initial_condition("Boolean")   # the streaming kernel used phi's second buffer as scratch
     # N > 1: the halo exchange hides behind the interior update (mode 1: boundary planes and exchange on
-    # a second stream; mode 2: boundary planes in-stream, only the exchange on the second stream) or
+    # a second stream; mode 2: boundary planes in-stream, only the exchange on the second stream; mode 3:
+    # as 1 with the streams swapping roles every pass) or
     # follows the whole slab's update (mode 0).  Which is fastest depends on the fabric, which this code
-    # has never seen: all three are timed over a few untimed set-up steps and every rank takes the mode
+    # has never seen: all four are timed over a few untimed set-up steps and every rank takes the mode
     # that is fastest for the slowest rank (the default, 1, unless another wins by more than 2 %).
     overlap_choice = None
     if dist is not None and os.environ.get("WAFER_OVERLAP", "") == "" and args.steps >= 8:
         trial = {}
-        for mode in (1, 2, 0):
+        for mode in (1, 2, 3, 0):
             ctx.set_overlap(mode)
             ctx.evolve(0, 8)
             barrier()
@@ -229,7 +230,7 @@ def main():
         best = min(trial, key=lambda m: trial[m] * (1.0 if m == 1 else 1.02))
         ctx.set_overlap(best)
         overlap_choice = {"mode": best, "ms_per_step": {"1_overlap": trial[1], "2_overlap_boundary_in_stream": trial[2],
-                                                        "0_no_overlap": trial[0]}}
+                                                        "3_overlap_alternating_streams": trial[3], "0_no_overlap": trial[0]}}
         ctx.set_initial_condition("Boolean")
     if args.warmup > 0:
         ctx.evolve(0, args.warmup)

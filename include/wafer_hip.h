@@ -268,7 +268,9 @@ int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn 
  * both on a second stream, beside the interior update; 0 = the exchange after the whole slab's update;
  * 2 = like 1 with the boundary kernels in order on the main stream and only the exchange on the second
  * (saves a cross-stream hop, but the exchange's kernels then reach the CUs after the interior's: only for
- * links fast enough to need less than half a pass).  All three give identical results. */
+ * links fast enough to need less than half a pass); 3 = like 1 with the two streams swapping roles every
+ * fused pass (the next pass's boundary kernels follow the interior in stream order: one event hop less per
+ * pass; ground-state fused passes only, otherwise as 1).  All modes give identical results. */
 int wafer_set_overlap(wafer_ctx *ctx, int enabled);
 /* run every kernel on a caller-owned hipStream_t (NULL = the context's own) */
 int wafer_set_stream(wafer_ctx *ctx, void *hip_stream);

@@ -116,7 +116,7 @@ def wa():
     return wafer_amd
 
 
-@pytest.mark.parametrize("overlap", [True, False, 2])   # 2: boundary kernels in-stream (wafer_set_overlap)
+@pytest.mark.parametrize("overlap", [True, False, 2, 3])   # 2: boundary kernels in-stream, 3: alternating stream roles (wafer_set_overlap)
 @pytest.mark.parametrize("world,shape,ext", [(2, (40, 24, 32), 1), (3, (33, 17, 31), 2), (2, (20, 20, 12), 3),
                                             (4, (130, 12, 40), 1)])
 def test_ground_state_slabs_bit_exact(wa, world, shape, ext, overlap):
@@ -146,7 +146,7 @@ def test_ground_state_slabs_bit_exact(wa, world, shape, ext, overlap):
     assert all(n == steps for n in fabric.halo_calls)   # one exchange per step, none extra
 
 
-@pytest.mark.parametrize("overlap", [True, False, 2])   # 2: boundary kernels in-stream (wafer_set_overlap)
+@pytest.mark.parametrize("overlap", [True, False, 2, 3])   # 2: boundary kernels in-stream, 3: alternating stream roles (wafer_set_overlap)
 @pytest.mark.parametrize("world,shape,ext,steps", [(2, (40, 24, 32), 1, 12), (3, (33, 17, 31), 2, 7), (4, (130, 12, 40), 1, 9),
                                                   (2, (300, 70, 96), 1, 6), (2, (130, 40, 100), 2, 5)])   # thick slabs: the mixed long / short interior launch
 def test_fused_kernel_on_slabs_bit_exact(wa, world, shape, ext, steps, overlap):
@@ -231,7 +231,7 @@ def test_excited_state_and_solve_on_slabs(wa):
     assert np.allclose(ground, want_states[0], rtol=0, atol=1e-8)
 
 
-@pytest.mark.parametrize("overlap", [True, False, 2])   # 2: boundary kernels in-stream (wafer_set_overlap)
+@pytest.mark.parametrize("overlap", [True, False, 2, 3])   # 2: boundary kernels in-stream, 3: alternating stream roles (wafer_set_overlap)
 @pytest.mark.parametrize("world,shape,ext,wnum", [(2, (40, 24, 32), 1, 1), (3, (33, 17, 30), 2, 2), (4, (130, 20, 40), 1, 3)])
 def test_excited_state_steps_on_slabs(wa, world, shape, ext, wnum, overlap):
     """excited-state evolve (renormalise + Gram-Schmidt every step) on z-slabs against one context:

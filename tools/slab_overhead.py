@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--cd", type=int, default=1)
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--wnum", type=int, default=0, help="excited-state steps against this many stored states")
+    ap.add_argument("--modes", default="1,0", help="halo schedules to time (wafer_set_overlap modes)")
     ap.add_argument("--rccl", action="store_true",
                     help="also serve the hook with RCCL send/recv to this same rank (wafer_amd.slab.TorchSlabComm, "
                          "world of one): adds the host cost of the Python hook + batch_isend_irecv per pass")
@@ -83,7 +84,7 @@ def main():
         return 0
 
     mid = wafer_amd.Params(n, n, pl * args.world, z_begin=pl * (args.world // 2), z_count=pl, halo_depth=2 * ext, **kw)
-    for overlap in (True, False):
+    for overlap in [int(m) for m in args.modes.split(',')]:
         calls["halo"] = 0
         out[f"slab_ms_per_step_overlap_{int(overlap)}"] = run(mid, (halo, allreduce), overlap)
     if args.rccl:
@@ -100,7 +101,7 @@ def main():
             lower = 0
             upper = 0
 
-        for overlap in (True, False):
+        for overlap in [int(m) for m in args.modes.split(',')]:
             with wafer_amd.Context(mid) as ctx:
                 comm = SelfNeighbours(ctx, 0, 1, dev)
                 comm.warm_up()
@@ -121,7 +122,7 @@ def main():
                 out[f"slab_rccl_self_ms_per_step_overlap_{int(overlap)}"] = sorted(ts)[2]
                 del comm
         from wafer_amd.slab import NativeRcclSlabComm
-        for overlap in (True, False):
+        for overlap in [int(m) for m in args.modes.split(',')]:
             with wafer_amd.Context(mid) as ctx:
                 comm = NativeRcclSlabComm(ctx, 0, 1, dev, self_neighbours=True)
                 comm.warm_up()

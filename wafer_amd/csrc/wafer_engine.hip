@@ -123,6 +123,8 @@ struct wafer_ctx {
     void *hook_user = nullptr;
     bool overlap = true;
     bool bdry_main = false; // split passes: boundary kernels in order on the main stream (see bdry_on_main)
+    bool alternate = false; // fused split passes: the two streams swap roles every pass (wafer_set_overlap mode 3)
+    hipEvent_t ev_intr = nullptr; // mode 3: end of an interior launch that ran on the second stream
     int halo_valid = 0; // ghost planes of phi[cur] (counted from the owned region) known to be current
 
     uint64_t last_steps = 0;
@@ -697,8 +699,10 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->g = wafer_make_geom((int)p->nx, (int)p->ny, (int)p->nz, R, G, (int)zb, (int)zc, (int)c->esz);
     c->bx = (c->g.px + 63) / 64; // covers both the work area and the padded extent
     c->by = (c->g.py + 3) / 4;
-    c->overlap = env_int("WAFER_OVERLAP", 1) != 0;
-    c->bdry_main = env_int("WAFER_BDRY_MAIN", 0) != 0;
+    const int ov_mode = env_int("WAFER_OVERLAP", 1); // the modes of wafer_set_overlap
+    c->overlap = ov_mode != 0;
+    c->bdry_main = ov_mode == 2 || env_int("WAFER_BDRY_MAIN", 0) != 0;
+    c->alternate = ov_mode == 3;
 
     auto cleanup_fail = [&](int rc) {
         wafer_ctx_destroy(c);
@@ -723,6 +727,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_bdry, hipEventDisableTiming));
+    HIP_TRYC(hipEventCreateWithFlags(&c->ev_intr, hipEventDisableTiming));
 
     // a and b are allocated on first use (ensure_ab): the default kernels form them from V in registers
     void **arrays[] = {&c->phi[0], &c->phi[1], &c->v};
@@ -756,7 +761,7 @@ int wafer_ctx_destroy(wafer_ctx *c)
     if (c->scal) (void)hipFree(c->scal);
     if (c->gram) (void)hipFree(c->gram);
     if (c->scal_host) (void)hipHostFree(c->scal_host);
-    for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join, c->ev_bdry})
+    for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join, c->ev_bdry, c->ev_intr})
         if (e) (void)hipEventDestroy(e);
     if (c->s_own) (void)hipStreamDestroy(c->s_own);
     if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
@@ -1168,11 +1173,47 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     const bool fuse = wnum == 0 && active_variant(c) == 2 && R <= 2 &&
                       (!c->sharded() || (g.G >= 2 * R && g.nzl >= 2 * R));
     HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
+    bool intr_on_aux = false, have_join = false; // mode 3 (alternating stream roles), see below
     for (uint64_t s = 0; s < steps;) {
         const int src = c->cur, dst = c->cur ^ 1;
         if (fuse && steps - s >= 2) {
             TRY(ensure_halo(c, 2 * R));
             const bool split = c->sharded() && c->overlap && g.nzl > 4 * R;
+            if (split && c->alternate) {
+                // Mode 3: as below, but the two streams swap roles every pass.  The boundary kernels of this
+                // pass run on the stream that ran the interior of the previous one, so that dependency is
+                // stream order instead of an event hop (19 us in the kernel trace); the previous exchange,
+                // on the other stream, has long finished.  The hop that remains -- boundary kernels ->
+                // interior -- is the one that lets the exchange reach the CUs first.  Measured with the rank as
+                // its own neighbour: 0.369 -> 0.352 ms/step under the native RCCL hooks -- but the kernel
+                // trace shows RCCL's kernel starting 2 us AFTER the interior again (RCCL pays ~6 us more per
+                // call when the user stream changes between calls), i.e. the exchange is starved of CUs as in
+                // mode 2.  Not the default; bench.py times it with the other modes on the fabric it runs on.
+                const hipStream_t sE = intr_on_aux ? c->s_aux : c->s_main, sI = intr_on_aux ? c->s_main : c->s_aux;
+                if (have_join) HIP_TRY(hipStreamWaitEvent(sE, c->ev_join, 0)); // ghost planes of the previous exchange
+                if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + 2 * R, sE));
+                if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - 2 * R, hi, sE));
+                HIP_TRY(hipEventRecord(c->ev_bdry, sE));
+                TRY(exchange_halo(c, dst, sE, 2 * R));
+                HIP_TRY(hipEventRecord(c->ev_join, sE));
+                have_join = true;
+                HIP_TRY(hipStreamWaitEvent(sI, c->ev_bdry, 0));
+                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + 2 * R : lo, c->has_hi() ? hi - 2 * R : hi, sI, true));
+                intr_on_aux = (sI == c->s_aux);
+                c->halo_valid = 2 * R;
+                c->cur = dst;
+                s += 2;
+                if (!(fuse && steps - s >= 2)) { // last fused pass of this call: everything back onto the main stream
+                    if (intr_on_aux) {
+                        HIP_TRY(hipEventRecord(c->ev_intr, c->s_aux));
+                        HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_intr, 0));
+                    }
+                    HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
+                    intr_on_aux = false;
+                    have_join = false;
+                }
+                continue;
+            }
             if (split) {
                 // Second stream: boundary planes, then their exchange.  Main stream: the interior, released
                 // by an event recorded after the boundary kernels.  The exchange is enqueued BEFORE the
@@ -1587,9 +1628,10 @@ int wafer_set_comm_hooks(wafer_ctx *c, wafer_halo_fn halo, wafer_allreduce_fn al
 int wafer_set_overlap(wafer_ctx *c, int enabled)
 {
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
-    if (enabled < 0 || enabled > 2) return fail(WAFER_ERR_INVALID, "overlap mode 0, 1 or 2");
+    if (enabled < 0 || enabled > 3) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 3");
     c->overlap = enabled != 0;
     c->bdry_main = enabled == 2;
+    c->alternate = enabled == 3;
     return WAFER_OK;
 }
 

@@ -445,7 +445,7 @@ class Context:
         self._check(self._L.wafer_set_comm_hooks(self._h, self._hooks[0], self._hooks[1], None))
 
     def set_overlap(self, enabled) -> None:
-        """halo schedule of a z-slab: False / 0, True / 1 (default), or 2 (include/wafer_hip.h)"""
+        """halo schedule of a z-slab: False / 0, True / 1 (default), 2 or 3 (include/wafer_hip.h)"""
         self._check(self._L.wafer_set_overlap(self._h, int(enabled)))
 
     def set_stream(self, stream_ptr: int | None) -> None:
