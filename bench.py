@@ -5,20 +5,39 @@ updates/sec on 512^3 fp64, achieved HBM GB/s vs peak).
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE imaginary-time step (grid.rs:562-686, wnum = 0) of the whole
-grid.  N = 1: the 512^3 fp64 ThreePoint Coulomb grid of BASELINE configs[2],
-ground-state evolve, potential / phi generated in HBM (no host traffic in the
-timed region).  N > 1 (launched by torch.distributed.run, one rank per GPU):
-the grid is (1024, 1024, 128*N) -- 2^27 points per GPU, i.e. configs[3]'s
-1024^3 at N = 8 -- z-slab decomposed with RCCL halo exchange; "weak" scaling.
+grid; potential and phi are generated in HBM (no host traffic in the timed
+region).
+
+N = 1: the 512^3 fp64 ThreePoint Coulomb grid of BASELINE configs[2], ground-state
+evolve.  After the timed region the SAME kernel instance is held against the CPU
+oracle bit for bit ("parity" in the result line; a mismatch is exit code 3), and
+the state the timed steps produced is reproduced by the independent single-step
+kernel (checksum of every cell's bits).
+
+N > 1: BASELINE configs[3], the 1024^3 SimpleCornell grid, STRONG scaling -- z-slabs
+of 1024/N planes per GPU, RCCL halo exchange behind the interior update.  Rank 0
+then runs the same 1024^3 grid undecomposed on its own GPU for the same steps:
+`single_gpu_ref` carries T1 (so T1 / (N * TN) needs no second run) and every slab's
+checksum must equal the undecomposed run's over the same planes.
+`--scaling weak` keeps 2^27 points per GPU instead: (1024, 1024, 128 N).
+
+Launching: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+(one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment),
+or bare `python bench.py --gpus N`: the parent then starts the N ranks itself as
+child processes BEFORE anything touches a GPU, forwards rank 0's line and exits
+non-zero if fewer than N devices or ranks materialise.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra
-objects "roofline" and "cpu_baseline".
+objects "roofline", "cpu_baseline" (N = 1), "parity", "comm" and "single_gpu_ref"
+(N > 1).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,9 +47,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 BYTES_PER_UPDATE = {"f64": 32, "f32": 16, "f32fast": 16}  # phi, a, b in + phi' out
+RC_PARITY = 3                 # exit code when the timed kernel's result differs from the oracle's
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -38,14 +58,18 @@ def parse_args():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "f32fast"])
     ap.add_argument("--grid", default=None, help="override: NX,NY,NZ (global work area)")
     ap.add_argument("--cd", type=int, default=1, help="central difference ext: 1/2/3")
-    ap.add_argument("--potential", default="Coulomb")
+    ap.add_argument("--potential", default=None, help="default: Coulomb at N = 1, SimpleCornell at N > 1")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = 1024^3 split over the ranks (default); weak = 1024x1024x128 per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle / cross-kernel / undecomposed checks")
     ap.add_argument("--variant", type=int, default=-1, help="stencil kernel variant (-1 = default)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def physical_cores() -> int:
+    """Wafer's own thread rule (main.rs:190-196): the rayon pool gets num_cpus::get_physical()."""
     try:
         import psutil
         n = psutil.cpu_count(logical=False)
@@ -56,14 +80,77 @@ def physical_cores() -> int:
     return max(1, len(os.sched_getaffinity(0)))
 
 
-def cpu_baseline(shape, ext, potential, dn, dt, mass, target_seconds):
+# ---------------------------------------------------------------------------------------------
+# launcher: bare `bench.py --gpus N` -> N rank processes, started before any GPU call
+# ---------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    n = args.gpus
+    host_transport = os.environ.get("WAFER_BENCH_TRANSPORT", "rccl") == "host"
+    import torch  # device_count() does not initialise the GPU; nothing else of torch.cuda is touched here
+    ndev = torch.cuda.device_count()
+    if ndev < n and not host_transport:
+        print(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible; refusing to mislabel a smaller run",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WAFER_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    rc = 0
+    pending = set(range(n))
+    while pending and rc == 0:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+        if pending and rc == 0:
+            time.sleep(0.2)
+    if rc != 0:   # one rank failed: the others would wait in a collective for ever
+        for r in pending:
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    if rc == 0:
+        try:
+            res = json.loads(lines[-1])
+            if res.get("n_gpus") != n or res.get("ranks") != n:
+                print(f"bench.py: rank 0 reports n_gpus={res.get('n_gpus')} ranks={res.get('ranks')}, expected {n}",
+                      file=sys.stderr)
+                rc = 2
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: no result line from rank 0 ({e!r})", file=sys.stderr)
+            rc = 2
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU legs (rank 0, N = 1): the oracle as the reported baseline and as the checker
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline(shape, ext, potential, dn, dt, mass, sig, target_seconds):
     """The oracle (kind "port": a C restatement of Wafer's rayon path, same pass
     structure: stencil into work, copy back) timed on this host's cores on a
-    bounded number of steps of the SAME grid.  Reported, not the target."""
+    bounded number of steps of the SAME grid.  Reported, not the target.
+    Returns (record, phi after `total_steps` steps, total_steps) so that the same
+    CPU work also serves as the parity reference."""
     from oracle import wafer_oracle as wo
-    cores = physical_cores()  # Wafer's own thread rule, main.rs:190-196
+    cores = physical_cores()
     wo.set_threads(cores)
-    cfg = wo.Config(*shape, ext=ext, potential=potential, dn=dn, dt=dt, mass=mass)
+    cfg = wo.Config(*shape, ext=ext, potential=potential, dn=dn, dt=dt, mass=mass, sig=sig)
     v = wo.potential_generate(cfg)
     a, b = wo.ab(cfg, v)
     del v
@@ -76,7 +163,7 @@ def cpu_baseline(shape, ext, potential, dn, dt, mass, target_seconds):
     wo.evolve(cfg, 0, a, b, phi, [], steps)
     dt_s = time.perf_counter() - t0
     pts = shape[0] * shape[1] * shape[2]
-    return {
+    rec = {
         "value": pts * steps / dt_s,
         "unit": "updates/s",
         "cores": cores,
@@ -84,10 +171,40 @@ def cpu_baseline(shape, ext, potential, dn, dt, mass, target_seconds):
         "sample": f"{steps} steps of the same {shape[0]}x{shape[1]}x{shape[2]} fp64 {potential} grid "
                   f"(oracle/wafer_oracle.c wo_evolve, OpenMP, {dt_s:.1f} s)",
     }
+    return rec, phi, steps + 1
+
+
+def max_ulp(got, want) -> int:
+    """largest distance in units in the last place between two float64 arrays (0 = the same bits,
+    up to the sign of zero)"""
+    import numpy as np
+    worst = 0
+    g, w = got.reshape(-1), want.reshape(-1)
+    for i in range(0, g.size, 1 << 24):   # bounded temporaries
+        a = g[i:i + (1 << 24)].view(np.int64).copy()
+        b = w[i:i + (1 << 24)].view(np.int64).copy()
+        a[a < 0] = np.int64(-2**63) - a[a < 0]   # sign-magnitude -> two's complement order
+        b[b < 0] = np.int64(-2**63) - b[b < 0]
+        d = np.abs(a - b)
+        nan = np.isnan(g[i:i + (1 << 24)]) | np.isnan(w[i:i + (1 << 24)])
+        if nan.any():
+            return 2**62
+        worst = max(worst, int(d.max(initial=0)))
+    return worst
+
+
+def boolean_norm2(shape, ext) -> float:
+    """sum phi^2 over the work area of the Boolean initial condition (config.rs:676-683: 1 where all
+    three PADDED indices are odd): the product over the axes of the number of odd indices in [ext, ext + n)"""
+    out = 1.0
+    for n in shape:
+        out *= len([i for i in range(ext, ext + n) if i % 2 == 1])
+    return out
 
 
 def pmc_traffic(kernel_name: str):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if any."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if any (a STATIC figure:
+    counters cannot be read inside a timed run)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
@@ -100,11 +217,13 @@ def pmc_traffic(kernel_name: str):
     return None
 
 
-def main():
+# ---------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------
+def run_rank(args) -> int:
     # RCCL caches its parameters at first use, which is torch's own communicator: the channel limit the
     # slab transport wants (wafer_rccl_hooks.h) has to be in the environment before that
     os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "8")
-    args = parse_args()
     # stdout carries exactly ONE line, the JSON result: native libraries that write to the C stdout
     # (RCCL prints a version banner there, flushed at exit) are sent to stderr instead
     sys.stdout.flush()
@@ -114,9 +233,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
-    if world > 1 and world != n_gpus:
-        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
 
+    import numpy as np
     import torch
     import wafer_amd
 
@@ -127,10 +245,13 @@ def main():
     # (tests/test_gpu_multiprocess.py); the default is RCCL, one GPU per rank, the hooks served by
     # RCCL's C API directly (WAFER_TRANSPORT=torch: through torch.distributed)
     host_transport = os.environ.get("WAFER_BENCH_TRANSPORT", "rccl") == "host"
+    ndev = torch.cuda.device_count()
     # a launcher that narrows each rank's view to its own GPU (ROCR_/HIP_VISIBLE_DEVICES per rank) leaves
     # one visible device with index 0; the host-staged test transport folds ranks onto the GPUs present
-    if host_transport or local_rank >= torch.cuda.device_count():
-        local_rank %= max(1, torch.cuda.device_count())
+    if host_transport or (ndev == 1 and world > 1 and os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))):
+        local_rank %= max(1, ndev)
+    if local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {ndev} GPU(s) visible: one GPU per rank is required")
     torch.cuda.set_device(local_rank)
 
     dist = None
@@ -141,31 +262,40 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != n_gpus:
+            raise SystemExit(f"--gpus {n_gpus} but the process group has {dist.get_world_size()} ranks")
+    coll_dev = "cpu" if host_transport else f"cuda:{local_rank}"
 
     ext = args.cd
     if args.grid:
         shape = tuple(int(s) for s in args.grid.split(","))
     elif n_gpus == 1:
         shape = (512, 512, 512)
+    elif args.scaling == "strong":
+        shape = (1024, 1024, 1024)
     else:
         shape = (1024, 1024, 128 * n_gpus)
     if n_gpus == 1:
         dn, dt, mass = 0.05, 5e-4, 1.0
-        potential = args.potential
+        potential = args.potential or "Coulomb"
     else:
         dn, dt, mass = 0.02, 8e-5, 2.35           # config #4: SimpleCornell, sig 0.223
-        potential = "SimpleCornell" if args.potential == "Coulomb" else args.potential
+        potential = args.potential or "SimpleCornell"
+    sig = 0.223
 
     nz = shape[2]
     z_begin, z_count = 0, 0
     if world > 1:
         from wafer_amd import slab
         z_begin, z_count = slab.partition(nz, world, rank)
-    par = wafer_amd.Params(shape[0], shape[1], shape[2], dn=dn, dt=dt, mass=mass, sig=0.223,
-                           central_difference=ext, dtype=args.dtype, max_states=1, device=local_rank,
-                           z_begin=z_begin, z_count=z_count,
-                           halo_depth=2 * ext if world > 1 else 0)  # 2*ext ghost planes: two fused steps per exchange
-    ctx = wafer_amd.Context(par)
+
+    def make_params(zb, zc, halo):
+        return wafer_amd.Params(shape[0], shape[1], shape[2], dn=dn, dt=dt, mass=mass, sig=sig,
+                                central_difference=ext, dtype=args.dtype, max_states=1, device=local_rank,
+                                z_begin=zb, z_count=zc, halo_depth=halo)
+
+    # 2*ext ghost planes: two fused steps per exchange
+    ctx = wafer_amd.Context(make_params(z_begin, z_count, 2 * ext if world > 1 else 0))
     if args.variant >= 0:
         ctx.set_stencil_variant(args.variant)
     comm, transport_name = None, None
@@ -185,28 +315,35 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # the box itself next to the 8 TB/s datasheet peak (SURVEY.md 8d): the bandwidth its own
-    # properties imply and what a flat streaming kernel reaches on the same buffers.  Measured
-    # during set-up, before the warm-up steps (it also brings the clocks up from idle).
-    device_info = None
-    if True:   # every rank (the same set-up work everywhere); rank 0 reports
-        try:
-            di = ctx.device_info()
-            mclk_khz, width = di["memory_clock_khz"], di["memory_bus_bits"]
-            device_info = {
-                "name": di["name"], "arch": di["arch"], "compute_units": di["compute_units"],
-                "hbm_GB": round(di["total_bytes"] / 2**30, 1),
-                "memory_clock_MHz": mclk_khz / 1e3, "memory_bus_bits": width,
-                # HBM3E moves 4 bits per pin per reported memory clock (2 GHz -> 8 Gb/s/pin):
-                # 8192 pins x 8 Gb/s = 8.19 TB/s, the datasheet's "8 TB/s"
-                "hbm_GBps_from_props": 4.0 * mclk_khz * 1e3 * width / 8 / 1e9,
-                "measured_stream_GBps_1r1w": round(ctx.stream_bandwidth(1, 300), 1),
-                "measured_stream_GBps_3r1w": round(ctx.stream_bandwidth(3, 300), 1),
-            }
-        except Exception as e:  # informational
-            device_info = {"error": repr(e)}
+    # the initial condition against its closed form (exact: a sum of ones)
+    ic_check = None
+    if not args.no_parity:
+        n2 = ctx.norm2()   # all-reduced over the slabs
+        ic_check = {"norm2": n2, "closed_form": boolean_norm2(shape, ext)}
+        if n2 != ic_check["closed_form"]:
+            print(f"bench.py: initial condition norm2 {n2} != closed form {ic_check['closed_form']}", file=sys.stderr)
+            return RC_PARITY
 
-    ctx.set_initial_condition("Boolean")   # the streaming kernel used phi's second buffer as scratch
+    # the box itself next to the 8 TB/s datasheet peak (SURVEY.md 8d): the bandwidth its own
+    # properties imply and what a 16 B-per-lane device copy reaches on the same buffers.  Measured
+    # during set-up, before the warm-up steps (it also brings the clocks up from idle).
+    try:
+        di = ctx.device_info()
+        mclk_khz, width = di["memory_clock_khz"], di["memory_bus_bits"]
+        device_info = {
+            "name": di["name"], "arch": di["arch"], "compute_units": di["compute_units"],
+            "hbm_GB": round(di["total_bytes"] / 2**30, 1),
+            "memory_clock_MHz": mclk_khz / 1e3, "memory_bus_bits": width,
+            # HBM3E moves 4 bits per pin per reported memory clock (2 GHz -> 8 Gb/s/pin):
+            # 8192 pins x 8 Gb/s = 8.19 TB/s, the datasheet's "8 TB/s"
+            "hbm_GBps_from_props": 4.0 * mclk_khz * 1e3 * width / 8 / 1e9,
+            # read + written bytes of a device-to-device copy of one array (wafer_k_copy16)
+            "measured_copy_GBps": round(ctx.copy_bandwidth(100, 4, 8), 1),
+        }
+    except Exception as e:  # informational
+        device_info = {"error": repr(e)}
+    ctx.set_initial_condition("Boolean")   # the copy used phi's second buffer as scratch
+
     # N > 1: the halo exchange hides behind the interior update (mode 1: boundary planes and exchange on
     # a second stream; mode 2: boundary planes in-stream, only the exchange on the second stream; mode 3:
     # as 1 with the streams swapping roles every pass) or
@@ -223,8 +360,7 @@ def main():
             t_ = time.perf_counter()
             ctx.evolve(0, 40)
             barrier()
-            tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64,
-                              device="cpu" if host_transport else f"cuda:{local_rank}")
+            tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             trial[mode] = float(tt[0]) / 40 * 1e3
         best = min(trial, key=lambda m: trial[m] * (1.0 if m == 1 else 1.02))
@@ -232,6 +368,10 @@ def main():
         overlap_choice = {"mode": best, "ms_per_step": {"1_overlap": trial[1], "2_overlap_boundary_in_stream": trial[2],
                                                         "3_overlap_alternating_streams": trial[3], "0_no_overlap": trial[0]}}
         ctx.set_initial_condition("Boolean")
+    elif dist is not None:
+        overlap_choice = {"mode": int(os.environ.get("WAFER_OVERLAP", "1") or 1), "ms_per_step": None}
+
+    # ---- the timed region ------------------------------------------------------------------------
     if args.warmup > 0:
         ctx.evolve(0, args.warmup)
     barrier()
@@ -240,14 +380,18 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, ksteps = ctx.last_evolve_ms()     # HIP events on the engine's own stream
+    pts_rank = shape[0] * shape[1] * (z_count if z_count else shape[2])
+    ranks_seen = 1
     if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64,
-                         device="cpu" if host_transport else f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, kernel_ms, float(pts_rank)], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+        elapsed, kernel_ms, pts_rank = float(t[0]), float(t[1]), int(t[2])   # the slowest rank, the largest slab
+        one = torch.ones(1, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one[0])
+    total_steps = args.warmup + args.steps    # what phi has been through since the initial condition
 
     pts_total = shape[0] * shape[1] * shape[2]
-    pts_rank = shape[0] * shape[1] * (z_count if z_count else shape[2])
     value = pts_total * args.steps / elapsed
     bpu = BYTES_PER_UPDATE[args.dtype]
     spl = ctx.steps_per_launch()                  # the fused kernel advances two steps per launch
@@ -256,16 +400,25 @@ def main():
     kname = ctx.stencil_kernel_name()
     traffic = pmc_traffic(kname) if (n_gpus == 1 and not args.grid and args.dtype == "f64" and ext == 1) else None
 
+    comm_info = None
+    if comm is not None:
+        comm_info = {"transport": transport_name}
+        if hasattr(comm, "info"):
+            comm_info.update(comm.info())   # ncclCommCount etc. of the communicator the hooks use
+        comm_info["process_group_ranks"] = dist.get_world_size()
+        comm_info["halo_overlap_mode"] = overlap_choice["mode"] if overlap_choice else None
+
     result = {
         "metric": "grid_point_updates_per_sec",
         "value": value,
         "unit": "updates/s",
         "n_gpus": n_gpus,
+        "ranks": ranks_seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if n_gpus > 1 else "strong",
         "vs_baseline": None,   # the reference publishes no number for this metric
         "dtype": args.dtype,
         "data": "synthetic",
@@ -288,21 +441,110 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "traffic_source": ("profiles/pmc_traffic.json (static: rocprofv3 --pmc of this kernel on this workload, "
+                               "not re-measured in this run)") if traffic else None,
             "kernel": kname,
             "avg_launch_ms": launch_s * 1e3,
             "steps_per_launch": spl,
             "algorithmic_bytes_per_launch": pts_rank * bpu * spl,
-            # what the kernel really moved per second (PMC traffic / launch time), next to the accounting figure
+            # what the kernel really moved per second (static PMC traffic / this run's launch time)
             "traffic_GBps": (traffic / launch_s / 1e9) if traffic else None,
         },
         "device": device_info,
     }
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        try:
-            result["cpu_baseline"] = cpu_baseline(shape, ext, potential, dn, dt, mass, args.cpu_seconds)
-        except Exception as e:  # the baseline is reported, never required
-            result["cpu_baseline"] = {"value": None, "unit": "updates/s", "cores": physical_cores(),
-                                      "kind": "port", "sample": f"failed: {e!r}"}
+    if comm_info:
+        result["comm"] = comm_info
+    rc = 0
+
+    # ---- N > 1: the same grid undecomposed on rank 0's GPU: T1, and the slabs' bits -----------------
+    if dist is not None and not args.no_parity:
+        mine = ctx.checksum(z_begin, z_count)
+        sums = [None] * world
+        dist.all_gather_object(sums, (z_begin, z_count, mine))
+        if rank == 0:
+            ref = wafer_amd.Context(make_params(0, 0, 0))
+            if args.variant >= 0:
+                ref.set_stencil_variant(args.variant)
+            ref.set_potential(potential)
+            ref.set_initial_condition("Boolean")
+            if args.warmup > 0:
+                ref.evolve(0, args.warmup)
+            ref.synchronize()
+            t_ = time.perf_counter()
+            ref.evolve(0, args.steps)
+            ref.synchronize()
+            ref_elapsed = time.perf_counter() - t_
+            ref_kernel_ms, ref_ksteps = ref.last_evolve_ms()
+            bad = [(zb, zc) for zb, zc, s in sums if ref.checksum(zb, zc) != s]
+            ref_kname = ref.stencil_kernel_name()
+            ref.close()
+            result["single_gpu_ref"] = {
+                "grid": list(shape), "ms_per_step": ref_elapsed / args.steps * 1e3,
+                "kernel_ms_per_step": ref_kernel_ms / max(1, ref_ksteps), "value": pts_total * args.steps / ref_elapsed,
+                "kernel": ref_kname, "steps": args.steps, "warmup": args.warmup,
+                "note": "the same grid, potential and steps on rank 0's GPU alone, after the timed region",
+            }
+            result["single_gpu_ref_ms_per_step"] = ref_elapsed / args.steps * 1e3
+            result["parity"] = {
+                "kind": "every slab's checksum (a hash of each cell's bits and global index, summed mod 2^64) against the "
+                        "undecomposed run's over the same planes",
+                "steps": total_steps, "slabs": world, "identical": not bad, "differing_slabs": bad,
+                "initial_condition": ic_check,
+            }
+            if bad:
+                rc = RC_PARITY
+        flag = torch.tensor([float(rc)], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        rc = int(flag[0])
+
+    # ---- N = 1: the oracle beside it (baseline), and as the checker of the timed kernel instance --------
+    if dist is None and rank == 0:
+        phi_cpu, n_cpu = None, 0
+        if not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"], phi_cpu, n_cpu = cpu_baseline(shape, ext, potential, dn, dt, mass, sig, args.cpu_seconds)
+            except Exception as e:  # the baseline is reported, never required
+                result["cpu_baseline"] = {"value": None, "unit": "updates/s", "cores": physical_cores(),
+                                          "kind": "port", "sample": f"failed: {e!r}"}
+        if not args.no_parity:
+            parity = {"initial_condition": ic_check}
+            timed_sum = ctx.checksum()
+            if phi_cpu is None:   # no baseline leg: a short oracle run of its own
+                from oracle import wafer_oracle as wo
+                wo.set_threads(physical_cores())
+                cfg = wo.Config(*shape, ext=ext, potential=potential, dn=dn, dt=dt, mass=mass, sig=sig)
+                v = wo.potential_generate(cfg)
+                a_, b_ = wo.ab(cfg, v)
+                del v
+                phi_cpu, n_cpu = wo.initial_condition(cfg, "Boolean"), 3
+                wo.evolve(cfg, 0, a_, b_, phi_cpu, [], n_cpu)
+                del a_, b_
+            # (1) the timed kernel instance -- same context, same variant, same launch geometry -- against the
+            #     oracle from the same start, cell by cell
+            ctx.set_initial_condition("Boolean")
+            ctx.evolve(0, n_cpu)
+            got = ctx.download_phi()
+            if args.dtype == "f64":
+                parity.update({"against": "oracle/wafer_oracle.c (CPU restatement of grid.rs:544-687)",
+                               "steps": n_cpu, "max_ulp": max_ulp(got, phi_cpu)})
+                if parity["max_ulp"] != 0:
+                    rc = RC_PARITY
+            else:   # fp32 storage: not a bit-for-bit path; the largest deviation is reported
+                parity.update({"against": "oracle/wafer_oracle.c (fp64)", "steps": n_cpu,
+                               "max_abs_diff": float(np.max(np.abs(got - phi_cpu)))})
+            del got, phi_cpu
+            # (2) the state the TIMED steps left behind, reproduced by the independent single-step kernel
+            #     (another code path, itself bit-exact against the oracle in tests/): same bits expected
+            if kname != "wafer_k_step_lds" and args.dtype != "f32fast":
+                ctx.set_stencil_variant(1)
+                ctx.set_initial_condition("Boolean")
+                ctx.evolve(0, total_steps)
+                parity["timed_state_reproduced_by_single_step_kernel"] = {
+                    "steps": total_steps, "identical": ctx.checksum() == timed_sum}
+                if not parity["timed_state_reproduced_by_single_step_kernel"]["identical"]:
+                    rc = RC_PARITY
+            result["parity"] = parity
+
     if dist is not None:   # the process group goes first: its work objects refer to the engine's streams
         ctx.synchronize()
         if hasattr(comm, "close"):
@@ -313,7 +555,24 @@ def main():
     if rank == 0:
         result_out.write(json.dumps(result) + "\n")
         result_out.flush()
+        if rc != 0:
+            print("bench.py: PARITY FAILURE -- the timed kernel's result differs from the reference: "
+                  + json.dumps(result.get("parity")), file=sys.stderr)
+    return rc
+
+
+def main() -> int:
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        return launch_ranks(args)          # bare call: this process never touches a GPU
+    if world_env is not None and int(world_env) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to mislabel the run", file=sys.stderr)
+        return 2
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

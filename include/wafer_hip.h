@@ -241,6 +241,17 @@ int wafer_set_stencil_variant(wafer_ctx *ctx, int variant);
  * measured HBM ceiling next to which the stencil's rate is reported. */
 int wafer_diag_stream_bw(wafer_ctx *ctx, int n_reads, int iters, double *gbps);
 
+/* Diagnostic: the device's copy ceiling -- 16 B per lane, `unroll` (1, 2, 4, 8) vectors in flight per
+ * lane, grid-stride over blocks_per_cu x CUs workgroups of 256 threads, V -> phi's scratch buffer;
+ * GB/s of read + written bytes.  MI355X_MICROARCH.md quotes ~6.3 TB/s for this pattern. */
+int wafer_diag_copy_bw(wafer_ctx *ctx, int iters, int unroll, int blocks_per_cu, double *gbps);
+
+/* Diagnostic: integer checksum (sum mod 2^64 of a hash of each cell's bits and its GLOBAL index) of the
+ * work cells of global work planes [z_begin, z_begin + z_count) that this context owns.  Order
+ * independent, so the checksums of the slabs of a decomposed run must equal those of the same plane
+ * ranges of an undecomposed run whenever the bits agree: bench.py's N > 1 parity check. */
+int wafer_diag_checksum(wafer_ctx *ctx, uint32_t z_begin, uint32_t z_count, uint64_t *out);
+
 /* Diagnostic: the divisions by loop-invariant denominators (c*dn^2*m in the stencil update, the norm in
  * the excited-state transform) use a hoisted reciprocal with two exact remainders instead of the IEEE
  * sequence (wafer_div_invariant, wafer_stencil.hip.h).  Draws n_operands (rounded up to 2^18) doubles

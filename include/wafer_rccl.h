@@ -25,6 +25,8 @@ int wafer_rccl_attach(wafer_ctx *ctx, int rank, int world, const void *unique_id
  * scratch: >= 4 KiB of device memory, stream: any stream of the device */
 int wafer_rccl_warm_up(void *handle, void *scratch, void *stream);
 long wafer_rccl_halo_calls(void *handle);
+/* ncclCommCount, ncclCommUserRank, the z-neighbour ranks in use (-1 = none), ncclGetVersion */
+int wafer_rccl_comm_info(void *handle, int *nranks, int *rank, int *lower, int *upper, int *version);
 int wafer_rccl_detach(wafer_ctx *ctx, void *handle);
 
 #ifdef __cplusplus

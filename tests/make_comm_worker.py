@@ -35,6 +35,17 @@ def main():
             slab.NativeRcclSlabComm = real
         assert isinstance(comm, slab.TorchSlabComm) and "torch.distributed" in name, name
         comm.warm_up()
+        # a LOCAL failure (library missing on this node) is agreed on before anything collective
+        real_pre = slab.NativeRcclSlabComm.precheck
+
+        def broken_pre(rank):
+            raise ImportError("simulated: libwafer_rccl.so is missing")
+        slab.NativeRcclSlabComm.precheck = staticmethod(broken_pre)
+        try:
+            comm, name = slab.make_slab_comm(ctx, 0, 1, dev)
+        finally:
+            slab.NativeRcclSlabComm.precheck = staticmethod(real_pre)
+        assert isinstance(comm, slab.TorchSlabComm) and "torch.distributed" in name, name
         comm, name = slab.make_slab_comm(ctx, 0, 1, dev, "torch")
         assert isinstance(comm, slab.TorchSlabComm)
     torch.cuda.synchronize()

@@ -82,7 +82,7 @@ def test_rccl_hook_library_exports_its_header():
     lib = C.CDLL(build.RCCL_LIB)
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "wafer_rccl.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(wafer_rccl_[a-z0-9_]+)\s*\(", text)))
-    assert len(names) == 7
+    assert len(names) == 8
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/wafer_rccl.h but not exported"
     lib.wafer_rccl_unique_id_bytes.restype = C.c_int
@@ -105,3 +105,24 @@ def test_rust_binding_declares_every_entry_point():
         n_c = 0 if args.strip() in ("", "void") else args.count(",") + 1
         n_rs = len([a for a in m.group(1).split(",") if a.strip()])
         assert n_c == n_rs, (name, n_c, n_rs)
+
+
+def _bench(*args, **env_extra):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "WAFER_BENCH_TRANSPORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                          env=env, timeout=300, cwd=ROOT)
+
+
+def test_bench_bare_multi_gpu_call_refuses_without_the_devices():
+    """`python bench.py --gpus 8` with no launcher and fewer than 8 GPUs (none here) must exit non-zero
+    and print no result line -- never a smaller run under an 8-GPU label (ADVICE bench.py:117)"""
+    r = _bench("--gpus", "8", "--steps", "4", "--warmup", "0")
+    assert r.returncode == 2 and r.stdout.strip() == "" and "refusing" in r.stderr
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    r = _bench("--gpus", "8", "--steps", "4", "--warmup", "0", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    assert r.returncode == 2 and r.stdout.strip() == "" and "WORLD_SIZE=2" in r.stderr

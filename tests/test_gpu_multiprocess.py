@@ -30,9 +30,25 @@ def test_slab_ranks_as_processes(world):
     assert f"MP-OK {world}" in r.stdout
 
 
+def _check_bench_two_rank_line(d):
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["steps"] == 8 and d["scaling"] == "strong" and d["value"] > 0
+    ho = d["config"]["halo_overlap"]      # the exchange schedules were tried during set-up, one was chosen for all ranks
+    assert ho["mode"] in (0, 1, 2, 3) and len(ho["ms_per_step"]) == 4 and all(v > 0 for v in ho["ms_per_step"].values())
+    assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 64
+    assert d["roofline"]["steps_per_launch"] == 2 and "cpu_baseline" not in d
+    # the same grid undecomposed on rank 0's GPU: T1 in the same line, and every slab's bits against it
+    ref = d["single_gpu_ref"]
+    assert ref["grid"] == [256, 256, 128] and ref["ms_per_step"] > 0 and d["single_gpu_ref_ms_per_step"] == ref["ms_per_step"]
+    par = d["parity"]
+    assert par["identical"] is True and par["slabs"] == 2 and par["steps"] == 10 and par["differing_slabs"] == []
+    assert par["initial_condition"]["norm2"] == par["initial_condition"]["closed_form"] == 128 * 128 * 64
+    assert d["comm"]["process_group_ranks"] == 2 and d["comm"]["halo_overlap_mode"] == ho["mode"]
+
+
 def test_bench_multi_rank_path():
-    """bench.py's N > 1 leg end to end (slab partition, hooks, max-over-ranks timing, one JSON line
-    from rank 0) with two ranks on the one GPU over the host-staged transport"""
+    """bench.py's N > 1 leg end to end (slab partition, hooks, max-over-ranks timing, the undecomposed
+    reference run and the slab-by-slab checksum comparison, one JSON line from rank 0) with two ranks on
+    the one GPU over the host-staged transport"""
     import json
     env_extra = {"WAFER_BENCH_TRANSPORT": "host"}
     os.environ.update(env_extra)
@@ -45,12 +61,32 @@ def test_bench_multi_rank_path():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["value"] > 0
-    ho = d["config"]["halo_overlap"]      # both exchange schedules were tried during set-up, one was chosen for all ranks
-    assert ho["mode"] in (0, 1, 2, 3) and len(ho["ms_per_step"]) == 4 and all(v > 0 for v in ho["ms_per_step"].values())
-    assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 64
-    assert d["roofline"]["steps_per_launch"] == 2 and "cpu_baseline" not in d
+    _check_bench_two_rank_line(json.loads(lines[0]))
+
+
+def test_bench_bare_call_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the two ranks itself
+    (before touching a GPU) and forwards rank 0's line"""
+    import json
+    env = dict(os.environ, WAFER_BENCH_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
+                        "--grid", "256,256,128"], capture_output=True, text=True, env=env, timeout=420, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    _check_bench_two_rank_line(json.loads(lines[0]))
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """a bare `--gpus 8` on a box with fewer GPUs must fail, not run a smaller job under the label"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "WAFER_BENCH_TRANSPORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "{" not in r.stdout and "refusing" in r.stderr
 
 
 @pytest.mark.parametrize("ext", [1, 2])

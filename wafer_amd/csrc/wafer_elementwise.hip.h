@@ -245,6 +245,60 @@ __global__ __launch_bounds__(256) void wafer_k_stream(const wafer_f4 *__restrict
     }
 }
 
+// The device's copy ceiling (MI355X_MICROARCH.md: ~6.3 TB/s for a float4 copy): every lane moves
+// U independent 16 B vectors per trip of a grid-stride loop -- U loads in flight before the first
+// store -- with a grid of a few 256-thread workgroups per CU.  wafer_k_stream above issues one load
+// per trip and under-reads the device by a quarter.
+template <int U>
+__global__ __launch_bounds__(256) void wafer_k_copy16(const wafer_f4 *__restrict__ src, wafer_f4 *__restrict__ dst, long long n16)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        wafer_f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+// ---- diagnostic: position-dependent checksum of the work cells of global planes [kz_lo, kz_hi) that
+// this slab owns: sum (mod 2^64) of mix(bits(cell) ^ mix(global linear index)).  An integer sum is
+// order independent, so a slab-decomposed run and an undecomposed one must give the same value plane
+// range by plane range -- a bit-exactness test that moves 8 bytes instead of the grid.
+__device__ __forceinline__ unsigned long long wafer_hash64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void wafer_k_checksum(WaferRowArgs a, const T *__restrict__ phi, int kz_lo, int kz_hi,
+                                                        unsigned long long *__restrict__ out)
+{
+    const WaferGeom &g = a.g;
+    const int lz0 = max(a.lz_lo, kz_lo - g.z_begin + g.G), lz1 = min(a.lz_hi, kz_hi - g.z_begin + g.G);
+    unsigned long long acc = 0;
+    const long long rows = (long long)max(0, lz1 - lz0) * g.ny;
+    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+        const int y = (int)(row % g.ny), z = lz0 + (int)(row / g.ny);
+        const long long kg = (long long)g.z_begin + (z - g.G);
+        const long long p0 = (long long)z * g.plane + (long long)(y + g.R) * g.pitch + g.xoff + g.R;
+        const unsigned long long lin0 = ((unsigned long long)kg * (unsigned long long)g.ny + (unsigned long long)y) * (unsigned long long)g.nx;
+        for (int x = threadIdx.x & 63; x < g.nx; x += 64) {
+            unsigned long long bits;
+            if constexpr (sizeof(T) == 8) bits = (unsigned long long)__double_as_longlong((double)phi[p0 + x]);
+            else bits = (unsigned long long)__float_as_uint((float)phi[p0 + x]);
+            acc += wafer_hash64(bits ^ wafer_hash64(lin0 + (unsigned long long)x + 0x9e3779b97f4a7c15ull));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 // ---- diagnostic: wafer_div_invariant against the IEEE division ------------------------------------
 // Every thread draws `per_thread` operands x from a counter-based generator (splitmix64 of the global
 // operand index and the seed): uniform significand and sign, biased exponent uniform in [lo_exp, hi_exp].

@@ -59,6 +59,50 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 // ---------------------------------------------------------------------------
+// roctx ranges: evolve / observables / halo exchange show up by name on a
+// rocprofv3 --marker-trace timeline.  The library is looked up at first use (rocprofiler-sdk's roctx,
+// then the legacy libroctx64) so that nothing is linked; without it the ranges are no-ops.
+// WAFER_ROCTX=0 switches them off.
+// ---------------------------------------------------------------------------
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = getenv("WAFER_ROCTX");
+        if (e && *e == '0') return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+static Roctx &roctx()
+{
+    static Roctx r;
+    return r;
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char *name) : on(roctx().push != nullptr)
+    {
+        if (on) roctx().push(name);
+    }
+    ~RoctxRange()
+    {
+        if (on) roctx().pop();
+    }
+};
+} // namespace
+
+// ---------------------------------------------------------------------------
 // host restatement of the two scalar helpers FullCornell needs
 // (potential.rs:374-391, 394-398); evaluated once per context.
 // ---------------------------------------------------------------------------
@@ -264,6 +308,7 @@ static int exchange_halo(wafer_ctx *c, int buf, hipStream_t s, int planes)
 {
     if (!c->sharded()) return WAFER_OK;
     if (!c->halo_hook) return fail(WAFER_ERR_COMM, "context owns a z-slab but no halo hook is installed");
+    RoctxRange range_("wafer_halo_exchange");
     const WaferGeom &g = c->g;
     if (planes > g.G || planes > g.nzl) return fail(WAFER_ERR_INVALID, "halo exchange deeper than the slab allows");
     char *base = static_cast<char *>(c->phi[buf]);
@@ -1163,6 +1208,7 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     if (wnum > c->states.size()) return fail(WAFER_ERR_STATE, "wnum %u but w_store holds %zu states", wnum, c->states.size());
     if (wnum + 2 > SCAL_SLOTS) return fail(WAFER_ERR_INVALID, "wnum too large");
     HIP_TRY(hipSetDevice(c->P.device));
+    RoctxRange range_(wnum ? "wafer_evolve_excited" : "wafer_evolve_ground");
     const WaferGeom &g = c->g;
     const int R = g.R;
     const int lo = g.G, hi = g.G + g.nzl;
@@ -1362,6 +1408,7 @@ int wafer_observables(wafer_ctx *c, wafer_observables_t *out)
     if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
     if (!c->have_pot || !c->have_phi) return fail(WAFER_ERR_STATE, "potential and phi must be set");
     HIP_TRY(hipSetDevice(c->P.device));
+    RoctxRange range_("wafer_observables");
     TRY(ensure_halo(c, c->g.R));
     WaferObsArgs a;
     a.g = c->g;
@@ -1586,6 +1633,67 @@ int wafer_diag_stream_bw(wafer_ctx *c, int n_reads, int iters, double *gbps)
     // the scratch buffer's frame must be zero again
     HIP_TRY(hipMemsetAsync(alloc_base(c, c->phi[c->cur ^ 1]), 0, (size_t)c->g.total * c->esz, c->s_main));
     *gbps = (double)n16 * 16.0 * (n_reads + 1) * iters / (ms * 1e-3) / 1e9;
+    return WAFER_OK;
+}
+
+// the device's copy ceiling: 16 B per lane, `unroll` (1, 2, 4, 8) vectors in flight per lane, a
+// grid-stride loop over blocks_per_cu x CUs workgroups of 256 threads; V -> phi's scratch buffer
+int wafer_diag_copy_bw(wafer_ctx *c, int iters, int unroll, int blocks_per_cu, double *gbps)
+{
+    if (!c || !gbps) return fail(WAFER_ERR_INVALID, "null argument");
+    if (iters < 1 || blocks_per_cu < 1 || blocks_per_cu > 64) return fail(WAFER_ERR_INVALID, "iters >= 1, blocks_per_cu in 1..64");
+    HIP_TRY(hipSetDevice(c->P.device));
+    const long long n16 = (long long)c->g.total * (long long)c->esz / 16;
+    const wafer_f4 *src = as<const wafer_f4>(alloc_base(c, c->v));
+    wafer_f4 *dst = as<wafer_f4>(alloc_base(c, c->phi[c->cur ^ 1])); // scratch between steps
+    const dim3 grid((unsigned)(c->num_cus * blocks_per_cu)), block(256);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int it = -2; it < iters; ++it) { // two warm-up launches
+        if (it == 0) HIP_TRY(hipEventRecord(e0, c->s_main));
+        switch (unroll) {
+        case 1: hipLaunchKernelGGL((wafer_k_copy16<1>), grid, block, 0, c->s_main, src, dst, n16); break;
+        case 2: hipLaunchKernelGGL((wafer_k_copy16<2>), grid, block, 0, c->s_main, src, dst, n16); break;
+        case 8: hipLaunchKernelGGL((wafer_k_copy16<8>), grid, block, 0, c->s_main, src, dst, n16); break;
+        default: hipLaunchKernelGGL((wafer_k_copy16<4>), grid, block, 0, c->s_main, src, dst, n16); break;
+        }
+    }
+    HIP_TRY(hipEventRecord(e1, c->s_main));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIP_TRY(hipMemsetAsync(alloc_base(c, c->phi[c->cur ^ 1]), 0, (size_t)c->g.total * c->esz, c->s_main)); // the scratch buffer's frame
+    *gbps = (double)n16 * 16.0 * 2.0 * iters / (ms * 1e-3) / 1e9;
+    return WAFER_OK;
+}
+
+// position-dependent integer checksum of the work cells of global work planes [z_begin, z_begin + z_count)
+// that this context owns (wafer_k_checksum): equal for equal bits, whatever the decomposition
+int wafer_diag_checksum(wafer_ctx *c, uint32_t z_begin, uint32_t z_count, uint64_t *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
+    HIP_TRY(hipSetDevice(c->P.device));
+    HIP_TRY(hipStreamSynchronize(c->s_aux));
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(c->scal + 20);
+    HIP_TRY(hipMemsetAsync(d, 0, sizeof *d, c->s_main));
+    WaferRowArgs ra;
+    ra.g = c->g;
+    ra.lz_lo = c->g.G;
+    ra.lz_hi = c->g.G + c->g.nzl;
+    const int lo = (int)z_begin, hi = (int)std::min<uint64_t>((uint64_t)z_begin + z_count, (uint64_t)c->g.nz);
+    if (c->f32)
+        hipLaunchKernelGGL((wafer_k_checksum<float>), dim3(c->num_cus * 8), dim3(256), 0, c->s_main, ra, as<float>(c->phi[c->cur]), lo, hi, d);
+    else
+        hipLaunchKernelGGL((wafer_k_checksum<double>), dim3(c->num_cus * 8), dim3(256), 0, c->s_main, ra, as<double>(c->phi[c->cur]), lo, hi, d);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, c->s_main));
+    HIP_TRY(hipStreamSynchronize(c->s_main));
+    *out = (uint64_t)h;
     return WAFER_OK;
 }
 

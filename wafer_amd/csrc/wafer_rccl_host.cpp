@@ -22,6 +22,7 @@
 #include <thread>
 #include <vector>
 
+#include <sys/stat.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -125,25 +126,57 @@ int main(int argc, char **argv)
     if (world > 1) {
         const char *path = getenv("WAFER_NCCL_ID_FILE");
         if (!path) { fprintf(stderr, "WAFER_NCCL_ID_FILE must name a file all ranks can reach\n"); return 2; }
+        // The file carries a run nonce in front of the id so that a file left over from an earlier run is
+        // never mistaken for this one's: the launcher's TORCHELASTIC_RUN_ID / WAFER_RUN_ID when it sets
+        // one, else the file must be younger than this process (rank 0 removes any old file before it
+        // generates the id, writes to .tmp and renames; it removes the file again after ncclCommInitRank).
+        const char *nonce_env = getenv("WAFER_RUN_ID") ? getenv("WAFER_RUN_ID") : getenv("TORCHELASTIC_RUN_ID");
+        char nonce[64];
+        memset(nonce, 0, sizeof nonce);
+        if (nonce_env) strncpy(nonce, nonce_env, sizeof nonce - 1);
+        const auto started = std::chrono::system_clock::now();
         if (rank == 0) {
+            remove(path);
             NCCLCHECK(ncclGetUniqueId(&id));
             const std::string tmp = std::string(path) + ".tmp";
             FILE *f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(&id, sizeof id, 1, f) != 1) { fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
+            if (!f || fwrite(nonce, sizeof nonce, 1, f) != 1 || fwrite(&id, sizeof id, 1, f) != 1) { fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
             fclose(f);
             rename(tmp.c_str(), path);
         } else {
-            FILE *f = nullptr;
-            for (int tries = 0; tries < 6000 && !(f = fopen(path, "rb")); ++tries)
-                std::this_thread::sleep_for(std::chrono::milliseconds(10));
-            if (!f || fread(&id, sizeof id, 1, f) != 1) { fprintf(stderr, "cannot read %s\n", path); return 1; }
-            fclose(f);
+            bool got = false;
+            const char *why = "no such file";
+            for (int tries = 0; tries < 6000 && !got; ++tries) {
+                FILE *f = fopen(path, "rb");
+                if (f) {
+                    char seen[64];
+                    struct stat st;
+                    if (fread(seen, sizeof seen, 1, f) == 1 && fread(&id, sizeof id, 1, f) == 1) {
+                        if (nonce_env) {
+                            got = memcmp(seen, nonce, sizeof nonce) == 0;
+                            why = "its run id is not this run's (a file left over from another run?)";
+                        } else {
+                            // no launcher nonce: accept only a file written after this process started (minus
+                            // clock slack between ranks of one node)
+                            got = stat(path, &st) == 0 &&
+                                  std::chrono::system_clock::from_time_t(st.st_mtime) + std::chrono::seconds(2) >= started;
+                            why = "it is older than this run (a file left over from another run? set WAFER_RUN_ID)";
+                        }
+                    } else {
+                        why = "it is shorter than a nonce + ncclUniqueId";
+                    }
+                    fclose(f);
+                }
+                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+            if (!got) { fprintf(stderr, "rank %d: no usable ncclUniqueId in %s after 60 s: %s\n", rank, path, why); return 1; }
         }
     } else {
         NCCLCHECK(ncclGetUniqueId(&id));
     }
     wafer_rccl_default_env();
     NCCLCHECK(ncclCommInitRank(&fab.comm, world, id, rank));
+    if (world > 1 && rank == 0) remove(getenv("WAFER_NCCL_ID_FILE")); // every rank has read it: ncclCommInitRank is collective
 
     // ---- slab of this rank ----------------------------------------------------------------------------
     wafer_params p;

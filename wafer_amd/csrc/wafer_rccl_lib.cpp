@@ -68,6 +68,25 @@ int wafer_rccl_warm_up(void *handle, void *scratch, void *stream)
 
 long wafer_rccl_halo_calls(void *handle) { return static_cast<WaferRcclFabric *>(handle)->halo_calls; }
 
+// what RCCL itself says about the communicator: ncclCommCount / ncclCommUserRank, the z-neighbours in
+// use and RCCL's version (bench.py reports them next to the numbers they produced)
+int wafer_rccl_comm_info(void *handle, int *nranks, int *rank, int *lower, int *upper, int *version)
+{
+    WaferRcclFabric *f = static_cast<WaferRcclFabric *>(handle);
+    if (!f) { g_err = "null handle"; return 1; }
+    int n = 0, r = -1, v = 0;
+    ncclResult_t e = ncclCommCount(f->comm, &n);
+    if (e == ncclSuccess) e = ncclCommUserRank(f->comm, &r);
+    if (e == ncclSuccess) e = ncclGetVersion(&v);
+    if (e != ncclSuccess) return fail("ncclCommCount / ncclCommUserRank", e);
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (lower) *lower = f->lower;
+    if (upper) *upper = f->upper;
+    if (version) *version = v;
+    return 0;
+}
+
 int wafer_rccl_detach(wafer_ctx *ctx, void *handle)
 {
     WaferRcclFabric *f = static_cast<WaferRcclFabric *>(handle);

@@ -39,6 +39,7 @@ EXPORTS = [
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_diag_stream_bw", "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
     "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check",
+    "wafer_diag_copy_bw", "wafer_diag_checksum",
 ]
 
 
@@ -131,6 +132,8 @@ def load_library():
     L.wafer_symmetrise.argtypes = [vp, C.c_int]
     L.wafer_download_phi_owned.argtypes = [vp, dp]
     L.wafer_diag_div_check.argtypes = [vp, C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    L.wafer_diag_copy_bw.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
+    L.wafer_diag_checksum.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.wafer_set_initial_condition.argtypes = [vp, C.c_int, C.c_uint64]
     L.wafer_upload_phi.argtypes = [vp, dp]
     L.wafer_download_phi.argtypes = [vp, dp]
@@ -421,6 +424,20 @@ class Context:
         v = C.c_double(0.0)
         self._check(self._L.wafer_diag_stream_bw(self._h, n_reads, iters, C.byref(v)))
         return v.value
+
+    def copy_bandwidth(self, iters: int = 50, unroll: int = 4, blocks_per_cu: int = 8) -> float:
+        """measured GB/s (read + written) of a 16 B-per-lane device copy: the device's own ceiling"""
+        v = C.c_double(0.0)
+        self._check(self._L.wafer_diag_copy_bw(self._h, iters, unroll, blocks_per_cu, C.byref(v)))
+        return v.value
+
+    def checksum(self, z_begin: int = 0, z_count: int | None = None) -> int:
+        """position-dependent integer checksum of the owned work cells of global planes
+        [z_begin, z_begin + z_count): equal bits <=> equal checksums, whatever the decomposition"""
+        v = C.c_uint64(0)
+        n = self.params.nz if z_count is None else z_count
+        self._check(self._L.wafer_diag_checksum(self._h, z_begin, n, C.byref(v)))
+        return int(v.value)
 
     # -- multi-GPU ---------------------------------------------------------------------------------
     def set_comm_hooks(self, halo, allreduce) -> None:

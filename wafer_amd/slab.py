@@ -226,11 +226,15 @@ class NativeRcclSlabComm:
     `self_neighbours=True` (tests): world of one rank whose z-neighbours are itself.
     """
 
-    def __init__(self, ctx, rank: int, world: int, device, group=None, self_neighbours: bool = False):
+    @staticmethod
+    def precheck(rank: int):
+        """Phase 1, LOCAL and free of collectives: load libwafer_rccl.so, bind it, and on rank 0 make
+        the ncclUniqueId.  Returns (library, id buffer); raises on any failure.  make_slab_comm
+        all-reduces whether every rank got through before anyone enters the collective phase 2, so a
+        rank with a missing or unloadable library can no longer leave the others in a broadcast."""
         import ctypes as C
         import os
-        import torch  # before librccl: the process-wide RCCL / HIP runtime are torch's (same sonames)
-        self.torch, self.ctx, self.rank, self.world, self.device = torch, ctx, rank, world, device
+        import torch  # noqa: F401 -- before librccl: the process-wide RCCL / HIP runtime are torch's (same sonames)
         # RCCL's send / recv kernels take whole CUs away from the stencil for as long as the links are
         # busy (their workgroups cannot share a CU with a stencil workgroup); left alone RCCL launches
         # 64 of them for the four transfers of a pass.  8 channels still move the 2 x 17.7 MB of a
@@ -241,17 +245,29 @@ class NativeRcclSlabComm:
         path = os.path.join(here, "libwafer_rccl.so")
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: build it with `python -m wafer_amd.build`")
-        L = self._L = C.CDLL(path)
+        L = C.CDLL(path)
         L.wafer_rccl_last_error.restype = C.c_char_p
         L.wafer_rccl_attach.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.wafer_rccl_warm_up.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.wafer_rccl_detach.argtypes = [C.c_void_p, C.c_void_p]
         L.wafer_rccl_halo_calls.argtypes = [C.c_void_p]
         L.wafer_rccl_halo_calls.restype = C.c_long
-        n = L.wafer_rccl_unique_id_bytes()
-        uid = C.create_string_buffer(n)
+        ip = C.POINTER(C.c_int)
+        L.wafer_rccl_comm_info.argtypes = [C.c_void_p, ip, ip, ip, ip, ip]
+        uid = C.create_string_buffer(L.wafer_rccl_unique_id_bytes())
         if rank == 0 and L.wafer_rccl_unique_id(uid) != 0:
             raise RuntimeError("wafer_rccl_unique_id: " + L.wafer_rccl_last_error().decode())
+        return L, uid
+
+    def __init__(self, ctx, rank: int, world: int, device, group=None, self_neighbours: bool = False, prechecked=None):
+        """Phase 2, COLLECTIVE (broadcast of rank 0's id, ncclCommInitRank): every rank of `group` must
+        call it, which make_slab_comm guarantees by agreeing on phase 1 first."""
+        import ctypes as C
+        import torch
+        self.torch, self.ctx, self.rank, self.world, self.device = torch, ctx, rank, world, device
+        L, uid = prechecked if prechecked is not None else self.precheck(rank)
+        self._L = L
+        n = L.wafer_rccl_unique_id_bytes()
         if world > 1:
             import torch.distributed as dist
             box = [uid.raw]
@@ -274,6 +290,17 @@ class NativeRcclSlabComm:
 
     def halo_calls(self) -> int:
         return int(self._L.wafer_rccl_halo_calls(self._handle))
+
+    def info(self) -> dict:
+        """what RCCL reports for the communicator the hooks use (ncclCommCount, ncclCommUserRank,
+        ncclGetVersion), the z-neighbours in use and the channel limit in force"""
+        import ctypes as C
+        import os
+        v = [C.c_int(-1) for _ in range(5)]
+        if self._L.wafer_rccl_comm_info(self._handle, *[C.byref(x) for x in v]) != 0:
+            raise RuntimeError("wafer_rccl_comm_info: " + self._L.wafer_rccl_last_error().decode())
+        return {"rccl_ranks": v[0].value, "rccl_rank": v[1].value, "lower": v[2].value, "upper": v[3].value,
+                "rccl_version": v[4].value, "NCCL_MAX_P2P_NCHANNELS": os.environ.get("NCCL_MAX_P2P_NCHANNELS")}
 
     def close(self):
         if getattr(self, "_handle", None):
@@ -304,17 +331,31 @@ def make_slab_comm(ctx, rank: int, world: int, device, transport: Optional[str] 
     if transport == "host":
         return HostStagedSlabComm(ctx, rank, world, device), "host-staged gloo"
     if transport == "native":
-        comm, ok = None, 1
-        try:
-            comm = NativeRcclSlabComm(ctx, rank, world, device)
-        except Exception as e:  # noqa: BLE001 -- any failure means "use the torch path"
+        def agreed(ok: int) -> bool:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        def complain(e):
             print(f"wafer_amd.slab: native RCCL hooks unavailable on rank {rank} ({e!r}); falling back to torch.distributed",
                   file=sys.stderr, flush=True)
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            return comm, "RCCL (native hooks)"
-        if comm is not None:
-            comm.close()
+
+        # phase 1: local checks only (library present and loadable, rank 0's unique id) -- agreed on
+        # BEFORE anything collective, so a one-sided failure cannot strand the other ranks
+        pre = None
+        try:
+            pre = NativeRcclSlabComm.precheck(rank)
+        except Exception as e:  # noqa: BLE001 -- any failure means "use the torch path"
+            complain(e)
+        if agreed(1 if pre is not None else 0):
+            # phase 2: id broadcast + ncclCommInitRank on every rank, then agree on the outcome
+            comm = None
+            try:
+                comm = NativeRcclSlabComm(ctx, rank, world, device, prechecked=pre)
+            except Exception as e:  # noqa: BLE001
+                complain(e)
+            if agreed(1 if comm is not None else 0):
+                return comm, "RCCL (native hooks)"
+            if comm is not None:
+                comm.close()
     return TorchSlabComm(ctx, rank, world, device), "RCCL (torch.distributed hooks)"
