@@ -835,10 +835,35 @@ def test_full_size_512_properties(wa):
         ctx.set_initial_condition("Boolean")
         ctx.normalise(ctx.norm2())
         assert ctx.norm2() == pytest.approx(1.0, abs=1e-12)
+        # Gram-Schmidt at the headline size (grid.rs:477-492): the stored state is the evolved sine mode
+        # `got` (not normalised: <l|l> = c), so one projection leaves <l|phi'> = s (1 - c) with s = <l|phi>,
+        # and a second one multiplies that by (1 - c) again -- modified Gram-Schmidt exactly as the
+        # reference applies it, whatever the norm of the stored state
+        c = float(np.sum(got * got))
+        b0 = ctx.download_phi()
+        s = float(np.sum(got * b0))
+        del b0
         ctx.orthogonalise(1)
+        p1 = ctx.download_phi()
+        assert float(np.sum(got * p1)) == pytest.approx(s * (1 - c), rel=1e-9, abs=1e-13 * abs(s) * c)
         ctx.orthogonalise(1)
-        lower = got / np.sqrt(np.sum(got * got))
-        del got, phi
+        p2 = ctx.download_phi()
+        assert float(np.sum(got * p2)) == pytest.approx(s * (1 - c) ** 2, rel=1e-9, abs=1e-13 * abs(s) * c * c)
+        del p1, p2
+        # ... and with an orthoNORMAL store the projection annihilates the overlap and is idempotent
+        ctx.clear_states()
+        lower = got / np.sqrt(c)
+        ctx.load_state(0, lower)
+        ctx.set_initial_condition("Boolean")
+        ctx.normalise(ctx.norm2())
+        ctx.orthogonalise(1)
+        p1 = ctx.download_phi()
+        assert abs(float(np.sum(lower * p1))) < 1e-13 * float(np.sqrt(np.sum(p1 * p1)))
+        ctx.orthogonalise(1)
+        p2 = ctx.download_phi()
+        assert ulp_diff(p1[1:-1, 1:-1, 1:-1], p2[1:-1, 1:-1, 1:-1]) <= 1 or np.max(np.abs(p2 - p1)) < 1e-16
+        assert not p2[0].any() and not p2[:, -1].any()                  # the frame is still zero
+        del got, phi, lower, p1, p2
 
 
 @pytest.mark.skipif(os.environ.get("WAFER_SKIP_BIG") == "1", reason="WAFER_SKIP_BIG=1")

@@ -224,3 +224,228 @@ def test_symmetrise_needs_the_seven_point_frame(oracle):
     phi = np.ones(cfg.padded_shape)
     wo.symmetrise(cfg, "NotConstrained", phi)                  # does nothing, any frame
     assert (phi == 1).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# Independent numpy forms of ALL built-in potentials, written from the text of
+# /root/reference/src/potential.rs:188-319 (+ :326-398) -- not from the oracle's C and not from the
+# engine's HIP, which share an author.  Vectorised over index grids, so a slip that the C and HIP
+# siblings (oracle/wafer_oracle.c:158-243, wafer_setup.hip.h:52-118) have in common would show here.
+# ---------------------------------------------------------------------------------------------
+def np_alphas(mu):
+    """potential.rs:374-391"""
+    nf = 2.0
+    b0 = 11. - 2. * nf / 3.
+    b1 = 51. - 19. * nf / 3.
+    b2 = 2857. - 5033. * nf / 9. + 325. * nf * nf / 27.
+    r = 2.3
+    l = 2. * np.log(mu / r)
+    return (4. * np.pi * (1. - 2. * b1 * np.log(l) / (b0 * b0 * l)
+                          + 4. * b1 * b1 * ((np.log(l) - 0.5) * (np.log(l) - 0.5) + b2 * b0 / (8. * b1 * b1) - 5.0 / 4.0)
+                          / (b0 * b0 * b0 * b0 * l * l)) / (b0 * l))
+
+
+def np_mu(t):
+    """potential.rs:394-398"""
+    nf, tc = 2.0, 0.2
+    return 1.4 * np.sqrt((1. + nf / 6.) * 4. * np.pi * np_alphas(2. * np.pi * t)) * t * tc
+
+
+def np_potential(name, n, ext, dn, mass, sig):
+    """V on the PADDED index grid (potential.rs:46-62 calls potential() with padded indices; every
+    centre is (n + 1) / 2 of the UNPADDED size, potential.rs:366-371)."""
+    nx, ny, nz = n
+    shape = (nx + 2 * ext, ny + 2 * ext, nz + 2 * ext)
+    ix, iy, iz = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")     # integer indices
+    fx, fy, fz = ix.astype(float), iy.astype(float), iz.astype(float)
+    dx, dy, dz = fx - (nx + 1.) / 2., fy - (ny + 1.) / 2., fz - (nz + 1.) / 2.
+    r2 = dx * dx + dy * dy + dz * dz
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if name == "NoPotential":
+            return np.zeros(shape)
+        if name in ("Cube", "QuadWell"):      # :191-210, usize arithmetic: integer division
+            zlo, zhi = (nz // 4, 3 * nz // 4) if name == "Cube" else (3 * nz // 8, 5 * nz // 8)
+            inside = ((ix > nx // 4) & (ix <= 3 * nx // 4) & (iy > ny // 4) & (iy <= 3 * ny // 4)
+                      & (iz > zlo) & (iz <= zhi))
+            return np.where(inside, -10.0, 0.0)
+        if name == "Periodic":                # :211-220
+            t = np.sin(2. * np.pi * (fx - 1.) / (nx - 1.)) ** 2
+            t = t * np.sin(2. * np.pi * (fy - 1.) / (ny - 1.)) ** 2
+            t = t * np.sin(2. * np.pi * (fz - 1.) / (nz - 1.)) ** 2
+            return -t + 1.
+        if name in ("Coulomb", "ComplexCoulomb"):   # :221-229
+            r = dn * np.sqrt(r2)
+            return np.where(r < dn, -1. / dn, -1. / r)
+        if name == "ElipticalCoulomb":        # :230-240
+            dz2 = dz * 2.
+            r = dn * np.sqrt(dx * dx + dy * dy + dz2 * dz2)
+            return np.where(r < dn, 0.0, -1. / r + 1. / dn)
+        if name == "SimpleCornell":           # :241-249
+            r = dn * np.sqrt(r2)
+            return np.where(r < dn, 4. * mass, (-0.5 * (4. / 3.)) / r + sig * r + 4. * mass)
+        if name == "FullCornell":             # :250-269, t = 1, xi = 0
+            t, xi = 1.0, 0.0
+            r = dn * np.sqrt(r2)
+            md = np_mu(t) * (1. + (0.07 * xi ** 0.2) * (1. - dn * dn * dz * dz / (r * r))) * ((1. + xi) ** -0.29)
+            full = ((-np_alphas(2. * np.pi * t) * (4. / 3.)) * np.exp(-md * r) / r + sig * (1. - np.exp(-md * r)) / md
+                    - (0.8 * sig) / (4. * mass * mass * r) + 4. * mass)
+            return np.where(r < dn, 4. * mass, full)
+        if name in ("Harmonic", "ComplexHarmonic"):   # :270-274
+            r = dn * np.sqrt(r2)
+            return r * r / 2.
+        if name == "Dodecahedron":            # :275-312: twelve half-spaces in normalised coordinates
+            x, y, z = dx / ((nx - 1.) / 2.), dy / ((ny - 1.) / 2.), dz / ((nz - 1.) / 2.)
+            A, B, Cc = 12.70820393249937, 11.210068307552588, 14.674169922690343
+            D, E, F = 5.605034153776295, 3.23606797749979, 1.2360679774997896
+            G, H, I_ = 4.23606797749979, 5.23606797749979, 18.1382715378281
+            J, K, Lc = 3.464101615137755, 9.06913576891405, 15.70820393249937
+            M, N_, O = 9.70820393249937, 5.605034153776294, 6.47213595499958
+            P, Q, S_ = 25.41640786499874, 1.7320508075688772, 8.47213595499958
+            inside = ((A + B * x >= Cc * z) & (B * x <= A + Cc * z)
+                      & (D * (E * x - F * z) <= 6. * (G + H * y))
+                      & (I_ * x + J * z <= A)
+                      & (K * x + Lc * y <= A + J * z)
+                      & (M * y <= A + N_ * x + Cc * z)
+                      & (A + N_ * x + M * y + Cc * z >= 0.)
+                      & (Lc * y + J * z <= A + K * x)
+                      & (D * (-O * x - F * z) <= P)
+                      & (J * z <= K * x + 3. * (G + H * y))
+                      & (Q * (E * x + S_ * z) <= 3. * (G + E * y))
+                      & (N_ * x + M * y + Cc * z <= A))
+            return np.where(inside, -100.0, 0.0)
+    raise ValueError(name)
+
+
+def np_potsub(name, n, dn, mass, sig):
+    """pot_sub (potential.rs:134-153, 326-363): ('array', A) on the UNPADDED index grid for FullCornell,
+    ('scalar', s) when s > 0, else ('none', None)"""
+    if name == "FullCornell":                 # :326-340 -- note the grouping differs from potential()'s md
+        nx, ny, nz = n
+        ix, iy, iz = np.meshgrid(*[np.arange(s, dtype=float) for s in n], indexing="ij")
+        dx, dy, dz = ix - (nx + 1.) / 2., iy - (ny + 1.) / 2., iz - (nz + 1.) / 2.
+        r = dn * np.sqrt(dx * dx + dy * dy + dz * dz)
+        t, xi = 1.0, 0.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            md = np_mu(t) * 1. + (0.07 * xi ** 0.2) * (1. - dn * dn * dz * dz / (r * r)) * ((1. + xi) ** -0.29)
+        return "array", sig / md + 4. * mass
+    s = {"ElipticalCoulomb": 1. / dn, "SimpleCornell": 4.0 * mass}.get(name, 0.0)
+    return ("scalar", s) if s > 0.0 else ("none", None)
+
+
+ALL_POTENTIALS = ["NoPotential", "Cube", "QuadWell", "Periodic", "Coulomb", "ComplexCoulomb", "ElipticalCoulomb",
+                  "SimpleCornell", "FullCornell", "Harmonic", "ComplexHarmonic", "Dodecahedron"]
+
+
+def test_reference_vectors_of_the_numpy_forms(ref_vectors):
+    """the numpy forms themselves against the reference's own unit-test values (potential.rs:445-454)"""
+    assert np_alphas(3.2) == pytest.approx(6.189593433886306, abs=1e-14)
+    assert np_mu(5.2) == pytest.approx(2.604838027702063, abs=1e-14)
+
+
+@pytest.mark.parametrize("ext", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(12, 9, 17), (16, 16, 16), (7, 10, 8)])
+@pytest.mark.parametrize("pot", ALL_POTENTIALS)
+def test_every_builtin_potential_vs_numpy_form_of_the_rs_text(oracle, pot, shape, ext):
+    """all 12 closed forms, anisotropic even / odd grids (odd sizes put a cell on r = 0: the r < dn
+    clamps of Coulomb / Cornell and FullCornell's 0/0), every frame width; a, b as potential.rs:101-110"""
+    dn, mass, sig, dt = 0.13, 2.35, 0.223, 1e-3
+    cfg = oracle.Config(*shape, ext=ext, potential=pot, dn=dn, dt=dt, mass=mass, sig=sig)
+    v = oracle.potential_generate(cfg)
+    want = np_potential(pot, shape, ext, dn, mass, sig)
+    assert v.shape == want.shape
+    if pot in ("Periodic", "FullCornell"):     # libm sin / exp / log against numpy's: an ulp or two
+        assert np.allclose(v, want, rtol=1e-13, atol=1e-13)
+    else:
+        assert np.array_equal(v, want)
+    assert np.isfinite(v).all()
+    a, b = oracle.ab(cfg, v)
+    bw = 1. / (1. + dt * v / 2.)
+    assert np.array_equal(b, bw) and np.array_equal(a, (1. - dt * v / 2.) * bw)
+    kind, scalar, arr = oracle.potential_sub(cfg)
+    wk, wv = np_potsub(pot, shape, dn, mass, sig)
+    assert kind == {"none": 0, "scalar": 1, "array": 2}[wk]
+    if wk == "scalar":
+        assert scalar == wv
+    if wk == "array":
+        assert arr.shape == tuple(shape)
+        both_nan = np.isnan(arr) & np.isnan(wv)       # r = 0 on odd grids: 0 * NaN (hazard kept, DESIGN.md section 3)
+        assert np.allclose(arr[~both_nan], wv[~both_nan], rtol=1e-13) and (np.isnan(arr) == np.isnan(wv)).all()
+
+
+def test_potential_clamps_are_exercised():
+    """the grids above really hit the special branches the forms were written for"""
+    v = np_potential("Coulomb", (7, 9, 11), 1, 0.13, 1.0, 1.0)
+    assert np.isfinite(v).all() and v[4, 5, 6] == -1. / 0.13   # the cell with r = 0 < dn (padded index = centre (n+1)/2)
+    assert (v == -1. / 0.13).sum() == 7                     # ... and its six neighbours at r = dn exactly, where -1/r is the same number
+    v = np_potential("SimpleCornell", (7, 9, 11), 2, 0.13, 2.35, 0.223)
+    assert (v == 4 * 2.35).sum() == 1
+    v = np_potential("FullCornell", (7, 9, 11), 1, 0.13, 2.35, 0.223)
+    assert np.isfinite(v).all() and (v == 4 * 2.35).sum() == 1   # md is NaN there, the clamp wins
+    k, a = np_potsub("FullCornell", (7, 9, 11), 0.13, 2.35, 0.223)
+    assert np.isnan(a).sum() == 1
+    d = np_potential("Dodecahedron", (24, 24, 24), 1, 0.1, 1.0, 1.0)
+    assert 0.05 < (d == -100.0).mean() < 0.5                # a solid body, neither empty nor everything
+    c, q = np_potential("Cube", (10, 13, 17), 1, 0.1, 1.0, 1.0), np_potential("QuadWell", (10, 13, 17), 1, 0.1, 1.0, 1.0)
+    assert (c == -10).sum() == 5 * 6 * 8 and (q == -10).sum() == 5 * 6 * 4   # usize division: 10/4=2, 30/4=7 ...
+
+
+# ---------------------------------------------------------------------------------------------
+# Dense-matrix pin (SURVEY.md 8c pin 2): at N <= 8 the Dirichlet operator of every stencil order
+# is built as an explicit matrix, cell by cell from the coefficients of grid.rs:582-588 / 608-620 /
+# 642-659, and one evolve step and the energy sum are compared with plain matrix algebra.
+# ---------------------------------------------------------------------------------------------
+def dense_laplacian(shape, e):
+    """L with (L phi)[cell] = the bracketed sum S at that work cell, zero frame outside"""
+    w, centre, _ = COEFF[e]
+    nx, ny, nz = shape
+    idx = lambda i, j, k: (i * ny + j) * nz + k   # noqa: E731
+    L = np.zeros((nx * ny * nz,) * 2)
+    for i in range(nx):
+        for j in range(ny):
+            for k in range(nz):
+                row = idx(i, j, k)
+                L[row, row] = -centre
+                for off, wt in w.items():
+                    for d in (-off, off):
+                        for ax in range(3):
+                            c = [i, j, k]
+                            c[ax] += d
+                            if 0 <= c[0] < nx and 0 <= c[1] < ny and 0 <= c[2] < nz:   # else: the Dirichlet frame's zero
+                                L[row, idx(*c)] += wt
+    return L
+
+
+@pytest.mark.parametrize("ext", [1, 2, 3])
+@pytest.mark.parametrize("shape,pot", [((6, 5, 7), "Harmonic"), ((8, 8, 8), "Coulomb"), ((4, 7, 5), "NoPotential")])
+def test_dense_matrix_step_and_rayleigh_quotient(oracle, ext, shape, pot):
+    e = ext
+    cfg = oracle.Config(*shape, ext=e, potential=pot, dn=0.3, dt=0.004, mass=1.3)
+    v = oracle.potential_generate(cfg)
+    a, b = oracle.ab(cfg, v)
+    rng = np.random.default_rng(11 * e + shape[0])
+    phi = np.zeros(cfg.padded_shape)
+    phi[e:-e, e:-e, e:-e] = rng.standard_normal(shape)
+    x = phi[e:-e, e:-e, e:-e].reshape(-1)
+    L = dense_laplacian(shape, e)
+    assert np.array_equal(L, L.T)                                   # the discrete operator is symmetric
+    den = COEFF[e][2] * cfg.dn * cfg.dn * cfg.mass
+    vw, aw, bw = (arr[e:-e, e:-e, e:-e].reshape(-1) for arr in (v, a, b))
+    # one evolve step = (diag(a) + dt/den diag(b) L) x      (grid.rs:580-589)
+    want = aw * x + bw * cfg.dt * (L @ x) / den
+    got = phi.copy()
+    oracle.evolve(cfg, 0, a, b, got, [], 1)
+    assert np.allclose(got[e:-e, e:-e, e:-e].reshape(-1), want, rtol=0, atol=1e-12 * np.abs(want).max())
+    assert not got[:e].any() and not got[:, :, -e:].any()          # the frame is never written
+    # energy sum = x^T (diag(V) - L/den) x = x^T H x        (grid.rs:325-332)
+    H = np.diag(vw) - L / den
+    obs = oracle.observables(cfg, v, phi)
+    assert obs["energy"] == pytest.approx(x @ H @ x, rel=1e-11)
+    assert obs["norm2"] == pytest.approx(x @ x, rel=1e-13)
+    # the lowest eigenvalue of H bounds the Rayleigh quotient from below; k steps of evolve from the
+    # dense ground state leave its direction unchanged to O(dt^2)
+    evals, evecs = np.linalg.eigh(H)
+    assert obs["energy"] / obs["norm2"] >= evals[0] - 1e-9
+    g = np.zeros(cfg.padded_shape)
+    g[e:-e, e:-e, e:-e] = evecs[:, 0].reshape(shape)
+    og = oracle.observables(cfg, v, g)
+    assert og["energy"] / og["norm2"] == pytest.approx(evals[0], rel=1e-10, abs=1e-10)
