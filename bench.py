@@ -338,7 +338,7 @@ def run_rank(args) -> int:
             # 8192 pins x 8 Gb/s = 8.19 TB/s, the datasheet's "8 TB/s"
             "hbm_GBps_from_props": 4.0 * mclk_khz * 1e3 * width / 8 / 1e9,
             # read + written bytes of a device-to-device copy of one array (wafer_k_copy16)
-            "measured_copy_GBps": round(ctx.copy_bandwidth(100, 4, 8), 1),
+            "measured_copy_GBps": round(ctx.copy_bandwidth(100, 4, 1), 1),   # the best setting of tools/copy_sweep.py (profiles/r02_copy_sweep.jsonl)
         }
     except Exception as e:  # informational
         device_info = {"error": repr(e)}

@@ -11,117 +11,6 @@
 #include "wafer_geom.h"
 #include "wafer_stencil.hip.h"
 
-struct WaferEwArgs {
-    WaferGeom g;
-    int lz_lo, lz_hi; // local planes to touch
-    int zchunk;
-};
-
-// Common thread -> column mapping of the elementwise kernels:
-// grid (ceil(nx/64), ceil(ny/4), nchunks), block (64,4), work cells only
-// (frame cells are zero in every array, so the reference's whole-padded-array
-// passes (grid.rs:467, 483-490) and these work-area passes agree).
-#define WAFER_EW_PROLOGUE(R_)                                                          \
-    const WaferGeom &g = a.g;                                                          \
-    const int i = blockIdx.x * 64 + threadIdx.x;                                       \
-    const int j = blockIdx.y * 4 + threadIdx.y;                                        \
-    const int zs = a.lz_lo + blockIdx.z * a.zchunk;                                    \
-    const int ze = min(zs + a.zchunk, a.lz_hi);                                        \
-    const bool active = (i < g.nx) && (j < g.ny);                                      \
-    const long long col = (long long)(j + (R_)) * g.pitch + g.xoff + (i + (R_));       \
-    const int tid = threadIdx.y * 64 + threadIdx.x;                                    \
-    const size_t blin = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-
-// get_norm_squared (grid.rs:454-457)
-template <typename T>
-__global__ __launch_bounds__(256) void wafer_k_norm2(WaferEwArgs a, const T *__restrict__ phi,
-                                                     double *__restrict__ partials)
-{
-    __shared__ double red[4];
-    WAFER_EW_PROLOGUE(g.R)
-    double acc = 0.0;
-    if (active)
-        for (int z = zs; z < ze; ++z) {
-            const double el = (double)phi[col + (long long)z * g.plane];
-            acc += el * el;
-        }
-    const double s = wafer_block_sum<4>(acc, red, tid);
-    if (tid == 0) partials[blin] = s;
-}
-
-// normalise_wavefunction (grid.rs:465-468): el /= sqrt(norm2), fused with the
-// first Gram-Schmidt overlap sum_l0 (grid.rs:482-487) when `lower` != nullptr.
-// norm2 comes from *norm2_dev if non-null, else norm2_imm.
-template <typename T, typename C>
-__global__ __launch_bounds__(256) void wafer_k_normalise_dot(WaferEwArgs a, T *__restrict__ phi,
-                                                             const double *__restrict__ norm2_dev,
-                                                             double norm2_imm,
-                                                             const T *__restrict__ lower,
-                                                             double *__restrict__ partials)
-{
-    __shared__ double red[4];
-    WAFER_EW_PROLOGUE(g.R)
-    const double norm2 = norm2_dev ? *norm2_dev : norm2_imm;
-    const C norm = (C)sqrt(norm2);
-    double acc = 0.0;
-    if (active)
-        for (int z = zs; z < ze; ++z) {
-            const long long p = col + (long long)z * g.plane;
-            const T r = (T)wafer_div_invariant<C>((C)phi[p], norm);
-            phi[p] = r;
-            if (lower) acc += (double)((C)lower[p] * (C)r);
-        }
-    if (lower) {
-        const double s = wafer_block_sum<4>(acc, red, tid);
-        if (tid == 0) partials[blin] = s;
-    }
-}
-
-// Gram-Schmidt projection *w -= lower * overlap_sum (grid.rs:488-490), fused
-// with the NEXT lower state's overlap (modified Gram-Schmidt order is kept:
-// the next overlap is taken with the already-projected phi).
-template <typename T, typename C>
-__global__ __launch_bounds__(256) void wafer_k_axpy_dot(WaferEwArgs a, T *__restrict__ phi,
-                                                        const T *__restrict__ lower,
-                                                        const double *__restrict__ overlap_dev,
-                                                        const T *__restrict__ next,
-                                                        double *__restrict__ partials)
-{
-    __shared__ double red[4];
-    WAFER_EW_PROLOGUE(g.R)
-    const C s = (C)(*overlap_dev);
-    double acc = 0.0;
-    if (active)
-        for (int z = zs; z < ze; ++z) {
-            const long long p = col + (long long)z * g.plane;
-            const T r = (T)((C)phi[p] - (C)lower[p] * s);
-            phi[p] = r;
-            if (next) acc += (double)((C)next[p] * (C)r);
-        }
-    if (next) {
-        const double t = wafer_block_sum<4>(acc, red, tid);
-        if (tid == 0) partials[blin] = t;
-    }
-}
-
-// plain overlap sum_l (lower * phi), used by wafer_orthogonalise's first state
-template <typename T, typename C>
-__global__ __launch_bounds__(256) void wafer_k_dot(WaferEwArgs a, const T *__restrict__ phi,
-                                                   const T *__restrict__ lower,
-                                                   double *__restrict__ partials)
-{
-    __shared__ double red[4];
-    WAFER_EW_PROLOGUE(g.R)
-    double acc = 0.0;
-    if (active)
-        for (int z = zs; z < ze; ++z) {
-            const long long p = col + (long long)z * g.plane;
-            acc += (double)((C)lower[p] * (C)phi[p]);
-        }
-    const double s = wafer_block_sum<4>(acc, red, tid);
-    if (tid == 0) partials[blin] = s;
-}
-
 // Fixed-order second stage: out[q] = sum of partials[q*stride .. q*stride+n).
 // One 256-thread block per quantity; strided serial sums, then an LDS tree.
 __global__ __launch_bounds__(256) void wafer_k_reduce(const double *__restrict__ partials,
@@ -154,6 +43,78 @@ struct WaferRowArgs {
 template <typename T> struct WaferRowVec;
 template <> struct WaferRowVec<double> { static constexpr int N = 2; typedef double __attribute__((ext_vector_type(2))) type; };
 template <> struct WaferRowVec<float> { static constexpr int N = 4; typedef float __attribute__((ext_vector_type(4))) type; };
+
+// The once-per-block elementwise passes of solve (grid.rs:126-135) and of the kernel-per-projection
+// excited-state path, all on the row-vectorised walk (16 B per lane):
+//   OP 0  get_norm_squared (grid.rs:454-457):            partial sums of phi^2
+//   OP 1  overlap sum(lower * phi) (grid.rs:482-487)
+//   OP 2  normalise_wavefunction (grid.rs:465-468): phi /= sqrt(norm2), fused with the first overlap
+//         sum(lower * phi) when `lower` is given; norm2 = *scal_dev if non-null, else imm
+//   OP 3  Gram-Schmidt projection phi -= lower * s (grid.rs:488-490), s = *scal_dev, fused with the NEXT
+//         state's overlap (taken with the already-projected phi: modified Gram-Schmidt order is kept)
+// Work cells only: frame cells are zero in every array, so the reference's whole-padded-array passes
+// and these work-area passes agree.  One partial per workgroup, summed in a fixed order.
+template <typename T, typename C, int OP>
+__global__ __launch_bounds__(256) void wafer_k_row_op(WaferRowArgs a, T *__restrict__ phi, const T *__restrict__ lower,
+                                                      const T *__restrict__ next, const double *__restrict__ scal_dev,
+                                                      double imm, double *__restrict__ partials)
+{
+    using VT = typename WaferRowVec<T>::type;
+    constexpr int VEC = WaferRowVec<T>::N;
+    __shared__ double red[4];
+    const WaferGeom &g = a.g;
+    const double sval = scal_dev ? *scal_dev : imm;
+    const C coef = (OP == 2) ? (C)sqrt(sval) : (C)sval;
+    const T *dotwith = (OP == 1 || OP == 2) ? lower : (OP == 3 ? next : nullptr);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nsegx = (g.nx + 64 * VEC - 1) / (64 * VEC);
+    const long long total = (long long)(a.lz_hi - a.lz_lo) * g.ny * nsegx;
+    const int wlim = g.pitch - g.xoff - g.R;
+    double acc = 0.0;
+    for (long long seg = (long long)blockIdx.x * 4 + wave; seg < total; seg += (long long)gridDim.x * 4) {
+        const int xs = (int)(seg % nsegx);
+        const long long t = seg / nsegx;
+        const int y = (int)(t % g.ny), z = a.lz_lo + (int)(t / g.ny);
+        const int xi = xs * 64 * VEC + lane * VEC;
+        if (xi >= wlim || xi >= g.nx) continue;
+        const long long p = (long long)z * g.plane + (long long)(y + g.R) * g.pitch + g.xoff + g.R + xi;
+        VT w = *reinterpret_cast<const VT *>(phi + p);
+        if constexpr (OP == 2) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) w[v] = (T)wafer_div_invariant<C>((C)w[v], coef);
+        }
+        if constexpr (OP == 3) {
+            const VT l = __builtin_nontemporal_load(reinterpret_cast<const VT *>(lower + p));
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) w[v] = (T)((C)w[v] - (C)l[v] * coef);
+        }
+        if constexpr (OP >= 2) {
+            if (xi + VEC <= g.nx) {
+                *reinterpret_cast<VT *>(phi + p) = w;
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (xi + v < g.nx) phi[p + v] = w[v];
+            }
+        }
+        if constexpr (OP == 0) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (xi + v < g.nx) acc += (double)w[v] * (double)w[v];
+        } else {
+            if (dotwith) {
+                const VT d = __builtin_nontemporal_load(reinterpret_cast<const VT *>(dotwith + p));
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (xi + v < g.nx) acc += (double)((C)d[v] * (C)w[v]);
+            }
+        }
+    }
+    if (OP <= 1 || dotwith) {
+        const double s = wafer_block_sum<4>(acc, red, threadIdx.x);
+        if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    }
+}
 
 // Normalise + the whole modified Gram-Schmidt chain of one excited-state step
 // (grid.rs:679-680) in ONE pass.  The step kernel has left in scal[]:

@@ -473,17 +473,29 @@ static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
 }
 
 
-// elementwise launches -------------------------------------------------------
-static WaferEwArgs ew_args(wafer_ctx *c, int *nblocks, dim3 *grid)
+// elementwise launches (wafer_k_row_op) -----------------------------------------
+// OP 0 norm2, 1 dot, 2 normalise (+ dot), 3 axpy (+ dot).  Returns the number of partial sums through *nb.
+template <int OP>
+static int launch_row_op(wafer_ctx *c, void *phi, const void *lower, const void *next, const double *scal_dev, double imm,
+                         hipStream_t s, int *nb)
 {
-    WaferEwArgs a;
-    a.g = c->g;
-    a.lz_lo = c->g.G;
-    a.lz_hi = c->g.G + c->g.nzl;
-    a.zchunk = pick_zchunk(c, c->g.nzl, env_int("WAFER_TARGET_BLOCKS", 4096));
-    *grid = dim3(c->bx, c->by, nchunks_of(c->g.nzl, a.zchunk));
-    *nblocks = (int)(grid->x * grid->y * grid->z);
-    return a;
+    WaferRowArgs ra;
+    ra.g = c->g;
+    ra.lz_lo = c->g.G;
+    ra.lz_hi = c->g.G + c->g.nzl;
+    // eight workgroups per CU, fewer on grids with fewer 1 KiB row segments than that
+    const long long segs = (long long)c->g.nzl * c->g.ny * ((c->g.nx + (int)(1024 / c->esz) - 1) / (int)(1024 / c->esz));
+    const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((long long)c->num_cus * 8, (segs + 3) / 4))), block(256);
+    *nb = (int)grid.x;
+    if ((size_t)grid.x > c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
+    return dispatch(c, [&](auto t, auto cc, auto) {
+        using T = decltype(t);
+        using C = decltype(cc);
+        hipLaunchKernelGGL((wafer_k_row_op<T, C, OP>), grid, block, 0, s, ra, as<T>(phi), as<T>(lower), as<T>(next), scal_dev, imm,
+                           c->partials);
+        HIP_TRY(hipGetLastError());
+        return (int)WAFER_OK;
+    });
 }
 
 // normalise (+ optional overlap with lower) on buffer `buf`; norm2 from scal[slot] or immediate
@@ -491,16 +503,7 @@ static int launch_normalise(wafer_ctx *c, int buf, const double *norm2_dev, doub
                             void *lower, int out_slot, hipStream_t s)
 {
     int nb;
-    dim3 grid;
-    WaferEwArgs a = ew_args(c, &nb, &grid);
-    TRY(dispatch(c, [&](auto t, auto cc, auto) {
-        using T = decltype(t);
-        using C = decltype(cc);
-        hipLaunchKernelGGL((wafer_k_normalise_dot<T, C>), grid, dim3(64, 4), 0, s, a, as<T>(c->phi[buf]),
-                           norm2_dev, norm2_imm, (const T *)lower, c->partials);
-        HIP_TRY(hipGetLastError());
-        return (int)WAFER_OK;
-    }));
+    TRY(launch_row_op<2>(c, c->phi[buf], lower, nullptr, norm2_dev, norm2_imm, s, &nb));
     if (lower) TRY(reduce_to_scal(c, 1, nb, out_slot, s));
     return WAFER_OK;
 }
@@ -509,33 +512,15 @@ static int launch_axpy(wafer_ctx *c, int buf, void *lower, int overlap_slot, voi
                        hipStream_t s)
 {
     int nb;
-    dim3 grid;
-    WaferEwArgs a = ew_args(c, &nb, &grid);
-    TRY(dispatch(c, [&](auto t, auto cc, auto) {
-        using T = decltype(t);
-        using C = decltype(cc);
-        hipLaunchKernelGGL((wafer_k_axpy_dot<T, C>), grid, dim3(64, 4), 0, s, a, as<T>(c->phi[buf]),
-                           (const T *)lower, c->scal + overlap_slot, (const T *)next, c->partials);
-        HIP_TRY(hipGetLastError());
-        return (int)WAFER_OK;
-    }));
+    TRY(launch_row_op<3>(c, c->phi[buf], lower, next, c->scal + overlap_slot, 0.0, s, &nb));
     if (next) TRY(reduce_to_scal(c, 1, nb, out_slot, s));
     return WAFER_OK;
 }
 
-static int launch_dot(wafer_ctx *c, int buf, void *lower, int out_slot, hipStream_t s)
+static int launch_dot(wafer_ctx *c, void *phi, void *lower, int out_slot, hipStream_t s)
 {
     int nb;
-    dim3 grid;
-    WaferEwArgs a = ew_args(c, &nb, &grid);
-    TRY(dispatch(c, [&](auto t, auto cc, auto) {
-        using T = decltype(t);
-        using C = decltype(cc);
-        hipLaunchKernelGGL((wafer_k_dot<T, C>), grid, dim3(64, 4), 0, s, a, as<T>(c->phi[buf]),
-                           (const T *)lower, c->partials);
-        HIP_TRY(hipGetLastError());
-        return (int)WAFER_OK;
-    }));
+    TRY(launch_row_op<1>(c, phi, lower, nullptr, nullptr, 0.0, s, &nb));
     return reduce_to_scal(c, 1, nb, out_slot, s);
 }
 
@@ -544,7 +529,7 @@ static int launch_dot(wafer_ctx *c, int buf, void *lower, int out_slot, hipStrea
 static int gs_chain(wafer_ctx *c, int buf, uint32_t wnum, bool first_dot_done, hipStream_t s)
 {
     if (wnum == 0) return WAFER_OK;
-    if (!first_dot_done) TRY(launch_dot(c, buf, c->states[0], 1, s));
+    if (!first_dot_done) TRY(launch_dot(c, c->phi[buf], c->states[0], 1, s));
     for (uint32_t l = 0; l < wnum; ++l) {
         void *next = (l + 1 < wnum) ? c->states[l + 1] : nullptr;
         TRY(launch_axpy(c, buf, c->states[l], 1 + (int)l, next, 2 + (int)l, s));
@@ -559,18 +544,7 @@ static int recompute_gram(wafer_ctx *c)
     memset(c->gram_host, 0, sizeof c->gram_host);
     for (size_t j = 1; j < n; ++j)
         for (size_t i = 0; i < j; ++i) {
-            int nb;
-            dim3 grid;
-            WaferEwArgs a = ew_args(c, &nb, &grid);
-            TRY(dispatch(c, [&](auto t, auto cc, auto) {
-                using T = decltype(t);
-                using C = decltype(cc);
-                hipLaunchKernelGGL((wafer_k_dot<T, C>), grid, dim3(64, 4), 0, c->s_main, a, as<T>(c->states[j]),
-                                   as<T>(c->states[i]), c->partials);
-                HIP_TRY(hipGetLastError());
-                return (int)WAFER_OK;
-            }));
-            TRY(reduce_to_scal(c, 1, nb, 13, c->s_main));
+            TRY(launch_dot(c, c->states[j], c->states[i], 13, c->s_main));
             TRY(read_scal(c, 13, 1, &c->gram_host[j * WAFER_MAX_LOW + i], c->s_main));
         }
     HIP_TRY(hipMemcpyAsync(c->gram, c->gram_host, sizeof c->gram_host, hipMemcpyHostToDevice, c->s_main));
@@ -778,7 +752,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     void **arrays[] = {&c->phi[0], &c->phi[1], &c->v};
     for (void **arr : arrays)
         if (alloc_grid_array(c, arr, c->s_main) != WAFER_OK) return cleanup_fail(WAFER_ERR_HIP);
-    c->partials_stride = (size_t)c->bx * c->by * 64 + 1024;
+    c->partials_stride = std::max<size_t>((size_t)c->bx * c->by * 64 + 1024, (size_t)c->num_cus * 8); // column kernels / row kernels
     HIP_TRYC(hipMalloc((void **)&c->partials, sizeof(double) * (WAFER_MAX_LOW + 1) * c->partials_stride));
     HIP_TRYC(hipMalloc((void **)&c->gram, sizeof(double) * WAFER_MAX_LOW * WAFER_MAX_LOW));
     HIP_TRYC(hipMemsetAsync(c->gram, 0, sizeof(double) * WAFER_MAX_LOW * WAFER_MAX_LOW, c->s_main));
@@ -1410,26 +1384,49 @@ int wafer_observables(wafer_ctx *c, wafer_observables_t *out)
     HIP_TRY(hipSetDevice(c->P.device));
     RoctxRange range_("wafer_observables");
     TRY(ensure_halo(c, c->g.R));
-    WaferObsArgs a;
-    a.g = c->g;
-    a.zchunk = pick_zchunk(c, c->g.nzl, env_int("WAFER_TARGET_BLOCKS", 4096));
-    const dim3 grid(c->bx, c->by, nchunks_of(c->g.nzl, a.zchunk));
-    a.nblocks = (long long)c->partials_stride;
-    const long long nb = (long long)grid.x * grid.y * grid.z;
-    if ((size_t)nb > c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
     const int R = c->g.R;
     const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
-    a.den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:314 / 337 / 367
-    a.potsub_kind = c->potsub_kind;
-    a.potsub_scalar = c->potsub_scalar;
-    TRY(dispatch(c, [&](auto t, auto, auto r) {
-        using T = decltype(t);
-        constexpr int RR = decltype(r)::value;
-        hipLaunchKernelGGL((wafer_k_observables<T, RR>), grid, dim3(64, 4), 0, c->s_main, a,
-                           as<T>(c->phi[c->cur]), as<T>(c->v), as<T>(c->potsub), c->partials);
-        HIP_TRY(hipGetLastError());
-        return (int)WAFER_OK;
-    }));
+    const double den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:314 / 337 / 367
+    long long nb = 0;
+    if (env_int("WAFER_OBS_LDS", 1) != 0) {
+        // the LDS pipeline of the step kernel in its observables mode: 16 B per lane from HBM
+        WaferStepArgs sa{};
+        sa.g = c->g;
+        sa.lz_lo = c->g.G;
+        sa.lz_hi = c->g.G + c->g.nzl;
+        sa.dt = c->P.dt;
+        sa.den = den;
+        sa.target_blocks = c->num_cus;
+        sa.potsub_kind = c->potsub_kind;
+        sa.potsub_scalar = c->potsub_scalar;
+        TRY(dispatch(c, [&](auto t, auto, auto r) {
+            using T = decltype(t);
+            constexpr int RR = decltype(r)::value;
+            if (wafer_launch_observables_lds<T, RR>(sa, as<T>(c->phi[c->cur]), as<T>(c->v), as<T>(c->potsub), c->partials,
+                                                    c->partials_stride, c->s_main, &nb) != hipSuccess)
+                return fail(WAFER_ERR_HIP, "observables launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return (int)WAFER_OK;
+        }));
+    } else {
+        WaferObsArgs a;
+        a.g = c->g;
+        a.zchunk = pick_zchunk(c, c->g.nzl, env_int("WAFER_TARGET_BLOCKS", 4096));
+        const dim3 grid(c->bx, c->by, nchunks_of(c->g.nzl, a.zchunk));
+        a.nblocks = (long long)c->partials_stride;
+        nb = (long long)grid.x * grid.y * grid.z;
+        if ((size_t)nb > c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
+        a.den = den;
+        a.potsub_kind = c->potsub_kind;
+        a.potsub_scalar = c->potsub_scalar;
+        TRY(dispatch(c, [&](auto t, auto, auto r) {
+            using T = decltype(t);
+            constexpr int RR = decltype(r)::value;
+            hipLaunchKernelGGL((wafer_k_observables<T, RR>), grid, dim3(64, 4), 0, c->s_main, a,
+                               as<T>(c->phi[c->cur]), as<T>(c->v), as<T>(c->potsub), c->partials);
+            HIP_TRY(hipGetLastError());
+            return (int)WAFER_OK;
+        }));
+    }
     TRY(reduce_to_scal(c, 4, nb, 8, c->s_main));
     double r[4];
     TRY(read_scal(c, 8, 4, r, c->s_main));
@@ -1446,13 +1443,7 @@ int wafer_norm2(wafer_ctx *c, double *out)
     if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
     HIP_TRY(hipSetDevice(c->P.device));
     int nb;
-    dim3 grid;
-    WaferEwArgs a = ew_args(c, &nb, &grid);
-    if (c->f32)
-        hipLaunchKernelGGL((wafer_k_norm2<float>), grid, dim3(64, 4), 0, c->s_main, a, as<float>(c->phi[c->cur]), c->partials);
-    else
-        hipLaunchKernelGGL((wafer_k_norm2<double>), grid, dim3(64, 4), 0, c->s_main, a, as<double>(c->phi[c->cur]), c->partials);
-    HIP_TRY(hipGetLastError());
+    TRY(launch_row_op<0>(c, c->phi[c->cur], nullptr, nullptr, nullptr, 0.0, c->s_main, &nb));
     TRY(reduce_to_scal(c, 1, nb, 12, c->s_main));
     return read_scal(c, 12, 1, out, c->s_main);
 }

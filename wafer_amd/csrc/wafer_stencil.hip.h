@@ -125,6 +125,9 @@ struct WaferStepArgs {
     // planes; nsub <= 1: every tile is cut into workgroups of zchunk planes
     int n_long, nsub;
     double dt, den;
+    // observables mode of the LDS kernel (NLOW = -2): wafer_potsub_kind and the scalar pot_sub
+    int potsub_kind = 0;
+    double potsub_scalar = 0.0;
 };
 
 // ---------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 // that hit L2 / Infinity Cache.  No MFMA: 12-42 flop per 32 B is bandwidth bound.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "wafer_geom.h"
 #include "wafer_stencil.hip.h"
 
@@ -126,6 +127,11 @@ __device__ __forceinline__ void wafer_st_stream(VT *p, VT v)
 //   x = phi/norm - sum_j l_j s_j        (grid.rs:467, 488-490; the operations of wafer_k_gs_apply)
 // with norm and s_j formed from the previous step's scalars xscal[0..NLOW] and the Gram matrix.
 // That folds the apply pass into the next step: (3+k)*8 B per update instead of (5+2k)*8 B.
+// NLOW = -2: compute_observables (grid.rs:303-445) on the same pipeline -- `pa` is V, nothing is
+// written, and the four work-area sums (energy integrand V w^2 - w S / den, w^2, w^2 pot_sub,
+// w^2 r^2 with the WORK-area index, grid.rs:429-435) go to partials[q * pstride + workgroup];
+// an array pot_sub rides in low.p[0].  16 B per lane from HBM instead of the scalar loads of
+// wafer_k_observables (kept as the plain reference kernel: WAFER_OBS_LDS=0).
 template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty, int swz,
                                                         const T *__restrict__ phi,
@@ -137,8 +143,10 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                                                         const double *__restrict__ xgram = nullptr)
 {
     constexpr bool NORM = NLOW >= 0;
+    constexpr bool OBS = NLOW == -2;
     constexpr int NL = NLOW > 0 ? NLOW : 0;
     static_assert(!XF || NL > 0, "transform-on-load needs stored states");
+    static_assert(!OBS || (ABV && std::is_same<C, double>::value), "observables: V in pa's slot, fp64 sums");
     using Cfg = WaferLdsCfg<T, R, RY, NW>;
     using VT = typename WaferVec<T>::type;
     constexpr int VEC = Cfg::VEC, TX = Cfg::TX, TY = Cfg::TY, HX = Cfg::HX, LP = Cfg::LP;
@@ -312,6 +320,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
     double acc_t[NL > 0 ? NL : 1];
 #pragma unroll
     for (int j = 0; j < NL; ++j) acc_t[j] = 0.0;
+    double ob_e = 0.0, ob_n = 0.0, ob_v = 0.0, ob_r = 0.0; // OBS: the four sums of grid.rs:405-437
     for (int z = zs; z < ze; ++z) {
         const bool more = z + 1 < ze;   // wave-uniform
         const long long zo = (long long)z * g.plane;
@@ -364,9 +373,14 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
 
         // ---- 3. update plane z
         const T *ct = lds + (z & 1) * Cfg::TILE;
+        [[maybe_unused]] const double ob_dz = (double)(g.z_begin + (z - g.G)) - ((double)g.nz + 1.) / 2.;
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             VT res;
+            [[maybe_unused]] VT psub = zero;
+            if constexpr (OBS) {
+                if (a.potsub_kind == 2) psub = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(static_cast<const T *>(low.p[0]) + zo + rowoff[r]));
+            }
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
@@ -385,6 +399,21 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                     }
                 }
                 const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
+                if constexpr (OBS) {
+                    if (rowin[r] && xi + v < g.nx) {
+                        const double vv = (double)ab_a[r][v];
+                        ob_e += vv * w * w - w * S / a.den; // grid.rs:325-332
+                        ob_n += w * w;                      // grid.rs:407
+                        if (a.potsub_kind == 2) ob_v += w * w * (double)psub[v];      // grid.rs:410-418
+                        else if (a.potsub_kind == 1) ob_v += w * w * a.potsub_scalar; // grid.rs:419-424
+                        // potential::calculate_r2 on the WORK-AREA index (grid.rs:429-435, potential.rs:366-371)
+                        const double dx = (double)(xi + v) - ((double)g.nx + 1.) / 2.;
+                        const double dy = (double)(y0 + yl + r) - ((double)g.ny + 1.) / 2.;
+                        ob_r += w * w * (dx * dx + dy * dy + ob_dz * ob_dz); // grid.rs:428-437
+                    }
+                    res[v] = T(0);
+                    continue;
+                }
                 C ca, cb;
                 if constexpr (ABV) { // potential.rs:104-110
                     const C vv = (C)ab_a[r][v];
@@ -404,7 +433,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                     }
                 }
             }
-            if (rowin[r]) {
+            if (!OBS && rowin[r]) {
                 T *dst = out + zo + rowoff[r];
                 if (xi + VEC <= g.nx) {
                     wafer_st_stream<NT>(reinterpret_cast<VT *>(dst), res);
@@ -440,6 +469,14 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                     for (int j = 0; j < NL; ++j) lq[m][r][j] = lq[m + 1][r][j];
         }
     }
+    if constexpr (OBS) {
+        const double sums[4] = {ob_e, ob_n, ob_v, ob_r};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double s = wafer_block_sum<NW>(sums[q], red, tid);
+            if (tid == 0) partials[(size_t)q * pstride + blockIdx.x] = s;
+        }
+    }
     if constexpr (NORM) {
         const double s = wafer_block_sum<NW>(acc, red, tid);
         if (tid == 0) partials[blockIdx.x] = s;
@@ -465,7 +502,7 @@ static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLd
     const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
     const long long nblocks = (long long)ntx * nty * ntz;
-    if (NLOW >= 0 && (size_t)nblocks > partials_cap) return hipErrorInvalidValue;
+    if ((NLOW >= 0 || NLOW == -2) && (size_t)nblocks > partials_cap) return hipErrorInvalidValue;
     hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NLOW, NT, ABV, XF, NW>), dim3((unsigned)nblocks), dim3(Cfg::NT), (size_t)o.pad, s,
                        a, ntx, nty, o.swz, phi, pa, pb, out, partials, (long long)partials_cap, low, xscal, xgram);
     return hipGetLastError();
@@ -523,6 +560,24 @@ static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T 
     case 4: return wafer_launch_step_lds_ry<T, C, R, 2, 4, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
     default: return hipErrorInvalidValue;
     }
+}
+
+// compute_observables on the LDS pipeline: 8 waves on 128x16 tiles (ThreePoint / FivePoint), 4 waves on
+// 128x8 (SevenPoint).  *nblocks_out = partial sums written per quantity.
+template <typename T, int R>
+static inline hipError_t wafer_launch_observables_lds(WaferStepArgs a, const T *phi, const T *pv, const T *potsub,
+                                                      double *partials, size_t partials_cap, hipStream_t s, long long *nblocks_out)
+{
+    WaferLdsOpts o = wafer_lds_opts();
+    o.ry = 2;
+    constexpr int NW = R <= 2 ? 8 : 4;
+    using Cfg = WaferLdsCfg<T, R, 2, NW>;
+    WaferLowPtrs low;
+    low.p[0] = potsub;
+    if (NW == 8) a.target_blocks = (a.target_blocks + 1) / 2; // one workgroup per CU
+    const int zc = wafer_lds_zchunk<T, R>(a.g, a.lz_hi - a.lz_lo, 2 * (NW / 4), a.target_blocks);
+    *nblocks_out = (long long)((a.g.nx + Cfg::TX - 1) / Cfg::TX) * ((a.g.ny + Cfg::TY - 1) / Cfg::TY) * ((a.lz_hi - a.lz_lo + zc - 1) / zc);
+    return wafer_launch_step_lds_ry<T, double, R, 2, -2, true, true, false, NW>(a, o, phi, pv, pv, nullptr, partials, partials_cap, s, low);
 }
 
 template <typename T, int R>

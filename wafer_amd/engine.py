@@ -425,7 +425,7 @@ class Context:
         self._check(self._L.wafer_diag_stream_bw(self._h, n_reads, iters, C.byref(v)))
         return v.value
 
-    def copy_bandwidth(self, iters: int = 50, unroll: int = 4, blocks_per_cu: int = 8) -> float:
+    def copy_bandwidth(self, iters: int = 50, unroll: int = 4, blocks_per_cu: int = 1) -> float:
         """measured GB/s (read + written) of a 16 B-per-lane device copy: the device's own ceiling"""
         v = C.c_double(0.0)
         self._check(self._L.wafer_diag_copy_bw(self._h, iters, unroll, blocks_per_cu, C.byref(v)))
