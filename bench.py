@@ -294,8 +294,10 @@ def run_rank(args) -> int:
                                 central_difference=ext, dtype=args.dtype, max_states=1, device=local_rank,
                                 z_begin=zb, z_count=zc, halo_depth=halo)
 
-    # 2*ext ghost planes: two fused steps per exchange
-    ctx = wafer_amd.Context(make_params(z_begin, z_count, 2 * ext if world > 1 else 0))
+    # 2*ext ghost planes: two fused steps per exchange; 4*ext where the slabs are thick enough, so that
+    # the set-up trial can also time one exchange per TWO fused passes (wafer_set_halo_cycle)
+    deep = world > 1 and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 8 * ext
+    ctx = wafer_amd.Context(make_params(z_begin, z_count, (4 * ext if deep else 2 * ext) if world > 1 else 0))
     if args.variant >= 0:
         ctx.set_stencil_variant(args.variant)
     comm, transport_name = None, None
@@ -353,8 +355,9 @@ def run_rank(args) -> int:
     overlap_choice = None
     if dist is not None and os.environ.get("WAFER_OVERLAP", "") == "" and args.steps >= 8:
         trial = {}
-        for mode in (1, 2, 3, 0):
+        for mode, cycle in [(1, 1), (2, 1), (3, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []):
             ctx.set_overlap(mode)
+            ctx.set_halo_cycle(cycle)
             ctx.evolve(0, 8)
             barrier()
             t_ = time.perf_counter()
@@ -362,14 +365,17 @@ def run_rank(args) -> int:
             barrier()
             tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            trial[mode] = float(tt[0]) / 40 * 1e3
-        best = min(trial, key=lambda m: trial[m] * (1.0 if m == 1 else 1.02))
-        ctx.set_overlap(best)
-        overlap_choice = {"mode": best, "ms_per_step": {"1_overlap": trial[1], "2_overlap_boundary_in_stream": trial[2],
-                                                        "3_overlap_alternating_streams": trial[3], "0_no_overlap": trial[0]}}
+            trial[(mode, cycle)] = float(tt[0]) / 40 * 1e3
+        best = min(trial, key=lambda k: trial[k] * (1.0 if k == (1, 1) else 1.02))
+        ctx.set_overlap(best[0])
+        ctx.set_halo_cycle(best[1])
+        names = {1: "1_overlap", 2: "2_overlap_boundary_in_stream", 3: "3_overlap_alternating_streams", 0: "0_no_overlap"}
+        overlap_choice = {"mode": best[0], "fused_passes_per_exchange": best[1],
+                          "ms_per_step": {names[m] + ("" if cy == 1 else f"_exchange_every_{cy}_passes"): v for (m, cy), v in trial.items()}}
         ctx.set_initial_condition("Boolean")
     elif dist is not None:
-        overlap_choice = {"mode": int(os.environ.get("WAFER_OVERLAP", "1") or 1), "ms_per_step": None}
+        ctx.set_halo_cycle(1)
+        overlap_choice = {"mode": int(os.environ.get("WAFER_OVERLAP", "1") or 1), "fused_passes_per_exchange": 1, "ms_per_step": None}
 
     # ---- the timed region ------------------------------------------------------------------------
     if args.warmup > 0:

@@ -283,6 +283,12 @@ int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn 
  * fused pass (the next pass's boundary kernels follow the interior in stream order: one event hop less per
  * pass; ground-state fused passes only, otherwise as 1).  All modes give identical results. */
 int wafer_set_overlap(wafer_ctx *ctx, int enabled);
+/* z-slabs, ground state: fused passes (two time steps each) per halo exchange.  With `passes` > 1 the
+ * exchange moves 2 * ext * passes planes at once and the passes in between run unsplit over the owned
+ * planes plus the ghost planes that are still valid -- fewer boundary launches, exchanges and stream hops
+ * for a few redundant planes.  Needs wafer_params.halo_depth >= 2 * ext * passes; the default is the
+ * largest value the context's ghost depth allows.  All settings give identical results. */
+int wafer_set_halo_cycle(wafer_ctx *ctx, int passes);
 /* run every kernel on a caller-owned hipStream_t (NULL = the context's own) */
 int wafer_set_stream(wafer_ctx *ctx, void *hip_stream);
 /* geometry of the local slab, for hosts that need it */

@@ -173,6 +173,45 @@ def test_fused_kernel_on_slabs_bit_exact(wa, world, shape, ext, steps, overlap):
     assert np.array_equal(assemble(base, world, res), want)
 
 
+@pytest.mark.parametrize("overlap", [True, False, 2])
+@pytest.mark.parametrize("cycle", [2, 3])
+@pytest.mark.parametrize("world,shape,ext,steps", [(2, (40, 24, 32), 1, 12), (3, (33, 17, 37), 2, 7), (4, (130, 12, 40), 1, 9),
+                                                  (2, (300, 70, 96), 1, 10), (2, (20, 20, 12), 1, 8)])
+def test_deep_halo_cycles_bit_exact(wa, world, shape, ext, steps, cycle, overlap):
+    """deep halos (wafer_set_halo_cycle): 2 * ext * cycle ghost planes exchanged once per `cycle` fused
+    passes, the passes in between run unsplit over the owned planes plus the still-valid ghost planes.
+    Same bits as one context, and fewer exchanges than one per pass."""
+    base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=ext, halo_depth=2 * ext * cycle)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=ext)) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)
+        ctx.evolve(0, 8)
+        want = ctx.download_phi()
+
+    def body(ctx, rank):
+        ctx.set_stencil_variant(2)
+        ctx.set_overlap(overlap)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)           # an odd count: a trailing single step and its ext-plane exchange in between
+        ctx.evolve(0, 8)
+        return ctx.download_phi()
+
+    res, fabric = run_slabs(wa, base, world, body)
+    assert np.array_equal(assemble(base, world, res), want)
+    passes = steps // 2 + 1 + 4
+    assert all(n <= passes // cycle + 6 for n in fabric.halo_calls), fabric.halo_calls   # fewer exchanges than passes
+    with pytest.raises(wa.WaferError):
+        with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, z_begin=0, z_count=shape[2] // 2,
+                                  halo_depth=2 * ext)) as ctx:
+            ctx.set_halo_cycle(2)      # needs 4 * ext ghost planes
+    with pytest.raises(wa.WaferError):     # a ghost zone deeper than the slab: the neighbour would need planes this rank does not own
+        wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, z_begin=0, z_count=2 * ext, halo_depth=2 * ext + 1))
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f32fast"])
 def test_fp32_storage_on_slabs_bit_exact(wa, dtype):
     """fp32 storage (and fp32 step arithmetic) on z-slabs: the same bits as one context"""

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--wnum", type=int, default=0, help="excited-state steps against this many stored states")
     ap.add_argument("--modes", default="1,0", help="halo schedules to time (wafer_set_overlap modes)")
+    ap.add_argument("--cycles", default="1", help="fused passes per halo exchange to time (wafer_set_halo_cycle): e.g. 1,2,3")
+    ap.add_argument("--torch-hooks", action="store_true", help="with --rccl: also the torch.distributed hooks")
     ap.add_argument("--rccl", action="store_true",
                     help="also serve the hook with RCCL send/recv to this same rank (wafer_amd.slab.TorchSlabComm, "
                          "world of one): adds the host cost of the Python hook + batch_isend_irecv per pass")
@@ -83,10 +85,19 @@ def main():
     def allreduce(ptr, count, stream):
         return 0
 
-    mid = wafer_amd.Params(n, n, pl * args.world, z_begin=pl * (args.world // 2), z_count=pl, halo_depth=2 * ext, **kw)
-    for overlap in [int(m) for m in args.modes.split(',')]:
-        calls["halo"] = 0
-        out[f"slab_ms_per_step_overlap_{int(overlap)}"] = run(mid, (halo, allreduce), overlap)
+    cycles = [int(c) for c in args.cycles.split(',')]
+
+    def mid_params(cycle):
+        return wafer_amd.Params(n, n, pl * args.world, z_begin=pl * (args.world // 2), z_count=pl, halo_depth=2 * ext * cycle, **kw)
+
+    def tag(cycle):
+        return "" if cycle == 1 else f"_cycle{cycle}"
+
+    mid = mid_params(1)
+    for cycle in cycles:
+        for overlap in [int(m) for m in args.modes.split(',')]:
+            calls["halo"] = 0
+            out[f"slab_ms_per_step_overlap_{int(overlap)}{tag(cycle)}"] = run(mid_params(cycle), (halo, allreduce), overlap)
     if args.rccl:
         import torch
         import torch.distributed as dist
@@ -101,7 +112,7 @@ def main():
             lower = 0
             upper = 0
 
-        for overlap in [int(m) for m in args.modes.split(',')]:
+        for overlap in ([int(m) for m in args.modes.split(',')] if args.torch_hooks else []):
             with wafer_amd.Context(mid) as ctx:
                 comm = SelfNeighbours(ctx, 0, 1, dev)
                 comm.warm_up()
@@ -122,8 +133,8 @@ def main():
                 out[f"slab_rccl_self_ms_per_step_overlap_{int(overlap)}"] = sorted(ts)[2]
                 del comm
         from wafer_amd.slab import NativeRcclSlabComm
-        for overlap in [int(m) for m in args.modes.split(',')]:
-            with wafer_amd.Context(mid) as ctx:
+        for cycle, overlap in [(cy, int(m)) for cy in cycles for m in args.modes.split(',')]:
+            with wafer_amd.Context(mid_params(cycle)) as ctx:
                 comm = NativeRcclSlabComm(ctx, 0, 1, dev, self_neighbours=True)
                 comm.warm_up()
                 ctx.set_overlap(overlap)
@@ -140,11 +151,11 @@ def main():
                     ctx.evolve(args.wnum, args.steps)
                     ms, k = ctx.last_evolve_ms()
                     ts.append(ms / k)
-                out[f"slab_native_rccl_self_ms_per_step_overlap_{int(overlap)}"] = sorted(ts)[2]
+                out[f"slab_native_rccl_self_ms_per_step_overlap_{int(overlap)}{tag(cycle)}"] = sorted(ts)[2]
                 comm.close()
         torch.cuda.synchronize()
         dist.destroy_process_group()
-    out["halo_calls_per_step"] = calls["halo"] / (100 + 5 * args.steps)
+    out["halo_calls_per_step_last_loopback_run"] = calls["halo"] / (100 + 5 * args.steps)
     out["halo_bytes_per_direction_per_call"] = calls["bytes"]
     out["slab_over_undecomposed"] = out["slab_ms_per_step_overlap_1"] / out["undecomposed_ms_per_step"]
     out["grid"] = [n, n, pl]

@@ -170,6 +170,7 @@ struct wafer_ctx {
     bool alternate = false; // fused split passes: the two streams swap roles every pass (wafer_set_overlap mode 3)
     hipEvent_t ev_intr = nullptr; // mode 3: end of an interior launch that ran on the second stream
     int halo_valid = 0; // ghost planes of phi[cur] (counted from the owned region) known to be current
+    int halo_cycle = 1; // fused passes per halo exchange: the exchange moves 2R * halo_cycle planes (<= G), see wafer_evolve
 
     uint64_t last_steps = 0;
     bool timing_valid = false;
@@ -700,6 +701,8 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     const int G = p->halo_depth ? (int)p->halo_depth : R;
     if (G < R) return fail(WAFER_ERR_INVALID, "halo_depth must be >= ext");
     if (zc < p->nz && (int)zc < 2 * R) return fail(WAFER_ERR_INVALID, "a z-slab needs at least 2*ext planes");
+    if (zc < p->nz && (int)zc < G)
+        return fail(WAFER_ERR_INVALID, "halo_depth %d is deeper than this slab's %u planes: a rank sends its own planes only", G, zc);
 
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -722,6 +725,9 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->overlap = ov_mode != 0;
     c->bdry_main = ov_mode == 2 || env_int("WAFER_BDRY_MAIN", 0) != 0;
     c->alternate = ov_mode == 3;
+    // as many fused passes per exchange as the ghost depth the host asked for allows
+    c->halo_cycle = std::max(1, env_int("WAFER_HALO_CYCLE", G / (2 * R)));
+    if (2 * R * c->halo_cycle > G) c->halo_cycle = std::max(1, G / (2 * R));
 
     auto cleanup_fail = [&](int rc) {
         wafer_ctx_destroy(c);
@@ -1197,9 +1203,25 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     for (uint64_t s = 0; s < steps;) {
         const int src = c->cur, dst = c->cur ^ 1;
         if (fuse && steps - s >= 2) {
-            TRY(ensure_halo(c, 2 * R));
-            const bool split = c->sharded() && c->overlap && g.nzl > 4 * R;
-            if (split && c->alternate) {
+            // Deep halos: with E = 2R * halo_cycle ghost planes exchanged at once, only every halo_cycle-th
+            // pass needs boundary-first kernels, an exchange and the event hops around them.  The passes in
+            // between run UNSPLIT over the owned planes plus the ghost planes that are still good for one more
+            // pass: each fused pass consumes 2R planes of validity per side (the neighbour computes the
+            // same cells from the same values, so the bits agree).  halo_cycle = 2 at the 1024 x 1024 x 128
+            // bench slab: 4 redundant planes per two passes against two thin boundary launches, one
+            // exchange launch and two cross-stream hops.
+            const int E = c->sharded() ? std::min(g.G, 2 * R * c->halo_cycle) : 2 * R; // the same on every rank: the neighbours receive what this one sends
+            if (c->sharded() && c->halo_valid < 2 * R) TRY(ensure_halo(c, E));
+            if (c->sharded() && c->halo_valid >= 4 * R) {
+                const int ext = c->halo_valid - 2 * R; // ghost planes still valid after this pass
+                TRY(launch_step2(c, src, dst, c->has_lo() ? lo - ext : lo, c->has_hi() ? hi + ext : hi, c->s_main));
+                c->halo_valid = ext;
+                c->cur = dst;
+                s += 2;
+                continue;
+            }
+            const bool split = c->sharded() && c->overlap && g.nzl > 2 * E;
+            if (split && c->alternate && E == 2 * R) {
                 // Mode 3: as below, but the two streams swap roles every pass.  The boundary kernels of this
                 // pass run on the stream that ran the interior of the previous one, so that dependency is
                 // stream order instead of an event hop (19 us in the kernel trace); the previous exchange,
@@ -1211,16 +1233,16 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 // mode 2.  Not the default; bench.py times it with the other modes on the fabric it runs on.
                 const hipStream_t sE = intr_on_aux ? c->s_aux : c->s_main, sI = intr_on_aux ? c->s_main : c->s_aux;
                 if (have_join) HIP_TRY(hipStreamWaitEvent(sE, c->ev_join, 0)); // ghost planes of the previous exchange
-                if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + 2 * R, sE));
-                if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - 2 * R, hi, sE));
+                if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + E, sE));
+                if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - E, hi, sE));
                 HIP_TRY(hipEventRecord(c->ev_bdry, sE));
-                TRY(exchange_halo(c, dst, sE, 2 * R));
+                TRY(exchange_halo(c, dst, sE, E));
                 HIP_TRY(hipEventRecord(c->ev_join, sE));
                 have_join = true;
                 HIP_TRY(hipStreamWaitEvent(sI, c->ev_bdry, 0));
-                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + 2 * R : lo, c->has_hi() ? hi - 2 * R : hi, sI, true));
+                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + E : lo, c->has_hi() ? hi - E : hi, sI, true));
                 intr_on_aux = (sI == c->s_aux);
-                c->halo_valid = 2 * R;
+                c->halo_valid = c->sharded() ? E : 2 * R;
                 c->cur = dst;
                 s += 2;
                 if (!(fuse && steps - s >= 2)) { // last fused pass of this call: everything back onto the main stream
@@ -1248,11 +1270,11 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                     HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
                     HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
                 }
-                if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + 2 * R, sb));
-                if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - 2 * R, hi, sb));
+                if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + E, sb));
+                if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - E, hi, sb));
                 HIP_TRY(hipEventRecord(c->ev_bdry, sb));
                 if (sb == c->s_main) HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_bdry, 0));
-                TRY(exchange_halo(c, dst, c->s_aux, 2 * R));
+                TRY(exchange_halo(c, dst, c->s_aux, E));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
                 if (sb == c->s_aux) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
                 // The exchange's kernels hold a few CUs for as long as the links need (RCCL's workgroups
@@ -1262,13 +1284,13 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 // Cutting EVERY tile into four workgroups fixes that at 3 planes of pipeline fill per
                 // workgroup (0.396); cutting only the last 1/16 of the tiles -- dispatched last, they
                 // fill the holes -- keeps the long workgroups' efficiency.
-                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + 2 * R : lo, c->has_hi() ? hi - 2 * R : hi, c->s_main, true));
+                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + E : lo, c->has_hi() ? hi - E : hi, c->s_main, true));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
             } else {
                 TRY(launch_step2(c, src, dst, lo, hi, c->s_main));
-                TRY(exchange_halo(c, dst, c->s_main, 2 * R));
+                TRY(exchange_halo(c, dst, c->s_main, E));
             }
-            c->halo_valid = 2 * R;
+            c->halo_valid = c->sharded() ? E : 2 * R;
             c->cur = dst;
             s += 2;
             continue;
@@ -1731,6 +1753,16 @@ int wafer_set_overlap(wafer_ctx *c, int enabled)
     c->overlap = enabled != 0;
     c->bdry_main = enabled == 2;
     c->alternate = enabled == 3;
+    return WAFER_OK;
+}
+
+int wafer_set_halo_cycle(wafer_ctx *c, int passes)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    if (passes < 1 || 2 * c->g.R * passes > c->g.G)
+        return fail(WAFER_ERR_INVALID, "halo cycle %d needs %d ghost planes, the context has %d (wafer_params.halo_depth)", passes,
+                    2 * c->g.R * passes, c->g.G);
+    c->halo_cycle = passes;
     return WAFER_OK;
 }
 

@@ -39,7 +39,7 @@ EXPORTS = [
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_diag_stream_bw", "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
     "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check",
-    "wafer_diag_copy_bw", "wafer_diag_checksum",
+    "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_set_halo_cycle",
 ]
 
 
@@ -162,6 +162,7 @@ def load_library():
     L.wafer_diag_stream_bw.argtypes = [vp, C.c_int, C.c_int, dp]
     L.wafer_set_comm_hooks.argtypes = [vp, HALO_FN, ALLREDUCE_FN, vp]
     L.wafer_set_overlap.argtypes = [vp, C.c_int]
+    L.wafer_set_halo_cycle.argtypes = [vp, C.c_int]
     L.wafer_set_stream.argtypes = [vp, vp]
     L.wafer_get_slab_info.argtypes = [vp, C.POINTER(_SlabInfo)]
     L.wafer_get_device_info.argtypes = [vp, C.POINTER(_DeviceInfo)]
@@ -464,6 +465,10 @@ class Context:
     def set_overlap(self, enabled) -> None:
         """halo schedule of a z-slab: False / 0, True / 1 (default), 2 or 3 (include/wafer_hip.h)"""
         self._check(self._L.wafer_set_overlap(self._h, int(enabled)))
+
+    def set_halo_cycle(self, passes: int) -> None:
+        """fused passes per halo exchange of a z-slab (needs halo_depth >= 2 * ext * passes)"""
+        self._check(self._L.wafer_set_halo_cycle(self._h, int(passes)))
 
     def set_stream(self, stream_ptr: int | None) -> None:
         self._check(self._L.wafer_set_stream(self._h, stream_ptr))
