@@ -74,7 +74,7 @@ def test_config2_256_cubed_harmonic_ten_steps_bit_exact(wo, wa):
     phi = wo.initial_condition(cfg, "Boolean")
     wo.evolve(cfg, 0, a, b, phi, [], 10)
     with wa.Context(par) as ctx:
-        assert ctx.stencil_kernel_name() == "wafer_k_step2_fused"
+        assert ctx.stencil_kernel_name() == "wafer_k_step3_fused"
         ctx.set_potential("Harmonic")
         ctx.set_initial_condition("Boolean")
         ctx.evolve(0, 10)

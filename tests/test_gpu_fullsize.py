@@ -62,8 +62,19 @@ def run_case(wa, n, dtype, dn, dt, mass):
         ctx.set_stencil_variant(-1)
         ctx.set_initial_condition("Boolean")
         ctx.evolve(0, 2)
-        assert ctx.stencil_kernel_name() == "wafer_k_step2_fused"
+        assert ctx.stencil_kernel_name() == ("wafer_k_step3_fused" if dtype == "f64" else "wafer_k_step2_fused")
         assert ctx.norm2() == two_single
+        # ... and three fused steps (fp64 ThreePoint: one pass of the three-step kernel) equal three single steps
+        ctx.set_stencil_variant(1)
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 3)
+        three_single = ctx.norm2()
+        ctx.set_stencil_variant(-1)
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 3)
+        assert ctx.norm2() == three_single
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 2)
         # linearity: twice the wavefunction, four times the norm, bit for bit (powers of two)
         ctx.normalise(0.25)                                             # phi / sqrt(1/4) = 2 phi
         assert ctx.norm2() == 4.0 * two_single

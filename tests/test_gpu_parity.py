@@ -211,6 +211,66 @@ def test_fused_two_step_kernel_bit_exact(wo, wa, shape, ext, steps):
         assert ulp_diff(ctx.download_phi(), phi) == 0
 
 
+@pytest.mark.parametrize("steps", [3, 7, 11, 12])
+@pytest.mark.parametrize("shape", SHAPES + [(150, 37, 29), (257, 20, 11), (128, 16, 9), (129, 33, 40), (300, 50, 7)])
+def test_fused_three_step_kernel_bit_exact(wo, wa, shape, steps, monkeypatch):
+    """variant 3 (THREE ThreePoint steps per pass over HBM, wafer_stencil_fused3.hip.h): the same bits as
+    `steps` single reference steps -- counts that leave a two-step and a single-step remainder, ragged
+    tiles, grids smaller than a tile (forced onto the kernel), every frame cell still exactly zero"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    cfg, par = make_pair(shape, ext=1, potential="Coulomb", dn=0.2, dt=0.004, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=12)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(3)
+        assert ctx.stencil_kernel_name() == "wafer_k_step3_fused" and ctx.steps_per_launch() == 3
+        ctx.set_potential("Coulomb")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, steps)
+        wo.evolve(cfg, 0, a, b, phi, [], steps)
+        got = ctx.download_phi()
+        assert ulp_diff(got, phi) == 0
+        assert not got[0].any() and not got[-1].any() and not got[:, 0].any() and not got[:, :, -1].any()
+
+
+@pytest.mark.parametrize("zchunk", ["1", "2", "3", "5", "1000"])
+def test_fused3_zchunk_independence(wo, wa, zchunk, monkeypatch):
+    monkeypatch.setenv("WAFER_ZCHUNK", zchunk)
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    cfg, par = make_pair((70, 21, 13), ext=1, potential="Harmonic", dn=0.1, dt=0.002)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=2)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(3)
+        ctx.set_potential("Harmonic")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 6)
+        wo.evolve(cfg, 0, a, b, phi, [], 6)
+        assert ulp_diff(ctx.download_phi(), phi) == 0
+
+
+def test_fused3_thousand_steps_64cubed_and_default_dispatch(wo, wa):
+    """1000 steps (333 three-step passes + one single step) at 64^3 against the oracle; the three-step
+    kernel is what an undecomposed ThreePoint fp64 context runs by default, the two-step kernel what
+    FivePoint, fp32 storage and z-slabs run"""
+    cfg, par = make_pair((64, 64, 64), ext=1, potential="Harmonic", dn=0.2, dt=8e-3, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = wo.initial_condition(cfg, "Boolean")
+    wo.evolve(cfg, 0, a, b, phi, [], 1000)
+    with wa.Context(par) as ctx:
+        assert ctx.stencil_kernel_name() == "wafer_k_step3_fused" and ctx.steps_per_launch() == 3
+        ctx.set_potential("Harmonic")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 1000)
+        assert ulp_diff(ctx.download_phi(), phi) == 0
+    for kw in (dict(central_difference=2), dict(dtype="f32"), dict(z_begin=16, z_count=16, halo_depth=2)):
+        with wa.Context(wa.Params(64, 64, 64, dn=0.2, dt=8e-3, **kw)) as ctx:
+            assert ctx.stencil_kernel_name() == "wafer_k_step2_fused" and ctx.steps_per_launch() == 2
+
+
 @pytest.mark.parametrize("zchunk", ["1", "2", "5", "1000"])
 def test_fused_zchunk_independence(wo, wa, zchunk, monkeypatch):
     monkeypatch.setenv("WAFER_ZCHUNK", zchunk)

@@ -24,6 +24,7 @@
 #include "wafer_stencil.hip.h"
 #include "wafer_stencil_lds.hip.h"
 #include "wafer_stencil_fused2.hip.h"
+#include "wafer_stencil_fused3.hip.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -345,6 +346,7 @@ static const VariantInfo kVariants[] = {
     {"wafer_k_step_direct"},
     {"wafer_k_step_lds"},
     {"wafer_k_step2_fused"},
+    {"wafer_k_step3_fused"},
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -355,6 +357,8 @@ static int default_variant(const wafer_ctx *c)
     // FivePoint on fp32 storage: the fused kernel needs 256 VGPRs (and spills) there; the single-step
     // kernel is faster (512^3: 0.337 against 0.383 ms/step, f32fast 0.287 against 0.302)
     if (c->f32 && c->g.R == 2) return 1;
+    // ThreePoint, fp64: three steps per pass (wafer_stencil_fused3.hip.h); everything else two
+    if (!c->f32 && c->g.R == 1 && env_int("WAFER_FUSE3", 1) != 0) return 3;
     return 2;
 }
 
@@ -439,6 +443,30 @@ static int launch_step(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, boo
         return norm ? launch_step_t<T, C, R, true>(c, src, dst, lz_lo, lz_hi, s)
                     : launch_step_t<T, C, R, false>(c, src, dst, lz_lo, lz_hi, s);
     }, !norm);
+}
+
+// the three-step kernel serves undecomposed ThreePoint fp64 grids whose rows fill its 128 x 16 tiles; slabs
+// (which would need 3 * ext ghost planes per pass) and everything else take the two-step kernel
+static bool fuse3_applies(const wafer_ctx *c)
+{
+    return active_variant(c) == 3 && c->g.R == 1 && !c->f32 && !c->sharded() && c->g.ny >= env_int("WAFER_FUSE3_MIN_NY", 16);
+}
+
+// three fused steps over planes [lz_lo, lz_hi): phi[dst] = step(step(step(phi[src])))
+static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s)
+{
+    if (lz_hi <= lz_lo) return WAFER_OK;
+    WaferStepArgs a{};
+    a.g = c->g;
+    a.lz_lo = lz_lo;
+    a.lz_hi = lz_hi;
+    a.dt = c->P.dt;
+    a.target_blocks = c->num_cus;
+    a.v_in_range = c->v_in_range ? 1 : 0;
+    a.den = 2. * c->P.dn * c->P.dn * c->P.mass; // grid.rs:569
+    if (wafer_launch_step3_fused<double, double>(a, as<double>(c->phi[src]), as<double>(c->v), as<double>(c->phi[dst]), s) != hipSuccess)
+        return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return WAFER_OK;
 }
 
 // two fused steps over planes [lz_lo, lz_hi): phi[dst] = step(step(phi[src]))
@@ -1196,12 +1224,19 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     // two steps per pass where nothing happens between steps (ground state) and, when the grid
     // is sharded, the slab carries 2R ghost planes
     // (ext = 3 spills registers in the fused kernel and stays on the single-step path)
-    const bool fuse = wnum == 0 && active_variant(c) == 2 && R <= 2 &&
+    const bool fuse = wnum == 0 && active_variant(c) >= 2 && R <= 2 &&
                       (!c->sharded() || (g.G >= 2 * R && g.nzl >= 2 * R));
+    const bool fuse3 = wnum == 0 && fuse3_applies(c);
     HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
     bool intr_on_aux = false, have_join = false; // mode 3 (alternating stream roles), see below
     for (uint64_t s = 0; s < steps;) {
         const int src = c->cur, dst = c->cur ^ 1;
+        if (fuse3 && steps - s >= 3) {
+            TRY(launch_step3(c, src, dst, lo, hi, c->s_main));
+            c->cur = dst;
+            s += 3;
+            continue;
+        }
         if (fuse && steps - s >= 2) {
             // Deep halos: with E = 2R * halo_cycle ghost planes exchanged at once, only every halo_cycle-th
             // pass needs boundary-first kernels, an exchange and the event hops around them.  The passes in
@@ -1378,14 +1413,16 @@ const char *wafer_stencil_kernel_name(wafer_ctx *c)
 {
     if (!c) return "";
     int v = active_variant(c);
-    if (v == 2 && wafer_stencil_steps_per_launch(c) == 1) v = 1; // fused not applicable: LDS single-step
+    const int spl = wafer_stencil_steps_per_launch(c);
+    if (v >= 2) v = spl == 3 ? 3 : spl == 2 ? 2 : 1; // what the fused variants fall back to where they do not apply
     return kVariants[(v >= 0 && v < kNumVariants) ? v : 0].name;
 }
 
 int wafer_stencil_steps_per_launch(wafer_ctx *c)
 {
     if (!c) return 0;
-    const bool fuse = active_variant(c) == 2 && c->g.R <= 2 &&
+    if (fuse3_applies(c)) return 3;
+    const bool fuse = active_variant(c) >= 2 && c->g.R <= 2 &&
                       (!c->sharded() || (c->g.G >= 2 * c->g.R && c->g.nzl >= 2 * c->g.R));
     return fuse ? 2 : 1;
 }
