@@ -357,6 +357,9 @@ static int default_variant(const wafer_ctx *c)
     // FivePoint on fp32 storage: the fused kernel needs 256 VGPRs (and spills) there; the single-step
     // kernel is faster (512^3: 0.337 against 0.383 ms/step, f32fast 0.287 against 0.302)
     if (c->f32 && c->g.R == 2) return 1;
+    // SevenPoint: the two-step kernel exists (variant 2, bit-exact, 128 x 8 tiles) but recomputes phi1 on 14 rows
+    // per 8 and is issue-bound: 0.93 ms/step at 512^3 against 0.63 for the single-step kernel on 128 x 16 tiles
+    if (c->g.R == 3) return 1;
     // ThreePoint, fp64: three steps per pass (wafer_stencil_fused3.hip.h); everything else two
     if (!c->f32 && c->g.R == 1 && env_int("WAFER_FUSE3", 1) != 0) return 3;
     return 2;
@@ -452,6 +455,16 @@ static bool fuse3_applies(const wafer_ctx *c)
     return active_variant(c) == 3 && c->g.R == 1 && !c->f32 && !c->sharded() && c->g.ny >= env_int("WAFER_FUSE3_MIN_NY", 16);
 }
 
+// The two-step kernel: every stencil order in fp64 (SevenPoint on 128 x 8 tiles, a and b formed again at
+// the second step: its two seven-plane z-queues leave no registers for an a, b queue); ThreePoint /
+// FivePoint on fp32 storage (SevenPoint there spills 200 B per lane and stays on the single-step kernel).
+// Slabs need 2 * ext ghost planes.
+static bool fuse2_applies(const wafer_ctx *c)
+{
+    const int R = c->g.R;
+    return active_variant(c) >= 2 && (R <= 2 || !c->f32) && (!c->sharded() || (c->g.G >= 2 * R && c->g.nzl >= 2 * R));
+}
+
 // three fused steps over planes [lz_lo, lz_hi): phi[dst] = step(step(step(phi[src])))
 static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s)
 {
@@ -491,13 +504,9 @@ static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
         if (kernels_stream_ab(2)) TRY(ensure_ab(c));
-        if constexpr (R <= 2) { // ext 3 spills registers in this kernel and is never dispatched to it
-            if (wafer_launch_step2_fused<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->a), as<T>(c->b), as<T>(c->v), as<T>(c->phi[dst]), s) != hipSuccess)
-                return fail(WAFER_ERR_HIP, "fused stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
-            return (int)WAFER_OK;
-        } else {
-            return fail(WAFER_ERR_INVALID, "the fused two-step kernel is not built for SevenPoint");
-        }
+        if (wafer_launch_step2_fused<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->a), as<T>(c->b), as<T>(c->v), as<T>(c->phi[dst]), s) != hipSuccess)
+            return fail(WAFER_ERR_HIP, "fused stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return (int)WAFER_OK;
     }, true);
 }
 
@@ -1223,9 +1232,7 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     const uint64_t steps = n_steps == 0 ? 1 : n_steps; // grid.rs:682-685
     // two steps per pass where nothing happens between steps (ground state) and, when the grid
     // is sharded, the slab carries 2R ghost planes
-    // (ext = 3 spills registers in the fused kernel and stays on the single-step path)
-    const bool fuse = wnum == 0 && active_variant(c) >= 2 && R <= 2 &&
-                      (!c->sharded() || (g.G >= 2 * R && g.nzl >= 2 * R));
+    const bool fuse = wnum == 0 && fuse2_applies(c);
     const bool fuse3 = wnum == 0 && fuse3_applies(c);
     HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
     bool intr_on_aux = false, have_join = false; // mode 3 (alternating stream roles), see below
@@ -1422,9 +1429,7 @@ int wafer_stencil_steps_per_launch(wafer_ctx *c)
 {
     if (!c) return 0;
     if (fuse3_applies(c)) return 3;
-    const bool fuse = active_variant(c) >= 2 && c->g.R <= 2 &&
-                      (!c->sharded() || (c->g.G >= 2 * c->g.R && c->g.nzl >= 2 * c->g.R));
-    return fuse ? 2 : 1;
+    return fuse2_applies(c) ? 2 : 1;
 }
 
 int wafer_set_stencil_variant(wafer_ctx *c, int variant)

@@ -194,9 +194,9 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
     VT vq[R + 1][RY];     // V (or a) of planes z-R .. z (oldest first); only vq[R] is used by step 1
     VT bq[R + 1][RY];     // b of the same planes (!ABV only)
     // The halo-column wave keeps ITS state in the same registers: cell q of its CPL cells lives in
-    // component q of row slot 0 (q0[m][0][q], vq[R][0][q], ...), so the roles do not add up in the
+    // component q % VEC of row slot q / VEC (q0[m][q / VEC][q % VEC], vq[R][...], ...), so the roles do not add up in the
     // kernel's register budget.
-    static_assert(Cfg::CPL <= VEC, "halo-column cells per lane must fit one row slot");
+    static_assert(Cfg::CPL <= RY * VEC, "halo-column cells per lane must fit the row-slot registers");
 #pragma unroll
     for (int m = 0; m <= 2 * R; ++m) {
         const int p = z1 - R + m;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
             for (int r = 0; r < RY; ++r) q0[m][r] = *reinterpret_cast<const VT *>(phi + (long long)p * g.plane + rowoff[r]);
         } else {
 #pragma unroll
-            for (int q = 0; q < Cfg::CPL; ++q) q0[m][0][q] = phi[(long long)p * g.plane + c_off[q]];
+            for (int q = 0; q < Cfg::CPL; ++q) q0[m][q / VEC][q % VEC] = phi[(long long)p * g.plane + c_off[q]];
         }
     }
 #pragma unroll
@@ -226,8 +226,8 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
     } else {
 #pragma unroll
         for (int q = 0; q < Cfg::CPL; ++q) {
-            vq[R][0][q] = pv[(long long)z1 * g.plane + c_off[q]];
-            if constexpr (!ABV) bq[R][0][q] = pb[(long long)z1 * g.plane + c_off[q]];
+            vq[R][q / VEC][q % VEC] = pv[(long long)z1 * g.plane + c_off[q]];
+            if constexpr (!ABV) bq[R][q / VEC][q % VEC] = pb[(long long)z1 * g.plane + c_off[q]];
         }
     }
     // phi1 z-queue (main waves), planes z-2R .. z; starts empty (zeros never reach an output:
@@ -237,10 +237,13 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
     for (int m = 0; m <= 2 * R; ++m)
 #pragma unroll
         for (int r = 0; r < RY; ++r) q1[m][r] = zero;
-    // ABV: the a, b formed for step 1 at plane z serve step 2 at the same plane R iterations later
-    VT caq[R + 1][RY], cbq[R + 1][RY];
+    // ABV: the a, b formed for step 1 at plane z serve step 2 at the same plane R iterations later -- for
+    // ThreePoint / FivePoint.  SevenPoint's two seven-plane z-queues leave no room for an (R+1)-deep a, b
+    // queue (64 VGPRs): step 2 forms them again from V (same expressions, same bits).
+    constexpr bool CARRY_AB = R < 3;
+    VT caq[CARRY_AB ? R + 1 : 1][RY], cbq[CARRY_AB ? R + 1 : 1][RY];
 #pragma unroll
-    for (int m = 0; m <= R; ++m)
+    for (int m = 0; m <= (CARRY_AB ? R : 0); ++m)
 #pragma unroll
         for (int r = 0; r < RY; ++r) caq[m][r] = cbq[m][r] = zero;
 
@@ -261,7 +264,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                 *reinterpret_cast<VT *>(t0 + orow_lds[q]) = *reinterpret_cast<const VT *>(phi + (long long)z1 * g.plane + orow_off[q]);
 #pragma unroll
         for (int q = 0; q < Cfg::CPL; ++q)
-            if (is_hcol && lane + q * 64 < Cfg::NCOL) t0[c_lds0[q]] = q0[R][0][q];
+            if (is_hcol && lane + q * 64 < Cfg::NCOL) t0[c_lds0[q]] = q0[R][q / VEC][q % VEC];
     }
     VT orow_nxt[Cfg::OPW];
 #pragma unroll
@@ -298,9 +301,9 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
         } else {
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q) {
-                pre[0][q] = phi[zo + (long long)(R + 1) * g.plane + c_off[q]];
-                pre_v[0][q] = pv[zo + g.plane + c_off[q]];
-                if constexpr (!ABV) pre_b[0][q] = pb[zo + g.plane + c_off[q]];
+                pre[q / VEC][q % VEC] = phi[zo + (long long)(R + 1) * g.plane + c_off[q]];
+                pre_v[q / VEC][q % VEC] = pv[zo + g.plane + c_off[q]];
+                if constexpr (!ABV) pre_b[q / VEC][q % VEC] = pb[zo + g.plane + c_off[q]];
             }
         }
         // ---- 2. stage phi0 plane z+1 into the other buffer ------------------------------------------------
@@ -316,7 +319,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                 if (is_main && wave + q * Cfg::NW2 < Cfg::OUTER) *reinterpret_cast<VT *>(nt + orow_lds[q]) = orow_nxt[q];
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q)
-                if (is_hcol && lane + q * 64 < Cfg::NCOL) nt[c_lds0[q]] = q0[R + 1][0][q];
+                if (is_hcol && lane + q * 64 < Cfg::NCOL) nt[c_lds0[q]] = q0[R + 1][q / VEC][q % VEC];
         }
         // ---- 3. step 1: phi1 plane z ---------------------------------------------------------------------------
         const T *c0 = lds0 + (z & 1) * Cfg::TILE0;
@@ -355,8 +358,10 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                             if constexpr (ABV) {
                                 C ca, cb;
                                 wafer_ab_from_v<C>((C)vq[R][r][v], dt, vir, ca, cb);
-                                caq[R][r][v] = (T)ca;
-                                cbq[R][r][v] = (T)cb;
+                                if constexpr (CARRY_AB) {
+                                    caq[R][r][v] = (T)ca;
+                                    cbq[R][r][v] = (T)cb;
+                                }
                                 rs = (T)wafer_update<C>(w, ca, cb, dt, S, den);
                             } else rs = (T)wafer_update<C>(w, (C)vq[R][r][v], (C)bq[R][r][v], dt, S, den);
                             res[v] = (xi + v < g.nx) ? rs : T(0);
@@ -383,16 +388,16 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                         if (wplane && c_p1[q]) {
                             const int o0 = c_lds0[q];
                             C xs[2 * R + 1], ys[2 * R + 1], zz[2 * R + 1];
-                            const C w = (C)q0[R][0][q];
+                            const C w = (C)q0[R][q / VEC][q % VEC];
 #pragma unroll
                             for (int d = -R; d <= R; ++d) {
-                                zz[d + R] = (C)q0[R + d][0][q];
+                                zz[d + R] = (C)q0[R + d][q / VEC][q % VEC];
                                 xs[d + R] = (d == 0) ? w : (C)c0[o0 + d];
                                 ys[d + R] = (d == 0) ? w : (C)c0[o0 + d * LP0];
                             }
                             const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                            if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)vq[R][0][q], dt, S, den, vir);
-                            else rs = (T)wafer_update<C>(w, (C)vq[R][0][q], (C)bq[R][0][q], dt, S, den);
+                            if constexpr (ABV) rs = (T)wafer_update_v<C>(w, (C)vq[R][q / VEC][q % VEC], dt, S, den, vir);
+                            else rs = (T)wafer_update<C>(w, (C)vq[R][q / VEC][q % VEC], (C)bq[R][q / VEC][q % VEC], dt, S, den);
                         }
                         w1[c_lds1[q]] = rs;
                     }
@@ -438,8 +443,12 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                                     }
                                 }
                                 const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                                if constexpr (ABV) res2[r][v] = (T)wafer_update<C>(w, (C)caq[0][r][v], (C)cbq[0][r][v], dt, S, den);
-                                else res2[r][v] = (T)wafer_update<C>(w, (C)vq[0][r][v], (C)bq[0][r][v], dt, S, den);
+                                if constexpr (ABV && CARRY_AB) res2[r][v] = (T)wafer_update<C>(w, (C)caq[0][r][v], (C)cbq[0][r][v], dt, S, den);
+                                else if constexpr (ABV) {
+                                    C ca, cb;
+                                    wafer_ab_from_v<C>((C)vq[0][r][v], dt, vir, ca, cb);
+                                    res2[r][v] = (T)wafer_update<C>(w, ca, cb, dt, S, den);
+                                } else res2[r][v] = (T)wafer_update<C>(w, (C)vq[0][r][v], (C)bq[0][r][v], dt, S, den);
                             }
                         }
                     }
@@ -485,7 +494,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
             vq[R][r] = pre_v[r];
             if constexpr (!ABV) bq[R][r] = pre_b[r];
         }
-        if constexpr (ABV) {
+        if constexpr (ABV && CARRY_AB) {
 #pragma unroll
             for (int m = 0; m < R; ++m)
 #pragma unroll
