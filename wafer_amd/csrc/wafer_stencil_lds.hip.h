@@ -402,7 +402,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                 if constexpr (OBS) {
                     if (rowin[r] && xi + v < g.nx) {
                         const double vv = (double)ab_a[r][v];
-                        ob_e += vv * w * w - w * S / a.den; // grid.rs:325-332
+                        ob_e += vv * w * w - wafer_div_invariant<double>(w * S, den); // grid.rs:325-332 (the bits of the IEEE quotient)
                         ob_n += w * w;                      // grid.rs:407
                         if (a.potsub_kind == 2) ob_v += w * w * (double)psub[v];      // grid.rs:410-418
                         else if (a.potsub_kind == 1) ob_v += w * w * a.potsub_scalar; // grid.rs:419-424
@@ -574,7 +574,10 @@ static inline hipError_t wafer_launch_observables_lds(WaferStepArgs a, const T *
     using Cfg = WaferLdsCfg<T, R, 2, NW>;
     WaferLowPtrs low;
     low.p[0] = potsub;
-    if (NW == 8) a.target_blocks = (a.target_blocks + 1) / 2; // one workgroup per CU
+    { // two workgroups per CU (110 VGPRs at 512 threads): 0.51 -> 0.37 ms at 512^3 incl. the host sync; WAFER_OBS_WGS=1: one
+        const char *e = getenv("WAFER_OBS_WGS");
+        if (NW == 8 && e && atoi(e) == 1) a.target_blocks = (a.target_blocks + 1) / 2;
+    }
     const int zc = wafer_lds_zchunk<T, R>(a.g, a.lz_hi - a.lz_lo, 2 * (NW / 4), a.target_blocks);
     *nblocks_out = (long long)((a.g.nx + Cfg::TX - 1) / Cfg::TX) * ((a.g.ny + Cfg::TY - 1) / Cfg::TY) * ((a.lz_hi - a.lz_lo + zc - 1) / zc);
     return wafer_launch_step_lds_ry<T, double, R, 2, -2, true, true, false, NW>(a, o, phi, pv, pv, nullptr, partials, partials_cap, s, low);
