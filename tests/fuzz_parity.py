@@ -18,8 +18,9 @@ for it in range(int(os.environ.get("N", "60"))):
     if rng.random() < 0.5:
         shape = (shape[0], int(rng.integers(1, 40)), int(rng.integers(1, 40)))
     pot = str(rng.choice(["Harmonic", "Coulomb", "SimpleCornell", "NoPotential", "Cube"]))
-    steps = int(rng.integers(1, 6))
-    variant = int(rng.choice([-1, 0, 1, 2]))
+    steps = int(rng.integers(1, 9))
+    variant = int(rng.choice([-1, 0, 1, 2, 3]))
+    os.environ["WAFER_FUSE3_MIN_NY"] = str(rng.choice([1, 16]))   # the three-step kernel also on grids thinner than its tile
     dtype = "f64"
     try:
         cfg, par = make_pair(shape, ext=ext, potential=pot, dn=0.2, dt=0.004, mass=1.3, sig=0.3, dtype=dtype)
@@ -72,5 +73,6 @@ for it in range(int(os.environ.get("N", "60")) // 2):
         bad += 1
         print("ERROR excited", shape, ext, pot, wnum, steps, one_pass, repr(e)[:200], flush=True)
 os.environ.pop("WAFER_ONE_PASS", None)
+os.environ.pop("WAFER_FUSE3_MIN_NY", None)
 print("fuzz done, bad =", bad)
 sys.exit(1 if bad else 0)
