@@ -294,10 +294,12 @@ def run_rank(args) -> int:
                                 central_difference=ext, dtype=args.dtype, max_states=1, device=local_rank,
                                 z_begin=zb, z_count=zc, halo_depth=halo)
 
-    # 2*ext ghost planes: two fused steps per exchange; 4*ext where the slabs are thick enough, so that
-    # the set-up trial can also time one exchange per TWO fused passes (wafer_set_halo_cycle)
-    deep = world > 1 and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 8 * ext
-    ctx = wafer_amd.Context(make_params(z_begin, z_count, (4 * ext if deep else 2 * ext) if world > 1 else 0))
+    # ghost planes: 3*ext (ThreePoint: three fused steps per exchange; otherwise 2*ext: two); twice that where the
+    # slabs are thick enough, so that the set-up trial can also time one exchange per TWO fused passes
+    # (wafer_set_halo_cycle)
+    per_pass = 3 * ext if (ext == 1 and args.dtype == "f64") else 2 * ext
+    deep = world > 1 and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 4 * per_pass
+    ctx = wafer_amd.Context(make_params(z_begin, z_count, (2 * per_pass if deep else per_pass) if world > 1 else 0))
     if args.variant >= 0:
         ctx.set_stencil_variant(args.variant)
     comm, transport_name = None, None

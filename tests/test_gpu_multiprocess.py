@@ -36,7 +36,7 @@ def _check_bench_two_rank_line(d):
     assert ho["mode"] in (0, 1, 2, 3) and len(ho["ms_per_step"]) == 6 and all(v > 0 for v in ho["ms_per_step"].values())
     assert ho["fused_passes_per_exchange"] in (1, 2)
     assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 64
-    assert d["roofline"]["steps_per_launch"] == 2 and "cpu_baseline" not in d
+    assert d["roofline"]["steps_per_launch"] == 3 and d["config"]["kernel"] == "wafer_k_step3_fused" and "cpu_baseline" not in d
     # the same grid undecomposed on rank 0's GPU: T1 in the same line, and every slab's bits against it
     ref = d["single_gpu_ref"]
     assert ref["grid"] == [256, 256, 128] and ref["ms_per_step"] > 0 and d["single_gpu_ref_ms_per_step"] == ref["ms_per_step"]

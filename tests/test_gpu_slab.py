@@ -193,6 +193,7 @@ def test_deep_halo_cycles_bit_exact(wa, world, shape, ext, steps, cycle, overlap
     def body(ctx, rank):
         ctx.set_stencil_variant(2)
         ctx.set_overlap(overlap)
+        ctx.set_halo_cycle(cycle)
         ctx.set_potential("Coulomb")
         ctx.set_initial_condition("Boolean")
         ctx.evolve(0, steps)
@@ -210,6 +211,40 @@ def test_deep_halo_cycles_bit_exact(wa, world, shape, ext, steps, cycle, overlap
             ctx.set_halo_cycle(2)      # needs 4 * ext ghost planes
     with pytest.raises(wa.WaferError):     # a ghost zone deeper than the slab: the neighbour would need planes this rank does not own
         wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, z_begin=0, z_count=2 * ext, halo_depth=2 * ext + 1))
+
+
+@pytest.mark.parametrize("overlap", [True, False, 2, 3])
+@pytest.mark.parametrize("cycle", [1, 2])
+@pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 32), 12), (3, (140, 17, 37), 7), (4, (130, 33, 48), 10), (2, (300, 70, 96), 11)])
+def test_three_step_kernel_on_slabs_bit_exact(wa, world, shape, steps, cycle, overlap, monkeypatch):
+    """three fused ThreePoint steps per pass on z-slabs (3 ghost planes per pass and side; 6 with one exchange
+    per two passes): boundary-first overlap, the mixed long / short interior launch, two-step and single-step
+    remainders with their own exchange depths in between -- the same bits as one context"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1, halo_depth=3 * cycle)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1)) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 5)
+        ctx.evolve(0, 9)
+        want = ctx.download_phi()
+
+    def body(ctx, rank):
+        assert ctx.stencil_kernel_name() == "wafer_k_step3_fused" and ctx.steps_per_launch() == 3
+        ctx.set_overlap(overlap)
+        ctx.set_halo_cycle(cycle)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 5)           # one three-step pass + one two-step pass
+        ctx.evolve(0, 9)
+        return ctx.download_phi()
+
+    res, fabric = run_slabs(wa, base, world, body)
+    assert np.array_equal(assemble(base, world, res), want)
+    passes = -(-steps // 3) + 2 + 3
+    assert all(n <= passes // cycle + 6 for n in fabric.halo_calls), fabric.halo_calls
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f32fast"])

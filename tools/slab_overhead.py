@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--modes", default="1,0", help="halo schedules to time (wafer_set_overlap modes)")
     ap.add_argument("--cycles", default="1", help="fused passes per halo exchange to time (wafer_set_halo_cycle): e.g. 1,2,3")
     ap.add_argument("--torch-hooks", action="store_true", help="with --rccl: also the torch.distributed hooks")
+    ap.add_argument("--per-pass", type=int, default=0, help="ghost planes one fused pass consumes (default: 3 for --cd 1 = the three-step kernel, else 2*cd)")
     ap.add_argument("--rccl", action="store_true",
                     help="also serve the hook with RCCL send/recv to this same rank (wafer_amd.slab.TorchSlabComm, "
                          "world of one): adds the host cost of the Python hook + batch_isend_irecv per pass")
@@ -54,6 +55,7 @@ def main():
             if hooks:
                 ctx.set_comm_hooks(*hooks)
                 ctx.set_overlap(overlap)
+                ctx.set_halo_cycle(max(1, par.halo_depth // (args.per_pass or (3 if ext == 1 else 2 * ext))))
             ctx.set_potential("SimpleCornell")
             for j in range(args.wnum):
                 ctx.set_initial_condition("Gaussian", seed=j + 1)
@@ -88,7 +90,8 @@ def main():
     cycles = [int(c) for c in args.cycles.split(',')]
 
     def mid_params(cycle):
-        return wafer_amd.Params(n, n, pl * args.world, z_begin=pl * (args.world // 2), z_count=pl, halo_depth=2 * ext * cycle, **kw)
+        per_pass = args.per_pass or (3 if ext == 1 else 2 * ext)
+        return wafer_amd.Params(n, n, pl * args.world, z_begin=pl * (args.world // 2), z_count=pl, halo_depth=per_pass * cycle, **kw)
 
     def tag(cycle):
         return "" if cycle == 1 else f"_cycle{cycle}"
@@ -138,6 +141,7 @@ def main():
                 comm = NativeRcclSlabComm(ctx, 0, 1, dev, self_neighbours=True)
                 comm.warm_up()
                 ctx.set_overlap(overlap)
+                ctx.set_halo_cycle(cycle)
                 ctx.set_potential("SimpleCornell")
                 for j in range(args.wnum):
                     ctx.set_initial_condition("Gaussian", seed=j + 1)

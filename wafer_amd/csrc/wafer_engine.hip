@@ -448,11 +448,12 @@ static int launch_step(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, boo
     }, !norm);
 }
 
-// the three-step kernel serves undecomposed ThreePoint fp64 grids whose rows fill its 128 x 16 tiles; slabs
-// (which would need 3 * ext ghost planes per pass) and everything else take the two-step kernel
+// the three-step kernel serves ThreePoint fp64 grids whose rows fill its 128 x 16 tiles -- undecomposed, or
+// z-slabs created with at least 3 * ext ghost planes; everything else takes the two-step kernel
 static bool fuse3_applies(const wafer_ctx *c)
 {
-    return active_variant(c) == 3 && c->g.R == 1 && !c->f32 && !c->sharded() && c->g.ny >= env_int("WAFER_FUSE3_MIN_NY", 16);
+    return active_variant(c) == 3 && c->g.R == 1 && !c->f32 && c->g.ny >= env_int("WAFER_FUSE3_MIN_NY", 16) &&
+           (!c->sharded() || (c->g.G >= 3 * c->g.R && c->g.nzl >= 3 * c->g.R));
 }
 
 // The two-step kernel: every stencil order in fp64 (SevenPoint on 128 x 8 tiles, a and b formed again at
@@ -466,7 +467,7 @@ static bool fuse2_applies(const wafer_ctx *c)
 }
 
 // three fused steps over planes [lz_lo, lz_hi): phi[dst] = step(step(step(phi[src])))
-static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s)
+static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s, bool short_tail = false)
 {
     if (lz_hi <= lz_lo) return WAFER_OK;
     WaferStepArgs a{};
@@ -475,6 +476,7 @@ static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
     a.lz_hi = lz_hi;
     a.dt = c->P.dt;
     a.target_blocks = c->num_cus;
+    a.nsub = short_tail ? 4 : 0;
     a.v_in_range = c->v_in_range ? 1 : 0;
     a.den = 2. * c->P.dn * c->P.dn * c->P.mass; // grid.rs:569
     if (wafer_launch_step3_fused<double, double>(a, as<double>(c->phi[src]), as<double>(c->v), as<double>(c->phi[dst]), s) != hipSuccess)
@@ -762,8 +764,9 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->overlap = ov_mode != 0;
     c->bdry_main = ov_mode == 2 || env_int("WAFER_BDRY_MAIN", 0) != 0;
     c->alternate = ov_mode == 3;
-    // as many fused passes per exchange as the ghost depth the host asked for allows
-    c->halo_cycle = std::max(1, env_int("WAFER_HALO_CYCLE", G / (2 * R)));
+    // fused passes per halo exchange: 1 unless the host asks for deep halos (wafer_set_halo_cycle) -- a
+    // concentrated exchange outlasts the interior launch it hides behind on anything but a very fast link
+    c->halo_cycle = std::max(1, env_int("WAFER_HALO_CYCLE", 1));
     if (2 * R * c->halo_cycle > G) c->halo_cycle = std::max(1, G / (2 * R));
 
     auto cleanup_fail = [&](int rc) {
@@ -1238,32 +1241,32 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     bool intr_on_aux = false, have_join = false; // mode 3 (alternating stream roles), see below
     for (uint64_t s = 0; s < steps;) {
         const int src = c->cur, dst = c->cur ^ 1;
-        if (fuse3 && steps - s >= 3) {
-            TRY(launch_step3(c, src, dst, lo, hi, c->s_main));
-            c->cur = dst;
-            s += 3;
-            continue;
-        }
-        if (fuse && steps - s >= 2) {
-            // Deep halos: with E = 2R * halo_cycle ghost planes exchanged at once, only every halo_cycle-th
+        if ((fuse3 && steps - s >= 3) || (fuse && steps - s >= 2)) {
+            // K time steps per pass: three on the three-step kernel while at least three remain, else two
+            const int K = (fuse3 && steps - s >= 3) ? 3 : 2, H = K * R; // H: ghost planes one pass consumes per side
+            auto launch_pass = [&](int zlo, int zhi, hipStream_t st, bool short_tail) {
+                return K == 3 ? launch_step3(c, src, dst, zlo, zhi, st, short_tail) : launch_step2(c, src, dst, zlo, zhi, st, short_tail);
+            };
+            // Deep halos: with E = H * halo_cycle ghost planes exchanged at once, only every halo_cycle-th
             // pass needs boundary-first kernels, an exchange and the event hops around them.  The passes in
             // between run UNSPLIT over the owned planes plus the ghost planes that are still good for one more
-            // pass: each fused pass consumes 2R planes of validity per side (the neighbour computes the
+            // pass: each fused pass consumes H planes of validity per side (the neighbour computes the
             // same cells from the same values, so the bits agree).  halo_cycle = 2 at the 1024 x 1024 x 128
-            // bench slab: 4 redundant planes per two passes against two thin boundary launches, one
-            // exchange launch and two cross-stream hops.
-            const int E = c->sharded() ? std::min(g.G, 2 * R * c->halo_cycle) : 2 * R; // the same on every rank: the neighbours receive what this one sends
-            if (c->sharded() && c->halo_valid < 2 * R) TRY(ensure_halo(c, E));
-            if (c->sharded() && c->halo_valid >= 4 * R) {
-                const int ext = c->halo_valid - 2 * R; // ghost planes still valid after this pass
-                TRY(launch_step2(c, src, dst, c->has_lo() ? lo - ext : lo, c->has_hi() ? hi + ext : hi, c->s_main));
+            // bench slab: a few redundant planes per two passes against two thin boundary launches, one
+            // exchange launch and two cross-stream hops.  E is a whole number of passes' worth and the same
+            // on every rank (the neighbours receive what this one sends).
+            const int E = c->sharded() ? std::max(H, std::min(g.G, H * c->halo_cycle) / H * H) : H;
+            if (c->sharded() && c->halo_valid < H) TRY(ensure_halo(c, E));
+            if (c->sharded() && c->halo_valid >= 2 * H) {
+                const int ext = c->halo_valid - H; // ghost planes still valid after this pass
+                TRY(launch_pass(c->has_lo() ? lo - ext : lo, c->has_hi() ? hi + ext : hi, c->s_main, false));
                 c->halo_valid = ext;
                 c->cur = dst;
-                s += 2;
+                s += K;
                 continue;
             }
             const bool split = c->sharded() && c->overlap && g.nzl > 2 * E;
-            if (split && c->alternate && E == 2 * R) {
+            if (split && c->alternate && K == 2 && E == 2 * R) {
                 // Mode 3: as below, but the two streams swap roles every pass.  The boundary kernels of this
                 // pass run on the stream that ran the interior of the previous one, so that dependency is
                 // stream order instead of an event hop (19 us in the kernel trace); the previous exchange,
@@ -1275,18 +1278,18 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 // mode 2.  Not the default; bench.py times it with the other modes on the fabric it runs on.
                 const hipStream_t sE = intr_on_aux ? c->s_aux : c->s_main, sI = intr_on_aux ? c->s_main : c->s_aux;
                 if (have_join) HIP_TRY(hipStreamWaitEvent(sE, c->ev_join, 0)); // ghost planes of the previous exchange
-                if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + E, sE));
-                if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - E, hi, sE));
+                if (c->has_lo()) TRY(launch_pass(lo, lo + E, sE, false));
+                if (c->has_hi()) TRY(launch_pass(hi - E, hi, sE, false));
                 HIP_TRY(hipEventRecord(c->ev_bdry, sE));
                 TRY(exchange_halo(c, dst, sE, E));
                 HIP_TRY(hipEventRecord(c->ev_join, sE));
                 have_join = true;
                 HIP_TRY(hipStreamWaitEvent(sI, c->ev_bdry, 0));
-                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + E : lo, c->has_hi() ? hi - E : hi, sI, true));
+                TRY(launch_pass(c->has_lo() ? lo + E : lo, c->has_hi() ? hi - E : hi, sI, true));
                 intr_on_aux = (sI == c->s_aux);
-                c->halo_valid = c->sharded() ? E : 2 * R;
+                c->halo_valid = c->sharded() ? E : H;
                 c->cur = dst;
-                s += 2;
+                s += K;
                 if (!(fuse && steps - s >= 2)) { // last fused pass of this call: everything back onto the main stream
                     if (intr_on_aux) {
                         HIP_TRY(hipEventRecord(c->ev_intr, c->s_aux));
@@ -1312,8 +1315,8 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                     HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
                     HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
                 }
-                if (c->has_lo()) TRY(launch_step2(c, src, dst, lo, lo + E, sb));
-                if (c->has_hi()) TRY(launch_step2(c, src, dst, hi - E, hi, sb));
+                if (c->has_lo()) TRY(launch_pass(lo, lo + E, sb, false));
+                if (c->has_hi()) TRY(launch_pass(hi - E, hi, sb, false));
                 HIP_TRY(hipEventRecord(c->ev_bdry, sb));
                 if (sb == c->s_main) HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_bdry, 0));
                 TRY(exchange_halo(c, dst, c->s_aux, E));
@@ -1326,15 +1329,15 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 // Cutting EVERY tile into four workgroups fixes that at 3 planes of pipeline fill per
                 // workgroup (0.396); cutting only the last 1/16 of the tiles -- dispatched last, they
                 // fill the holes -- keeps the long workgroups' efficiency.
-                TRY(launch_step2(c, src, dst, c->has_lo() ? lo + E : lo, c->has_hi() ? hi - E : hi, c->s_main, true));
+                TRY(launch_pass(c->has_lo() ? lo + E : lo, c->has_hi() ? hi - E : hi, c->s_main, true));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
             } else {
-                TRY(launch_step2(c, src, dst, lo, hi, c->s_main));
+                TRY(launch_pass(lo, hi, c->s_main, false));
                 TRY(exchange_halo(c, dst, c->s_main, E));
             }
-            c->halo_valid = c->sharded() ? E : 2 * R;
+            c->halo_valid = c->sharded() ? E : H;
             c->cur = dst;
-            s += 2;
+            s += K;
             continue;
         }
         TRY(ensure_halo(c, R));

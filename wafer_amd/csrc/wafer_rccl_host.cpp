@@ -188,7 +188,7 @@ int main(int argc, char **argv)
     p.dn = 0.02; p.dt = 8e-5; p.mass = 2.35; p.sig = 0.223; // BASELINE config #4
     p.max_states = 1;
     p.device = device;
-    p.halo_depth = 2; // two fused steps per exchange
+    p.halo_depth = 3; // ThreePoint fp64: three fused steps per exchange (wafer_k_step3_fused)
     int rc = 0;
     if (self) {
         const uint32_t parts = 8, per = nz / parts;

@@ -28,7 +28,7 @@
 // steps (tests/test_gpu_parity.py::test_fused_three_step_kernel_bit_exact).  Cells of phi1 / phi2
 // outside the work area (Dirichlet frame, config.rs:597-622) and planes outside the global work range
 // are forced to 0 exactly as the reference never updates them.  z-chunks recompute two planes of
-// phi1 and one of phi2 on each side.
+// phi1 and one of phi2 on each side; slabs of a sharded grid need 3 valid ghost planes of phi0.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -78,10 +78,26 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
         const int n = gridDim.x, q = n >> 3, r = n & 7, k = bid & 7;
         bid = k * q + min(k, r) + (bid >> 3);
     }
-    const int tz_i = bid / (ntx * nty);
-    const int tx_i = bid % ntx, ty_i = (bid / ntx) % nty;
-    const int zs = a.lz_lo + tz_i * a.zchunk;
-    const int ze = min(zs + a.zchunk, a.lz_hi);
+    int tx_i, ty_i, zs, ze;
+    if (a.nsub > 1) { // mixed launch (slab interiors): long workgroups first, the last tiles as short ones (WaferStepArgs)
+        int tile, sub = 0;
+        if (bid < a.n_long) {
+            tile = bid;
+        } else {
+            tile = a.n_long + (bid - a.n_long) / a.nsub;
+            sub = (bid - a.n_long) % a.nsub;
+        }
+        tx_i = tile % ntx;
+        ty_i = tile / ntx;
+        zs = bid < a.n_long ? a.lz_lo : a.lz_lo + sub * a.zchunk;
+        ze = bid < a.n_long ? a.lz_hi : min(zs + a.zchunk, a.lz_hi);
+    } else {
+        const int tz_i = bid / (ntx * nty);
+        tx_i = bid % ntx;
+        ty_i = (bid / ntx) % nty;
+        zs = a.lz_lo + tz_i * a.zchunk;
+        ze = min(zs + a.zchunk, a.lz_hi);
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: role tests become scalar branches
     const int x0 = tx_i * TX, y0 = ty_i * TY;
@@ -439,7 +455,17 @@ static inline hipError_t wafer_launch_step3_fused(WaferStepArgs a, const T *phi,
     const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX;
     const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     const int nplanes = a.lz_hi - a.lz_lo;
-    { // planes per workgroup: one workgroup per CU marching a long column (as the two-step kernel)
+    int swz = o.swz;
+    long long nblocks = 0;
+    if (a.nsub > 1 && nplanes < 8 * a.nsub) a.nsub = 0; // too thin to cut
+    if (a.nsub > 1) { // the interior launch of a slab: see wafer_launch_step2_fused_nw
+        const int ntiles = ntx * nty;
+        const int nshort_tiles = ntiles / 16 > 0 ? ntiles / 16 : 1;
+        a.n_long = ntiles - nshort_tiles;
+        a.zchunk = (nplanes + a.nsub - 1) / a.nsub;
+        nblocks = a.n_long + (long long)nshort_tiles * a.nsub;
+        swz = 0; // the hardware's dispatch order is the point
+    } else { // planes per workgroup: one workgroup per CU marching a long column (as the two-step kernel)
         const char *f = getenv("WAFER_ZCHUNK");
         if (f && atoi(f) > 0) {
             a.zchunk = atoi(f);
@@ -454,12 +480,12 @@ static inline hipError_t wafer_launch_step3_fused(WaferStepArgs a, const T *phi,
             if (nch > nplanes) nch = nplanes;
             a.zchunk = (int)((nplanes + nch - 1) / nch);
         }
+        nblocks = (long long)ntx * nty * ((nplanes + a.zchunk - 1) / a.zchunk);
     }
-    const long long nblocks = (long long)ntx * nty * ((nplanes + a.zchunk - 1) / a.zchunk);
     const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
     if (a.v_in_range != 0)
-        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, true>), grid, block, (size_t)o.pad, s, a, ntx, nty, o.swz, phi, pv, out);
+        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, true>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, out);
     else
-        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, false>), grid, block, (size_t)o.pad, s, a, ntx, nty, o.swz, phi, pv, out);
+        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, false>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, out);
     return hipGetLastError();
 }
