@@ -37,6 +37,10 @@
 #include "wafer_stencil_lds.hip.h"
 #include "wafer_stencil_fused2.hip.h"
 
+#ifndef WAFER_F3_OPT_DEFAULT
+#define WAFER_F3_OPT_DEFAULT 0
+#endif
+
 template <typename T>
 struct WaferF3Cfg {
     static constexpr int VEC = WaferVec<T>::N;
@@ -58,7 +62,13 @@ struct WaferF3Cfg {
     static_assert(CPL <= RY * VEC, "halo-column cells per lane must fit the row-slot registers");
 };
 
-template <typename T, typename C, bool VIR>
+// OPT (tuning variants kept side by side for A/B runs on one box, WAFER_F3_OPT):
+//   bit 0: the outermost phi0 halo rows are fetched by the halo-row waves instead of main waves 0 and 1 (their
+//          staging registers leave the main waves' path, where the pressure is);
+//   bit 1: b is carried from level 1 to levels 2 and 3 in registers (a = (1 - dt V/2) b formed from it: the same
+//          expressions, the same bits) instead of being formed from V three times; the registers come from the
+//          phi1 z-queue, whose two older planes are read back from a THREE-slot phi1 LDS ring instead.
+template <typename T, typename C, bool VIR, int OPT>
 __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(WaferStepArgs a, int ntx, int nty, int swz,
                                                                           const T *__restrict__ phi,
                                                                           const T *__restrict__ pv, T *__restrict__ out)
@@ -69,7 +79,9 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     constexpr int VEC = Cfg::VEC, RY = Cfg::RY, TX = Cfg::TX, TY = Cfg::TY;
     constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, HX2 = Cfg::HX2, LP0 = Cfg::LP0, LP1 = Cfg::LP1, LP2 = Cfg::LP2;
     __shared__ __attribute__((aligned(16))) T lds0[2 * Cfg::TILE0];
-    __shared__ __attribute__((aligned(16))) T lds1[2 * Cfg::TILE1];
+    constexpr bool OROW_H = (OPT & 1) != 0, CARRY_B = (OPT & 2) != 0;
+    constexpr int NB1 = CARRY_B ? 3 : 2;                 // phi1 ring slots
+    __shared__ __attribute__((aligned(16))) T lds1[NB1 * Cfg::TILE1];
     __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
 
     const WaferGeom &g = a.g;
@@ -134,8 +146,8 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
         rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + xi;
     }
     // ---- outermost phi0 halo rows y0-3 and y0+18, fetched by main waves 0 and 1
-    const bool has_orow = is_main && wave < 2;
-    const int oy = (wave == 0) ? (y0 - 3) : (y0 + TY + 2);
+    const bool has_orow = OROW_H ? is_hrow : (is_main && wave < 2);
+    const int oy = ((OROW_H ? wave - Cfg::NW2 : wave) == 0) ? (y0 - 3) : (y0 + TY + 2);
     const long long orow_off = (long long)(oy + R) * g.pitch + g.xoff + R + xi;
     const int orow_lds = (oy - (y0 - 3)) * LP0 + HX0 + xl;
     // ---- halo-column cells of the last wave: cell c = lane + 64 q: row c / 6 of the phi0 tile, k = c % 6:
@@ -170,11 +182,24 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
         wafer_ab_from_v<C>(vv, dt, vir, ca, cb);
         return (T)wafer_update<C>(w, ca, cb, dt, S, den);
     };
+    // level 1 with CARRY_B: also hands b out; levels 2, 3: b given, a = (1 - dt V / 2) * b (potential.rs:108-110)
+    auto update_keep_b = [&](C w, C vv, C S, C &cb) -> T {
+        C ca;
+        wafer_ab_from_v<C>(vv, dt, vir, ca, cb);
+        return (T)wafer_update<C>(w, ca, cb, dt, S, den);
+    };
+    auto update_with_b = [&](C w, C vv, C cb, C S) -> T {
+        const C ca = (C(1) - dt * vv / C(2)) * cb;
+        return (T)wafer_update<C>(w, ca, cb, dt, S, den);
+    };
 
     // ---- prologue: first phi1 plane is z1 = zs - 2; the phi0 queue holds planes z1-1 .. z1+1
     const int z1 = zs - 2;
     VT q0[3][RY], q1[3][RY], q2[3][RY];
     VT vq[3][RY];   // V of planes z-2, z-1, z: levels 3, 2 and 1 of one iteration
+    VT cbq[CARRY_B ? 2 : 1][RY], cbnew[RY]; // CARRY_B: b of planes z-2, z-1 (levels 3, 2) and of plane z as level 1 forms it
+#pragma unroll
+    for (int r = 0; r < RY; ++r) cbq[0][r] = cbq[CARRY_B ? 1 : 0][r] = cbnew[r] = zero;
     // (the halo-column wave keeps cell q of its CPL cells in component q % VEC of row slot q / VEC)
 #pragma unroll
     for (int m = 0; m < 3; ++m)
@@ -199,7 +224,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
         for (int q = 0; q < Cfg::CPL; ++q) vq[2][q / VEC][q % VEC] = pv[(long long)z1 * g.plane + c_off[q]];
     }
     for (int i = tid; i < 2 * Cfg::TILE0; i += Cfg::NT_) lds0[i] = T(0);
-    for (int i = tid; i < 2 * Cfg::TILE1; i += Cfg::NT_) lds1[i] = T(0);
+    for (int i = tid; i < NB1 * Cfg::TILE1; i += Cfg::NT_) lds1[i] = T(0);
     for (int i = tid; i < 2 * Cfg::TILE2; i += Cfg::NT_) lds2[i] = T(0);
     __syncthreads();
     {
@@ -254,8 +279,11 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
             if (has_orow) *reinterpret_cast<VT *>(nt + orow_lds) = orow_nxt;
         }
         const T *c0 = lds0 + (z & 1) * Cfg::TILE0;
-        T *w1 = lds1 + (z & 1) * Cfg::TILE1;
-        const T *c1 = lds1 + ((z - 1) & 1) * Cfg::TILE1;
+        // phi1 ring: plane p lives in slot p mod NB1 (z1 may be negative: + 3 * 2^20 keeps the operand positive)
+        const int s1w = CARRY_B ? (z + 3145728) % 3 : (z & 1), s1c = CARRY_B ? (z - 1 + 3145728) % 3 : ((z - 1) & 1);
+        T *w1 = lds1 + s1w * Cfg::TILE1;
+        const T *c1 = lds1 + s1c * Cfg::TILE1;
+        [[maybe_unused]] const T *c1o = lds1 + (CARRY_B ? (z - 2 + 3145728) % 3 : 0) * Cfg::TILE1; // plane z-2 (CARRY_B)
         T *w2 = lds2 + ((z - 1) & 1) * Cfg::TILE2;
         const T *c2 = lds2 + (z & 1) * Cfg::TILE2;          // plane z-2
         const bool wplane1 = work_plane(z), wplane2 = work_plane(z - 1);
@@ -287,7 +315,12 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                             ys[0] = (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
                             ys[2] = (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                            const T rs = update(w, (C)vq[2][r][v], S);
+                            T rs;
+                            if constexpr (CARRY_B) {
+                                C cb;
+                                rs = update_keep_b(w, (C)vq[2][r][v], S, cb);
+                                cbnew[r][v] = (T)cb;
+                            } else rs = update(w, (C)vq[2][r][v], S);
                             res[v] = (xi + v < g.nx) ? rs : T(0);
                         }
                     }
@@ -299,11 +332,13 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
             else level1(std::false_type{});
             // ---- 4. level 2: phi2 plane z-1 from the phi1 queue; x / y neighbours from the phi1 ring slot written
             //         one iteration ago
+            if constexpr (!CARRY_B) {
 #pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                q1[0][r] = q1[1][r];
-                q1[1][r] = q1[2][r];
-                q1[2][r] = p1new[r];
+                for (int r = 0; r < RY; ++r) {
+                    q1[0][r] = q1[1][r];
+                    q1[1][r] = q1[2][r];
+                    q1[2][r] = p1new[r];
+                }
             }
             auto level2 = [&](auto interior_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
@@ -312,18 +347,30 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                     VT res = zero;
                     if (INTERIOR || (lvl2[r] && wplane2 && rowwk[r])) {
                         const int ly = yrow[r] - (y0 - 2);
+                        // the own column of phi1: planes z-2 and z-1 from the register queue, or (CARRY_B) back from the ring
+                        VT m0, m1;
+                        if constexpr (CARRY_B) {
+                            m0 = *reinterpret_cast<const VT *>(c1o + ly * LP1 + HX1 + xl);
+                            m1 = *reinterpret_cast<const VT *>(c1 + ly * LP1 + HX1 + xl);
+                        } else {
+                            m0 = q1[0][r];
+                            m1 = q1[1][r];
+                        }
+                        const VT m2 = CARRY_B ? p1new[r] : q1[2][r];
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
-                            const C w = (C)q1[1][r][v];
+                            const C w = (C)m1[v];
                             C xs[3], ys[3], zz[3];
-                            zz[0] = (C)q1[0][r][v]; zz[1] = w; zz[2] = (C)q1[2][r][v];
+                            zz[0] = (C)m0[v]; zz[1] = w; zz[2] = (C)m2[v];
                             xs[1] = ys[1] = w;
-                            xs[0] = (v >= 1) ? (C)q1[1][r][(v + VEC - 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v - 1];
-                            xs[2] = (v + 1 < VEC) ? (C)q1[1][r][(v + 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v + 1];
+                            xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v - 1];
+                            xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v + 1];
                             ys[0] = (C)c1[(ly - 1) * LP1 + HX1 + xl + v];
                             ys[2] = (C)c1[(ly + 1) * LP1 + HX1 + xl + v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                            const T rs = update(w, (C)vq[1][r][v], S);
+                            T rs;
+                            if constexpr (CARRY_B) rs = update_with_b(w, (C)vq[1][r][v], (C)cbq[1][r][v], S);
+                            else rs = update(w, (C)vq[1][r][v], S);
                             res[v] = (xi + v < g.nx) ? rs : T(0);
                         }
                     }
@@ -362,7 +409,8 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                                     ys[0] = (r >= 1) ? (C)q2[1][r - 1 < 0 ? 0 : r - 1][v] : (C)c2[(ly - 1) * LP2 + HX2 + xl + v];
                                     ys[2] = (r + 1 < RY) ? (C)q2[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c2[(ly + 1) * LP2 + HX2 + xl + v];
                                     const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                                    res3[r][v] = update(w, (C)vq[0][r][v], S);
+                                    if constexpr (CARRY_B) res3[r][v] = update_with_b(w, (C)vq[0][r][v], (C)cbq[0][r][v], S);
+                                    else res3[r][v] = update(w, (C)vq[0][r][v], S);
                                 }
                             }
                         }
@@ -399,17 +447,23 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                         xs[0] = (C)c0[o0 - 1]; xs[2] = (C)c0[o0 + 1];
                         ys[0] = (C)c0[o0 - LP0]; ys[2] = (C)c0[o0 + LP0];
                         const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                        rs = update(w, (C)vq[2][q / VEC][q % VEC], S);
+                        if constexpr (CARRY_B) {
+                            C cb;
+                            rs = update_keep_b(w, (C)vq[2][q / VEC][q % VEC], S, cb);
+                            cbnew[q / VEC][q % VEC] = (T)cb;
+                        } else rs = update(w, (C)vq[2][q / VEC][q % VEC], S);
                     }
                     w1[c_lds1[q]] = rs;
                 }
                 p1new[q / VEC][q % VEC] = rs;
             }
+            if constexpr (!CARRY_B) {
 #pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                q1[0][r] = q1[1][r];
-                q1[1][r] = q1[2][r];
-                q1[2][r] = p1new[r];
+                for (int r = 0; r < RY; ++r) {
+                    q1[0][r] = q1[1][r];
+                    q1[1][r] = q1[2][r];
+                    q1[2][r] = p1new[r];
+                }
             }
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q) {
@@ -417,14 +471,16 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                     T rs = T(0);
                     if (wplane2 && c_wk[q]) {
                         const int o1 = c_lds1[q];
-                        const C w = (C)q1[1][q / VEC][q % VEC];
+                        const C w = CARRY_B ? (C)c1[o1] : (C)q1[1][q / VEC][q % VEC];
                         C xs[3], ys[3], zz[3];
-                        zz[0] = (C)q1[0][q / VEC][q % VEC]; zz[1] = w; zz[2] = (C)q1[2][q / VEC][q % VEC];
+                        zz[0] = CARRY_B ? (C)c1o[o1] : (C)q1[0][q / VEC][q % VEC]; zz[1] = w;
+                        zz[2] = CARRY_B ? (C)p1new[q / VEC][q % VEC] : (C)q1[2][q / VEC][q % VEC];
                         xs[1] = ys[1] = w;
                         xs[0] = (C)c1[o1 - 1]; xs[2] = (C)c1[o1 + 1];
                         ys[0] = (C)c1[o1 - LP1]; ys[2] = (C)c1[o1 + LP1];
                         const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                        rs = update(w, (C)vq[1][q / VEC][q % VEC], S);
+                        if constexpr (CARRY_B) rs = update_with_b(w, (C)vq[1][q / VEC][q % VEC], (C)cbq[1][q / VEC][q % VEC], S);
+                        else rs = update(w, (C)vq[1][q / VEC][q % VEC], S);
                     }
                     w2[c_lds2[q]] = rs;
                 }
@@ -440,6 +496,10 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
             vq[0][r] = vq[1][r];
             vq[1][r] = vq[2][r];
             vq[2][r] = pre_v[r];
+            if constexpr (CARRY_B) {
+                cbq[0][r] = cbq[1][r];
+                cbq[1][r] = cbnew[r];
+            }
         }
         orow_nxt = orow_pre;
     }
@@ -483,9 +543,19 @@ static inline hipError_t wafer_launch_step3_fused(WaferStepArgs a, const T *phi,
         nblocks = (long long)ntx * nty * ((nplanes + a.zchunk - 1) / a.zchunk);
     }
     const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
-    if (a.v_in_range != 0)
-        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, true>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, out);
-    else
-        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, false>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, out);
-    return hipGetLastError();
+    const char *eo = getenv("WAFER_F3_OPT");
+    const int opt = (eo && *eo) ? atoi(eo) : WAFER_F3_OPT_DEFAULT;
+#define WAFER_F3_CASE(VIR_, OPT_)                                                                                          \
+    if ((a.v_in_range != 0) == VIR_ && opt == OPT_) {                                                                      \
+        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, OPT_>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, out); \
+        return hipGetLastError();                                                                                          \
+    }
+    WAFER_F3_CASE(true, 0)
+    WAFER_F3_CASE(true, 1)
+    WAFER_F3_CASE(true, 3)
+    WAFER_F3_CASE(false, 0)
+    WAFER_F3_CASE(false, 1)
+    WAFER_F3_CASE(false, 3)
+#undef WAFER_F3_CASE
+    return hipErrorInvalidValue;
 }
