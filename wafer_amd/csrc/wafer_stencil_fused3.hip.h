@@ -67,7 +67,8 @@ struct WaferF3Cfg {
 //          staging registers leave the main waves' path, where the pressure is);
 //   bit 1: b is carried from level 1 to levels 2 and 3 in registers (a = (1 - dt V/2) b formed from it: the same
 //          expressions, the same bits) instead of being formed from V three times; the registers come from the
-//          phi1 z-queue, whose two older planes are read back from a THREE-slot phi1 LDS ring instead.
+//          phi1 z-queue, whose two older planes are read back from a THREE-slot phi1 LDS ring instead;
+//   bit 2: s_setprio: main waves above the halo waves.
 template <typename T, typename C, bool VIR, int OPT>
 __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(WaferStepArgs a, int ntx, int nty, int swz,
                                                                           const T *__restrict__ phi,
@@ -79,7 +80,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     constexpr int VEC = Cfg::VEC, RY = Cfg::RY, TX = Cfg::TX, TY = Cfg::TY;
     constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, HX2 = Cfg::HX2, LP0 = Cfg::LP0, LP1 = Cfg::LP1, LP2 = Cfg::LP2;
     __shared__ __attribute__((aligned(16))) T lds0[2 * Cfg::TILE0];
-    constexpr bool OROW_H = (OPT & 1) != 0, CARRY_B = (OPT & 2) != 0;
+    constexpr bool OROW_H = (OPT & 1) != 0, CARRY_B = (OPT & 2) != 0, PRIO = (OPT & 4) != 0;
     constexpr int NB1 = CARRY_B ? 3 : 2;                 // phi1 ring slots
     __shared__ __attribute__((aligned(16))) T lds1[NB1 * Cfg::TILE1];
     __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
@@ -118,6 +119,11 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     const bool is_main = wave < Cfg::NW2;
     const bool is_hrow = wave >= Cfg::NW2 && wave < Cfg::NW2 + Cfg::NWH;
     const bool is_hcol = wave == Cfg::NW - 1;
+    // bit 2: the main waves (three levels per plane: the critical path to the barrier) issue ahead of the halo waves
+    if constexpr (PRIO) {
+        if (is_main) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+    }
 
     VT zero;
 #pragma unroll
@@ -553,9 +559,11 @@ static inline hipError_t wafer_launch_step3_fused(WaferStepArgs a, const T *phi,
     WAFER_F3_CASE(true, 0)
     WAFER_F3_CASE(true, 1)
     WAFER_F3_CASE(true, 3)
+    WAFER_F3_CASE(true, 4)
     WAFER_F3_CASE(false, 0)
     WAFER_F3_CASE(false, 1)
     WAFER_F3_CASE(false, 3)
+    WAFER_F3_CASE(false, 4)
 #undef WAFER_F3_CASE
     return hipErrorInvalidValue;
 }
