@@ -125,3 +125,65 @@ def test_slab_evolve_matches_global(tmp_path, world, shape, ext, wnum):
         assert np.array_equal(got, want[:, :, e:-e])   # halo exchange is exact
     else:  # global sums are associated differently per decomposition
         assert np.allclose(got, want[:, :, e:-e], rtol=0, atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------
+# make_slab_comm's two-phase agreement (slab.py:306) with REAL ranks on gloo: a rank whose
+# local pre-check fails (library missing on its node) must take every rank to the torch.distributed
+# hooks together, before anything collective of the native path has started -- nobody left in a broadcast
+# ---------------------------------------------------------------------------------------------
+class _FakeCtx:
+    """just enough of wafer_amd.Context for TorchSlabComm's constructor"""
+    handle = None
+
+    def set_comm_hooks(self, halo, allreduce):
+        self.hooks = (halo, allreduce)
+
+
+def _fallback_worker(rank, world, port, failing_rank, phase, out_dir):
+    from wafer_amd import slab
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        real_pre = slab.NativeRcclSlabComm.precheck
+        calls = {"phase2": 0}
+
+        def pre(r):
+            if phase == 1 and r == failing_rank:
+                raise ImportError("simulated: libwafer_rccl.so is missing on this node")
+            return ("library", "id")            # never used: phase 2 is replaced below
+
+        class Native(slab.NativeRcclSlabComm):
+            precheck = staticmethod(pre)
+
+            def __init__(self, ctx, r, w, device, group=None, self_neighbours=False, prechecked=None):
+                calls["phase2"] += 1
+                box = [b"id"]                   # the collective of the real phase 2: every rank must get here or none
+                dist.broadcast_object_list(box, src=0, group=group)
+                if phase == 2 and r == failing_rank:
+                    raise RuntimeError("simulated: ncclCommInitRank failed")
+                self._handle = None
+
+            def close(self):
+                pass
+
+        slab.NativeRcclSlabComm = Native
+        comm, name = slab.make_slab_comm(_FakeCtx(), rank, world, torch.device("cpu"))
+        ok = isinstance(comm, slab.TorchSlabComm) and "torch.distributed" in name
+        if phase == 1:
+            ok = ok and calls["phase2"] == 0   # nobody entered the collective phase
+        else:
+            ok = ok and calls["phase2"] == 1
+        dist.barrier()                           # every rank is still in step
+        with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+            f.write("1" if ok else "0")
+        slab.NativeRcclSlabComm.precheck = real_pre
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("phase,failing_rank", [(1, 1), (1, 0), (2, 1)])
+def test_native_hook_fallback_is_agreed_by_all_ranks(tmp_path, phase, failing_rank):
+    world = 2
+    mp.spawn(_fallback_worker, args=(world, _free_port(), failing_rank, phase, str(tmp_path)), nprocs=world, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(world)] == ["1"] * world
