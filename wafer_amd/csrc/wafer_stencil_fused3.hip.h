@@ -38,7 +38,7 @@
 #include "wafer_stencil_fused2.hip.h"
 
 #ifndef WAFER_F3_OPT_DEFAULT
-#define WAFER_F3_OPT_DEFAULT 0
+#define WAFER_F3_OPT_DEFAULT 8
 #endif
 
 template <typename T>
@@ -81,6 +81,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, HX2 = Cfg::HX2, LP0 = Cfg::LP0, LP1 = Cfg::LP1, LP2 = Cfg::LP2;
     __shared__ __attribute__((aligned(16))) T lds0[2 * Cfg::TILE0];
     constexpr bool OROW_H = (OPT & 1) != 0, CARRY_B = (OPT & 2) != 0, PRIO = (OPT & 4) != 0;
+    constexpr bool NOXMASK = (OPT & 8) != 0; // bit 3: INTERIOR also requires the tile's columns to be work columns: no per-cell x mask
     constexpr int NB1 = CARRY_B ? 3 : 2;                 // phi1 ring slots
     __shared__ __attribute__((aligned(16))) T lds1[NB1 * Cfg::TILE1];
     __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
@@ -298,7 +299,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
         for (int r = 0; r < RY; ++r) p1new[r] = p2new[r] = zero;
 
         if (!is_hcol) {
-            bool all_rows = true;
+            bool all_rows = NOXMASK ? (x0 + TX <= g.nx) : true;
 #pragma unroll
             for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];
             // ---- 3. level 1: phi1 plane z (main and halo-row waves).  INTERIOR: the plane and every row of this
@@ -327,7 +328,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                                 rs = update_keep_b(w, (C)vq[2][r][v], S, cb);
                                 cbnew[r][v] = (T)cb;
                             } else rs = update(w, (C)vq[2][r][v], S);
-                            res[v] = (xi + v < g.nx) ? rs : T(0);
+                            res[v] = ((NOXMASK && INTERIOR) || xi + v < g.nx) ? rs : T(0);
                         }
                     }
                     p1new[r] = res;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                             T rs;
                             if constexpr (CARRY_B) rs = update_with_b(w, (C)vq[1][r][v], (C)cbq[1][r][v], S);
                             else rs = update(w, (C)vq[1][r][v], S);
-                            res[v] = (xi + v < g.nx) ? rs : T(0);
+                            res[v] = ((NOXMASK && INTERIOR) || xi + v < g.nx) ? rs : T(0);
                         }
                     }
                     p2new[r] = res;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                         for (int r = 0; r < RY; ++r) {
                             if (INTERIOR || rowwk[r]) {
                                 T *dst = out + (long long)zo3 * g.plane + rowoff[r];
-                                if (xi + VEC <= g.nx) {
+                                if ((NOXMASK && INTERIOR) || xi + VEC <= g.nx) {
                                     *reinterpret_cast<VT *>(dst) = res3[r];
                                 } else {
 #pragma unroll
@@ -560,10 +561,12 @@ static inline hipError_t wafer_launch_step3_fused(WaferStepArgs a, const T *phi,
     WAFER_F3_CASE(true, 1)
     WAFER_F3_CASE(true, 3)
     WAFER_F3_CASE(true, 4)
+    WAFER_F3_CASE(true, 8)
     WAFER_F3_CASE(false, 0)
     WAFER_F3_CASE(false, 1)
     WAFER_F3_CASE(false, 3)
     WAFER_F3_CASE(false, 4)
+    WAFER_F3_CASE(false, 8)
 #undef WAFER_F3_CASE
     return hipErrorInvalidValue;
 }
