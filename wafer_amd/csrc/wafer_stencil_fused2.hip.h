@@ -80,7 +80,9 @@ __device__ __forceinline__ void wafer_ab_from_v(C vv, C dt, bool v_in_range, C &
 // VIR: the potential passed check_v_range, so b's reciprocal takes its short form -- a template
 // parameter rather than a kernel argument so that the updates of a plane form one basic block and
 // their division chains interleave.
-template <typename T, typename C, int R, bool NT, bool ABV, int NW2 = 4, bool VIR = false>
+// YR: step 1 takes the y neighbours that lie inside the lane's own RY rows from registers instead of LDS (as step 2
+// does): fewer LDS reads on the critical path, the same values.
+template <typename T, typename C, int R, bool NT, bool ABV, int NW2 = 4, bool VIR = false, bool YR = true>
 __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fused(
     WaferStepArgs a, int ntx, int nty, int swz, const T *__restrict__ phi, const T *__restrict__ pv,
     const T *__restrict__ pb, T *__restrict__ out)
@@ -330,8 +332,9 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
             // INTERIOR: the plane and every row of this wave are work cells (the common case) -- no
             // wave-uniform tests are left inside, so the RY x VEC updates form ONE basic block and
             // their division chains interleave; the general form tests per row.
-            auto step1 = [&](auto interior_tag) {
+            auto step1 = [&](auto interior_tag, auto adjacent_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
+                constexpr bool ADJ = decltype(adjacent_tag)::value; // the wave's RY rows are neighbours (main waves; the halo-row waves' are not)
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     VT res = zero;
@@ -350,7 +353,8 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                                 } else {
                                     xs[d + R] = (v + d >= 0 && v + d < VEC) ? (C)q0[R][r][(v + d + VEC) % VEC]
                                                                            : (C)c0[ly * LP0 + HX0 + xl + v + d];
-                                    ys[d + R] = (C)c0[(ly + d) * LP0 + HX0 + xl + v];
+                                    ys[d + R] = (YR && ADJ && r + d >= 0 && r + d < RY) ? (C)q0[R][(r + d + RY) % RY][v]
+                                                                                 : (C)c0[(ly + d) * LP0 + HX0 + xl + v];
                                 }
                             }
                             const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
@@ -374,8 +378,13 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
             bool all_rows = wplane;
 #pragma unroll
             for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];
-            if (all_rows) step1(std::true_type{});
-            else step1(std::false_type{});
+            if (is_main) {
+                if (all_rows) step1(std::true_type{}, std::true_type{});
+                else step1(std::false_type{}, std::true_type{});
+            } else {
+                if (all_rows) step1(std::true_type{}, std::false_type{});
+                else step1(std::false_type{}, std::false_type{});
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q) {
@@ -550,16 +559,27 @@ static inline hipError_t wafer_launch_step2_fused_nw(WaferStepArgs a, const Wafe
     }
     const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
     const bool vir = a.v_in_range != 0;
+    { // YR (register y neighbours in step 1), for the default variant only (ordinary loads, a and b from V).  Same-box
+      // A/B at 512^3: FivePoint fp64 0.4390 against 0.4439 ms/step with it; ThreePoint fp64 no change; fp32 storage
+      // 0.2674 against 0.2600 WITHOUT it -- so: on for FivePoint fp64, off elsewhere (WAFER_F2_YREG=0/1 overrides).
+        const char *ey = getenv("WAFER_F2_YREG");
+        const bool yr = (ey && *ey) ? atoi(ey) != 0 : (R == 2 && std::is_same<T, double>::value);
+        if (o.nt == 0 && o.abv != 0) {
+            if (vir && yr) hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, true, true>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
+            else if (vir) hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, true, false>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
+            else if (yr) hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, false, true>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
+            else hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, false, false>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
+            return hipGetLastError();
+        }
+    }
 #define WAFER_F2_CASE(NT_, ABV_, VIR_)                                                                          \
     if ((o.nt != 0) == NT_ && (o.abv != 0) == ABV_ && (!ABV_ || vir == VIR_)) {                                 \
-        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, NT_, ABV_, NW2, VIR_>), grid, block, (size_t)o.pad, s, \
+        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, NT_, ABV_, NW2, VIR_, false>), grid, block, (size_t)o.pad, s, \
                            a, ntx, nty, swz, phi, ABV_ ? pv : pa, pb, out);                                      \
         return hipGetLastError();                                                                               \
     }
     WAFER_F2_CASE(true, true, true)
     WAFER_F2_CASE(true, true, false)
-    WAFER_F2_CASE(false, true, true)
-    WAFER_F2_CASE(false, true, false)
     WAFER_F2_CASE(true, false, false)
     WAFER_F2_CASE(false, false, false)
 #undef WAFER_F2_CASE

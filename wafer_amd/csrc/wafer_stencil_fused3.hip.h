@@ -38,7 +38,7 @@
 #include "wafer_stencil_fused2.hip.h"
 
 #ifndef WAFER_F3_OPT_DEFAULT
-#define WAFER_F3_OPT_DEFAULT 8
+#define WAFER_F3_OPT_DEFAULT 40
 #endif
 
 template <typename T>
@@ -81,6 +81,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, HX2 = Cfg::HX2, LP0 = Cfg::LP0, LP1 = Cfg::LP1, LP2 = Cfg::LP2;
     __shared__ __attribute__((aligned(16))) T lds0[2 * Cfg::TILE0];
     constexpr bool OROW_H = (OPT & 1) != 0, CARRY_B = (OPT & 2) != 0, PRIO = (OPT & 4) != 0;
+    constexpr bool YREG = (OPT & 32) != 0;   // bit 5: y neighbours inside the lane's own two rows from registers at levels 1 and 2 (as level 3 does)
     constexpr bool NOXMASK = (OPT & 8) != 0; // bit 3: INTERIOR also requires the tile's columns to be work columns: no per-cell x mask
     constexpr int NB1 = CARRY_B ? 3 : 2;                 // phi1 ring slots
     __shared__ __attribute__((aligned(16))) T lds1[NB1 * Cfg::TILE1];
@@ -319,8 +320,8 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                             xs[1] = ys[1] = w;
                             xs[0] = (v >= 1) ? (C)q0[1][r][(v + VEC - 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v - 1];
                             xs[2] = (v + 1 < VEC) ? (C)q0[1][r][(v + 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v + 1];
-                            ys[0] = (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
-                            ys[2] = (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
+                            ys[0] = (YREG && r >= 1) ? (C)q0[1][r >= 1 ? r - 1 : 0][v] : (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
+                            ys[2] = (YREG && r + 1 < RY) ? (C)q0[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
                             T rs;
                             if constexpr (CARRY_B) {
@@ -372,8 +373,8 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                             xs[1] = ys[1] = w;
                             xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v - 1];
                             xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v + 1];
-                            ys[0] = (C)c1[(ly - 1) * LP1 + HX1 + xl + v];
-                            ys[2] = (C)c1[(ly + 1) * LP1 + HX1 + xl + v];
+                            ys[0] = (YREG && !CARRY_B && r >= 1) ? (C)q1[1][r >= 1 ? r - 1 : 0][v] : (C)c1[(ly - 1) * LP1 + HX1 + xl + v];
+                            ys[2] = (YREG && !CARRY_B && r + 1 < RY) ? (C)q1[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c1[(ly + 1) * LP1 + HX1 + xl + v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
                             T rs;
                             if constexpr (CARRY_B) rs = update_with_b(w, (C)vq[1][r][v], (C)cbq[1][r][v], S);
@@ -562,11 +563,13 @@ static inline hipError_t wafer_launch_step3_fused(WaferStepArgs a, const T *phi,
     WAFER_F3_CASE(true, 3)
     WAFER_F3_CASE(true, 4)
     WAFER_F3_CASE(true, 8)
+    WAFER_F3_CASE(true, 40)
     WAFER_F3_CASE(false, 0)
     WAFER_F3_CASE(false, 1)
     WAFER_F3_CASE(false, 3)
     WAFER_F3_CASE(false, 4)
     WAFER_F3_CASE(false, 8)
+    WAFER_F3_CASE(false, 40)
 #undef WAFER_F3_CASE
     return hipErrorInvalidValue;
 }
