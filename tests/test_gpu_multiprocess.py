@@ -35,14 +35,14 @@ def _check_bench_two_rank_line(d):
     ho = d["config"]["halo_overlap"]      # the exchange schedules were tried during set-up, one was chosen for all ranks
     assert ho["mode"] in (0, 1, 2, 3) and len(ho["ms_per_step"]) == 6 and all(v > 0 for v in ho["ms_per_step"].values())
     assert ho["fused_passes_per_exchange"] in (1, 2)
-    assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 64
+    assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 128
     assert d["roofline"]["steps_per_launch"] == 3 and d["config"]["kernel"] == "wafer_k_step3_fused" and "cpu_baseline" not in d
     # the same grid undecomposed on rank 0's GPU: T1 in the same line, and every slab's bits against it
     ref = d["single_gpu_ref"]
-    assert ref["grid"] == [256, 256, 128] and ref["ms_per_step"] > 0 and d["single_gpu_ref_ms_per_step"] == ref["ms_per_step"]
+    assert ref["grid"] == [256, 256, 256] and ref["ms_per_step"] > 0 and d["single_gpu_ref_ms_per_step"] == ref["ms_per_step"]
     par = d["parity"]
     assert par["identical"] is True and par["slabs"] == 2 and par["steps"] == 10 and par["differing_slabs"] == []
-    assert par["initial_condition"]["norm2"] == par["initial_condition"]["closed_form"] == 128 * 128 * 64
+    assert par["initial_condition"]["norm2"] == par["initial_condition"]["closed_form"] == 128 * 128 * 128
     assert d["comm"]["process_group_ranks"] == 2 and d["comm"]["halo_overlap_mode"] == ho["mode"]
 
 
@@ -55,7 +55,7 @@ def test_bench_multi_rank_path():
     os.environ.update(env_extra)
     try:
         r = launch(2, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
-                   "--grid", "256,256,128")
+                   "--grid", "256,256,256")
     finally:
         for k in env_extra:
             os.environ.pop(k, None)
@@ -73,7 +73,7 @@ def test_bench_bare_call_starts_its_own_ranks():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
-                        "--grid", "256,256,128"], capture_output=True, text=True, env=env, timeout=420, cwd=ROOT)
+                        "--grid", "256,256,256"], capture_output=True, text=True, env=env, timeout=420, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

@@ -251,10 +251,15 @@ def test_fused3_zchunk_independence(wo, wa, zchunk, monkeypatch):
         assert ulp_diff(ctx.download_phi(), phi) == 0
 
 
-def test_fused3_thousand_steps_64cubed_and_default_dispatch(wo, wa):
-    """1000 steps (333 three-step passes + one single step) at 64^3 against the oracle; the three-step
-    kernel is what an undecomposed ThreePoint fp64 context runs by default, the two-step kernel what
-    FivePoint, fp32 storage and z-slabs run"""
+def test_fused3_thousand_steps_64cubed_and_default_dispatch(wo, wa, monkeypatch):
+    """1000 steps (333 three-step passes + one single step) at 64^3 (forced onto the kernel) against the
+    oracle; the three-step kernel is what a ThreePoint fp64 context of 6 M cells or more runs by default,
+    the two-step kernel what small grids, FivePoint, fp32 storage and slabs with two ghost planes run"""
+    with wa.Context(wa.Params(64, 64, 64, dn=0.2, dt=8e-3)) as ctx:      # small: launch-bound, the two-step kernel is faster
+        assert ctx.stencil_kernel_name() == "wafer_k_step2_fused"
+    with wa.Context(wa.Params(256, 256, 192, dn=0.2, dt=8e-3, max_states=1)) as ctx:
+        assert ctx.stencil_kernel_name() == "wafer_k_step3_fused" and ctx.steps_per_launch() == 3
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
     cfg, par = make_pair((64, 64, 64), ext=1, potential="Harmonic", dn=0.2, dt=8e-3, mass=1.0)
     v = wo.potential_generate(cfg)
     a, b = wo.ab(cfg, v)

@@ -452,7 +452,14 @@ static int launch_step(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, boo
 // z-slabs created with at least 3 * ext ghost planes; everything else takes the two-step kernel
 static bool fuse3_applies(const wafer_ctx *c)
 {
-    return active_variant(c) == 3 && c->g.R == 1 && !c->f32 && c->g.ny >= env_int("WAFER_FUSE3_MIN_NY", 16) &&
+    // Small grids are launch- and fill-bound and the deeper pipeline costs there: 50^3 5.8 against 4.5 us/step for
+    // the two-step kernel, 64^3 6.0 / 4.7, 128^3 9.1 / 8.7; from 256^3 up it wins (40.5 / 41.9 us, 384^3 0.177 /
+    // 0.196 ms).  WAFER_FUSE3_MIN_NY (tests) lifts both thresholds.
+    const int ny_env = env_int("WAFER_FUSE3_MIN_NY", -1);
+    const int min_ny = ny_env >= 0 ? ny_env : 16;
+    const long long min_cells = ny_env >= 0 ? 0 : (long long)env_int("WAFER_FUSE3_MIN_CELLS", 6000000);
+    return active_variant(c) == 3 && c->g.R == 1 && !c->f32 && c->g.ny >= min_ny &&
+           (long long)c->g.nx * c->g.ny * c->g.nzl >= min_cells &&
            (!c->sharded() || (c->g.G >= 3 * c->g.R && c->g.nzl >= 3 * c->g.R));
 }
 
