@@ -657,6 +657,51 @@ def test_one_pass_excited_step_equals_two_pass(wa, wnum, ext, monkeypatch):
     assert np.array_equal(out["0"][0], out["1"][0]) and out["0"][1] == out["1"][1]
 
 
+@pytest.mark.parametrize("potential", ["Coulomb", "SimpleCornell", "Harmonic", "ComplexCoulomb", "ComplexHarmonic"])
+@pytest.mark.parametrize("ext", [1, 2, 3])
+@pytest.mark.parametrize("wnum", [1, 2, 3])
+def test_closed_form_potential_evaluated_in_the_excited_step_kernel(wa, wnum, ext, potential, monkeypatch):
+    """the excited-state step kernels evaluate Coulomb / SimpleCornell / Harmonic (potential.rs:221-229,
+    241-249, 270-274) per cell instead of streaming the stored V: the same function that filled the
+    array, so identical bits per cell and identical sums (WAFER_VGEN=0 streams V); odd axes put a cell
+    at r = 0 (the r < dn clamp), the ragged shape leaves partial tiles"""
+    shape = (133, 21, 19)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("WAFER_VGEN", mode)
+        par = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.3, sig=0.223, central_difference=ext, max_states=4)
+        with wa.Context(par) as ctx:
+            ctx.set_potential(potential)
+            for i in range(wnum):
+                ctx.set_initial_condition("Gaussian", seed=80 + i)
+                ctx.normalise(ctx.norm2())
+                ctx.push_state()
+            ctx.set_initial_condition("Gaussian", seed=90)
+            ctx.evolve(wnum, 6)
+            ctx.evolve(wnum, 1)
+            out[mode] = (ctx.download_phi(), ctx.norm2(), ctx.observables())
+    assert np.array_equal(out["0"][0], out["1"][0]) and out["0"][1] == out["1"][1]
+    assert out["0"][2] == out["1"][2]
+
+
+def test_closed_form_potential_is_dropped_when_the_potential_is_replaced(wo, wa):
+    """a host potential uploaded AFTER a built-in one must be the one the excited-state kernels use"""
+    cfg, par = make_pair((24, 20, 28), ext=1, potential="Harmonic", dn=0.3, dt=0.01)
+    v = wo.potential_generate(cfg) * 1.75 + 0.3
+    a, b = wo.ab(cfg, v)
+    low = random_phi(cfg, seed=31)
+    wo.normalise(low, wo.norm2(cfg, low))
+    phi = random_phi(cfg, seed=41)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("Harmonic")
+        ctx.set_potential_host(v)
+        ctx.load_state(0, low)
+        ctx.upload_phi(phi)
+        ctx.evolve(1, 9)
+        wo.evolve(cfg, 1, a, b, phi, [low], 9)
+        assert np.allclose(ctx.download_phi(), phi, rtol=0, atol=1e-13)
+
+
 def test_solve_matches_oracle(wo, wa):
     """grid.rs:50-246: same block table (step, tau, E, diff) and stop step for the
     ground state and two excited states.  Excited states start here from a fresh

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwafer_hip.so")
 SOURCES = ["wafer_engine.hip"]
-HEADERS = ["wafer_geom.h", "wafer_stencil.hip.h", "wafer_stencil_lds.hip.h", "wafer_stencil_fused2.hip.h",
+HEADERS = ["wafer_geom.h", "wafer_stencil.hip.h", "wafer_stencil_lds.hip.h", "wafer_stencil_fused2.hip.h", "wafer_stencil_fused3.hip.h",
            "wafer_elementwise.hip.h", "wafer_setup.hip.h"]
 # -ffp-contract=off: the stencil update must round exactly like the reference's
 # (rustc never fuses mul+add); see DESIGN.md "Arithmetic contract".

@@ -151,6 +151,7 @@ struct wafer_ctx {
     double potsub_scalar = 0.0;
     bool have_pot = false, have_phi = false;
     bool v_in_range = false; // 2^-400 < |1 + dt*V/2| < 2^400 everywhere (wafer_recip's short form is exact)
+    int vgen_type = 0;       // V was generated from this closed form (Coulomb / SimpleCornell / Harmonic), else 0: kernels may re-evaluate it instead of streaming it
 
     double *partials = nullptr; // [1 + WAFER_MAX_LOW][partials_stride]
     size_t partials_stride = 0;
@@ -634,11 +635,16 @@ static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum,
         a.v_in_range = c->v_in_range ? 1 : 0;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
+        a.vg_dn = c->P.dn; a.vg_mass = c->P.mass; a.vg_sig = c->P.sig;
+        // closed-form V in the kernel: fp64 contexts whose potential is one of the three forms, and whose
+        // radii dn .. dn * sqrt(3) (n + 1) / 2 lie inside the range of the short reciprocal (wafer_vgen_at)
+        const bool r_ok = c->P.dn > 0x1p-300 && c->P.dn * ((double)g.nx + g.ny + g.nz + 3.) < 0x1p300;
+        const int vg = (!c->f32 && r_ok && env_int("WAFER_VGEN", 1) != 0) ? c->vgen_type : 0;
         const long long nb = wafer_step_lds_excited_blocks<T, R>(g, lz_lo, lz_hi, target, (int)wnum, transform_on_load);
         if (pbase + nb > (long long)c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
         if (wafer_launch_step_lds_excited<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->v), as<T>(c->phi[dst]), c->partials + pbase,
                                                    c->partials_stride /* the row stride of the partials, too */, (int)wnum, low, s,
-                                                   transform_on_load ? c->scal : nullptr, c->gram) != hipSuccess)
+                                                   transform_on_load ? c->scal : nullptr, c->gram, vg) != hipSuccess)
             return fail(WAFER_ERR_HIP, "excited-state stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
         *nb_out = nb;
         return (int)WAFER_OK;
@@ -1018,6 +1024,10 @@ int wafer_set_potential_builtin(wafer_ctx *c, int potential)
         }
     }
     c->have_pot = true;
+    // the excited-state kernels can evaluate these instead of reading V (wafer_k_step_lds, VG)
+    c->vgen_type = (potential == WAFER_POT_COULOMB || potential == WAFER_POT_COMPLEXCOULOMB) ? WAFER_POT_COULOMB
+                   : (potential == WAFER_POT_HARMONIC || potential == WAFER_POT_COMPLEXHARMONIC) ? WAFER_POT_HARMONIC
+                   : (potential == WAFER_POT_SIMPLECORNELL) ? WAFER_POT_SIMPLECORNELL : 0;
     return check_v_range(c);
 }
 
@@ -1029,6 +1039,7 @@ int wafer_set_potential_host(wafer_ctx *c, const double *v, int potsub_kind, dou
     HIP_TRY(hipSetDevice(c->P.device));
     TRY(upload_padded(c, v, c->v));
     TRY(refresh_ab(c));
+    c->vgen_type = 0;
     c->potsub_kind = potsub_kind;
     c->potsub_scalar = (potsub_kind == WAFER_POTSUB_SCALAR) ? potsub_scalar : 0.0;
     if (potsub_kind == WAFER_POTSUB_ARRAY) {
@@ -1189,6 +1200,7 @@ int wafer_set_potential_resampled(wafer_ctx *c, const double *src, uint32_t sx, 
     HIP_TRY(hipSetDevice(c->P.device));
     TRY(resample_into(c, src, sx, sy, sz, basis, c->v));
     TRY(refresh_ab(c));
+    c->vgen_type = 0;
     c->potsub_kind = WAFER_POTSUB_NONE; // potential.rs:357-358: FromFile has no pot_sub of its own
     c->potsub_scalar = 0.0;
     c->have_pot = true;

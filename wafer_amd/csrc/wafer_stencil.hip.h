@@ -128,6 +128,9 @@ struct WaferStepArgs {
     // observables mode of the LDS kernel (NLOW = -2): wafer_potsub_kind and the scalar pot_sub
     int potsub_kind = 0;
     double potsub_scalar = 0.0;
+    // kernels that form V from its closed form instead of streaming it (template parameter VG of
+    // wafer_k_step_lds): the parameters potential.rs:188-274 reads
+    double vg_dn = 0.0, vg_mass = 0.0, vg_sig = 0.0;
 };
 
 // ---------------------------------------------------------------------------

@@ -18,6 +18,7 @@
 #include <type_traits>
 #include "wafer_geom.h"
 #include "wafer_stencil.hip.h"
+#include "wafer_setup.hip.h"
 
 template <typename T> struct WaferVec;
 template <> struct WaferVec<double> { static constexpr int N = 2; typedef double __attribute__((ext_vector_type(2))) type; };
@@ -114,6 +115,46 @@ __device__ __forceinline__ void wafer_st_stream(VT *p, VT v)
     else *p = v;
 }
 
+// ---- closed-form potentials evaluated in the step kernel (template parameter VG) -----------------
+// sqrt of r^2 = dx^2 + dy^2 + dz^2 (potential.rs:366-371): the argument is zero or lies in
+// [0.75, 3 (n+1)^2 / 4], so the scaling branch of hipcc's correctly rounded fp64 square root
+// (arguments below 2^-767) never applies; what is left of its expansion is spelled here -- v_rsq_f64,
+// the coupled Goldschmidt step and two Newton corrections of the root -- and gives the same bits
+// (tests: the kernel's V against the stored array, cell by cell, through identical phi).
+__device__ __forceinline__ double wafer_sqrt_r2(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x == 0.0 ? x : g;
+}
+
+// potential.rs:221-229 / 241-249 / 270-274 at PADDED global index (ix, iy, iz): the expressions of
+// wafer_potential_at (wafer_setup.hip.h) with the square root above and, for Coulomb, -1/r as the
+// negated short reciprocal (IEEE division is sign-symmetric; wafer_recip's short form holds for
+// 2^-400 < r < 2^400, which the engine checks on dn and the grid size before it selects VG).
+template <int VG>
+__device__ __forceinline__ double wafer_vgen_at(const WaferPotArgs &a, int ix, int iy, int iz)
+{
+    const double r = a.dn * wafer_sqrt_r2(wafer_r2(ix, iy, iz, a.g.nx, a.g.ny, a.g.nz));
+    if constexpr (VG == 4) { // Coulomb / ComplexCoulomb
+        return -wafer_recip((r < a.dn) ? a.dn : r, true);
+    } else if constexpr (VG == 7) { // SimpleCornell
+        const double far = (-0.5 * (4. / 3.)) / r + a.sig * r + 4. * a.mass;
+        return (r < a.dn) ? 4. * a.mass : far;
+    } else { // Harmonic / ComplexHarmonic
+        static_assert(VG == 9, "closed forms: Coulomb (4), SimpleCornell (7), Harmonic (9)");
+        return r * r / 2.;
+    }
+}
+
 // ABV: `pa` is the potential V and a, b are formed in registers exactly as
 // potential.rs:104-110 does (same expressions => the same bits as the stored
 // arrays), which removes one of the four HBM streams: 24 B instead of 32 B of
@@ -132,7 +173,19 @@ __device__ __forceinline__ void wafer_st_stream(VT *p, VT v)
 // w^2 r^2 with the WORK-area index, grid.rs:429-435) go to partials[q * pstride + workgroup];
 // an array pot_sub rides in low.p[0].  16 B per lane from HBM instead of the scalar loads of
 // wafer_k_observables (kept as the plain reference kernel: WAFER_OBS_LDS=0).
-template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false, int NW = 4>
+// VG != 0 (fp64, with ABV): V is not streamed at all.  The potential is one of the closed forms of
+// potential.rs:188-274 (VG = its wafer_potential number: Coulomb, SimpleCornell, Harmonic) and every
+// lane evaluates wafer_potential_at -- the function that filled the stored array, so the same bits --
+// for the cells it updates: 8 B per update less through the L2 <-> fabric path, which is what bounds
+// the excited-state kernels ((3+k)*8 -> (2+k)*8 B), paid for with a square root and a division per
+// cell out of the VALU time those kernels spend waiting.
+// VIRT: a.v_in_range known at compile time (1 / 0) instead of tested per cell (-1): no scalar branch
+// inside the update, so the RY x VEC cells of a lane share one basic block and their chains interleave.
+// DEEP (with XF): the lane's own cells of phi and of the stored states are requested TWO planes ahead --
+// raw, into a staging set that is transformed one iteration later -- so that two planes per array are
+// in flight per lane instead of one: with V no longer streamed a k = 1 step has only four 16-byte
+// vectors per lane under way, too few to cover the memory latency with one workgroup per CU.
+template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false, int NW = 4, int VG = 0, int VIRT = -1, bool DEEP = false>
 __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty, int swz,
                                                         const T *__restrict__ phi,
                                                         const T *__restrict__ pa,
@@ -147,6 +200,8 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
     constexpr int NL = NLOW > 0 ? NLOW : 0;
     static_assert(!XF || NL > 0, "transform-on-load needs stored states");
     static_assert(!OBS || (ABV && std::is_same<C, double>::value), "observables: V in pa's slot, fp64 sums");
+    static_assert(VG == 0 || (ABV && std::is_same<T, double>::value), "closed-form V: fp64 storage, a and b formed in registers");
+    static_assert(!DEEP || XF, "the two-plane prefetch is built for the transform-on-load kernels");
     using Cfg = WaferLdsCfg<T, R, RY, NW>;
     using VT = typename WaferVec<T>::type;
     constexpr int VEC = Cfg::VEC, TX = Cfg::TX, TY = Cfg::TY, HX = Cfg::HX, LP = Cfg::LP;
@@ -215,6 +270,13 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
     }
 
     const C dt = (C)a.dt, den = (C)a.den;
+    [[maybe_unused]] WaferPotArgs vgen;   // only the fields wafer_potential_at reads for these types
+    if constexpr (VG != 0) {
+        vgen.g = g;
+        vgen.type = VG;
+        vgen.dn = a.vg_dn; vgen.dt = a.dt; vgen.mass = a.vg_mass; vgen.sig = a.vg_sig;
+        vgen.mu_t = vgen.alphas_2pit = vgen.xi_coef = vgen.xi_fac = 0.0;
+    }
     VT zero;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) zero[v] = T(0);
@@ -234,19 +296,24 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
     }
     // loads one VEC group / one cell of phi at element offset `off`, transformed if XF;
     // lkeep (may be null) receives the stored states' values at the same cells
+    // x = phi/norm - sum_j l_j s_j on one VEC group (grid.rs:467, 488-490)
+    auto xform_vec = [&](VT w, const VT *l) -> VT {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            C x = wafer_div_invariant<C>((C)w[v], xnorm);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) x = x - (C)l[j][v] * xsj[j];
+            w[v] = (T)x;
+        }
+        return w;
+    };
     auto load_vec = [&](long long off, VT *lkeep) -> VT {
         VT w = *reinterpret_cast<const VT *>(phi + off);
         if constexpr (XF) {
             VT l[NL];
 #pragma unroll
             for (int j = 0; j < NL; ++j) l[j] = *reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + off);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                C x = wafer_div_invariant<C>((C)w[v], xnorm);
-#pragma unroll
-                for (int j = 0; j < NL; ++j) x = x - (C)l[j][v] * xsj[j];
-                w[v] = (T)x;
-            }
+            w = xform_vec(w, l);
             if (lkeep) {
 #pragma unroll
                 for (int j = 0; j < NL; ++j) lkeep[j] = l[j];
@@ -285,7 +352,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
     VT ab_a[RY], ab_b[RY];
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-        ab_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + (long long)zs * g.plane + rowoff[r]));
+        if constexpr (VG == 0) ab_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + (long long)zs * g.plane + rowoff[r]));
         if constexpr (!ABV)
             ab_b[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + (long long)zs * g.plane + rowoff[r]));
     }
@@ -314,6 +381,18 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
             hcol_nxt[qq] = load_cell((long long)(zs + 1) * g.plane + hcol_off[qq]);
     }
+    // DEEP: the raw own cells of plane zs+R+1, transformed during iteration zs
+    [[maybe_unused]] VT raw_w[RY];
+    [[maybe_unused]] VT raw_l[NL > 0 ? NL : 1][RY];
+    if constexpr (DEEP) {
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const long long off = (long long)(zs + R + 1) * g.plane + rowoff[r];
+            raw_w[r] = *reinterpret_cast<const VT *>(phi + off);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) raw_l[j][r] = *reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + off);
+        }
+    }
     __syncthreads();
 
     double acc = 0.0;
@@ -328,6 +407,37 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         VT pre[RY], pre_a[RY], pre_b[RY];
         VT hrow_pre[Cfg::HALO_ROWS_PER_WAVE];
         T hcol_pre[Cfg::HALO_X_ITERS];
+        [[maybe_unused]] VT nxt_w[RY];
+        [[maybe_unused]] VT nxt_l[NL > 0 ? NL : 1][RY];
+        if constexpr (DEEP) {
+            // the halo of plane z+2 first (its data is needed in this iteration; loads complete in order),
+            // then the raw own cells of plane z+R+2, which stay in flight over the barrier
+#pragma unroll
+            for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
+                hrow_pre[qq] = load_vec(zo + 2 * g.plane + hrow_off[qq], nullptr);
+#pragma unroll
+            for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
+                hcol_pre[qq] = load_cell(zo + 2 * g.plane + hcol_off[qq]);
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                const long long off = zo + (long long)(R + 2) * g.plane + rowoff[r];
+                nxt_w[r] = *reinterpret_cast<const VT *>(phi + off);
+#pragma unroll
+                for (int j = 0; j < NL; ++j) nxt_l[j][r] = *reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + off);
+                if constexpr (VG == 0) pre_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]));
+            }
+            // plane z+R+1, requested one iteration ago
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                VT l[NL > 0 ? NL : 1];
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    l[j] = raw_l[j][r];
+                    lq[R + 1][r][j] = l[j];
+                }
+                pre[r] = xform_vec(raw_w[r], l);
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             {
@@ -338,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                     for (int j = 0; j < NL; ++j) lq[R + 1][r][j] = keep[j];
                 }
             }
-            pre_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]));
+            if constexpr (VG == 0) pre_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]));
             if constexpr (!ABV) pre_b[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pb + zo + g.plane + rowoff[r]));
         }
 #pragma unroll
@@ -347,6 +457,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
             hcol_pre[qq] = load_cell(zo + 2 * g.plane + hcol_off[qq]);
+        }
 
         // stored states at this plane (only the cells this lane updates)
         VT lw[NL > 0 ? NL : 1][RY];
@@ -374,6 +485,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         // ---- 3. update plane z
         const T *ct = lds + (z & 1) * Cfg::TILE;
         [[maybe_unused]] const double ob_dz = (double)(g.z_begin + (z - g.G)) - ((double)g.nz + 1.) / 2.;
+        VT resq[RY];
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             VT res;
@@ -416,31 +528,43 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                 }
                 C ca, cb;
                 if constexpr (ABV) { // potential.rs:104-110
-                    const C vv = (C)ab_a[r][v];
-                    cb = wafer_recip(C(1) + dt * vv / C(2), a.v_in_range != 0);
+                    C vv;
+                    if constexpr (VG != 0) vv = (C)wafer_vgen_at<VG>(vgen, xi + v + R, y0 + yl + r + R, g.zp_of(z)); // potential.rs:46-62
+                    else vv = (C)ab_a[r][v];
+                    cb = wafer_recip(C(1) + dt * vv / C(2), VIRT < 0 ? a.v_in_range != 0 : VIRT != 0);
                     ca = (C(1) - dt * vv / C(2)) * cb;
                 } else {
                     ca = (C)ab_a[r][v];
                     cb = (C)ab_b[r][v];
                 }
-                const T rs = (T)wafer_update<C>(w, ca, cb, dt, S, den);
-                res[v] = rs;
-                if constexpr (NORM) {
-                    if (rowin[r] && xi + v < g.nx) {
-                        acc += (double)rs * (double)rs;
-#pragma unroll
-                        for (int j = 0; j < NL; ++j) acc_t[j] += (double)((C)lw[j][r][v] * (C)rs);
-                    }
-                }
+                res[v] = (T)wafer_update<C>(w, ca, cb, dt, S, den);
             }
-            if (!OBS && rowin[r]) {
+            resq[r] = res;
+        }
+        // sums: cells outside the work area contribute an exact zero through a select, not a branch (the
+        // update of all RY x VEC cells above stays one basic block); per accumulator the order is unchanged
+        if constexpr (NORM) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const C m = (rowin[r] && xi + v < g.nx) ? (C)resq[r][v] : C(0);
+                    acc += (double)m * (double)m;
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) acc_t[j] += (double)((C)lw[j][r][v] * m);
+                }
+        }
+        if constexpr (!OBS) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                if (!rowin[r]) continue;
                 T *dst = out + zo + rowoff[r];
                 if (xi + VEC <= g.nx) {
-                    wafer_st_stream<NT>(reinterpret_cast<VT *>(dst), res);
+                    wafer_st_stream<NT>(reinterpret_cast<VT *>(dst), resq[r]);
                 } else {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v)
-                        if (xi + v < g.nx) dst[v] = res[v];
+                        if (xi + v < g.nx) dst[v] = resq[r][v];
                 }
             }
         }
@@ -453,7 +577,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             q[2 * R][r] = pre[r];
-            ab_a[r] = pre_a[r];
+            if constexpr (VG == 0) ab_a[r] = pre_a[r];
             if constexpr (!ABV) ab_b[r] = pre_b[r];
         }
 #pragma unroll
@@ -467,6 +591,14 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                 for (int r = 0; r < RY; ++r)
 #pragma unroll
                     for (int j = 0; j < NL; ++j) lq[m][r][j] = lq[m + 1][r][j];
+        }
+        if constexpr (DEEP) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                raw_w[r] = nxt_w[r];
+#pragma unroll
+                for (int j = 0; j < NL; ++j) raw_l[j][r] = nxt_l[j][r];
+            }
         }
     }
     if constexpr (OBS) {
@@ -488,7 +620,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
     }
 }
 
-template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false, int NW = 4>
+template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false, int NW = 4, int VG = 0, int VIRT = -1, bool DEEP = false>
 static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLdsOpts &o, const T *phi,
                                                   const T *pa, const T *pb, T *out, double *partials,
                                                   size_t partials_cap, hipStream_t s,
@@ -503,7 +635,7 @@ static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLd
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
     const long long nblocks = (long long)ntx * nty * ntz;
     if ((NLOW >= 0 || NLOW == -2) && (size_t)nblocks > partials_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NLOW, NT, ABV, XF, NW>), dim3((unsigned)nblocks), dim3(Cfg::NT), (size_t)o.pad, s,
+    hipLaunchKernelGGL((wafer_k_step_lds<T, C, R, RY, NLOW, NT, ABV, XF, NW, VG, VIRT, DEEP>), dim3((unsigned)nblocks), dim3(Cfg::NT), (size_t)o.pad, s,
                        a, ntx, nty, o.swz, phi, pa, pb, out, partials, (long long)partials_cap, low, xscal, xgram);
     return hipGetLastError();
 }
@@ -523,10 +655,28 @@ template <typename T, typename C, int R>
 static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T *phi, const T *pv, T *out,
                                                        double *partials, size_t partials_cap, int nlow,
                                                        const WaferLowPtrs &low, hipStream_t s,
-                                                       const double *xscal = nullptr, const double *xgram = nullptr)
+                                                       const double *xscal = nullptr, const double *xgram = nullptr, int vg = 0)
 {
     WaferLdsOpts o = wafer_lds_opts();
     o.ry = 2;
+    if constexpr (std::is_same<T, double>::value && std::is_same<C, double>::value) {
+        // closed-form V in the kernel (fp64, transform-on-load, 8-wave tiles): one HBM stream fewer
+        if (vg != 0 && xscal && a.v_in_range != 0 && wafer_excited_nw(nlow) == 8) {
+            // two planes in flight where the registers allow it (k = 3 sits at 226 VGPRs already); WAFER_XF_DEEP=0: one
+            const char *ed = getenv("WAFER_XF_DEEP");
+            const bool deep = (ed && *ed) ? atoi(ed) != 0 : true;
+#define WAFER_VG_CASE(NLOW_, VG_)                                                                                          \
+    if (nlow == NLOW_ && vg == VG_) {                                                                                      \
+        if (deep && NLOW_ <= 2 && R <= 2)                                                                                  \
+            return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1, (NLOW_ <= 2 && R <= 2)>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
+        return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
+    }
+            WAFER_VG_CASE(1, 4) WAFER_VG_CASE(2, 4) WAFER_VG_CASE(3, 4)
+            WAFER_VG_CASE(1, 7) WAFER_VG_CASE(2, 7) WAFER_VG_CASE(3, 7)
+            WAFER_VG_CASE(1, 9) WAFER_VG_CASE(2, 9) WAFER_VG_CASE(3, 9)
+#undef WAFER_VG_CASE
+        }
+    }
     if (xscal) { // transform-on-load: phi is the raw previous step
         if (wafer_excited_nw(nlow) == 8) { // 128x16 tiles, 8 waves: half the halo rows per array
             switch (nlow) {
