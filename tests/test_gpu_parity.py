@@ -679,9 +679,14 @@ def test_closed_form_potential_evaluated_in_the_excited_step_kernel(wa, wnum, ex
             ctx.set_initial_condition("Gaussian", seed=90)
             ctx.evolve(wnum, 6)
             ctx.evolve(wnum, 1)
-            out[mode] = (ctx.download_phi(), ctx.norm2(), ctx.observables())
+            out[mode] = [ctx.download_phi(), ctx.norm2(), ctx.observables()]
+            # the single-step ground-state kernel and compute_observables take the closed form as well
+            ctx.set_stencil_variant(1)
+            ctx.evolve(0, 3)
+            out[mode] += [ctx.download_phi(), ctx.observables()]
     assert np.array_equal(out["0"][0], out["1"][0]) and out["0"][1] == out["1"][1]
     assert out["0"][2] == out["1"][2]
+    assert np.array_equal(out["0"][3], out["1"][3]) and out["0"][4] == out["1"][4]
 
 
 def test_closed_form_potential_is_dropped_when_the_potential_is_replaced(wo, wa):

@@ -368,6 +368,21 @@ static int default_variant(const wafer_ctx *c)
 
 static int active_variant(const wafer_ctx *c) { return c->variant >= 0 ? c->variant : default_variant(c); }
 
+// The closed form a kernel may evaluate instead of streaming V (0: none): fp64 contexts whose potential was
+// generated from Coulomb / SimpleCornell / Harmonic and whose radii dn .. dn * sqrt(3) (n + 1) / 2 lie inside
+// the range of the short reciprocal (wafer_vgen_at); WAFER_VGEN=0 keeps every kernel on the stored array.
+static int closed_form_vg(const wafer_ctx *c)
+{
+    const bool r_ok = c->P.dn > 0x1p-300 && c->P.dn * ((double)c->g.nx + c->g.ny + c->g.nz + 3.) < 0x1p300;
+    return (!c->f32 && r_ok && env_int("WAFER_VGEN", 1) != 0) ? c->vgen_type : 0;
+}
+static void set_vg_args(const wafer_ctx *c, WaferStepArgs &a)
+{
+    a.vg_dn = c->P.dn;
+    a.vg_mass = c->P.mass;
+    a.vg_sig = c->P.sig;
+}
+
 template <typename T, typename C, int R, bool NORM>
 static int launch_step_t(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s)
 {
@@ -383,6 +398,7 @@ static int launch_step_t(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, h
     a.v_in_range = c->v_in_range ? 1 : 0;
     const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
     a.den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:569 / 594 / 626
+    set_vg_args(c, a);
     const T *phi = as<T>(c->phi[src]);
     T *out = as<T>(c->phi[dst]);
     if (variant >= 1) {
@@ -391,7 +407,7 @@ static int launch_step_t(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, h
             e = wafer_launch_step_lds_excited<T, C, R>(a, phi, as<T>(c->v), out, c->partials, c->partials_stride, 0,
                                                        WaferLowPtrs(), s);
         else
-            e = wafer_launch_step_lds<T, C, R>(a, phi, as<T>(c->a), as<T>(c->b), as<T>(c->v), out, s);
+            e = wafer_launch_step_lds<T, C, R>(a, phi, as<T>(c->a), as<T>(c->b), as<T>(c->v), out, s, closed_form_vg(c));
         return e == hipSuccess ? WAFER_OK
                                : fail(WAFER_ERR_HIP, "LDS stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
@@ -635,11 +651,8 @@ static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum,
         a.v_in_range = c->v_in_range ? 1 : 0;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
         a.den = lead * c->P.dn * c->P.dn * c->P.mass;
-        a.vg_dn = c->P.dn; a.vg_mass = c->P.mass; a.vg_sig = c->P.sig;
-        // closed-form V in the kernel: fp64 contexts whose potential is one of the three forms, and whose
-        // radii dn .. dn * sqrt(3) (n + 1) / 2 lie inside the range of the short reciprocal (wafer_vgen_at)
-        const bool r_ok = c->P.dn > 0x1p-300 && c->P.dn * ((double)g.nx + g.ny + g.nz + 3.) < 0x1p300;
-        const int vg = (!c->f32 && r_ok && env_int("WAFER_VGEN", 1) != 0) ? c->vgen_type : 0;
+        set_vg_args(c, a);
+        const int vg = closed_form_vg(c);
         const long long nb = wafer_step_lds_excited_blocks<T, R>(g, lz_lo, lz_hi, target, (int)wnum, transform_on_load);
         if (pbase + nb > (long long)c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
         if (wafer_launch_step_lds_excited<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->v), as<T>(c->phi[dst]), c->partials + pbase,
@@ -1485,11 +1498,12 @@ int wafer_observables(wafer_ctx *c, wafer_observables_t *out)
         sa.target_blocks = c->num_cus;
         sa.potsub_kind = c->potsub_kind;
         sa.potsub_scalar = c->potsub_scalar;
+        set_vg_args(c, sa);
         TRY(dispatch(c, [&](auto t, auto, auto r) {
             using T = decltype(t);
             constexpr int RR = decltype(r)::value;
             if (wafer_launch_observables_lds<T, RR>(sa, as<T>(c->phi[c->cur]), as<T>(c->v), as<T>(c->potsub), c->partials,
-                                                    c->partials_stride, c->s_main, &nb) != hipSuccess)
+                                                    c->partials_stride, c->s_main, &nb, closed_form_vg(c)) != hipSuccess)
                 return fail(WAFER_ERR_HIP, "observables launch failed: %s", hipGetErrorString(hipGetLastError()));
             return (int)WAFER_OK;
         }));

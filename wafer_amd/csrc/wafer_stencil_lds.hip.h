@@ -513,7 +513,9 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                 const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
                 if constexpr (OBS) {
                     if (rowin[r] && xi + v < g.nx) {
-                        const double vv = (double)ab_a[r][v];
+                        double vv;
+                        if constexpr (VG != 0) vv = wafer_vgen_at<VG>(vgen, xi + v + R, y0 + yl + r + R, g.zp_of(z));
+                        else vv = (double)ab_a[r][v];
                         ob_e += vv * w * w - wafer_div_invariant<double>(w * S, den); // grid.rs:325-332 (the bits of the IEEE quotient)
                         ob_n += w * w;                      // grid.rs:407
                         if (a.potsub_kind == 2) ob_v += w * w * (double)psub[v];      // grid.rs:410-418
@@ -716,7 +718,8 @@ static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T 
 // 128x8 (SevenPoint).  *nblocks_out = partial sums written per quantity.
 template <typename T, int R>
 static inline hipError_t wafer_launch_observables_lds(WaferStepArgs a, const T *phi, const T *pv, const T *potsub,
-                                                      double *partials, size_t partials_cap, hipStream_t s, long long *nblocks_out)
+                                                      double *partials, size_t partials_cap, hipStream_t s, long long *nblocks_out,
+                                                      int vg = 0)
 {
     WaferLdsOpts o = wafer_lds_opts();
     o.ry = 2;
@@ -730,6 +733,9 @@ static inline hipError_t wafer_launch_observables_lds(WaferStepArgs a, const T *
     }
     const int zc = wafer_lds_zchunk<T, R>(a.g, a.lz_hi - a.lz_lo, 2 * (NW / 4), a.target_blocks);
     *nblocks_out = (long long)((a.g.nx + Cfg::TX - 1) / Cfg::TX) * ((a.g.ny + Cfg::TY - 1) / Cfg::TY) * ((a.lz_hi - a.lz_lo + zc - 1) / zc);
+    // (the closed-form V of the step kernels, template parameter VG, was measured here too: with two workgroups
+    //  per CU the kernel is short of issue slots, not of bytes -- 0.40 against 0.37 ms at 512^3 -- so V is streamed)
+    (void)vg;
     return wafer_launch_step_lds_ry<T, double, R, 2, -2, true, true, false, NW>(a, o, phi, pv, pv, nullptr, partials, partials_cap, s, low);
 }
 
@@ -747,12 +753,29 @@ static inline long long wafer_step_lds_excited_blocks(const WaferGeom &g, int lz
 
 template <typename T, typename C, int R>
 static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, const T *pa, const T *pb,
-                                               const T *pv, T *out, hipStream_t s)
+                                               const T *pv, T *out, hipStream_t s, int vg = 0)
 {
     WaferLdsOpts o = wafer_lds_opts(R);
     if (o.abv < 0) o.abv = 1;
     double *partials = nullptr;
     const size_t partials_cap = 0;
+    if constexpr (std::is_same<T, double>::value && std::is_same<C, double>::value) {
+        // closed-form V (fp64, the default tuning of each stencil order): 16 B per update instead of 24
+        const char *e = getenv("WAFER_LDS_NW");
+        const char *ry = getenv("WAFER_LDS_RY");
+        const bool dflt = !(e && *e) && !(ry && *ry) && o.abv != 0 && o.nt != 0 && a.v_in_range != 0;
+        // (ThreePoint 0.546 -> 0.422 ms/step at 512^3, FivePoint 0.556 -> 0.475; SevenPoint, 4 rows per lane on 4
+        //  waves, is short of issue slots: 0.617 -> 0.634 with Coulomb, so it keeps streaming V)
+        if constexpr (R <= 2) {
+            if (vg != 0 && dflt) {
+                a.target_blocks = (a.target_blocks + 1) / 2; // one workgroup per CU, as below
+                if (vg == 4) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 4, 1>(a, o, phi, pv, pb, out, partials, partials_cap, s);
+                if (vg == 7) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 7, 1>(a, o, phi, pv, pb, out, partials, partials_cap, s);
+                if (vg == 9) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 9, 1>(a, o, phi, pv, pb, out, partials, partials_cap, s);
+                return hipErrorInvalidValue;
+            }
+        }
+    }
     { // ThreePoint / FivePoint with a, b from V: 8 waves on a 128x16 tile, one workgroup per CU (half the
       // halo rows per tile: 0.56 -> 0.54 ms/step at 512^3); WAFER_LDS_NW=4 or an explicit WAFER_LDS_RY
       // select the 4-wave kernels
