@@ -646,7 +646,7 @@ static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum,
         // neighbour just loaded are gone again (512^3, 128x8 tiles: k = 2 1.24 -> 1.13 ms, k = 3
         // 1.45 -> 1.39).  The launcher doubles target_blocks.
         const int target = zchunk > 0 ? -zchunk  // planes per workgroup fixed by the caller (slab interior)
-                                      : (wnum >= 2 || wafer_excited_nw((int)wnum) == 8) ? (c->num_cus + 1) / 2 : c->num_cus;
+                                : (wnum >= 2 || wafer_excited_nw((int)wnum) == 8) ? (c->num_cus + 1) / 2 : c->num_cus;
         a.target_blocks = target;
         a.v_in_range = c->v_in_range ? 1 : 0;
         const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
