@@ -181,10 +181,15 @@ __device__ __forceinline__ double wafer_vgen_at(const WaferPotArgs &a, int ix, i
 // cell out of the VALU time those kernels spend waiting.
 // VIRT: a.v_in_range known at compile time (1 / 0) instead of tested per cell (-1): no scalar branch
 // inside the update, so the RY x VEC cells of a lane share one basic block and their chains interleave.
-// DEEP (with XF): the lane's own cells of phi and of the stored states are requested TWO planes ahead --
-// raw, into a staging set that is transformed one iteration later -- so that two planes per array are
-// in flight per lane instead of one: with V no longer streamed a k = 1 step has only four 16-byte
-// vectors per lane under way, too few to cover the memory latency with one workgroup per CU.
+// DEEP (with XF): every prefetched value -- the lane's own cells of phi and of the stored states for plane
+// z+R+2, the halo rows / columns of plane z+2 -- is requested RAW into a staging set at the top of iteration z,
+// right after that set's previous contents (requested one iteration earlier) were transformed.  No register
+// holding a load in flight is copied (a rotation would force the wait into the iteration that issued the load),
+// so the loads have a whole iteration, barrier included, to land, and the one wait sits at the top of the next
+// iteration.  Loads and stores complete in order on gfx9, so that wait counts the stores issued in between:
+// DEEP kernels therefore store every row of the tile as one full vector, cells outside the work area as the
+// zero they hold anyway (frame, pad and guard cells are zeros in every array: wafer_geom.h) -- a store count
+// the compiler knows, instead of exec-masked variants it has to assume absent.
 template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false, int NW = 4, int VG = 0, int VIRT = -1, bool DEEP = false>
 __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty, int swz,
                                                         const T *__restrict__ phi,
@@ -307,6 +312,12 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         }
         return w;
     };
+    auto xform_cell = [&](T w, const T *l) -> T {
+        C x = wafer_div_invariant<C>((C)w, xnorm);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) x = x - (C)l[j] * xsj[j];
+        return (T)x;
+    };
     auto load_vec = [&](long long off, VT *lkeep) -> VT {
         VT w = *reinterpret_cast<const VT *>(phi + off);
         if constexpr (XF) {
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
     // halo of plane zs+1, held in registers until it is written at iteration zs
     VT hrow_nxt[Cfg::HALO_ROWS_PER_WAVE];
     T hcol_nxt[Cfg::HALO_X_ITERS];
-    {
+    if constexpr (!DEEP) {
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
             hrow_nxt[qq] = load_vec((long long)(zs + 1) * g.plane + hrow_off[qq], nullptr);
@@ -381,18 +392,37 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
             hcol_nxt[qq] = load_cell((long long)(zs + 1) * g.plane + hcol_off[qq]);
     }
-    // DEEP: the raw own cells of plane zs+R+1, transformed during iteration zs
+    // DEEP: the raw staging set -- own cells of plane zs+R+1, halo of plane zs+1 -- transformed at the top of iteration zs
     [[maybe_unused]] VT raw_w[RY];
     [[maybe_unused]] VT raw_l[NL > 0 ? NL : 1][RY];
-    if constexpr (DEEP) {
+    [[maybe_unused]] VT raw_hw[Cfg::HALO_ROWS_PER_WAVE];
+    [[maybe_unused]] VT raw_hl[NL > 0 ? NL : 1][Cfg::HALO_ROWS_PER_WAVE];
+    [[maybe_unused]] T raw_cw[Cfg::HALO_X_ITERS];
+    [[maybe_unused]] T raw_cl[NL > 0 ? NL : 1][Cfg::HALO_X_ITERS];
+    // requests the staging set for the iteration that updates plane zn - 1: halo of plane zn, own cells of plane zn + R
+    auto issue_raw = [&](int zn) {
+        const long long zno = (long long)zn * g.plane;
+#pragma unroll
+        for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) {
+            raw_hw[qq] = *reinterpret_cast<const VT *>(phi + zno + hrow_off[qq]);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) raw_hl[j][qq] = *reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + zno + hrow_off[qq]);
+        }
+#pragma unroll
+        for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq) {
+            raw_cw[qq] = phi[zno + hcol_off[qq]];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) raw_cl[j][qq] = static_cast<const T *>(low.p[j])[zno + hcol_off[qq]];
+        }
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            const long long off = (long long)(zs + R + 1) * g.plane + rowoff[r];
+            const long long off = zno + (long long)R * g.plane + rowoff[r];
             raw_w[r] = *reinterpret_cast<const VT *>(phi + off);
 #pragma unroll
             for (int j = 0; j < NL; ++j) raw_l[j][r] = *reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + off);
         }
-    }
+    };
+    if constexpr (DEEP) issue_raw(zs + 1);
     __syncthreads();
 
     double acc = 0.0;
@@ -407,26 +437,8 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         VT pre[RY], pre_a[RY], pre_b[RY];
         VT hrow_pre[Cfg::HALO_ROWS_PER_WAVE];
         T hcol_pre[Cfg::HALO_X_ITERS];
-        [[maybe_unused]] VT nxt_w[RY];
-        [[maybe_unused]] VT nxt_l[NL > 0 ? NL : 1][RY];
         if constexpr (DEEP) {
-            // the halo of plane z+2 first (its data is needed in this iteration; loads complete in order),
-            // then the raw own cells of plane z+R+2, which stay in flight over the barrier
-#pragma unroll
-            for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
-                hrow_pre[qq] = load_vec(zo + 2 * g.plane + hrow_off[qq], nullptr);
-#pragma unroll
-            for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
-                hcol_pre[qq] = load_cell(zo + 2 * g.plane + hcol_off[qq]);
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                const long long off = zo + (long long)(R + 2) * g.plane + rowoff[r];
-                nxt_w[r] = *reinterpret_cast<const VT *>(phi + off);
-#pragma unroll
-                for (int j = 0; j < NL; ++j) nxt_l[j][r] = *reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + off);
-                if constexpr (VG == 0) pre_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]));
-            }
-            // plane z+R+1, requested one iteration ago
+            // the staging set requested one iteration ago: own cells of plane z+R+1, halo of plane z+1
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
                 VT l[NL > 0 ? NL : 1];
@@ -436,6 +448,26 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                     lq[R + 1][r][j] = l[j];
                 }
                 pre[r] = xform_vec(raw_w[r], l);
+            }
+#pragma unroll
+            for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) {
+                VT l[NL > 0 ? NL : 1];
+#pragma unroll
+                for (int j = 0; j < NL; ++j) l[j] = raw_hl[j][qq];
+                hrow_nxt[qq] = xform_vec(raw_hw[qq], l);
+            }
+#pragma unroll
+            for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq) {
+                T l[NL > 0 ? NL : 1];
+#pragma unroll
+                for (int j = 0; j < NL; ++j) l[j] = raw_cl[j][qq];
+                hcol_nxt[qq] = xform_cell(raw_cw[qq], l);
+            }
+            // ... and the same registers take the next set: halo of plane z+2, own cells of plane z+R+2
+            issue_raw(z + 2);
+            if constexpr (VG == 0) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r) pre_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]));
             }
         } else {
 #pragma unroll
@@ -556,7 +588,16 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                     for (int j = 0; j < NL; ++j) acc_t[j] += (double)((C)lw[j][r][v] * m);
                 }
         }
-        if constexpr (!OBS) {
+        if constexpr (DEEP) {
+            // one full vector per row, always: cells outside the work area get the zero they hold (see DEEP above)
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                VT o = resq[r];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o[v] = (rowin[r] && xi + v < g.nx) ? o[v] : T(0);
+                wafer_st_stream<NT>(reinterpret_cast<VT *>(out + zo + rowoff[r]), o);
+            }
+        } else if constexpr (!OBS) {
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
                 if (!rowin[r]) continue;
@@ -582,10 +623,12 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
             if constexpr (VG == 0) ab_a[r] = pre_a[r];
             if constexpr (!ABV) ab_b[r] = pre_b[r];
         }
+        if constexpr (!DEEP) {
 #pragma unroll
-        for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) hrow_nxt[qq] = hrow_pre[qq];
+            for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) hrow_nxt[qq] = hrow_pre[qq];
 #pragma unroll
-        for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq) hcol_nxt[qq] = hcol_pre[qq];
+            for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq) hcol_nxt[qq] = hcol_pre[qq];
+        }
         if constexpr (XF) {
 #pragma unroll
             for (int m = 0; m <= R; ++m)
@@ -593,14 +636,6 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                 for (int r = 0; r < RY; ++r)
 #pragma unroll
                     for (int j = 0; j < NL; ++j) lq[m][r][j] = lq[m + 1][r][j];
-        }
-        if constexpr (DEEP) {
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                raw_w[r] = nxt_w[r];
-#pragma unroll
-                for (int j = 0; j < NL; ++j) raw_l[j][r] = nxt_l[j][r];
-            }
         }
     }
     if constexpr (OBS) {
@@ -664,15 +699,15 @@ static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T 
     if constexpr (std::is_same<T, double>::value && std::is_same<C, double>::value) {
         // closed-form V in the kernel (fp64, transform-on-load, 8-wave tiles): one HBM stream fewer
         if (vg != 0 && xscal && a.v_in_range != 0 && wafer_excited_nw(nlow) == 8) {
-            // two planes in flight where the registers allow it (k = 3 sits at 226 VGPRs already); WAFER_XF_DEEP=0: one
+            // the raw staging pipeline (DEEP) where the registers allow it (FivePoint k = 3 and SevenPoint spill); WAFER_XF_DEEP=0: off
             const char *ed = getenv("WAFER_XF_DEEP");
             const bool deep = (ed && *ed) ? atoi(ed) != 0 : true;
             // (two workgroups per CU for k = 1 -- 128 VGPRs, 28 B/lane of scratch -- measured: 0.797 against 0.686 ms;
             //  twice the concurrent footprint in the XCD's L2, as without the closed form)
 #define WAFER_VG_CASE(NLOW_, VG_)                                                                                          \
     if (nlow == NLOW_ && vg == VG_) {                                                                                      \
-        if (deep && NLOW_ <= 2 && R <= 2)                                                                                  \
-            return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1, (NLOW_ <= 2 && R <= 2)>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
+        if (deep && (R == 1 || (R == 2 && NLOW_ <= 2)))                                                                    \
+            return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1, (R == 1 || (R == 2 && NLOW_ <= 2))>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
         return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
     }
             WAFER_VG_CASE(1, 4) WAFER_VG_CASE(2, 4) WAFER_VG_CASE(3, 4)
