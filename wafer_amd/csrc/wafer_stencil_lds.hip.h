@@ -463,12 +463,13 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                 for (int j = 0; j < NL; ++j) l[j] = raw_cl[j][qq];
                 hcol_nxt[qq] = xform_cell(raw_cw[qq], l);
             }
-            // ... and the same registers take the next set: halo of plane z+2, own cells of plane z+R+2
-            issue_raw(z + 2);
+            // V of plane z+1 first: it is copied at the end of THIS iteration, and loads complete in order
             if constexpr (VG == 0) {
 #pragma unroll
                 for (int r = 0; r < RY; ++r) pre_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]));
             }
+            // ... and the same registers take the next set: halo of plane z+2, own cells of plane z+R+2
+            issue_raw(z + 2);
         } else {
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
@@ -718,6 +719,14 @@ static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T 
     }
     if (xscal) { // transform-on-load: phi is the raw previous step
         if (wafer_excited_nw(nlow) == 8) { // 128x16 tiles, 8 waves: half the halo rows per array
+            if constexpr (R == 1 && std::is_same<T, double>::value) { // streamed V on the raw staging pipeline (DEEP) where it fits the registers
+                const char *ed = getenv("WAFER_XF_DEEP");
+                if (!(ed && *ed) || atoi(ed) != 0) {
+                    if (nlow == 1) return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true, 8, 0, -1, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+                    if (nlow == 2) return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true, 8, 0, -1, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+                    if (nlow == 3) return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, true, 8, 0, -1, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+                }
+            }
             switch (nlow) {
             case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
             case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
