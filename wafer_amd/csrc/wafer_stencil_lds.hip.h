@@ -182,14 +182,15 @@ __device__ __forceinline__ double wafer_vgen_at(const WaferPotArgs &a, int ix, i
 // VIRT: a.v_in_range known at compile time (1 / 0) instead of tested per cell (-1): no scalar branch
 // inside the update, so the RY x VEC cells of a lane share one basic block and their chains interleave.
 // DEEP (with XF): every prefetched value -- the lane's own cells of phi and of the stored states for plane
-// z+R+2, the halo rows / columns of plane z+2 -- is requested RAW into a staging set at the top of iteration z,
-// right after that set's previous contents (requested one iteration earlier) were transformed.  No register
-// holding a load in flight is copied (a rotation would force the wait into the iteration that issued the load),
-// so the loads have a whole iteration, barrier included, to land, and the one wait sits at the top of the next
-// iteration.  Loads and stores complete in order on gfx9, so that wait counts the stores issued in between:
-// DEEP kernels therefore store every row of the tile as one full vector, cells outside the work area as the
-// zero they hold anyway (frame, pad and guard cells are zeros in every array: wafer_geom.h) -- a store count
-// the compiler knows, instead of exec-masked variants it has to assume absent.
+// z+R+2, the halo rows / columns of plane z+3 -- is requested RAW into a staging set at the END of iteration z,
+// behind that iteration's stores and right after the set's previous contents (requested one iteration earlier)
+// were transformed.  No register holding a load in flight is copied (a rotation would force the wait into the
+// iteration that issued the load), so the loads have a whole iteration, barrier included, to land.  Loads and
+// stores complete in order on gfx9 and share one counter: with the requests behind the stores, the only
+// operations younger than a staging set when it is consumed are the next iteration's stores -- and DEEP kernels
+// store every row of the tile as one full vector, cells outside the work area as the zero they hold anyway
+// (frame, pad and guard cells are zeros in every array: wafer_geom.h), so that their number is known to the
+// compiler on every path (the first iteration included) and the wait is exact.
 template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false, int NW = 4, int VG = 0, int VIRT = -1, bool DEEP = false>
 __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int ntx, int nty, int swz,
                                                         const T *__restrict__ phi,
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
     // halo of plane zs+1, held in registers until it is written at iteration zs
     VT hrow_nxt[Cfg::HALO_ROWS_PER_WAVE];
     T hcol_nxt[Cfg::HALO_X_ITERS];
-    if constexpr (!DEEP) {
+    {
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq)
             hrow_nxt[qq] = load_vec((long long)(zs + 1) * g.plane + hrow_off[qq], nullptr);
@@ -392,16 +393,16 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
             hcol_nxt[qq] = load_cell((long long)(zs + 1) * g.plane + hcol_off[qq]);
     }
-    // DEEP: the raw staging set -- own cells of plane zs+R+1, halo of plane zs+1 -- transformed at the top of iteration zs
+    // DEEP: the raw staging set
     [[maybe_unused]] VT raw_w[RY];
     [[maybe_unused]] VT raw_l[NL > 0 ? NL : 1][RY];
     [[maybe_unused]] VT raw_hw[Cfg::HALO_ROWS_PER_WAVE];
     [[maybe_unused]] VT raw_hl[NL > 0 ? NL : 1][Cfg::HALO_ROWS_PER_WAVE];
     [[maybe_unused]] T raw_cw[Cfg::HALO_X_ITERS];
     [[maybe_unused]] T raw_cl[NL > 0 ? NL : 1][Cfg::HALO_X_ITERS];
-    // requests the staging set for the iteration that updates plane zn - 1: halo of plane zn, own cells of plane zn + R
-    auto issue_raw = [&](int zn) {
-        const long long zno = (long long)zn * g.plane;
+    // requests a staging set: the halo rows / columns of plane zh and the lane's own cells of plane zw
+    auto issue_raw = [&](int zh, int zw) {
+        const long long zno = (long long)zh * g.plane;
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) {
             raw_hw[qq] = *reinterpret_cast<const VT *>(phi + zno + hrow_off[qq]);
@@ -416,13 +417,13 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         }
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            const long long off = zno + (long long)R * g.plane + rowoff[r];
+            const long long off = (long long)zw * g.plane + rowoff[r];
             raw_w[r] = *reinterpret_cast<const VT *>(phi + off);
 #pragma unroll
             for (int j = 0; j < NL; ++j) raw_l[j][r] = *reinterpret_cast<const VT *>(static_cast<const T *>(low.p[j]) + off);
         }
     };
-    if constexpr (DEEP) issue_raw(zs + 1);
+    if constexpr (DEEP) issue_raw(zs + 2, zs + R + 1); // transformed at the end of iteration zs
     __syncthreads();
 
     double acc = 0.0;
@@ -438,38 +439,10 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         VT hrow_pre[Cfg::HALO_ROWS_PER_WAVE];
         T hcol_pre[Cfg::HALO_X_ITERS];
         if constexpr (DEEP) {
-            // the staging set requested one iteration ago: own cells of plane z+R+1, halo of plane z+1
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                VT l[NL > 0 ? NL : 1];
-#pragma unroll
-                for (int j = 0; j < NL; ++j) {
-                    l[j] = raw_l[j][r];
-                    lq[R + 1][r][j] = l[j];
-                }
-                pre[r] = xform_vec(raw_w[r], l);
-            }
-#pragma unroll
-            for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) {
-                VT l[NL > 0 ? NL : 1];
-#pragma unroll
-                for (int j = 0; j < NL; ++j) l[j] = raw_hl[j][qq];
-                hrow_nxt[qq] = xform_vec(raw_hw[qq], l);
-            }
-#pragma unroll
-            for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq) {
-                T l[NL > 0 ? NL : 1];
-#pragma unroll
-                for (int j = 0; j < NL; ++j) l[j] = raw_cl[j][qq];
-                hcol_nxt[qq] = xform_cell(raw_cw[qq], l);
-            }
-            // V of plane z+1 first: it is copied at the end of THIS iteration, and loads complete in order
-            if constexpr (VG == 0) {
+            if constexpr (VG == 0) { // V of plane z+1 (copied at the end of this iteration)
 #pragma unroll
                 for (int r = 0; r < RY; ++r) pre_a[r] = wafer_ld_stream<NT>(reinterpret_cast<const VT *>(pa + zo + g.plane + rowoff[r]));
             }
-            // ... and the same registers take the next set: halo of plane z+2, own cells of plane z+R+2
-            issue_raw(z + 2);
         } else {
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
@@ -611,6 +584,50 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                         if (xi + v < g.nx) dst[v] = resq[r][v];
                 }
             }
+        }
+        if constexpr (DEEP) {
+            // the staging set requested one iteration ago: own cells of plane z+R+1, halo of plane z+2
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                VT l[NL > 0 ? NL : 1];
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    l[j] = raw_l[j][r];
+                    lq[R + 1][r][j] = l[j];
+                }
+                pre[r] = xform_vec(raw_w[r], l);
+            }
+#pragma unroll
+            for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) {
+                VT l[NL > 0 ? NL : 1];
+#pragma unroll
+                for (int j = 0; j < NL; ++j) l[j] = raw_hl[j][qq];
+                hrow_nxt[qq] = xform_vec(raw_hw[qq], l);
+            }
+#pragma unroll
+            for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq) {
+                T l[NL > 0 ? NL : 1];
+#pragma unroll
+                for (int j = 0; j < NL; ++j) l[j] = raw_cl[j][qq];
+                hcol_nxt[qq] = xform_cell(raw_cw[qq], l);
+            }
+            // (neither the optimiser may sink these transforms towards their uses nor the scheduler lift the
+            //  requests below above them: the staging registers would then be live twice and the compiler falls
+            //  back to copying loads in flight, i.e. to waiting for them in the iteration that issued them)
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                asm volatile("" : "+v"(pre[r]));
+#pragma unroll
+                for (int j = 0; j < NL; ++j) asm volatile("" : "+v"(lq[R + 1][r][j]));
+            }
+#pragma unroll
+            for (int qq = 0; qq < Cfg::HALO_ROWS_PER_WAVE; ++qq) asm volatile("" : "+v"(hrow_nxt[qq]));
+#pragma unroll
+            for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq) asm volatile("" : "+v"(hcol_nxt[qq]));
+            __builtin_amdgcn_sched_barrier(0);
+            // ... and the same registers take the next set, behind this iteration's stores: halo of plane z+3, own
+            // cells of plane z+R+2
+            issue_raw(z + 3, z + R + 2);
         }
         __syncthreads();
         // ---- 4. rotate the register pipeline
