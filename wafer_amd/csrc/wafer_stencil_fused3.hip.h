@@ -136,7 +136,14 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     const int xl = lane * VEC, xi = x0 + xl;
     int yrow[RY];
     bool rowwk[RY], lvl2[RY];
+    // bit 6 (SROW): rowoff holds only the WAVE-UNIFORM part of a row's element offset (scalar registers) and the
+    // lane adds its 32-bit x offset at the access.  Per-lane 64-bit offsets cost six VGPRs in a kernel that sits at
+    // its 168-VGPR cap: the compiler spilled them, and reloading the store addresses from scratch put an
+    // s_waitcnt vmcnt(0) -- scratch loads share the counter -- in front of each store of the plane, i.e. a wait
+    // for every prefetch in flight and, before the second store, for the first store's write to complete.
+    constexpr bool SROW = (OPT & 64) != 0;
     long long rowoff[RY];
+    const unsigned xlu = SROW ? (unsigned)(lane * VEC) : 0u;
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
         int y;
@@ -151,12 +158,12 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
         yrow[r] = y;
         rowwk[r] = (y >= 0) && (y < g.ny);
         lvl2[r] = l2;
-        rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + xi;
+        rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + (SROW ? x0 : xi);
     }
     // ---- outermost phi0 halo rows y0-3 and y0+18, fetched by main waves 0 and 1
     const bool has_orow = OROW_H ? is_hrow : (is_main && wave < 2);
     const int oy = ((OROW_H ? wave - Cfg::NW2 : wave) == 0) ? (y0 - 3) : (y0 + TY + 2);
-    const long long orow_off = (long long)(oy + R) * g.pitch + g.xoff + R + xi;
+    const long long orow_off = (long long)(oy + R) * g.pitch + g.xoff + R + (SROW ? x0 : xi);   // as rowoff
     const int orow_lds = (oy - (y0 - 3)) * LP0 + HX0 + xl;
     // ---- halo-column cells of the last wave: cell c = lane + 64 q: row c / 6 of the phi0 tile, k = c % 6:
     //      k < 3: column x0-1-k, else column x0+TX+(k-3)
@@ -218,7 +225,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
         const long long po = (long long)(z1 - 1 + m) * g.plane;
         if (!is_hcol) {
 #pragma unroll
-            for (int r = 0; r < RY; ++r) q0[m][r] = *reinterpret_cast<const VT *>(phi + po + rowoff[r]);
+            for (int r = 0; r < RY; ++r) q0[m][r] = *reinterpret_cast<const VT *>((phi + po + rowoff[r]) + xlu);
         } else {
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q) q0[m][q / VEC][q % VEC] = phi[po + c_off[q]];
@@ -226,7 +233,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     }
     if (!is_hcol) {
 #pragma unroll
-        for (int r = 0; r < RY; ++r) vq[2][r] = *reinterpret_cast<const VT *>(pv + (long long)z1 * g.plane + rowoff[r]);
+        for (int r = 0; r < RY; ++r) vq[2][r] = *reinterpret_cast<const VT *>((pv + (long long)z1 * g.plane + rowoff[r]) + xlu);
     } else {
 #pragma unroll
         for (int q = 0; q < Cfg::CPL; ++q) vq[2][q / VEC][q % VEC] = pv[(long long)z1 * g.plane + c_off[q]];
@@ -245,10 +252,10 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
             for (int q = 0; q < Cfg::CPL; ++q)
                 if (c_ok[q]) t0[c_lds0[q]] = q0[1][q / VEC][q % VEC];
         }
-        if (has_orow) *reinterpret_cast<VT *>(t0 + orow_lds) = *reinterpret_cast<const VT *>(phi + (long long)z1 * g.plane + orow_off);
+        if (has_orow) *reinterpret_cast<VT *>(t0 + orow_lds) = *reinterpret_cast<const VT *>((phi + (long long)z1 * g.plane + orow_off) + xlu);
     }
     VT orow_nxt = zero;
-    if (has_orow) orow_nxt = *reinterpret_cast<const VT *>(phi + (long long)(z1 + 1) * g.plane + orow_off);
+    if (has_orow) orow_nxt = *reinterpret_cast<const VT *>((phi + (long long)(z1 + 1) * g.plane + orow_off) + xlu);
     __syncthreads();
 
     const int zend = ze + 2; // phi1 planes z1 .. zend-1
@@ -262,10 +269,10 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
         if (!is_hcol) {
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
-                pre[r] = *reinterpret_cast<const VT *>(phi + zo + 2 * g.plane + rowoff[r]);
-                pre_v[r] = *reinterpret_cast<const VT *>(pv + zo + g.plane + rowoff[r]);
+                pre[r] = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + rowoff[r]) + xlu);
+                pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + g.plane + rowoff[r]) + xlu);
             }
-            if (has_orow) orow_pre = *reinterpret_cast<const VT *>(phi + zo + 2 * g.plane + orow_off);
+            if (has_orow) orow_pre = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + orow_off) + xlu);
         } else {
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q) {
@@ -425,7 +432,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
 #pragma unroll
                         for (int r = 0; r < RY; ++r) {
                             if (INTERIOR || rowwk[r]) {
-                                T *dst = out + (long long)zo3 * g.plane + rowoff[r];
+                                T *dst = (out + (long long)zo3 * g.plane + rowoff[r]) + xlu;
                                 if ((NOXMASK && INTERIOR) || xi + VEC <= g.nx) {
                                     *reinterpret_cast<VT *>(dst) = res3[r];
                                 } else {
@@ -564,12 +571,14 @@ static inline hipError_t wafer_launch_step3_fused(WaferStepArgs a, const T *phi,
     WAFER_F3_CASE(true, 4)
     WAFER_F3_CASE(true, 8)
     WAFER_F3_CASE(true, 40)
+    WAFER_F3_CASE(true, 104)
     WAFER_F3_CASE(false, 0)
     WAFER_F3_CASE(false, 1)
     WAFER_F3_CASE(false, 3)
     WAFER_F3_CASE(false, 4)
     WAFER_F3_CASE(false, 8)
     WAFER_F3_CASE(false, 40)
+    WAFER_F3_CASE(false, 104)
 #undef WAFER_F3_CASE
     return hipErrorInvalidValue;
 }
