@@ -829,8 +829,9 @@ static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, co
         const bool dflt = !(e && *e) && !(ry && *ry) && o.abv != 0 && o.nt != 0 && a.v_in_range != 0;
         // (ThreePoint 0.546 -> 0.422 ms/step at 512^3, FivePoint 0.556 -> 0.475; SevenPoint, 4 rows per lane on 4
         //  waves, is short of issue slots: 0.617 -> 0.634 with Coulomb, so it keeps streaming V)
-        if constexpr (R <= 2) {
-            if (vg != 0 && dflt) {
+        {
+            const char *e7 = getenv("WAFER_SEVEN_VG");
+            if (vg != 0 && dflt && (R <= 2 || (e7 && atoi(e7) != 0))) {
                 a.target_blocks = (a.target_blocks + 1) / 2; // one workgroup per CU, as below
                 if (vg == 4) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 4, 1>(a, o, phi, pv, pb, out, partials, partials_cap, s);
                 if (vg == 7) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 7, 1>(a, o, phi, pv, pb, out, partials, partials_cap, s);
@@ -844,7 +845,10 @@ static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, co
       // select the 4-wave kernels
         const char *e = getenv("WAFER_LDS_NW");
         const char *ry = getenv("WAFER_LDS_RY");
-        const bool eight = (e && *e) ? atoi(e) == 8 : (R <= 2 && !(ry && *ry));
+        // SevenPoint as well (round 2): 8 waves x 2 rows on the 128x16 tile -- two waves per SIMD with half the
+        // registers each -- against 4 waves x 4 rows (256 VGPRs + 54 AGPRs, one wave per SIMD): 0.561 against
+        // 0.605 ms/step at 512^3.  (8 waves x 4 rows on 128x32 tiles spill 240 B/lane: 1.69 ms.)
+        const bool eight = (e && *e) ? atoi(e) == 8 : !(ry && *ry);
         if (eight && o.abv != 0) {
             a.target_blocks = (a.target_blocks + 1) / 2; // one workgroup per CU
             if (o.nt != 0) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8>(a, o, phi, pv, pb, out, partials, partials_cap, s);
