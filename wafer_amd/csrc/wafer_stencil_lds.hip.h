@@ -203,6 +203,8 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
 {
     constexpr bool NORM = NLOW >= 0;
     constexpr bool OBS = NLOW == -2;
+    // (full zero-masked stores in EVERY kernel of this family were measured -- same box, alternating libraries:
+    //  ThreePoint / FivePoint / fp32-storage single-step -1 %, SevenPoint +1.5 % -- and not adopted)
     constexpr int NL = NLOW > 0 ? NLOW : 0;
     static_assert(!XF || NL > 0, "transform-on-load needs stored states");
     static_assert(!OBS || (ABV && std::is_same<C, double>::value), "observables: V in pa's slot, fp64 sums");
