@@ -46,9 +46,11 @@ for it in range(int(os.environ.get("N", "60")) // 2):
     shape = tuple(int(x) for x in rng.choice([2, 3, 5, 8, 15, 16, 17, 31, 33, 64, 65, 129], size=3))
     wnum = int(rng.integers(1, 6))
     steps = int(rng.integers(1, 5))
-    pot = str(rng.choice(["Harmonic", "Coulomb", "NoPotential"]))
+    pot = str(rng.choice(["Harmonic", "Coulomb", "SimpleCornell", "NoPotential"]))
     one_pass = int(rng.integers(0, 2))
     os.environ["WAFER_ONE_PASS"] = str(one_pass)
+    os.environ["WAFER_VGEN"] = str(rng.integers(0, 2))      # closed-form V in the kernel / the stored array
+    os.environ["WAFER_XF_DEEP"] = str(rng.integers(0, 2))   # staging pipeline / plain prefetch
     try:
         cfg, par = make_pair(shape, ext=ext, potential=pot, dn=0.2, dt=0.004, mass=1.3, sig=0.3, max_states=wnum)
         v = wo.potential_generate(cfg); a, b = wo.ab(cfg, v)
@@ -73,6 +75,8 @@ for it in range(int(os.environ.get("N", "60")) // 2):
         bad += 1
         print("ERROR excited", shape, ext, pot, wnum, steps, one_pass, repr(e)[:200], flush=True)
 os.environ.pop("WAFER_ONE_PASS", None)
+os.environ.pop("WAFER_VGEN", None)
+os.environ.pop("WAFER_XF_DEEP", None)
 os.environ.pop("WAFER_FUSE3_MIN_NY", None)
 print("fuzz done, bad =", bad)
 sys.exit(1 if bad else 0)
