@@ -41,6 +41,10 @@ import subprocess
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's peer mappings fail with
+# "hipIpcGetMemHandle: invalid argument" otherwise); must be in the environment before the HSA runtime loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
