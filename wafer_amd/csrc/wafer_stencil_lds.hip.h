@@ -721,15 +721,15 @@ static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T 
     if constexpr (std::is_same<T, double>::value && std::is_same<C, double>::value) {
         // closed-form V in the kernel (fp64, transform-on-load, 8-wave tiles): one HBM stream fewer
         if (vg != 0 && xscal && a.v_in_range != 0 && wafer_excited_nw(nlow) == 8) {
-            // the raw staging pipeline (DEEP) where the registers allow it (FivePoint k = 3 and SevenPoint spill); WAFER_XF_DEEP=0: off
+            // the raw staging pipeline (DEEP) where the registers allow it (FivePoint from k = 2 and SevenPoint spill); WAFER_XF_DEEP=0: off
             const char *ed = getenv("WAFER_XF_DEEP");
             const bool deep = (ed && *ed) ? atoi(ed) != 0 : true;
             // (two workgroups per CU for k = 1 -- 128 VGPRs, 28 B/lane of scratch -- measured: 0.797 against 0.686 ms;
             //  twice the concurrent footprint in the XCD's L2, as without the closed form)
 #define WAFER_VG_CASE(NLOW_, VG_)                                                                                          \
     if (nlow == NLOW_ && vg == VG_) {                                                                                      \
-        if (deep && (R == 1 || (R == 2 && NLOW_ <= 2)))                                                                    \
-            return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1, (R == 1 || (R == 2 && NLOW_ <= 2))>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
+        if (deep && (R == 1 || (R == 2 && NLOW_ <= 1)))                                                                    \
+            return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1, (R == 1 || (R == 2 && NLOW_ <= 1))>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
         return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
     }
             WAFER_VG_CASE(1, 4) WAFER_VG_CASE(2, 4) WAFER_VG_CASE(3, 4)
