@@ -126,6 +126,38 @@ def test_config3_512_cubed_coulomb_three_stored_states_two_excited_steps(wo, wa)
 
 
 @BIG
+@pytest.mark.parametrize("potential", ["Coulomb", "SimpleCornell"])
+def test_512_cubed_excited_steps_closed_form_and_staging_pipeline_bit_identical(wa, potential, monkeypatch):
+    """the production kernels of BASELINE config #3's excited states at full size -- potential evaluated per cell
+    (VG), raw staging pipeline with full-vector stores (DEEP) -- against the kernels that stream the stored V on the
+    plain prefetch: the checksum of every cell's bits after 5 steps against k = 1, 2, 3 stored states, and the sums"""
+    n = 512
+    got = {}
+    for mode in ("plain", "production"):
+        if mode == "plain":
+            monkeypatch.setenv("WAFER_VGEN", "0")
+            monkeypatch.setenv("WAFER_XF_DEEP", "0")
+        else:
+            monkeypatch.delenv("WAFER_VGEN", raising=False)
+            monkeypatch.delenv("WAFER_XF_DEEP", raising=False)
+        par = wa.Params(n, n, n, dn=0.05, dt=5e-4, mass=1.0, sig=0.223, max_states=3)
+        out = []
+        with wa.Context(par) as ctx:
+            ctx.set_potential(potential)
+            for i in range(3):
+                ctx.set_initial_condition("Gaussian", seed=11 + i)
+                ctx.normalise(ctx.norm2())
+                ctx.push_state()
+            for k in (1, 2, 3):
+                ctx.set_initial_condition("Gaussian", seed=20 + k)
+                ctx.evolve(k, 4)
+                ctx.evolve(k, 1)
+                out.append((ctx.checksum(), ctx.norm2()))
+        got[mode] = out
+    assert got["plain"] == got["production"]
+
+
+@BIG
 def test_config5_512_cubed_file_potential_fp32_vs_fp64(tmp_path):
     """BASELINE config #5's cross-check at the size SURVEY.md 8d prescribes: the SAME user potential --
     a 64^3 array in a FILE (./input/potential.csv, the reference's `i,j,k,data` rows), read by the
