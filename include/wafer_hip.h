@@ -281,7 +281,11 @@ int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn 
  * (saves a cross-stream hop, but the exchange's kernels then reach the CUs after the interior's: only for
  * links fast enough to need less than half a pass); 3 = like 1 with the two streams swapping roles every
  * fused pass (the next pass's boundary kernels follow the interior in stream order: one event hop less per
- * pass; ground-state fused passes only, otherwise as 1).  All modes give identical results. */
+ * pass; ground-state fused passes only, otherwise as 1); 4 = the slab is updated as two half-slab launches in
+ * alternating order (A B | B A | ...), each followed by the exchange of ITS side's boundary planes, which the
+ * next launch never reads: no thin boundary launches, every exchange hides behind one half-slab launch (the
+ * hook is then called with one send and the opposite receive; ground-state fused passes with one exchange
+ * per pass only, otherwise as 1).  All modes give identical results. */
 int wafer_set_overlap(wafer_ctx *ctx, int enabled);
 /* z-slabs, ground state: fused passes (two time steps each) per halo exchange.  With `passes` > 1 the
  * exchange moves 2 * ext * passes planes at once and the passes in between run unsplit over the owned

@@ -171,6 +171,8 @@ struct wafer_ctx {
     bool bdry_main = false; // split passes: boundary kernels in order on the main stream (see bdry_on_main)
     bool alternate = false; // fused split passes: the two streams swap roles every pass (wafer_set_overlap mode 3)
     hipEvent_t ev_intr = nullptr; // mode 3: end of an interior launch that ran on the second stream
+    bool halves = false;          // fused split passes as two half-slab launches in alternating order (wafer_set_overlap mode 4)
+    hipEvent_t ev_half = nullptr, ev_hop = nullptr, ev_ex[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // mode 4
     int halo_valid = 0; // ghost planes of phi[cur] (counted from the owned region) known to be current
     int halo_cycle = 1; // fused passes per halo exchange: the exchange moves 2R * halo_cycle planes (<= G), see wafer_evolve
 
@@ -322,6 +324,28 @@ static int exchange_halo(wafer_ctx *c, int buf, hipStream_t s, int planes)
     void *recv_lo = c->has_lo() ? base + (size_t)(g.G - planes) * plane_b : nullptr;
     void *send_hi = c->has_hi() ? base + (size_t)(g.G + g.nzl - planes) * plane_b : nullptr;
     void *recv_hi = c->has_hi() ? base + (size_t)(g.G + g.nzl) * plane_b : nullptr;
+    if (c->halo_hook(c->hook_user, send_lo, send_hi, recv_lo, recv_hi, bytes, (void *)s) != 0)
+        return fail(WAFER_ERR_COMM, "halo hook failed");
+    return WAFER_OK;
+}
+
+// One direction of the exchange (wafer_set_overlap mode 4).  side 0: the LOWEST owned planes go to the lower
+// neighbour, the upper neighbour's lowest planes arrive in the UPPER ghost planes; side 1: the mirror image.  Every
+// rank calls the same side at the same point of a pass, so the sends and receives pair up.
+static int exchange_halo_side(wafer_ctx *c, int buf, hipStream_t s, int planes, int side)
+{
+    if (!c->halo_hook) return fail(WAFER_ERR_COMM, "context owns a z-slab but no halo hook is installed");
+    RoctxRange range_("wafer_halo_exchange");
+    const WaferGeom &g = c->g;
+    if (planes > g.G || planes > g.nzl) return fail(WAFER_ERR_INVALID, "halo exchange deeper than the slab allows");
+    char *base = static_cast<char *>(c->phi[buf]);
+    const size_t plane_b = (size_t)g.plane * c->esz;
+    const size_t bytes = ((size_t)(planes - 1) * (size_t)g.plane + (size_t)g.py * (size_t)g.pitch) * c->esz;
+    void *send_lo = (side == 0 && c->has_lo()) ? base + (size_t)g.G * plane_b : nullptr;
+    void *recv_hi = (side == 0 && c->has_hi()) ? base + (size_t)(g.G + g.nzl) * plane_b : nullptr;
+    void *send_hi = (side == 1 && c->has_hi()) ? base + (size_t)(g.G + g.nzl - planes) * plane_b : nullptr;
+    void *recv_lo = (side == 1 && c->has_lo()) ? base + (size_t)(g.G - planes) * plane_b : nullptr;
+    if (!send_lo && !send_hi && !recv_lo && !recv_hi) return WAFER_OK;
     if (c->halo_hook(c->hook_user, send_lo, send_hi, recv_lo, recv_hi, bytes, (void *)s) != 0)
         return fail(WAFER_ERR_COMM, "halo hook failed");
     return WAFER_OK;
@@ -790,6 +814,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->overlap = ov_mode != 0;
     c->bdry_main = ov_mode == 2 || env_int("WAFER_BDRY_MAIN", 0) != 0;
     c->alternate = ov_mode == 3;
+    c->halves = ov_mode == 4;
     // fused passes per halo exchange: 1 unless the host asks for deep halos (wafer_set_halo_cycle) -- a
     // concentrated exchange outlasts the interior launch it hides behind on anything but a very fast link
     c->halo_cycle = std::max(1, env_int("WAFER_HALO_CYCLE", 1));
@@ -819,6 +844,10 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_bdry, hipEventDisableTiming));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_intr, hipEventDisableTiming));
+    HIP_TRYC(hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
+    HIP_TRYC(hipEventCreateWithFlags(&c->ev_hop, hipEventDisableTiming));
+    for (int a_ = 0; a_ < 2; ++a_)
+        for (int b_ = 0; b_ < 2; ++b_) HIP_TRYC(hipEventCreateWithFlags(&c->ev_ex[a_][b_], hipEventDisableTiming));
 
     // a and b are allocated on first use (ensure_ab): the default kernels form them from V in registers
     void **arrays[] = {&c->phi[0], &c->phi[1], &c->v};
@@ -852,7 +881,8 @@ int wafer_ctx_destroy(wafer_ctx *c)
     if (c->scal) (void)hipFree(c->scal);
     if (c->gram) (void)hipFree(c->gram);
     if (c->scal_host) (void)hipHostFree(c->scal_host);
-    for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join, c->ev_bdry, c->ev_intr})
+    for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join, c->ev_bdry, c->ev_intr, c->ev_half, c->ev_hop, c->ev_ex[0][0],
+                         c->ev_ex[0][1], c->ev_ex[1][0], c->ev_ex[1][1]})
         if (e) (void)hipEventDestroy(e);
     if (c->s_own) (void)hipStreamDestroy(c->s_own);
     if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
@@ -1271,6 +1301,18 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     const bool fuse3 = wnum == 0 && fuse3_applies(c);
     HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
     bool intr_on_aux = false, have_join = false; // mode 3 (alternating stream roles), see below
+    // mode 4 (two half-slab launches per pass): exchanges of the previous pass not yet waited for, by side
+    bool hv_active = false;
+    int hv_first = 0, hv_pend[2] = {-1, -1};
+    uint64_t hv_pass = 0;
+    auto hv_drain = [&]() -> int {
+        if (!hv_active) return WAFER_OK;
+        for (int sd = 0; sd < 2; ++sd)
+            if (hv_pend[sd] >= 0) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[sd][hv_pend[sd]], 0));
+        hv_pend[0] = hv_pend[1] = -1;
+        hv_active = false;
+        return WAFER_OK;
+    };
     for (uint64_t s = 0; s < steps;) {
         const int src = c->cur, dst = c->cur ^ 1;
         if ((fuse3 && steps - s >= 3) || (fuse && steps - s >= 2)) {
@@ -1288,8 +1330,8 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             // exchange launch and two cross-stream hops.  E is a whole number of passes' worth and the same
             // on every rank (the neighbours receive what this one sends).
             const int E = c->sharded() ? std::max(H, std::min(g.G, H * c->halo_cycle) / H * H) : H;
-            if (c->sharded() && c->halo_valid < H) TRY(ensure_halo(c, E));
-            if (c->sharded() && c->halo_valid >= 2 * H) {
+            if (c->sharded() && !hv_active && c->halo_valid < H) TRY(ensure_halo(c, E));
+            if (c->sharded() && !hv_active && c->halo_valid >= 2 * H) {
                 const int ext = c->halo_valid - H; // ghost planes still valid after this pass
                 TRY(launch_pass(c->has_lo() ? lo - ext : lo, c->has_hi() ? hi + ext : hi, c->s_main, false));
                 c->halo_valid = ext;
@@ -1297,6 +1339,51 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 s += K;
                 continue;
             }
+            if (c->sharded() && c->overlap && c->halves && E == H && g.nzl >= 4 * H) {
+                // Mode 4.  The slab is updated as two half-slab launches, A = [lo, mid) and B = [mid, hi): full-size,
+                // efficient launches instead of two thin boundary launches (nine plane-iterations for three planes)
+                // and an interior.  After A its lowest E planes go down and the upper neighbour's arrive in the
+                // UPPER ghost planes (which only the next pass's B reads); after B the mirror image.  The order
+                // alternates -- A B | B A | A B ... -- so that the launch that follows an exchange never reads the
+                // ghost planes it fills: every exchange has one half-slab launch to hide behind.  Both halves read
+                // the pass's input buffer across their common face, so the split costs no redundant planes, only
+                // the pipeline fill of one more workgroup per tile.
+                if (!hv_active) {
+                    if (c->halo_valid < H) TRY(ensure_halo(c, E));
+                    hv_active = true;
+                    hv_first = 0;
+                    hv_pend[0] = hv_pend[1] = -1;
+                }
+                const int mid = lo + g.nzl / 2;
+                const int need[2] = {hv_pend[0], hv_pend[1]};   // the previous pass's exchanges
+                hv_pend[0] = hv_pend[1] = -1;
+                const int par = (int)(hv_pass & 1);
+                for (int i = 0; i < 2; ++i) {
+                    const int half = (hv_first + i) & 1;        // 0 = A (reads the lower ghost planes), 1 = B
+                    // A's ghost planes were filled by the exchange that followed the previous pass's B, and vice versa
+                    if (need[half ^ 1] >= 0) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[half ^ 1][need[half ^ 1]], 0));
+                    TRY(launch_pass(half == 0 ? lo : mid, half == 0 ? mid : hi, c->s_main, true));
+                    HIP_TRY(hipEventRecord(c->ev_half, c->s_main));
+                    HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_half, 0));
+                    HIP_TRY(hipEventRecord(c->ev_hop, c->s_aux));
+                    TRY(exchange_halo_side(c, dst, c->s_aux, E, half));
+                    HIP_TRY(hipEventRecord(c->ev_ex[half][par], c->s_aux));
+                    hv_pend[half] = par;
+                    // two event hops for the next launch against one for the exchange: its kernels reach the CUs first
+                    if (env_int("WAFER_HALVES_HOP", 1) != 0) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_hop, 0));
+                }
+                hv_first ^= 1;
+                ++hv_pass;
+                c->halo_valid = 0;   // (inside the mode; hv_drain restores the invariant)
+                c->cur = dst;
+                s += K;
+                if (!((fuse3 && steps - s >= 3) || (fuse && steps - s >= 2))) { // last fused pass of this call
+                    TRY(hv_drain());
+                    c->halo_valid = E;
+                }
+                continue;
+            }
+            TRY(hv_drain());
             const bool split = c->sharded() && c->overlap && g.nzl > 2 * E;
             if (split && c->alternate && K == 2 && E == 2 * R) {
                 // Mode 3: as below, but the two streams swap roles every pass.  The boundary kernels of this
@@ -1433,6 +1520,7 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
         c->cur = dst;
         s += 1;
     }
+    TRY(hv_drain());
     HIP_TRY(hipEventRecord(c->ev_stop, c->s_main));
     c->last_steps = steps;
     c->timing_valid = true;
@@ -1827,10 +1915,11 @@ int wafer_set_comm_hooks(wafer_ctx *c, wafer_halo_fn halo, wafer_allreduce_fn al
 int wafer_set_overlap(wafer_ctx *c, int enabled)
 {
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
-    if (enabled < 0 || enabled > 3) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 3");
+    if (enabled < 0 || enabled > 4) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 4");
     c->overlap = enabled != 0;
     c->bdry_main = enabled == 2;
     c->alternate = enabled == 3;
+    c->halves = enabled == 4;
     return WAFER_OK;
 }
 

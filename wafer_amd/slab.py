@@ -56,13 +56,15 @@ class SlabComm:
         dist = self.dist
         ops = []
         # receives first, then sends; NCCL groups them, gloo posts them asynchronously
-        if self.lower is not None:
+        # (a buffer may also be None on a side that HAS a neighbour: the engine's half-slab schedule,
+        #  wafer_set_overlap mode 4, exchanges one direction at a time)
+        if self.lower is not None and recv_lo is not None:
             ops.append(dist.P2POp(dist.irecv, recv_lo, self.lower, self.group))
-        if self.upper is not None:
+        if self.upper is not None and recv_hi is not None:
             ops.append(dist.P2POp(dist.irecv, recv_hi, self.upper, self.group))
-        if self.lower is not None:
+        if self.lower is not None and send_lo is not None:
             ops.append(dist.P2POp(dist.isend, send_lo, self.lower, self.group))
-        if self.upper is not None:
+        if self.upper is not None and send_hi is not None:
             ops.append(dist.P2POp(dist.isend, send_hi, self.upper, self.group))
         if not ops:
             return []
