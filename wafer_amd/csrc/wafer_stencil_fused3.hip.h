@@ -38,7 +38,7 @@
 #include "wafer_stencil_fused2.hip.h"
 
 #ifndef WAFER_F3_OPT_DEFAULT
-#define WAFER_F3_OPT_DEFAULT 40
+#define WAFER_F3_OPT_DEFAULT 104
 #endif
 
 template <typename T>
