@@ -65,6 +65,24 @@ def test_bench_multi_rank_path():
     _check_bench_two_rank_line(json.loads(lines[0]))
 
 
+def test_bench_eight_rank_path():
+    """the driver's N = 8 call shape on the one GPU (host-staged transport): eight slabs of 32 planes, the set-up
+    trial over all eight exchange schedules, three-step passes with a two-step remainder, every slab's bits
+    against the undecomposed run"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, WAFER_BENCH_TRANSPORT="host")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "11", "--warmup", "3",
+                        "--grid", "256,256,256"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["config"]["parallelism"] == "zslab8"
+    assert d["config"]["points_per_gpu"] == 256 * 256 * 32 and len(d["config"]["halo_overlap"]["ms_per_step"]) == 8
+    assert d["parity"]["identical"] is True and d["parity"]["slabs"] == 8 and d["parity"]["differing_slabs"] == []
+    assert d["single_gpu_ref"]["grid"] == [256, 256, 256] and d["comm"]["process_group_ranks"] == 8
+
+
 def test_bench_bare_call_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it: the parent starts the two ranks itself
     (before touching a GPU) and forwards rank 0's line"""
