@@ -38,15 +38,15 @@
 #include "wafer_stencil_fused2.hip.h"
 
 #ifndef WAFER_F3_OPT_DEFAULT
-#define WAFER_F3_OPT_DEFAULT 104
+#define WAFER_F3_OPT_DEFAULT 232
 #endif
 
-template <typename T>
+template <typename T, int NWH_ = 2>
 struct WaferF3Cfg {
     static constexpr int VEC = WaferVec<T>::N;
     static constexpr int RY = 2;
     static constexpr int NW2 = 8;                       // main waves: tile height 16
-    static constexpr int NWH = 2;                       // halo-row waves
+    static constexpr int NWH = NWH_;                    // halo-row waves (3: the balanced assignment, OPT bit 7)
     static constexpr int NW = NW2 + NWH + 1;            // + halo-column wave
     static constexpr int NT_ = NW * 64;
     static constexpr int TX = 64 * VEC, TY = NW2 * RY;
@@ -69,12 +69,19 @@ struct WaferF3Cfg {
 //          expressions, the same bits) instead of being formed from V three times; the registers come from the
 //          phi1 z-queue, whose two older planes are read back from a THREE-slot phi1 LDS ring instead;
 //   bit 2: s_setprio: main waves above the halo waves.
+//   bit 7 (BAL): the work of the helper waves spread evenly over the four SIMDs.  Waves go to SIMDs round robin, so
+//          with 8 main waves (6 row-updates per plane each: 2 rows x 3 levels), two halo-row waves (3 each: phi1 on
+//          two rows, phi2 on one) and the halo-column wave (about 1) the SIMDs carry 15 / 15 / 13 / 12 row-updates
+//          per plane, and the barrier waits for the fullest.  With THREE halo-row waves -- (y0-1: phi1 + phi2),
+//          (y0+16: phi1 + phi2), (y0-2 and y0+17: phi1) -- and the halo-column wave on the fourth SIMD it is
+//          14 / 14 / 14 / 13.  Twelve waves are three per SIMD, like eleven: the same 168-VGPR cap.
 template <typename T, typename C, bool VIR, int OPT>
-__global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(WaferStepArgs a, int ntx, int nty, int swz,
+__global__ __launch_bounds__((WaferF3Cfg<T, ((OPT & 128) ? 3 : 2)>::NT_)) void wafer_k_step3_fused(WaferStepArgs a, int ntx, int nty, int swz,
                                                                           const T *__restrict__ phi,
                                                                           const T *__restrict__ pv, T *__restrict__ out)
 {
-    using Cfg = WaferF3Cfg<T>;
+    constexpr bool BAL = (OPT & 128) != 0;
+    using Cfg = WaferF3Cfg<T, (BAL ? 3 : 2)>;
     using VT = typename WaferVec<T>::type;
     constexpr int R = 1;
     constexpr int VEC = Cfg::VEC, RY = Cfg::RY, TX = Cfg::TX, TY = Cfg::TY;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     //      halo rows / columns and three planes past the slab lie in the zero guard zone, wafer_geom.h)
     const int xl = lane * VEC, xi = x0 + xl;
     int yrow[RY];
-    bool rowwk[RY], lvl2[RY];
+    bool rowwk[RY], lvl2[RY], slot_on[RY];
     // bit 6 (SROW): rowoff holds only the WAVE-UNIFORM part of a row's element offset (scalar registers) and the
     // lane adds its 32-bit x offset at the access.  Per-lane 64-bit offsets cost six VGPRs in a kernel that sits at
     // its 168-VGPR cap: the compiler spilled them, and reloading the store addresses from scratch put an
@@ -147,8 +154,17 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
         int y;
-        bool l2 = true;
-        if (is_hrow) {
+        bool l2 = true, on = true;
+        if (is_hrow && BAL) {
+            const int h = wave - Cfg::NW2;   // 0: row y0-1 (phi1, phi2);  1: row y0+16 (phi1, phi2);  2: rows y0-2, y0+17 (phi1)
+            if (h == 2) {
+                y = (r == 0) ? (y0 - 2) : (y0 + TY + 1);
+                l2 = false;
+            } else {
+                y = (h == 0) ? (y0 - 1) : (y0 + TY);   // the second slot repeats the row (its loads are the same values) and computes nothing
+                l2 = on = (r == 0);
+            }
+        } else if (is_hrow) {
             const int h = wave - Cfg::NW2;                     // 0: rows y0-2, y0-1;  1: rows y0+16, y0+17
             y = (h == 0) ? (y0 - 2 + r) : (y0 + TY + r);
             l2 = (h == 0) ? (r == 1) : (r == 0);               // phi2 on the inner row only
@@ -156,8 +172,9 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
             y = y0 + wave * RY + r;                            // main (unused by the halo-column wave)
         }
         yrow[r] = y;
-        rowwk[r] = (y >= 0) && (y < g.ny);
+        rowwk[r] = on && (y >= 0) && (y < g.ny);
         lvl2[r] = l2;
+        slot_on[r] = on;
         rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + (SROW ? x0 : xi);
     }
     // ---- outermost phi0 halo rows y0-3 and y0+18, fetched by main waves 0 and 1
@@ -309,11 +326,13 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
         if (!is_hcol) {
             bool all_rows = NOXMASK ? (x0 + TX <= g.nx) : true;
 #pragma unroll
-            for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];
+            for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];   // (rowwk is false for a slot that is off)
             // ---- 3. level 1: phi1 plane z (main and halo-row waves).  INTERIOR: the plane and every row of this
             //         wave are work cells -- no tests inside, so the RY x VEC updates form one basic block
-            auto level1 = [&](auto interior_tag) {
+            // (BAL: the rows of a halo-row wave are not neighbours: their y neighbours come from LDS -- yreg_tag)
+            auto level1 = [&](auto interior_tag, auto yreg_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
+                constexpr bool YR = YREG && decltype(yreg_tag)::value;
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     VT res = zero;
@@ -327,8 +346,8 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                             xs[1] = ys[1] = w;
                             xs[0] = (v >= 1) ? (C)q0[1][r][(v + VEC - 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v - 1];
                             xs[2] = (v + 1 < VEC) ? (C)q0[1][r][(v + 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v + 1];
-                            ys[0] = (YREG && r >= 1) ? (C)q0[1][r >= 1 ? r - 1 : 0][v] : (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
-                            ys[2] = (YREG && r + 1 < RY) ? (C)q0[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
+                            ys[0] = (YR && r >= 1) ? (C)q0[1][r >= 1 ? r - 1 : 0][v] : (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
+                            ys[2] = (YR && r + 1 < RY) ? (C)q0[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
                             T rs;
                             if constexpr (CARRY_B) {
@@ -340,11 +359,16 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                         }
                     }
                     p1new[r] = res;
-                    *reinterpret_cast<VT *>(w1 + (yrow[r] - (y0 - 2)) * LP1 + HX1 + xl) = res;
+                    if (INTERIOR || !BAL || slot_on[r]) *reinterpret_cast<VT *>(w1 + (yrow[r] - (y0 - 2)) * LP1 + HX1 + xl) = res;
                 }
             };
-            if (all_rows && wplane1) level1(std::true_type{});
-            else level1(std::false_type{});
+            if (!BAL || is_main) {
+                if (all_rows && wplane1) level1(std::true_type{}, std::true_type{});
+                else level1(std::false_type{}, std::true_type{});
+            } else {
+                if (all_rows && wplane1) level1(std::true_type{}, std::false_type{});
+                else level1(std::false_type{}, std::false_type{});
+            }
             // ---- 4. level 2: phi2 plane z-1 from the phi1 queue; x / y neighbours from the phi1 ring slot written
             //         one iteration ago
             if constexpr (!CARRY_B) {
@@ -355,8 +379,9 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                     q1[2][r] = p1new[r];
                 }
             }
-            auto level2 = [&](auto interior_tag) {
+            auto level2 = [&](auto interior_tag, auto yreg_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
+                constexpr bool YR = YREG && decltype(yreg_tag)::value;
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     VT res = zero;
@@ -380,8 +405,8 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                             xs[1] = ys[1] = w;
                             xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v - 1];
                             xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v + 1];
-                            ys[0] = (YREG && !CARRY_B && r >= 1) ? (C)q1[1][r >= 1 ? r - 1 : 0][v] : (C)c1[(ly - 1) * LP1 + HX1 + xl + v];
-                            ys[2] = (YREG && !CARRY_B && r + 1 < RY) ? (C)q1[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c1[(ly + 1) * LP1 + HX1 + xl + v];
+                            ys[0] = (YR && !CARRY_B && r >= 1) ? (C)q1[1][r >= 1 ? r - 1 : 0][v] : (C)c1[(ly - 1) * LP1 + HX1 + xl + v];
+                            ys[2] = (YR && !CARRY_B && r + 1 < RY) ? (C)q1[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c1[(ly + 1) * LP1 + HX1 + xl + v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
                             T rs;
                             if constexpr (CARRY_B) rs = update_with_b(w, (C)vq[1][r][v], (C)cbq[1][r][v], S);
@@ -393,8 +418,9 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
                     if (INTERIOR || lvl2[r]) *reinterpret_cast<VT *>(w2 + (yrow[r] - (y0 - 1)) * LP2 + HX2 + xl) = res;
                 }
             };
-            if (is_main && all_rows && wplane2) level2(std::true_type{});
-            else level2(std::false_type{});
+            if (is_main && all_rows && wplane2) level2(std::true_type{}, std::true_type{});
+            else if (!BAL || is_main) level2(std::false_type{}, std::true_type{});
+            else level2(std::false_type{}, std::false_type{});
             // ---- 5. level 3 (main waves): phi3 plane z-2 from the phi2 queue, stored
             if (is_main) {
 #pragma unroll
@@ -557,11 +583,12 @@ static inline hipError_t wafer_launch_step3_fused(WaferStepArgs a, const T *phi,
         }
         nblocks = (long long)ntx * nty * ((nplanes + a.zchunk - 1) / a.zchunk);
     }
-    const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
+    const dim3 grid((unsigned)nblocks);
     const char *eo = getenv("WAFER_F3_OPT");
     const int opt = (eo && *eo) ? atoi(eo) : WAFER_F3_OPT_DEFAULT;
 #define WAFER_F3_CASE(VIR_, OPT_)                                                                                          \
     if ((a.v_in_range != 0) == VIR_ && opt == OPT_) {                                                                      \
+        const dim3 block(WaferF3Cfg<T, ((OPT_ & 128) ? 3 : 2)>::NT_);                                                      \
         hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, OPT_>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, out); \
         return hipGetLastError();                                                                                          \
     }
@@ -572,6 +599,7 @@ static inline hipError_t wafer_launch_step3_fused(WaferStepArgs a, const T *phi,
     WAFER_F3_CASE(true, 8)
     WAFER_F3_CASE(true, 40)
     WAFER_F3_CASE(true, 104)
+    WAFER_F3_CASE(true, 232)
     WAFER_F3_CASE(false, 0)
     WAFER_F3_CASE(false, 1)
     WAFER_F3_CASE(false, 3)
@@ -579,6 +607,7 @@ static inline hipError_t wafer_launch_step3_fused(WaferStepArgs a, const T *phi,
     WAFER_F3_CASE(false, 8)
     WAFER_F3_CASE(false, 40)
     WAFER_F3_CASE(false, 104)
+    WAFER_F3_CASE(false, 232)
 #undef WAFER_F3_CASE
     return hipErrorInvalidValue;
 }
