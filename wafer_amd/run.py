@@ -174,6 +174,7 @@ def main(argv=None) -> int:
 
     # RCCL caches its parameters at first use (torch's own communicator): see wafer_rccl_hooks.h
     os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "8")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL's peer mappings (as bench.py)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
