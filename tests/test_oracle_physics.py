@@ -109,6 +109,60 @@ def test_evolve_equals_repeated_steps_bitwise(oracle):
     assert np.array_equal(p0, p1)
 
 
+@pytest.mark.parametrize("ext,wnum", [(1, 1), (1, 3), (2, 2), (3, 1)])
+@pytest.mark.parametrize("pot", ["Harmonic", "Coulomb"])
+def test_excited_state_evolve_vs_numpy_form_of_the_rs_text(oracle, ext, wnum, pot):
+    """grid.rs:674-681 read a third time (neither the oracle's C nor the engine's HIP): after EVERY step the
+    norm squared over the WORK area (get_norm_squared, :454-457), the whole array divided by its square root
+    (normalise_wavefunction, :465-468: normalise comes first), then for each stored state IN ORDER the overlap
+    with the ALREADY UPDATED w summed over the whole array and w -= lower * overlap
+    (orthogonalise_wavefunction, :477-492: modified Gram-Schmidt).  The stored states are deliberately not
+    orthogonal to each other, so classical and modified Gram-Schmidt -- or projection before normalisation --
+    are told apart (asserted below)."""
+    rng = np.random.default_rng(100 * ext + wnum)
+    cfg = oracle.Config(9, 7, 8, ext=ext, potential=pot, dn=0.3, dt=0.01, mass=1.3)
+    v = oracle.potential_generate(cfg)
+    a, b = oracle.ab(cfg, v)
+    e = ext
+
+    def rand():
+        out = np.zeros(cfg.padded_shape)
+        out[e:-e, e:-e, e:-e] = rng.standard_normal(cfg.work_shape)
+        return out
+    lowers = []
+    for j in range(wnum):
+        l = rand() + (0.5 * lowers[0] if lowers else 0.0)      # correlated on purpose
+        l /= np.sqrt(np.sum(l * l))
+        lowers.append(np.ascontiguousarray(l))
+    phi = rand()
+    want = phi.copy()
+    for _ in range(6):
+        want[e:-e, e:-e, e:-e] = np_step(cfg, a, b, want)       # the stencil pass and the copy back (:562-673)
+        norm2 = np.sum(want[e:-e, e:-e, e:-e] ** 2)             # :675-678
+        want = want / np.sqrt(norm2)                            # :679
+        for l in lowers[:wnum]:                                 # :680
+            want = want - l * np.sum(l * want)
+    got = phi.copy()
+    oracle.evolve(cfg, wnum, a, b, got, lowers, 6)
+    assert np.allclose(got, want, rtol=0, atol=1e-13)
+    # the orderings this must NOT be: classical Gram-Schmidt (all overlaps from the same w) ...
+    if wnum >= 2:
+        cgs = phi.copy()
+        for _ in range(6):
+            cgs[e:-e, e:-e, e:-e] = np_step(cfg, a, b, cgs)
+            cgs = cgs / np.sqrt(np.sum(cgs[e:-e, e:-e, e:-e] ** 2))
+            cgs = cgs - sum(l * np.sum(l * cgs) for l in lowers[:wnum])
+        assert np.max(np.abs(cgs - want)) > 1e-8      # five orders above the bar of the comparison above
+    # ... or the projection before the normalisation
+    pfirst = phi.copy()
+    for _ in range(6):
+        pfirst[e:-e, e:-e, e:-e] = np_step(cfg, a, b, pfirst)
+        for l in lowers[:wnum]:
+            pfirst = pfirst - l * np.sum(l * pfirst)
+        pfirst = pfirst / np.sqrt(np.sum(pfirst[e:-e, e:-e, e:-e] ** 2))
+    assert np.max(np.abs(pfirst - want)) > 1e-8
+
+
 def test_boolean_and_constant_ic(oracle):
     cfg = oracle.Config(6, 5, 7, ext=2)
     phi = oracle.initial_condition(cfg, "Boolean")
