@@ -163,6 +163,67 @@ def test_excited_state_evolve_vs_numpy_form_of_the_rs_text(oracle, ext, wnum, po
     assert np.max(np.abs(pfirst - want)) > 1e-8
 
 
+@pytest.mark.parametrize("wnum,max_steps", [(0, None), (1, None), (0, 40)])
+def test_solve_loop_vs_numpy_form_of_the_rs_text(oracle, wnum, max_steps):
+    """grid.rs:122-221 read a third time: per block -- observables of the CURRENT phi (energy / norm2 is the row's
+    energy, tau = step * dt), normalise by THAT norm2, Gram-Schmidt if wnum > 0, the convergence test on
+    |E - E_last| BEFORE anything evolves (so the first row can never converge: E_last starts at f64::MAX), the
+    max_steps test as `step > max_steps` AFTER the convergence test, then screen_update steps of evolve.
+    Rows (step, tau, E, diff), the stop step and the final phi against the oracle's wo_solve."""
+    rng = np.random.default_rng(5 + wnum)
+    cfg = oracle.Config(10, 9, 11, ext=1, potential="Harmonic", dn=0.4, dt=0.03, mass=1.0)
+    v = oracle.potential_generate(cfg)
+    a, b = oracle.ab(cfg, v)
+    e, su, tol = 1, 20, 1e-7
+    den = COEFF[e][2] * cfg.dn ** 2 * cfg.mass
+
+    def rand():
+        out = np.zeros(cfg.padded_shape)
+        out[e:-e, e:-e, e:-e] = rng.standard_normal(cfg.work_shape)
+        return out
+    lowers = []
+    if wnum:
+        l = sine_mode(cfg, (1, 1, 1))
+        lowers = [l / np.sqrt(np.sum(l * l))]
+    phi0 = rand()
+    # --- the numpy reading
+    phi, step, last, rows, conv = phi0.copy(), 0, np.finfo(np.float64).max, [], False
+    while True:
+        c = phi[e:-e, e:-e, e:-e]
+        norm2 = np.sum(c * c)
+        energy = np.sum(v[e:-e, e:-e, e:-e] * c * c - c * np_stencil_sum(phi, e) / den)   # :325-332, :405-407
+        E = energy / norm2
+        phi = phi / np.sqrt(norm2)                                                          # :130
+        for l in lowers[:wnum]:                                                            # :133-135
+            phi = phi - l * np.sum(l * phi)
+        diff = abs(E - last)                                                               # :161
+        rows.append((step, step * cfg.dt, E, diff))
+        if diff < tol:
+            conv = True
+            break
+        last = E
+        if max_steps is not None and step > max_steps:                                     # :209-211
+            break
+        for _ in range(su):                                                                # evolve: :544-687
+            phi[e:-e, e:-e, e:-e] = np_step(cfg, a, b, phi)
+            if wnum > 0:
+                phi = phi / np.sqrt(np.sum(phi[e:-e, e:-e, e:-e] ** 2))
+                for l in lowers[:wnum]:
+                    phi = phi - l * np.sum(l * phi)
+        step += su
+    # --- the oracle
+    got = phi0.copy()
+    recs, oconv = oracle.solve(cfg, wnum, v, a, b, got, lowers, tol, su, max_steps=max_steps)
+    assert oconv == conv and len(recs) == len(rows)
+    if max_steps is not None:
+        assert not conv and rows[-1][0] == 60          # 0, 20, 40 pass `step > 40`; the block at step 60 stops
+    for r, (st, tau, E, diff) in zip(recs, rows):
+        assert r["step"] == st and r["tau"] == pytest.approx(tau, rel=1e-15, abs=0)
+        assert r["energy"] / r["norm2"] == pytest.approx(E, rel=1e-11)
+        assert r["diff"] == pytest.approx(diff, rel=1e-6, abs=1e-12)
+    assert np.allclose(got, phi, rtol=0, atol=1e-11)
+
+
 def test_boolean_and_constant_ic(oracle):
     cfg = oracle.Config(6, 5, 7, ext=2)
     phi = oracle.initial_condition(cfg, "Boolean")
