@@ -235,6 +235,41 @@ def test_boolean_and_constant_ic(oracle):
     assert np.array_equal(phi, want)
 
 
+@pytest.mark.parametrize("shape,ext", [((6, 5, 7), 2), ((8, 8, 8), 1), ((5, 7, 9), 3)])
+def test_coulomb_and_constant_ic_vs_numpy_form_of_the_rs_text(oracle, shape, ext):
+    """config.rs:638-665 (generate_coulomb) read from the text: the centre is init_size / 2 of the PADDED array
+    (not the (n + 1) / 2 of the potentials), r = dn * sqrt(dx^2 + dy^2 + dz^2), the four hydrogen-like terms;
+    an even padded size puts a cell at r = 0 where cos(theta) = 0 / 0 makes the value NaN in the reference too --
+    unless the frame zeroes it (config.rs:597-622), which it does not for the centre.  Constant is 0.1 inside the
+    frame (config.rs:594)."""
+    mass, dn = 1.3, 0.25
+    cfg = oracle.Config(*shape, ext=ext, potential="NoPotential", dn=dn, dt=0.004, mass=mass)
+    ps = cfg.padded_shape
+    i, j, k = np.meshgrid(*[np.arange(n, dtype=float) for n in ps], indexing="ij")
+    dx, dy, dz = i - ps[0] / 2.0, j - ps[1] / 2.0, k - ps[2] / 2.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        r = dn * np.sqrt(dx ** 2 + dy ** 2 + dz ** 2)
+        costheta = dn * dz / r
+        cosphi = dn * dx / r
+        mr2 = np.exp(-mass * r / 2.0)
+        want = (np.exp(-mass * r) + (2.0 - mass * r) * mr2 + mass * r * mr2 * costheta
+                + mass * r * mr2 * np.sqrt(1.0 - costheta ** 2) * cosphi)
+    e = ext
+    for arr in (want,):
+        arr[:e] = arr[-e:] = 0
+        arr[:, :e] = arr[:, -e:] = 0
+        arr[:, :, :e] = arr[:, :, -e:] = 0
+    got = oracle.initial_condition(cfg, "Coulomb")
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.isnan(want).sum() == (1 if all(n % 2 == 0 for n in ps) else 0)
+    ok = ~np.isnan(want)
+    assert np.allclose(got[ok], want[ok], rtol=1e-13, atol=1e-15)
+    const = oracle.initial_condition(cfg, "Constant")
+    inner = np.zeros(ps)
+    inner[e:-e, e:-e, e:-e] = 0.1
+    assert np.array_equal(const, inner)
+
+
 def test_potential_centres_and_special_axes(oracle):
     """potentials use the PADDED index with the unpadded centre (potential.rs:52-53, 366-371)"""
     cfg = oracle.Config(8, 6, 10, ext=2, potential="Harmonic", dn=0.5)
