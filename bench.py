@@ -216,9 +216,10 @@ def pmc_traffic(kernel_name: str):
     try:
         with open(path) as f:
             d = json.load(f)
-        for k, v in d.get("kernels", {}).items():
-            if k in kernel_name or kernel_name in k:
-                return v.get("hbm_bytes_per_launch")
+        hits = [v for k, v in d.get("kernels", {}).items() if k in kernel_name or kernel_name in k]
+        hits.sort(key=lambda v: "from" in v)   # entries tagged "from" are earlier builds / variants kept for the record
+        if hits:
+            return hits[0].get("hbm_bytes_per_launch")
     except Exception:
         pass
     return None
