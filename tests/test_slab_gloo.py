@@ -40,7 +40,7 @@ def test_partition():
         partition(8, 2, 2)
 
 
-def _worker(rank, world, port, shape, ext, wnum, steps, out_dir):
+def _worker(rank, world, port, shape, ext, wnum, steps, out_dir, one_sided=False):
     from oracle import wafer_oracle as wo
     from wafer_amd.slab import SlabComm, partition
     wo.set_threads(1)
@@ -73,10 +73,18 @@ def _worker(rank, world, port, shape, ext, wnum, steps, out_dir):
             t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr))
             send_lo, send_hi = t(p[:, :, e:2 * e]), t(p[:, :, zc:zc + e])
             recv_lo, recv_hi = torch.empty_like(send_lo), torch.empty_like(send_hi)
-            comm.exchange(send_lo if comm.lower is not None else None,
-                          send_hi if comm.upper is not None else None,
-                          recv_lo if comm.lower is not None else None,
-                          recv_hi if comm.upper is not None else None)
+            if one_sided:
+                # the engine's half-slab schedule (wafer_set_overlap mode 4): one direction at a time -- what goes
+                # down arrives in the lower neighbour's UPPER ghost planes, then the mirror image
+                comm.exchange(send_lo if comm.lower is not None else None, None, None,
+                              recv_hi if comm.upper is not None else None)
+                comm.exchange(None, send_hi if comm.upper is not None else None,
+                              recv_lo if comm.lower is not None else None, None)
+            else:
+                comm.exchange(send_lo if comm.lower is not None else None,
+                              send_hi if comm.upper is not None else None,
+                              recv_lo if comm.lower is not None else None,
+                              recv_hi if comm.upper is not None else None)
             if comm.lower is not None:
                 p[:, :, :e] = recv_lo.numpy()
             if comm.upper is not None:
@@ -107,15 +115,17 @@ def _worker(rank, world, port, shape, ext, wnum, steps, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape,ext,wnum", [
-    (2, (9, 8, 12), 1, 0),
-    (2, (8, 9, 13), 2, 0),
-    (3, (7, 6, 19), 3, 0),
-    (2, (8, 8, 10), 1, 2),
+@pytest.mark.parametrize("world,shape,ext,wnum,one_sided", [
+    (2, (9, 8, 12), 1, 0, False),
+    (2, (8, 9, 13), 2, 0, False),
+    (3, (7, 6, 19), 3, 0, False),
+    (2, (8, 8, 10), 1, 2, False),
+    (3, (7, 6, 17), 1, 0, True),     # one direction per exchange call, three ranks: a middle rank sends and receives in both
+    (2, (8, 8, 10), 2, 1, True),
 ])
-def test_slab_evolve_matches_global(tmp_path, world, shape, ext, wnum):
+def test_slab_evolve_matches_global(tmp_path, world, shape, ext, wnum, one_sided):
     steps = 6
-    mp.spawn(_worker, args=(world, _free_port(), shape, ext, wnum, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), shape, ext, wnum, steps, str(tmp_path), one_sided), nprocs=world, join=True)
     from wafer_amd.slab import partition
     want = np.load(tmp_path / "global.npy")
     e = ext
