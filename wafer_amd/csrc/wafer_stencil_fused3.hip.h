@@ -13,7 +13,7 @@
 // stored.  phi1 and phi2 exist only in registers (own z-columns) and in two-slot LDS rings (x / y
 // neighbours).  One s_barrier per plane, as in the two-step kernel.
 //
-// Wave roles (11 waves, RY = 2 rows per lane):
+// Wave roles (11 waves, RY = 2 rows per lane; OPT bit 7 -- the default -- uses 12: see BAL below):
 //   waves 0..7   "main": own rows y0..y0+15 at all three levels;
 //   wave  8, 9   "halo-row": rows (y0-2, y0-1) and (y0+16, y0+17): phi1 on both rows, phi2 on the
 //                inner one (y0-1 / y0+16);
