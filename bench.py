@@ -314,6 +314,13 @@ def run_rank(args) -> int:
     if world > 1:
         comm, transport_name = slab.make_slab_comm(ctx, rank, world, torch.device("cuda", local_rank),
                                                    "host" if host_transport else None)
+        # A scaling record must never be a fallback's number by accident: the native RCCL hooks are what this benchmark
+        # measures.  If they could not be installed (make_slab_comm then agrees on the torch.distributed hooks on every
+        # rank), say so and stop, unless the caller asked for that transport by name.
+        if not host_transport and "native" not in transport_name and os.environ.get("WAFER_TRANSPORT", "native") == "native":
+            print(f"bench.py: rank {rank}: the native RCCL hooks are not in use (got '{transport_name}'); "
+                  "set WAFER_TRANSPORT=torch to measure the torch.distributed hooks on purpose", file=sys.stderr)
+            return 4
         comm.warm_up()   # RCCL channel set-up is not part of any step
     ctx.set_potential(potential)
     ctx.set_initial_condition("Boolean")   # deterministic, "good for benchmarks" (config.rs:168)
@@ -356,42 +363,40 @@ def run_rank(args) -> int:
         device_info = {"error": repr(e)}
     ctx.set_initial_condition("Boolean")   # the copy used phi's second buffer as scratch
 
-    # N > 1: the halo exchange hides behind the interior update (mode 1: boundary planes and exchange on
-    # a second stream; mode 2: boundary planes in-stream, only the exchange on the second stream; mode 3:
-    # as 1 with the streams swapping roles every pass; mode 4: two half-slab launches per pass in alternating
-    # order, each followed by its own side's exchange) or
-    # follows the whole slab's update (mode 0).  Which is fastest depends on the fabric, which this code
-    # has never seen: all four are timed over a few untimed set-up steps and every rank takes the mode
-    # that is fastest for the slowest rank (the default, 1, unless another wins by more than 2 %).
+    # N > 1: how the halo exchange is scheduled (wafer_set_overlap).  Mode 1: boundary planes and their exchange on a
+    # second stream beside the interior update (three launches per pass); mode 2: ONE launch per three-step pass, the slab
+    # as two halves marched outwards, each half's exchange released by its completion counter; mode 0: the exchange
+    # follows the whole slab's update.  Which is fastest depends on the fabric, which this code has never seen: all are
+    # timed over a few untimed set-up steps (and one exchange per TWO passes where the slabs are thick enough), and
+    # every rank takes the schedule that is fastest for the slowest rank (the default, 2, unless another wins by more
+    # than 2 %).
     overlap_choice = None
+    DEFAULT_MODE = (2, 1)
     if dist is not None and os.environ.get("WAFER_OVERLAP", "") == "" and args.steps >= 8:
         trial = {}
-        # (mode 4 twice: with and without the extra event hop in front of the launch that follows an exchange --
-        #  mode 40 below; the engine reads WAFER_HALVES_HOP at every pass)
-        for mode, cycle in [(1, 1), (2, 1), (3, 1), (4, 1), (40, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []):
-            os.environ["WAFER_HALVES_HOP"] = "0" if mode == 40 else "1"
-            ctx.set_overlap(4 if mode == 40 else mode)
+        for mode, cycle in [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []):
+            ctx.set_overlap(mode)
             ctx.set_halo_cycle(cycle)
-            ctx.evolve(0, 8)
+            ctx.evolve(0, 9)
             barrier()
             t_ = time.perf_counter()
-            ctx.evolve(0, 40)
+            ctx.evolve(0, 42)
             barrier()
             tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            trial[(mode, cycle)] = float(tt[0]) / 40 * 1e3
-        best = min(trial, key=lambda k: trial[k] * (1.0 if k == (1, 1) else 1.02))
-        os.environ["WAFER_HALVES_HOP"] = "0" if best[0] == 40 else "1"
-        ctx.set_overlap(4 if best[0] == 40 else best[0])
+            trial[(mode, cycle)] = float(tt[0]) / 42 * 1e3
+        best = min(trial, key=lambda k: trial[k] * (1.0 if k == DEFAULT_MODE else 1.02))
+        ctx.set_overlap(best[0])
         ctx.set_halo_cycle(best[1])
-        names = {1: "1_overlap", 2: "2_overlap_boundary_in_stream", 3: "3_overlap_alternating_streams",
-                 4: "4_overlap_two_half_slab_launches", 40: "4_overlap_two_half_slab_launches_no_extra_hop", 0: "0_no_overlap"}
-        overlap_choice = {"mode": 4 if best[0] == 40 else best[0], "extra_hop": best[0] != 40, "fused_passes_per_exchange": best[1],
+        names = {2: "2_single_launch_two_halves", 1: "1_boundary_first_three_launches", 0: "0_no_overlap"}
+        overlap_choice = {"mode": best[0], "fused_passes_per_exchange": best[1],
                           "ms_per_step": {names[m] + ("" if cy == 1 else f"_exchange_every_{cy}_passes"): v for (m, cy), v in trial.items()}}
         ctx.set_initial_condition("Boolean")
     elif dist is not None:
+        mode = int(os.environ.get("WAFER_OVERLAP", "") or DEFAULT_MODE[0])
+        ctx.set_overlap(mode)
         ctx.set_halo_cycle(1)
-        overlap_choice = {"mode": int(os.environ.get("WAFER_OVERLAP", "1") or 1), "fused_passes_per_exchange": 1, "ms_per_step": None}
+        overlap_choice = {"mode": mode, "fused_passes_per_exchange": 1, "ms_per_step": None}
 
     # Set-up, untimed: the device's clocks follow the load, and the few milliseconds of a short run (the
     # driver's --steps 20 --warmup 5) would otherwise be spent ramping them up -- the same 20 steps are 7 %

@@ -130,7 +130,6 @@ extern "C" {
     pub fn wafer_stencil_kernel_name(ctx: *mut wafer_ctx) -> *const c_char;
     pub fn wafer_stencil_steps_per_launch(ctx: *mut wafer_ctx) -> c_int;
     pub fn wafer_set_stencil_variant(ctx: *mut wafer_ctx, variant: c_int) -> c_int;
-    pub fn wafer_diag_stream_bw(ctx: *mut wafer_ctx, n_reads: c_int, iters: c_int, gbps: *mut f64) -> c_int;
     pub fn wafer_set_halo_cycle(ctx: *mut wafer_ctx, passes: c_int) -> c_int;
     pub fn wafer_diag_copy_bw(ctx: *mut wafer_ctx, iters: c_int, unroll: c_int, blocks_per_cu: c_int, gbps: *mut f64) -> c_int;
     pub fn wafer_diag_checksum(ctx: *mut wafer_ctx, z_begin: u32, z_count: u32, out: *mut u64) -> c_int;

@@ -236,11 +236,6 @@ int wafer_stencil_steps_per_launch(wafer_ctx *ctx);
 /* choose a stencil kernel variant by index (tuning / A-B runs); -1 = default */
 int wafer_set_stencil_variant(wafer_ctx *ctx, int variant);
 
-/* Diagnostic: achieved GB/s of a flat 16-B/lane streaming kernel with n_reads
- * (1..3) read streams + 1 write stream over the context's own buffers -- the
- * measured HBM ceiling next to which the stencil's rate is reported. */
-int wafer_diag_stream_bw(wafer_ctx *ctx, int n_reads, int iters, double *gbps);
-
 /* Diagnostic: the device's copy ceiling -- 16 B per lane, `unroll` (1, 2, 4, 8) vectors in flight per
  * lane, grid-stride over blocks_per_cu x CUs workgroups of 256 threads, V -> phi's scratch buffer;
  * GB/s of read + written bytes.  MI355X_MICROARCH.md quotes ~6.3 TB/s for this pattern. */
@@ -275,23 +270,26 @@ typedef int (*wafer_halo_fn)(void *user, void *send_lo, void *send_hi, void *rec
                              size_t bytes, void *hip_stream);
 typedef int (*wafer_allreduce_fn)(void *user, void *dev_ptr, size_t count, void *hip_stream);
 int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn allreduce, void *user);
-/* z-slabs, how the halo exchange is scheduled: 1 (default) = boundary planes first, then their exchange,
- * both on a second stream, beside the interior update; 0 = the exchange after the whole slab's update;
- * 2 = like 1 with the boundary kernels in order on the main stream and only the exchange on the second
- * (saves a cross-stream hop, but the exchange's kernels then reach the CUs after the interior's: only for
- * links fast enough to need less than half a pass); 3 = like 1 with the two streams swapping roles every
- * fused pass (the next pass's boundary kernels follow the interior in stream order: one event hop less per
- * pass; ground-state fused passes only, otherwise as 1); 4 = the slab is updated as two half-slab launches in
- * alternating order (A B | B A | ...), each followed by the exchange of ITS side's boundary planes, which the
- * next launch never reads: no thin boundary launches, every exchange hides behind one half-slab launch (the
- * hook is then called with one send and the opposite receive; ground-state fused passes with one exchange
- * per pass only, otherwise as 1).  All modes give identical results. */
-int wafer_set_overlap(wafer_ctx *ctx, int enabled);
-/* z-slabs, ground state: fused passes (two time steps each) per halo exchange.  With `passes` > 1 the
- * exchange moves 2 * ext * passes planes at once and the passes in between run unsplit over the owned
- * planes plus the ghost planes that are still valid -- fewer boundary launches, exchanges and stream hops
- * for a few redundant planes.  Needs wafer_params.halo_depth >= 2 * ext * passes; the default is the
- * largest value the context's ghost depth allows.  All settings give identical results. */
+/* The halo hook may be called with only one direction non-NULL (send_lo + recv_hi, or send_hi + recv_lo: the
+ * single-launch pass of wafer_set_overlap mode 2 exchanges the two sides at different times): a hook must
+ * tolerate a NULL on a side that has a neighbour, and pair send_lo with the lower neighbour's recv_hi. */
+/* z-slabs, how the halo exchange is scheduled.  All modes give identical results.
+ *  0 = the exchange follows the whole slab's update (nothing overlaps);
+ *  1 (default) = boundary planes first, then their exchange, both on a second stream, beside the interior update:
+ *      three launches per pass;
+ *  2 = ONE launch per three-step pass updates the whole slab as two halves marched outwards from the middle plane;
+ *      workgroups count themselves done and the second stream releases each half's exchange as soon as that half
+ *      is complete; the ghost planes an exchange fills are announced by a device flag that only the workgroups
+ *      reading them poll, shortly before the end of their column.  Ground-state three-step passes with one exchange
+ *      per pass; every other kind of step runs as in mode 1.  The order of the halves alternates from pass to pass,
+ *      so every rank must make the same sequence of wafer_evolve calls (as it must anyway). */
+int wafer_set_overlap(wafer_ctx *ctx, int mode);
+/* z-slabs, ground state: fused passes per halo exchange.  One fused pass advances K time steps and consumes
+ * K * ext ghost planes per side (K = 3 where the three-step kernel applies: ThreePoint fp64 with
+ * halo_depth >= 3 * ext; else K = 2).  With `passes` > 1 the exchange moves K * ext * passes planes at once and
+ * the passes in between run unsplit over the owned planes plus the ghost planes that are still valid -- fewer
+ * boundary launches, exchanges and stream hops for a few redundant planes.  Needs wafer_params.halo_depth >=
+ * K * ext * passes (WAFER_ERR_INVALID otherwise); the default is 1.  All settings give identical results. */
 int wafer_set_halo_cycle(wafer_ctx *ctx, int passes);
 /* run every kernel on a caller-owned hipStream_t (NULL = the context's own) */
 int wafer_set_stream(wafer_ctx *ctx, void *hip_stream);

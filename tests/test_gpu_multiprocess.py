@@ -33,7 +33,7 @@ def test_slab_ranks_as_processes(world):
 def _check_bench_two_rank_line(d):
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["steps"] == 8 and d["scaling"] == "strong" and d["value"] > 0
     ho = d["config"]["halo_overlap"]      # the exchange schedules were tried during set-up, one was chosen for all ranks
-    assert ho["mode"] in (0, 1, 2, 3, 4) and len(ho["ms_per_step"]) == 8 and all(v > 0 for v in ho["ms_per_step"].values())
+    assert ho["mode"] in (0, 1, 2) and len(ho["ms_per_step"]) == 5 and all(v > 0 for v in ho["ms_per_step"].values())
     assert ho["fused_passes_per_exchange"] in (1, 2)
     assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 128
     assert d["roofline"]["steps_per_launch"] == 3 and d["config"]["kernel"] == "wafer_k_step3_fused" and "cpu_baseline" not in d
@@ -78,7 +78,7 @@ def test_bench_eight_rank_path():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["config"]["parallelism"] == "zslab8"
-    assert d["config"]["points_per_gpu"] == 256 * 256 * 32 and len(d["config"]["halo_overlap"]["ms_per_step"]) == 8
+    assert d["config"]["points_per_gpu"] == 256 * 256 * 32 and len(d["config"]["halo_overlap"]["ms_per_step"]) in (3, 5)
     assert d["parity"]["identical"] is True and d["parity"]["slabs"] == 8 and d["parity"]["differing_slabs"] == []
     assert d["single_gpu_ref"]["grid"] == [256, 256, 256] and d["comm"]["process_group_ranks"] == 8
 

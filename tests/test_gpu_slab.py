@@ -49,7 +49,7 @@ class FakeFabric:
                 assert hip.hipMemcpy(rlo, self.send[rank - 1]["hi"], nbytes, 3) == 0
             if rhi:
                 assert hip.hipMemcpy(rhi, self.send[rank + 1]["lo"], nbytes, 3) == 0
-            # (None also on a side that has a neighbour: overlap mode 4 exchanges one direction at a time)
+            # (None also on a side that has a neighbour: overlap mode 2 exchanges one direction at a time)
             assert (rlo is None or rank > 0) and (rhi is None or rank < self.world - 1)
             # a device-to-device hipMemcpy may return before the copy is done (no host-side
             # synchronisation for that kind), and the engine's streams are non-blocking: wait here
@@ -117,7 +117,7 @@ def wa():
     return wafer_amd
 
 
-@pytest.mark.parametrize("overlap", [True, False, 2, 3])   # 2: boundary kernels in-stream, 3: alternating stream roles (wafer_set_overlap)
+@pytest.mark.parametrize("overlap", [True, False, 2])   # 2: the single-launch pass (three-step passes only: here as mode 1)
 @pytest.mark.parametrize("world,shape,ext", [(2, (40, 24, 32), 1), (3, (33, 17, 31), 2), (2, (20, 20, 12), 3),
                                             (4, (130, 12, 40), 1)])
 def test_ground_state_slabs_bit_exact(wa, world, shape, ext, overlap):
@@ -147,7 +147,7 @@ def test_ground_state_slabs_bit_exact(wa, world, shape, ext, overlap):
     assert all(n == steps for n in fabric.halo_calls)   # one exchange per step, none extra
 
 
-@pytest.mark.parametrize("overlap", [True, False, 2, 3, 4])   # 2: boundary kernels in-stream, 3: alternating stream roles (wafer_set_overlap)
+@pytest.mark.parametrize("overlap", [True, False, 2])
 @pytest.mark.parametrize("world,shape,ext,steps", [(2, (40, 24, 32), 1, 12), (3, (33, 17, 31), 2, 7), (4, (130, 12, 40), 1, 9),
                                                   (2, (300, 70, 96), 1, 6), (2, (130, 40, 100), 2, 5)])   # thick slabs: the mixed long / short interior launch
 def test_fused_kernel_on_slabs_bit_exact(wa, world, shape, ext, steps, overlap):
@@ -214,7 +214,7 @@ def test_deep_halo_cycles_bit_exact(wa, world, shape, ext, steps, cycle, overlap
         wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, z_begin=0, z_count=2 * ext, halo_depth=2 * ext + 1))
 
 
-@pytest.mark.parametrize("overlap", [True, False, 2, 3, 4])   # 4: two half-slab launches per pass in alternating order
+@pytest.mark.parametrize("overlap", [True, False, 2])   # 2: ONE launch per pass, two halves marched outwards, exchanges released by counters
 @pytest.mark.parametrize("cycle", [1, 2])
 @pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 32), 12), (3, (140, 17, 37), 7), (4, (130, 33, 48), 10), (2, (300, 70, 96), 11)])
 def test_three_step_kernel_on_slabs_bit_exact(wa, world, shape, steps, cycle, overlap, monkeypatch):
@@ -245,8 +245,61 @@ def test_three_step_kernel_on_slabs_bit_exact(wa, world, shape, steps, cycle, ov
     res, fabric = run_slabs(wa, base, world, body)
     assert np.array_equal(assemble(base, world, res), want)
     passes = -(-steps // 3) + 2 + 3
-    per_pass = 2 if (overlap == 4 and cycle == 1) else 1   # mode 4: one hook call per half-slab launch
+    per_pass = 2 if (overlap == 2 and cycle == 1) else 1   # mode 2: one hook call per half of the slab
     assert all(n <= per_pass * passes // cycle + 6 for n in fabric.halo_calls), fabric.halo_calls
+
+
+@pytest.mark.parametrize("gate", ["0", "1"])   # stream memory operations / gate kernels on the exchange stream
+@pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 10), 12), (3, (140, 40, 13), 9), (2, (300, 70, 96), 15), (4, (130, 33, 17), 6)])
+def test_single_launch_pass_thin_and_uneven_slabs_bit_exact(wa, world, shape, steps, gate, monkeypatch):
+    """overlap mode 2 on slabs whose halves are thinner than the exchange depth (the side's boundary planes then reach
+    into the other half: its exchange waits for both counters), on uneven partitions, with both ways of releasing the
+    exchange stream; several evolve calls, so that the alternating order of the halves carries over between calls"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    monkeypatch.setenv("WAFER_GATE", gate)
+    base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1, halo_depth=3)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1)) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)
+        ctx.evolve(0, 7)
+        want = ctx.download_phi()
+        want_n2 = ctx.norm2()
+
+    def body(ctx, rank):
+        ctx.set_overlap(2)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)           # ONE single-launch pass: the order of the halves flips between calls
+        ctx.evolve(0, 7)
+        return ctx.download_phi(), ctx.norm2()
+
+    res, fabric = run_slabs(wa, base, world, body)
+    assert np.array_equal(assemble(base, world, [r[0] for r in res]), want)
+    assert all(r[1] == pytest.approx(want_n2, rel=1e-12) for r in res)
+    assert len(set(fabric.halo_calls)) == 1   # every rank made the same number of exchange calls
+
+
+def test_kernel_choice_on_slabs_does_not_depend_on_the_local_thickness(wa, monkeypatch):
+    """ranks exchange K * ext planes per K-step pass, so K must not depend on anything local: an uneven partition whose
+    slabs straddle the cell threshold of the three-step kernel (WAFER_FUSE3_MIN_CELLS) still gives every rank K = 3"""
+    from wafer_amd.slab import partition
+    import dataclasses
+    shape, world = (64, 32, 45), 2
+    sizes = [partition(shape[2], world, r)[1] for r in range(world)]
+    assert len(set(sizes)) == 2
+    monkeypatch.setenv("WAFER_FUSE3_MIN_CELLS", str(shape[0] * shape[1] * max(sizes) - 1))   # between the two slabs' cell counts
+    base = wa.Params(*shape, dn=0.2, dt=0.004, central_difference=1, halo_depth=3)
+    ks = []
+    for r in range(world):
+        zb, zc = partition(shape[2], world, r)
+        with wa.Context(dataclasses.replace(base, z_begin=zb, z_count=zc)) as ctx:
+            ks.append(ctx.steps_per_launch())
+    assert ks == [3, 3]
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=1)) as ctx:   # the undecomposed grid is below the threshold
+        assert ctx.steps_per_launch() == 2
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f32fast"])
@@ -307,7 +360,7 @@ def test_excited_state_and_solve_on_slabs(wa):
     assert np.allclose(ground, want_states[0], rtol=0, atol=1e-8)
 
 
-@pytest.mark.parametrize("overlap", [True, False, 2, 3])   # 2: boundary kernels in-stream, 3: alternating stream roles (wafer_set_overlap)
+@pytest.mark.parametrize("overlap", [True, False, 2])
 @pytest.mark.parametrize("world,shape,ext,wnum", [(2, (40, 24, 32), 1, 1), (3, (33, 17, 30), 2, 2), (4, (130, 20, 40), 1, 3)])
 def test_excited_state_steps_on_slabs(wa, world, shape, ext, wnum, overlap):
     """excited-state evolve (renormalise + Gram-Schmidt every step) on z-slabs against one context:

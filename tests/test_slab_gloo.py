@@ -74,7 +74,7 @@ def _worker(rank, world, port, shape, ext, wnum, steps, out_dir, one_sided=False
             send_lo, send_hi = t(p[:, :, e:2 * e]), t(p[:, :, zc:zc + e])
             recv_lo, recv_hi = torch.empty_like(send_lo), torch.empty_like(send_hi)
             if one_sided:
-                # the engine's half-slab schedule (wafer_set_overlap mode 4): one direction at a time -- what goes
+                # the engine's half-slab schedule (wafer_set_overlap mode 2): one direction at a time -- what goes
                 # down arrives in the lower neighbour's UPPER ghost planes, then the mirror image
                 comm.exchange(send_lo if comm.lower is not None else None, None, None,
                               recv_hi if comm.upper is not None else None)

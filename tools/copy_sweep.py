@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The device's copy ceiling (wafer_diag_copy_bw) over vectors in flight per lane and workgroups per
-CU, next to the older one-load-per-trip stream kernel: prints one JSON line per setting."""
+CU: prints one JSON line per setting."""
 import json
 import os
 import sys
@@ -12,7 +12,6 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 with wafer_amd.Context(wafer_amd.Params(n, n, n, dn=0.05, dt=5e-4, max_states=1)) as ctx:
     ctx.set_potential("Coulomb")
     ctx.set_initial_condition("Boolean")
-    print(json.dumps({"kernel": "wafer_k_stream<1> (1 read + 1 write, one load per trip)", "GBps": round(ctx.stream_bandwidth(1, 100), 1)}))
     for unroll in (1, 2, 4, 8):
         for bpc in (1, 2, 4, 8, 16, 32):
             print(json.dumps({"kernel": "wafer_k_copy16", "unroll": unroll, "blocks_per_cu": bpc,

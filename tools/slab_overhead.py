@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--cd", type=int, default=1)
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--wnum", type=int, default=0, help="excited-state steps against this many stored states")
-    ap.add_argument("--modes", default="1,0", help="halo schedules to time (wafer_set_overlap modes)")
+    ap.add_argument("--modes", default="2,1,0", help="halo schedules to time (wafer_set_overlap modes)")
     ap.add_argument("--cycles", default="1", help="fused passes per halo exchange to time (wafer_set_halo_cycle): e.g. 1,2,3")
     ap.add_argument("--torch-hooks", action="store_true", help="with --rccl: also the torch.distributed hooks")
     ap.add_argument("--per-pass", type=int, default=0, help="ghost planes one fused pass consumes (default: 3 for --cd 1 = the three-step kernel, else 2*cd)")
@@ -161,7 +161,8 @@ def main():
         dist.destroy_process_group()
     out["halo_calls_per_step_last_loopback_run"] = calls["halo"] / (100 + 5 * args.steps)
     out["halo_bytes_per_direction_per_call"] = calls["bytes"]
-    out["slab_over_undecomposed"] = out["slab_ms_per_step_overlap_1"] / out["undecomposed_ms_per_step"]
+    first = int(args.modes.split(',')[0])
+    out["slab_over_undecomposed"] = out[f"slab_ms_per_step_overlap_{first}"] / out["undecomposed_ms_per_step"]
     out["grid"] = [n, n, pl]
     print(json.dumps(out))
 

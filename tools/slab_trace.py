@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A few overlapped fused passes on the bench slab with a loopback hook, for `rocprofv3 --kernel-trace`:
-    rocprofv3 --kernel-trace --output-format csv -d out -o t -- python3 tools/slab_trace.py
+"""A few overlapped fused passes on the bench slab with a loopback hook (or, --rccl, native RCCL to this same rank), for
+`rocprofv3 --kernel-trace`:
+    rocprofv3 --kernel-trace --output-format csv -d out -o t -- python3 tools/slab_trace.py [--rccl] [--mode 2]
 tools/slab_trace.py --parse out/.../t_kernel_trace.csv   prints the per-pass timeline."""
 import ctypes as C
 import csv
@@ -12,8 +13,9 @@ sys.path.insert(0, ROOT)
 
 
 def parse(path):
-    rows = [r for r in csv.DictReader(open(path)) if "step2_fused" in r["Kernel_Name"] or "ccl" in r["Kernel_Name"].lower()
-            or "copyBuffer" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "step2_fused" in r["Kernel_Name"] or "step3_fused" in r["Kernel_Name"]
+            or "ccl" in r["Kernel_Name"].lower() or "copyBuffer" in r["Kernel_Name"] or "wafer_k_gate" in r["Kernel_Name"]
+            or "wafer_k_post" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     rows = rows[-24:]
     t0 = int(rows[0]["Start_Timestamp"])
@@ -36,11 +38,15 @@ def main():
     hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
 
     def halo(slo, shi, rlo, rhi, nbytes, stream):
-        hip.hipMemcpyAsync(rlo, shi, nbytes, 3, stream)
-        hip.hipMemcpyAsync(rhi, slo, nbytes, 3, stream)
+        if rlo and shi:
+            hip.hipMemcpyAsync(rlo, shi, nbytes, 3, stream)
+        if rhi and slo:
+            hip.hipMemcpyAsync(rhi, slo, nbytes, 3, stream)
         return 0
-    par = wafer_amd.Params(1024, 1024, 1024, dn=0.02, dt=8e-5, mass=2.35, sig=0.223, z_begin=512, z_count=128, halo_depth=2)
+    mode = int(sys.argv[sys.argv.index("--mode") + 1]) if "--mode" in sys.argv else 2
+    par = wafer_amd.Params(1024, 1024, 1024, dn=0.02, dt=8e-5, mass=2.35, sig=0.223, z_begin=512, z_count=128, halo_depth=3)
     with wafer_amd.Context(par) as ctx:
+        ctx.set_overlap(mode)
         comm = None
         if "--rccl" in sys.argv:
             import torch
@@ -51,7 +57,7 @@ def main():
             ctx.set_comm_hooks(halo, lambda p, n, s: 0)
         ctx.set_potential("SimpleCornell")
         ctx.set_initial_condition("Boolean")
-        ctx.evolve(0, 40)
+        ctx.evolve(0, 42)
         ctx.synchronize()
         if comm is not None:
             comm.close()

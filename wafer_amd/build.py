@@ -12,12 +12,17 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwafer_hip.so")
-SOURCES = ["wafer_engine.hip"]
-HEADERS = ["wafer_geom.h", "wafer_stencil.hip.h", "wafer_stencil_lds.hip.h", "wafer_stencil_fused2.hip.h", "wafer_stencil_fused3.hip.h",
-           "wafer_elementwise.hip.h", "wafer_setup.hip.h"]
+# One translation unit per kernel family (wafer_launch.h): they compile in parallel and an edit to one kernel
+# rebuilds one unit.  The engine unit holds the host logic and the small elementwise / set-up kernels.
+SOURCES = ["wafer_engine.hip", "wafer_tu_lds.hip", "wafer_tu_excited_r1.hip", "wafer_tu_excited_r2.hip", "wafer_tu_excited_r3.hip",
+           "wafer_tu_fused2.hip", "wafer_tu_fused3.hip"]
+HEADERS = ["wafer_geom.h", "wafer_tuning.h", "wafer_launch.h", "wafer_stencil.hip.h", "wafer_stencil_lds.hip.h",
+           "wafer_stencil_fused2.hip.h", "wafer_stencil_fused3.hip.h", "wafer_elementwise.hip.h", "wafer_setup.hip.h",
+           "wafer_tu_excited.inc"]
 # -ffp-contract=off: the stencil update must round exactly like the reference's
 # (rustc never fuses mul+add); see DESIGN.md "Arithmetic contract".
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC"]
+OBJDIR = os.path.join(HERE, "build")
 
 
 def hipcc() -> str:
@@ -86,12 +91,53 @@ def build_rccl_lib(force: bool = False, verbose: bool = False) -> str:
     return RCCL_LIB
 
 
+def _unit_deps(src: str) -> list:
+    """headers a unit includes (transitively, by name): a stale check without running the preprocessor"""
+    seen, todo = set(), [src]
+    while todo:
+        f = todo.pop()
+        try:
+            text = open(os.path.join(CSRC, f)).read()
+        except OSError:
+            continue
+        for line in text.splitlines():
+            line = line.strip()
+            if line.startswith('#include "'):
+                name = line.split('"')[1]
+                base = os.path.basename(name)
+                if base not in seen:
+                    seen.add(base)
+                    todo.append(base)
+    return [os.path.join(CSRC, h) for h in seen if os.path.exists(os.path.join(CSRC, h))] + \
+           [os.path.join(os.path.dirname(HERE), "include", "wafer_hip.h")]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or is_stale():
         # WAFER_IEEE_DIV=1 at build time keeps hipcc's IEEE division sequence for the divisions by
         # loop-invariant denominators (wafer_div_invariant, wafer_stencil.hip.h) -- for A/B runs
         extra = ["-DWAFER_IEEE_DIV"] if os.environ.get("WAFER_IEEE_DIV", "") not in ("", "0") else []
-        cmd = [hipcc(), *FLAGS, *extra, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+        os.makedirs(OBJDIR, exist_ok=True)
+        stamp = os.path.join(OBJDIR, "flags.txt")
+        flags_now = " ".join(FLAGS + extra)
+        if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+            force = True
+        jobs = []
+        for src in SOURCES:
+            obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+            deps = [os.path.join(CSRC, src)] + _unit_deps(src)
+            if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(d) for d in deps):
+                cmd = [hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                jobs.append((src, subprocess.Popen(cmd, cwd=CSRC)))
+        failed = [src for src, p in jobs if p.wait() != 0]
+        if failed:
+            raise RuntimeError("hipcc failed on " + ", ".join(failed))
+        with open(stamp, "w") as f:
+            f.write(flags_now)
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC",
+               *[os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES], "-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)

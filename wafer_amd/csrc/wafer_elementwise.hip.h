@@ -185,31 +185,12 @@ __global__ void wafer_k_identity_scalars(double *__restrict__ scal, int n)
 }
 
 // ---------------------------------------------------------------------------
-// Diagnostics: flat streaming kernels over the same buffers, to measure the
-// HBM ceiling of this device for (a) a copy and (b) the stencil's stream mix
-// (3 reads + 1 write per element) without any neighbour traffic.
+// Diagnostic: the device's copy ceiling (MI355X_MICROARCH.md: ~6.3 TB/s for a float4 copy): every lane moves
+// U independent 16 B vectors per trip of a grid-stride loop -- U loads in flight before the first
+// store -- with a grid of a few 256-thread workgroups per CU.
 // ---------------------------------------------------------------------------
 typedef float __attribute__((ext_vector_type(4))) wafer_f4;
 
-template <int NREAD>
-__global__ __launch_bounds__(256) void wafer_k_stream(const wafer_f4 *__restrict__ r0,
-                                                      const wafer_f4 *__restrict__ r1,
-                                                      const wafer_f4 *__restrict__ r2,
-                                                      wafer_f4 *__restrict__ w, long long n16)
-{
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
-        wafer_f4 v = r0[i];
-        if constexpr (NREAD >= 2) v += r1[i];
-        if constexpr (NREAD >= 3) v += r2[i];
-        w[i] = v;
-    }
-}
-
-// The device's copy ceiling (MI355X_MICROARCH.md: ~6.3 TB/s for a float4 copy): every lane moves
-// U independent 16 B vectors per trip of a grid-stride loop -- U loads in flight before the first
-// store -- with a grid of a few 256-thread workgroups per CU.  wafer_k_stream above issues one load
-// per trip and under-reads the device by a quarter.
 template <int U>
 __global__ __launch_bounds__(256) void wafer_k_copy16(const wafer_f4 *__restrict__ src, wafer_f4 *__restrict__ dst, long long n16)
 {

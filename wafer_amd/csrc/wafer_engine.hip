@@ -25,6 +25,8 @@
 #include "wafer_stencil_lds.hip.h"
 #include "wafer_stencil_fused2.hip.h"
 #include "wafer_stencil_fused3.hip.h"
+#include "wafer_launch.h"
+#include "wafer_tuning.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -167,12 +169,22 @@ struct wafer_ctx {
     wafer_halo_fn halo_hook = nullptr;
     wafer_allreduce_fn allreduce_hook = nullptr;
     void *hook_user = nullptr;
-    bool overlap = true;
-    bool bdry_main = false; // split passes: boundary kernels in order on the main stream (see bdry_on_main)
-    bool alternate = false; // fused split passes: the two streams swap roles every pass (wafer_set_overlap mode 3)
-    hipEvent_t ev_intr = nullptr; // mode 3: end of an interior launch that ran on the second stream
-    bool halves = false;          // fused split passes as two half-slab launches in alternating order (wafer_set_overlap mode 4)
-    hipEvent_t ev_half = nullptr, ev_hop = nullptr, ev_ex[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // mode 4
+    int overlap_mode = 1;   // wafer_set_overlap: 0 exchange after the pass, 1 boundary-first split pass, 2 single-launch half-slab pass
+    WaferTuning tune;       // WAFER_* knobs, read once in wafer_ctx_create
+    // three-step kernel: workgroup tables by launch shape (device copies), and the words of the single-launch slab pass
+    struct F3Table {
+        int kind, lz_lo, lz_hi, aux;
+        WaferF3Block *dev;
+        int nblocks, nbump[2];
+    };
+    std::vector<F3Table> f3_tables;
+    unsigned long long *hv_cnt[2] = {nullptr, nullptr}; // finished workgroups per half: signal memory (hipStreamWaitValue64) or coherent host memory (gate kernel)
+    unsigned long long *hv_flag = nullptr;  // [2] exchanges completed per ghost side, written by the exchange stream
+    unsigned *hv_err = nullptr;             // set by a workgroup whose wait gave up
+    unsigned long long hv_cnt_target[2] = {0, 0}, hv_flag_epoch[2] = {0, 0};
+    int hv_first = 0;                       // which half the next single-launch pass dispatches first
+    bool hv_use_memops = false;             // the exchange stream waits / signals with stream memory operations (else: gate kernels)
+    hipEvent_t ev_ex[2] = {nullptr, nullptr}; // single-launch pass: the last exchange of each side
     int halo_valid = 0; // ghost planes of phi[cur] (counted from the owned region) known to be current
     int halo_cycle = 1; // fused passes per halo exchange: the exchange moves 2R * halo_cycle planes (<= G), see wafer_evolve
 
@@ -186,17 +198,10 @@ struct wafer_ctx {
     bool sharded() const { return has_lo() || has_hi(); }
 };
 
-static int env_int(const char *name, int dflt)
-{
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
-
 // planes per workgroup so that a launch over `nplanes` has >= target blocks
 static int pick_zchunk(const wafer_ctx *c, int nplanes, int target_blocks)
 {
-    const int forced = env_int("WAFER_ZCHUNK", 0);
-    if (forced > 0) return forced;
+    if (c->tune.zchunk > 0) return c->tune.zchunk;
     const long long per_layer = (long long)c->bx * c->by;
     long long nch = (target_blocks + per_layer - 1) / per_layer;
     if (nch < 1) nch = 1;
@@ -262,7 +267,7 @@ static int refresh_ab(wafer_ctx *c)
     HIP_TRY(hipGetLastError());
     return WAFER_OK;
 }
-static bool kernels_stream_ab(int variant) { return variant == 0 || env_int("WAFER_ABV", 1) == 0; }
+static bool kernels_stream_ab(const wafer_ctx *c, int variant) { return variant == 0 || c->tune.abv == 0; }
 
 // after V changed: may the kernels that form a, b from V use the short reciprocal?
 static int check_v_range(wafer_ctx *c)
@@ -377,8 +382,7 @@ static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
 static int default_variant(const wafer_ctx *c)
 {
-    const char *e = getenv("WAFER_STENCIL_VARIANT");
-    if (e && *e) return atoi(e);
+    if (c->tune.stencil_variant >= 0) return c->tune.stencil_variant;
     // FivePoint on fp32 storage: the fused kernel needs 256 VGPRs (and spills) there; the single-step
     // kernel is faster (512^3: 0.337 against 0.383 ms/step, f32fast 0.287 against 0.302)
     if (c->f32 && c->g.R == 2) return 1;
@@ -386,7 +390,7 @@ static int default_variant(const wafer_ctx *c)
     // per 8 and is issue-bound: 0.93 ms/step at 512^3 against 0.63 for the single-step kernel on 128 x 16 tiles
     if (c->g.R == 3) return 1;
     // ThreePoint, fp64: three steps per pass (wafer_stencil_fused3.hip.h); everything else two
-    if (!c->f32 && c->g.R == 1 && env_int("WAFER_FUSE3", 1) != 0) return 3;
+    if (!c->f32 && c->g.R == 1 && c->tune.fuse3 != 0) return 3;
     return 2;
 }
 
@@ -398,7 +402,7 @@ static int active_variant(const wafer_ctx *c) { return c->variant >= 0 ? c->vari
 static int closed_form_vg(const wafer_ctx *c)
 {
     const bool r_ok = c->P.dn > 0x1p-300 && c->P.dn * ((double)c->g.nx + c->g.ny + c->g.nz + 3.) < 0x1p300;
-    return (!c->f32 && r_ok && env_int("WAFER_VGEN", 1) != 0) ? c->vgen_type : 0;
+    return (!c->f32 && r_ok && c->tune.vgen != 0) ? c->vgen_type : 0;
 }
 static void set_vg_args(const wafer_ctx *c, WaferStepArgs &a)
 {
@@ -407,52 +411,28 @@ static void set_vg_args(const wafer_ctx *c, WaferStepArgs &a)
     a.vg_sig = c->P.sig;
 }
 
-template <typename T, typename C, int R, bool NORM>
-static int launch_step_t(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s)
+// storage / arithmetic types of a launch (wafer_launch.h): WAFER_F32_FAST computes the ground-state stencil steps in
+// fp32 as well (sums, projections and observables stay fp64); plain fp32 storage widens to fp64 in registers
+static int type_combo(const wafer_ctx *c, bool step_kernel)
 {
-    if (lz_hi <= lz_lo) return WAFER_OK;
-    const int variant = active_variant(c);
-    if (kernels_stream_ab(variant)) TRY(ensure_ab(c));
-    WaferStepArgs a;
+    if (!c->f32) return WAFER_TC_F64;
+    return (c->f32_arith && step_kernel) ? WAFER_TC_F32_F32 : WAFER_TC_F32_F64;
+}
+
+static WaferStepArgs step_args(const wafer_ctx *c, int lz_lo, int lz_hi)
+{
+    WaferStepArgs a{};
     a.g = c->g;
     a.lz_lo = lz_lo;
     a.lz_hi = lz_hi;
     a.dt = c->P.dt;
     a.target_blocks = c->num_cus;
     a.v_in_range = c->v_in_range ? 1 : 0;
+    const int R = c->g.R;
     const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
     a.den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:569 / 594 / 626
     set_vg_args(c, a);
-    const T *phi = as<T>(c->phi[src]);
-    T *out = as<T>(c->phi[dst]);
-    if (variant >= 1) {
-        hipError_t e;
-        if (NORM) // norm only (more stored states than the fused-overlap kernel carries)
-            e = wafer_launch_step_lds_excited<T, C, R>(a, phi, as<T>(c->v), out, c->partials, c->partials_stride, 0,
-                                                       WaferLowPtrs(), s);
-        else
-            e = wafer_launch_step_lds<T, C, R>(a, phi, as<T>(c->a), as<T>(c->b), as<T>(c->v), out, s, closed_form_vg(c));
-        return e == hipSuccess ? WAFER_OK
-                               : fail(WAFER_ERR_HIP, "LDS stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
-    }
-    a.zchunk = pick_zchunk(c, lz_hi - lz_lo, env_int("WAFER_TARGET_BLOCKS", 4096));
-    const dim3 grid(c->bx, c->by, nchunks_of(lz_hi - lz_lo, a.zchunk));
-    if ((size_t)grid.x * grid.y * grid.z > c->partials_stride)
-        return fail(WAFER_ERR_INVALID, "partials buffer too small");
-    hipLaunchKernelGGL((wafer_k_step_direct<T, C, R, NORM>), grid, dim3(64, 4), 0, s, a, phi,
-                       as<T>(c->a), as<T>(c->b), out, c->partials);
-    HIP_TRY(hipGetLastError());
-    return WAFER_OK;
-}
-
-// number of partials the NORM variant of the last step launch wrote
-template <typename T, typename C, int R>
-static long long step_partials_count(wafer_ctx *c, int lz_lo, int lz_hi)
-{
-    const int variant = active_variant(c);
-    if (variant >= 1) return wafer_step_lds_excited_blocks<T, R>(c->g, lz_lo, lz_hi, c->num_cus);
-    const int zc = pick_zchunk(c, lz_hi - lz_lo, env_int("WAFER_TARGET_BLOCKS", 4096));
-    return (long long)c->bx * c->by * nchunks_of(lz_hi - lz_lo, zc);
+    return a;
 }
 
 template <typename F>
@@ -478,56 +458,141 @@ static int dispatch(wafer_ctx *c, F &&f, bool step_kernel = false)
     return f(float{}, double{}, std::integral_constant<int, 3>{});
 }
 
+static int direct_target_blocks(const wafer_ctx *c) { return c->tune.target_blocks > 0 ? c->tune.target_blocks : 4096; }
+
+// one step over local planes [lz_lo, lz_hi); norm: also sum phi'^2 into the partials (more stored states than the
+// fused-overlap kernel carries)
 static int launch_step(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, bool norm, hipStream_t s)
 {
+    if (lz_hi <= lz_lo) return WAFER_OK;
+    const int variant = active_variant(c);
+    if (kernels_stream_ab(c, variant)) TRY(ensure_ab(c));
+    WaferStepArgs a = step_args(c, lz_lo, lz_hi);
+    if (variant >= 1) {
+        const int tc = type_combo(c, !norm);
+        const hipError_t e =
+            norm ? wafer_entry_step_lds_excited(tc, c->g.R, c->tune, a, c->phi[src], c->v, c->phi[dst], c->partials, c->partials_stride, 0,
+                                                WaferLowPtrs(), s, nullptr, nullptr, 0)
+                 : wafer_entry_step_lds(tc, c->g.R, c->tune, a, c->phi[src], c->a, c->b, c->v, c->phi[dst], s, closed_form_vg(c));
+        return e == hipSuccess ? WAFER_OK
+                               : fail(WAFER_ERR_HIP, "LDS stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    a.zchunk = pick_zchunk(c, lz_hi - lz_lo, direct_target_blocks(c));
+    const dim3 grid(c->bx, c->by, nchunks_of(lz_hi - lz_lo, a.zchunk));
+    if ((size_t)grid.x * grid.y * grid.z > c->partials_stride)
+        return fail(WAFER_ERR_INVALID, "partials buffer too small");
     return dispatch(c, [&](auto t, auto cc, auto r) {
         using T = decltype(t);
         using C = decltype(cc);
         constexpr int R = decltype(r)::value;
-        return norm ? launch_step_t<T, C, R, true>(c, src, dst, lz_lo, lz_hi, s)
-                    : launch_step_t<T, C, R, false>(c, src, dst, lz_lo, lz_hi, s);
+        if (norm)
+            hipLaunchKernelGGL((wafer_k_step_direct<T, C, R, true>), grid, dim3(64, 4), 0, s, a, as<T>(c->phi[src]), as<T>(c->a), as<T>(c->b),
+                               as<T>(c->phi[dst]), c->partials);
+        else
+            hipLaunchKernelGGL((wafer_k_step_direct<T, C, R, false>), grid, dim3(64, 4), 0, s, a, as<T>(c->phi[src]), as<T>(c->a), as<T>(c->b),
+                               as<T>(c->phi[dst]), c->partials);
+        HIP_TRY(hipGetLastError());
+        return (int)WAFER_OK;
     }, !norm);
 }
 
+// number of partials the norm variant of the last step launch wrote
+static long long step_partials_count(wafer_ctx *c, int lz_lo, int lz_hi)
+{
+    if (active_variant(c) >= 1)
+        return dispatch(c, [&](auto t, auto, auto r) {
+            return (int)wafer_step_lds_excited_blocks<decltype(t), decltype(r)::value>(c->tune, c->g, lz_lo, lz_hi, c->num_cus);
+        });
+    const int zc = pick_zchunk(c, lz_hi - lz_lo, direct_target_blocks(c));
+    return (long long)c->bx * c->by * nchunks_of(lz_hi - lz_lo, zc);
+}
+
 // the three-step kernel serves ThreePoint fp64 grids whose rows fill its 128 x 16 tiles -- undecomposed, or
-// z-slabs created with at least 3 * ext ghost planes; everything else takes the two-step kernel
+// z-slabs created with at least 3 * ext ghost planes; everything else takes the two-step kernel.
+// Every rank of a decomposed run must take the same decision (the ranks exchange K * ext planes per K-step pass):
+// for a slab it therefore depends only on what all ranks share -- the global nx, ny, the ghost depth the host created
+// every context with and the variant -- never on the local slab thickness (slab.partition hands out uneven z_counts
+// when nz % world != 0; wafer_ctx_create has already refused a slab thinner than its ghost depth).
 static bool fuse3_applies(const wafer_ctx *c)
 {
-    // Small grids are launch- and fill-bound and the deeper pipeline costs there: 50^3 5.8 against 4.5 us/step for
-    // the two-step kernel, 64^3 6.0 / 4.7, 128^3 9.1 / 8.7; from 256^3 up it wins (40.5 / 41.9 us, 384^3 0.177 /
-    // 0.196 ms).  WAFER_FUSE3_MIN_NY (tests) lifts both thresholds.
-    const int ny_env = env_int("WAFER_FUSE3_MIN_NY", -1);
+    // Small undecomposed grids are launch- and fill-bound and the deeper pipeline costs there: 50^3 5.8 against 4.5
+    // us/step for the two-step kernel, 64^3 6.0 / 4.7, 128^3 9.1 / 8.7; from 256^3 up it wins (40.5 / 41.9 us, 384^3
+    // 0.177 / 0.196 ms).  WAFER_FUSE3_MIN_NY (tests) lifts both thresholds.
+    const int ny_env = c->tune.fuse3_min_ny;
     const int min_ny = ny_env >= 0 ? ny_env : 16;
-    const long long min_cells = ny_env >= 0 ? 0 : (long long)env_int("WAFER_FUSE3_MIN_CELLS", 6000000);
-    return active_variant(c) == 3 && c->g.R == 1 && !c->f32 && c->g.ny >= min_ny &&
-           (long long)c->g.nx * c->g.ny * c->g.nzl >= min_cells &&
-           (!c->sharded() || (c->g.G >= 3 * c->g.R && c->g.nzl >= 3 * c->g.R));
+    const long long min_cells = ny_env >= 0 ? 0 : c->tune.fuse3_min_cells;
+    if (!(active_variant(c) == 3 && c->g.R == 1 && !c->f32 && c->g.ny >= min_ny)) return false;
+    if (c->sharded()) return c->g.G >= 3 * c->g.R;
+    return (long long)c->g.nx * c->g.ny * c->g.nz >= min_cells;
 }
 
 // The two-step kernel: every stencil order in fp64 (SevenPoint on 128 x 8 tiles, a and b formed again at
 // the second step: its two seven-plane z-queues leave no registers for an a, b queue); ThreePoint /
 // FivePoint on fp32 storage (SevenPoint there spills 200 B per lane and stays on the single-step kernel).
-// Slabs need 2 * ext ghost planes.
+// Slabs need 2 * ext ghost planes (rank-invariant, as above).
 static bool fuse2_applies(const wafer_ctx *c)
 {
     const int R = c->g.R;
-    return active_variant(c) >= 2 && (R <= 2 || !c->f32) && (!c->sharded() || (c->g.G >= 2 * R && c->g.nzl >= 2 * R));
+    return active_variant(c) >= 2 && (R <= 2 || !c->f32) && (!c->sharded() || c->g.G >= 2 * R);
+}
+
+// ---- workgroup tables of the three-step kernel (wafer_stencil_fused3.hip.h), built once per launch shape ---------
+enum { F3_PLAIN = 0, F3_MIXED = 1, F3_HALVES = 2 };
+static int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const wafer_ctx::F3Table **out)
+{
+    for (const auto &t : c->f3_tables)
+        if (t.kind == kind && t.lz_lo == lz_lo && t.lz_hi == lz_hi && t.aux == aux) {
+            *out = &t;
+            return WAFER_OK;
+        }
+    using Cfg = WaferF3Cfg<double>;
+    const int ntx = (c->g.nx + Cfg::TX - 1) / Cfg::TX, nty = (c->g.ny + Cfg::TY - 1) / Cfg::TY;
+    std::vector<WaferF3Block> host;
+    if (kind == F3_PLAIN) {
+        wafer_f3_schedule_plain(host, ntx, nty, lz_lo, lz_hi, aux /* planes per workgroup */, c->tune.swz != 0);
+    } else if (kind == F3_MIXED) {
+        wafer_f3_schedule_mixed(host, ntx, nty, lz_lo, lz_hi, aux /* short workgroups per tile */);
+    } else {
+        // the single-launch pass: aux = the half dispatched first.  Both sides wait for their flag whether or not a
+        // neighbour exists there: the flag also says that this rank's SEND of the planes about to be overwritten two
+        // passes later has completed
+        const bool need_wait[2] = {true, true};
+        const int ntiles = ntx * nty;
+        wafer_f3_schedule_halves(host, ntx, nty, lz_lo, lz_hi, lz_lo + (lz_hi - lz_lo) / 2, aux, need_wait, ntiles >= 64 ? ntiles / 16 : 0, 4);
+    }
+    wafer_ctx::F3Table t{};
+    t.kind = kind; t.lz_lo = lz_lo; t.lz_hi = lz_hi; t.aux = aux;
+    t.nblocks = (int)host.size();
+    for (const auto &k : host)
+        if (k.bump >= 0) ++t.nbump[k.bump];
+    HIP_TRY(hipMalloc((void **)&t.dev, sizeof(WaferF3Block) * host.size()));
+    hipError_t e = hipMemcpy(t.dev, host.data(), sizeof(WaferF3Block) * host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(t.dev);
+        return fail(WAFER_ERR_HIP, "workgroup table upload failed: %s", hipGetErrorString(e));
+    }
+    if (c->f3_tables.size() > 64) { // (shapes come from a handful of launch sites; a host cycling through slab shapes must not leak)
+        for (auto &old : c->f3_tables) (void)hipFree(old.dev);
+        c->f3_tables.clear();
+    }
+    c->f3_tables.push_back(t);
+    *out = &c->f3_tables.back();
+    return WAFER_OK;
 }
 
 // three fused steps over planes [lz_lo, lz_hi): phi[dst] = step(step(step(phi[src])))
+// short_tail: the interior launch of a split slab pass (see wafer_f3_schedule_mixed)
 static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s, bool short_tail = false)
 {
     if (lz_hi <= lz_lo) return WAFER_OK;
-    WaferStepArgs a{};
-    a.g = c->g;
-    a.lz_lo = lz_lo;
-    a.lz_hi = lz_hi;
-    a.dt = c->P.dt;
-    a.target_blocks = c->num_cus;
-    a.nsub = short_tail ? 4 : 0;
-    a.v_in_range = c->v_in_range ? 1 : 0;
-    a.den = 2. * c->P.dn * c->P.dn * c->P.mass; // grid.rs:569
-    if (wafer_launch_step3_fused<double, double>(a, as<double>(c->phi[src]), as<double>(c->v), as<double>(c->phi[dst]), s) != hipSuccess)
+    using Cfg = WaferF3Cfg<double>;
+    const int ntx = (c->g.nx + Cfg::TX - 1) / Cfg::TX, nty = (c->g.ny + Cfg::TY - 1) / Cfg::TY;
+    const WaferStepArgs a = step_args(c, lz_lo, lz_hi);
+    const wafer_ctx::F3Table *tab = nullptr;
+    if (short_tail && lz_hi - lz_lo >= 8 * 4) TRY(f3_table(c, F3_MIXED, lz_lo, lz_hi, 4, &tab));
+    else TRY(f3_table(c, F3_PLAIN, lz_lo, lz_hi, wafer_f3_zchunk(c->tune, ntx, nty, lz_hi - lz_lo, c->num_cus), &tab));
+    if (wafer_entry_step3_fused(c->tune, a, tab->dev, tab->nblocks, WaferF3Sync(), as<double>(c->phi[src]), as<double>(c->v),
+                                as<double>(c->phi[dst]), s) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
     return WAFER_OK;
 }
@@ -538,26 +603,13 @@ static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
 static int launch_step2(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s, bool short_tail = false)
 {
     if (lz_hi <= lz_lo) return WAFER_OK;
-    return dispatch(c, [&](auto t, auto cc, auto r) {
-        using T = decltype(t);
-        using C = decltype(cc);
-        constexpr int R = decltype(r)::value;
-        WaferStepArgs a;
-        a.g = c->g;
-        a.lz_lo = lz_lo;
-        a.lz_hi = lz_hi;
-        a.dt = c->P.dt;
-        a.target_blocks = c->num_cus;
-        a.n_long = 0;
-        a.nsub = short_tail ? 4 : 0;
-        a.v_in_range = c->v_in_range ? 1 : 0;
-        const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
-        a.den = lead * c->P.dn * c->P.dn * c->P.mass;
-        if (kernels_stream_ab(2)) TRY(ensure_ab(c));
-        if (wafer_launch_step2_fused<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->a), as<T>(c->b), as<T>(c->v), as<T>(c->phi[dst]), s) != hipSuccess)
-            return fail(WAFER_ERR_HIP, "fused stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
-        return (int)WAFER_OK;
-    }, true);
+    WaferStepArgs a = step_args(c, lz_lo, lz_hi);
+    a.n_long = 0;
+    a.nsub = short_tail ? 4 : 0;
+    if (kernels_stream_ab(c, 2)) TRY(ensure_ab(c));
+    if (wafer_entry_step2_fused(type_combo(c, true), c->g.R, c->tune, a, c->phi[src], c->a, c->b, c->v, c->phi[dst], s) != hipSuccess)
+        return fail(WAFER_ERR_HIP, "fused stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return WAFER_OK;
 }
 
 
@@ -656,50 +708,25 @@ static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum,
     if (lz_hi <= lz_lo) return WAFER_OK;
     WaferLowPtrs low;
     for (uint32_t j = 0; j < wnum; ++j) low.p[j] = c->states[j];
-    return dispatch(c, [&](auto t, auto cc, auto r) {
-        using T = decltype(t);
-        using C = decltype(cc);
-        constexpr int R = decltype(r)::value;
-        WaferStepArgs a{};
-        a.g = g;
-        a.lz_lo = lz_lo;
-        a.lz_hi = lz_hi;
-        a.dt = c->P.dt;
-        // ONE workgroup per CU (8 waves on a 128x16 tile for k <= 3): every workgroup streams 3 + k
-        // arrays a plane ahead, and two per CU overflow the XCD's 4 MB L2, so the halo rows a
-        // neighbour just loaded are gone again (512^3, 128x8 tiles: k = 2 1.24 -> 1.13 ms, k = 3
-        // 1.45 -> 1.39).  The launcher doubles target_blocks.
-        const int target = zchunk > 0 ? -zchunk  // planes per workgroup fixed by the caller (slab interior)
-                                : (wnum >= 2 || wafer_excited_nw((int)wnum) == 8) ? (c->num_cus + 1) / 2 : c->num_cus;
-        a.target_blocks = target;
-        a.v_in_range = c->v_in_range ? 1 : 0;
-        const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
-        a.den = lead * c->P.dn * c->P.dn * c->P.mass;
-        set_vg_args(c, a);
-        const int vg = closed_form_vg(c);
-        const long long nb = wafer_step_lds_excited_blocks<T, R>(g, lz_lo, lz_hi, target, (int)wnum, transform_on_load);
-        if (pbase + nb > (long long)c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
-        if (wafer_launch_step_lds_excited<T, C, R>(a, as<T>(c->phi[src]), as<T>(c->v), as<T>(c->phi[dst]), c->partials + pbase,
-                                                   c->partials_stride /* the row stride of the partials, too */, (int)wnum, low, s,
-                                                   transform_on_load ? c->scal : nullptr, c->gram, vg) != hipSuccess)
-            return fail(WAFER_ERR_HIP, "excited-state stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
-        *nb_out = nb;
-        return (int)WAFER_OK;
+    WaferStepArgs a = step_args(c, lz_lo, lz_hi);
+    // ONE workgroup per CU (8 waves on a 128x16 tile for k <= 3): every workgroup streams 3 + k
+    // arrays a plane ahead, and two per CU overflow the XCD's 4 MB L2, so the halo rows a
+    // neighbour just loaded are gone again (512^3, 128x8 tiles: k = 2 1.24 -> 1.13 ms, k = 3
+    // 1.45 -> 1.39).  The launcher doubles target_blocks.
+    const int target = zchunk > 0 ? -zchunk  // planes per workgroup fixed by the caller (slab interior)
+                            : (wnum >= 2 || wafer_excited_nw(c->tune, (int)wnum) == 8) ? (c->num_cus + 1) / 2 : c->num_cus;
+    a.target_blocks = target;
+    const long long nb = dispatch(c, [&](auto t, auto, auto r) {
+        return (int)wafer_step_lds_excited_blocks<decltype(t), decltype(r)::value>(c->tune, g, lz_lo, lz_hi, target, (int)wnum, transform_on_load);
     });
+    if (pbase + nb > (long long)c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
+    if (wafer_entry_step_lds_excited(type_combo(c, false), g.R, c->tune, a, c->phi[src], c->v, c->phi[dst], c->partials + pbase,
+                                     c->partials_stride /* the row stride of the partials, too */, (int)wnum, low, s,
+                                     transform_on_load ? c->scal : nullptr, c->gram, closed_form_vg(c)) != hipSuccess)
+        return fail(WAFER_ERR_HIP, "excited-state stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    *nb_out = nb;
+    return WAFER_OK;
 }
-
-// Where the boundary kernels of a split pass run.  Default: on the SECOND stream, with the exchange
-// directly behind them in stream order and the interior released by ev_bdry -- the interior pays the
-// cross-stream event hop (a few microseconds), and that is the point: the exchange's kernels reach the
-// CUs before the interior launch fills them.  WAFER_BDRY_MAIN=1 runs the boundary kernels in order on
-// the main stream and lets only the exchange hop: the interior then wins the race for the CUs by ~6 us,
-// RCCL's workgroups (which cannot share a CU with a stencil workgroup) wait until the first long
-// workgroups retire, and the exchange gets the second half of the pass only (kernel trace: RCCL kernel
-// 0.60 ms long instead of 0.33, ending 60 us before the pass).  With a device-to-device loopback that
-// still hides and the saved hop shows as 0.371 -> 0.359 ms/step; on a real link, where the transfer
-// needs most of the pass, it would be exposed.  Kept as a mode (wafer_set_overlap(ctx, 2)) that a host
-// can time against the default on real fabric, as bench.py does during set-up.
-static bool bdry_on_main(const wafer_ctx *c) { return c->bdry_main; }
 
 // the whole slab in one launch, then the 1 + wnum sums (all-reduced when sharded)
 static int excited_step_launch(wafer_ctx *c, int src, int dst, uint32_t wnum, bool transform_on_load, hipStream_t s)
@@ -716,18 +743,15 @@ static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32
     const WaferGeom &g = c->g;
     const int R = g.R, lo = g.G, hi = g.G + g.nzl;
     long long nb_lo = 0, nb_hi = 0, nb_in = 0;
-    const hipStream_t sb = bdry_on_main(c) ? c->s_main : c->s_aux;
-    if (sb == c->s_aux) {
-        HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
-        HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
-    }
+    const hipStream_t sb = c->s_aux;
+    HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
+    HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
     if (c->has_lo()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, lo, lo + R, 0, sb, &nb_lo));
     if (c->has_hi()) TRY(excited_stencil_launch(c, src, dst, wnum, transform_on_load, hi - R, hi, nb_lo, sb, &nb_hi));
     HIP_TRY(hipEventRecord(c->ev_bdry, sb));
-    if (sb == c->s_main) HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_bdry, 0));
     TRY(exchange_halo(c, dst, c->s_aux, R));        // enqueued before the interior: its kernels reach the CUs first
     HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
-    if (sb == c->s_aux) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
+    HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
     // (one long workgroup per tile here: shorter ones -- the fused ground-state split's answer to CUs
     //  held by the exchange -- cost this kernel more in pipeline refills than the tail they avoid:
     //  k = 1 0.98 vs 1.01 ms, k = 3 1.57 vs 1.53 under an 8-channel RCCL kernel)
@@ -810,14 +834,11 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->g = wafer_make_geom((int)p->nx, (int)p->ny, (int)p->nz, R, G, (int)zb, (int)zc, (int)c->esz);
     c->bx = (c->g.px + 63) / 64; // covers both the work area and the padded extent
     c->by = (c->g.py + 3) / 4;
-    const int ov_mode = env_int("WAFER_OVERLAP", 1); // the modes of wafer_set_overlap
-    c->overlap = ov_mode != 0;
-    c->bdry_main = ov_mode == 2 || env_int("WAFER_BDRY_MAIN", 0) != 0;
-    c->alternate = ov_mode == 3;
-    c->halves = ov_mode == 4;
+    c->tune = wafer_tuning_from_env(); // the only place the WAFER_* tuning variables are read
+    c->overlap_mode = (c->tune.overlap >= 0 && c->tune.overlap <= 2) ? c->tune.overlap : 1; // the modes of wafer_set_overlap
     // fused passes per halo exchange: 1 unless the host asks for deep halos (wafer_set_halo_cycle) -- a
     // concentrated exchange outlasts the interior launch it hides behind on anything but a very fast link
-    c->halo_cycle = std::max(1, env_int("WAFER_HALO_CYCLE", 1));
+    c->halo_cycle = std::max(1, c->tune.halo_cycle);
     if (2 * R * c->halo_cycle > G) c->halo_cycle = std::max(1, G / (2 * R));
 
     auto cleanup_fail = [&](int rc) {
@@ -843,11 +864,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRYC(hipEventCreateWithFlags(&c->ev_bdry, hipEventDisableTiming));
-    HIP_TRYC(hipEventCreateWithFlags(&c->ev_intr, hipEventDisableTiming));
-    HIP_TRYC(hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
-    HIP_TRYC(hipEventCreateWithFlags(&c->ev_hop, hipEventDisableTiming));
-    for (int a_ = 0; a_ < 2; ++a_)
-        for (int b_ = 0; b_ < 2; ++b_) HIP_TRYC(hipEventCreateWithFlags(&c->ev_ex[a_][b_], hipEventDisableTiming));
+    for (int a_ = 0; a_ < 2; ++a_) HIP_TRYC(hipEventCreateWithFlags(&c->ev_ex[a_], hipEventDisableTiming));
 
     // a and b are allocated on first use (ensure_ab): the default kernels form them from V in registers
     void **arrays[] = {&c->phi[0], &c->phi[1], &c->v};
@@ -862,7 +879,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     HIP_TRYC(hipHostMalloc((void **)&c->scal_host, sizeof(double) * SCAL_SLOTS, hipHostMallocDefault));
     HIP_TRYC(hipStreamSynchronize(c->s_main));
 #undef HIP_TRYC
-    c->kernel_name = kVariants[default_variant(c) < kNumVariants ? default_variant(c) : 0].name;
+    c->kernel_name = kVariants[(default_variant(c) >= 0 && default_variant(c) < kNumVariants) ? default_variant(c) : 0].name;
     *out = c;
     return WAFER_OK;
 }
@@ -881,9 +898,13 @@ int wafer_ctx_destroy(wafer_ctx *c)
     if (c->scal) (void)hipFree(c->scal);
     if (c->gram) (void)hipFree(c->gram);
     if (c->scal_host) (void)hipHostFree(c->scal_host);
-    for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join, c->ev_bdry, c->ev_intr, c->ev_half, c->ev_hop, c->ev_ex[0][0],
-                         c->ev_ex[0][1], c->ev_ex[1][0], c->ev_ex[1][1]})
+    for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join, c->ev_bdry, c->ev_ex[0], c->ev_ex[1]})
         if (e) (void)hipEventDestroy(e);
+    for (auto &t : c->f3_tables) (void)hipFree(t.dev);
+    for (int h = 0; h < 2; ++h)
+        if (c->hv_cnt[h]) (void)(c->hv_use_memops ? hipFree(c->hv_cnt[h]) : hipHostFree(c->hv_cnt[h]));
+    if (c->hv_flag) (void)hipHostFree(c->hv_flag);
+    if (c->hv_err) (void)hipHostFree(c->hv_err);
     if (c->s_own) (void)hipStreamDestroy(c->s_own);
     if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
     delete c;
@@ -1283,6 +1304,121 @@ int wafer_download_phi_owned(wafer_ctx *c, double *out)
 }
 
 // ---- evolve (grid.rs:544-687) ----------------------------------------------------
+// ---- the single-launch pass of a z-slab (wafer_set_overlap mode 2) ----------------------------------------------------
+// One launch per three-step pass updates the whole slab as two halves marched outwards from the cut (wafer_f3_schedule_halves).
+// A half's workgroups count themselves done (cnt[half], system-scope atomics after their last stores); the exchange stream
+// waits for that count and sends the half's boundary planes while the other half -- or the next pass -- computes; the
+// ghost planes an exchange fills are announced by flag[side], which the workgroups that read them poll just before their
+// first load of a ghost plane, i.e. near the END of their column.  No thin boundary launches, no event hops between the
+// streams, one pipeline fill more per tile than an undecomposed slab.
+__global__ void wafer_k_gate(const unsigned long long *cnt, unsigned long long target, unsigned *err)
+{
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1u << 25)) {
+                __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+}
+__global__ void wafer_k_post(unsigned long long *flag, unsigned long long value)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static int ensure_hv(wafer_ctx *c)
+{
+    if (c->hv_flag) return WAFER_OK;
+    int can = 0;
+    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->P.device);
+    c->hv_use_memops = can != 0 && c->tune.gate == 0;
+    // flags (written by the exchange stream, polled by workgroups) and the give-up word: host memory every agent sees
+    // coherently; counters: signal memory for hipStreamWaitValue64, else the same kind of memory for the gate kernel
+    HIP_TRY(hipHostMalloc((void **)&c->hv_flag, 2 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void **)&c->hv_err, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    c->hv_flag[0] = c->hv_flag[1] = 0;
+    *c->hv_err = 0;
+    for (int h = 0; h < 2; ++h) {
+        if (c->hv_use_memops) HIP_TRY(hipExtMallocWithFlags((void **)&c->hv_cnt[h], 8, hipMallocSignalMemory));
+        else HIP_TRY(hipHostMalloc((void **)&c->hv_cnt[h], 64, hipHostMallocCoherent | hipHostMallocMapped));
+        *c->hv_cnt[h] = 0;
+    }
+    return WAFER_OK;
+}
+
+// exchange stream: wait until every workgroup of `half` of the current launch has finished
+static int hv_gate(wafer_ctx *c, int half)
+{
+    if (c->hv_use_memops) {
+        HIP_TRY(hipStreamWaitValue64(c->s_aux, c->hv_cnt[half], c->hv_cnt_target[half], hipStreamWaitValueGte, ~0ull));
+    } else {
+        hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, c->s_aux, c->hv_cnt[half], c->hv_cnt_target[half], c->hv_err);
+        HIP_TRY(hipGetLastError());
+    }
+    return WAFER_OK;
+}
+// exchange stream: ghost side g has been filled once more
+static int hv_post(wafer_ctx *c, int g)
+{
+    const unsigned long long v = ++c->hv_flag_epoch[g];
+    if (c->hv_use_memops) {
+        HIP_TRY(hipStreamWriteValue64(c->s_aux, c->hv_flag + g, v, 0));
+    } else {
+        hipLaunchKernelGGL(wafer_k_post, dim3(1), dim3(64), 0, c->s_aux, c->hv_flag + g, v);
+        HIP_TRY(hipGetLastError());
+    }
+    return WAFER_OK;
+}
+
+static int check_hv_err(wafer_ctx *c)
+{
+    if (c->hv_err && *c->hv_err != 0) {
+        const unsigned e = *c->hv_err;
+        *c->hv_err = 0;
+        return fail(WAFER_ERR_COMM, "single-launch slab pass: a %s gave up waiting (halo exchange never completed)",
+                    e == 2 ? "gate kernel" : "workgroup");
+    }
+    return WAFER_OK;
+}
+
+// one three-step pass of the whole slab in ONE launch; the two exchanges follow on the second stream
+static int launch_halves_pass(wafer_ctx *c, int src, int dst, int E)
+{
+    const WaferGeom &g = c->g;
+    const int lo = g.G, hi = g.G + g.nzl, mid = lo + g.nzl / 2;
+    const int first = c->hv_first;
+    const wafer_ctx::F3Table *tab = nullptr;
+    TRY(f3_table(c, F3_HALVES, lo, hi, first, &tab));
+    WaferF3Sync sy;
+    sy.cnt[0] = c->hv_cnt[0];
+    sy.cnt[1] = c->hv_cnt[1];
+    sy.flag = c->hv_flag;
+    sy.need[0] = c->hv_flag_epoch[0];   // every exchange enqueued so far
+    sy.need[1] = c->hv_flag_epoch[1];
+    sy.err = c->hv_err;
+    const WaferStepArgs a = step_args(c, lo, hi);
+    if (wafer_entry_step3_fused(c->tune, a, tab->dev, tab->nblocks, sy, as<double>(c->phi[src]), as<double>(c->v), as<double>(c->phi[dst]),
+                                c->s_main) != hipSuccess)
+        return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    c->hv_cnt_target[0] += (unsigned long long)tab->nbump[0];
+    c->hv_cnt_target[1] += (unsigned long long)tab->nbump[1];
+    for (int i = 0; i < 2; ++i) {
+        const int half = (first + i) & 1;
+        TRY(hv_gate(c, half));
+        // a half thinner than the exchange depth: its side's boundary planes reach into the other half
+        if ((half == 0 ? mid - lo : hi - mid) < E) TRY(hv_gate(c, half ^ 1));
+        // side 0: the lowest owned planes go down, the upper ghost planes are filled (read by half B); side 1: the mirror image
+        TRY(exchange_halo_side(c, dst, c->s_aux, E, half));
+        TRY(hv_post(c, half ^ 1));
+        HIP_TRY(hipEventRecord(c->ev_ex[half], c->s_aux));
+    }
+    c->hv_first ^= 1;
+    return WAFER_OK;
+}
+
 int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
 {
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
@@ -1300,17 +1436,15 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     const bool fuse = wnum == 0 && fuse2_applies(c);
     const bool fuse3 = wnum == 0 && fuse3_applies(c);
     HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
-    bool intr_on_aux = false, have_join = false; // mode 3 (alternating stream roles), see below
-    // mode 4 (two half-slab launches per pass): exchanges of the previous pass not yet waited for, by side
+    // single-launch passes in flight: their last exchanges have not been waited for by the main stream
     bool hv_active = false;
-    int hv_first = 0, hv_pend[2] = {-1, -1};
-    uint64_t hv_pass = 0;
+    int hv_depth = 0;
     auto hv_drain = [&]() -> int {
         if (!hv_active) return WAFER_OK;
-        for (int sd = 0; sd < 2; ++sd)
-            if (hv_pend[sd] >= 0) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[sd][hv_pend[sd]], 0));
-        hv_pend[0] = hv_pend[1] = -1;
+        HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[0], 0));
+        HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[1], 0));
         hv_active = false;
+        c->halo_valid = hv_depth;
         return WAFER_OK;
     };
     for (uint64_t s = 0; s < steps;) {
@@ -1325,13 +1459,27 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             // pass needs boundary-first kernels, an exchange and the event hops around them.  The passes in
             // between run UNSPLIT over the owned planes plus the ghost planes that are still good for one more
             // pass: each fused pass consumes H planes of validity per side (the neighbour computes the
-            // same cells from the same values, so the bits agree).  halo_cycle = 2 at the 1024 x 1024 x 128
-            // bench slab: a few redundant planes per two passes against two thin boundary launches, one
-            // exchange launch and two cross-stream hops.  E is a whole number of passes' worth and the same
+            // same cells from the same values, so the bits agree).  E is a whole number of passes' worth and the same
             // on every rank (the neighbours receive what this one sends).
             const int E = c->sharded() ? std::max(H, std::min(g.G, H * c->halo_cycle) / H * H) : H;
-            if (c->sharded() && !hv_active && c->halo_valid < H) TRY(ensure_halo(c, E));
-            if (c->sharded() && !hv_active && c->halo_valid >= 2 * H) {
+            // Mode 2: the whole slab in one launch (three-step passes with one exchange per pass; every rank takes this
+            // branch or none: K, E and H depend on nothing local)
+            if (c->sharded() && c->overlap_mode == 2 && K == 3 && E == H) {
+                if (!hv_active) {
+                    TRY(ensure_hv(c));
+                    TRY(ensure_halo(c, E));   // the first pass's ghost planes: a plain exchange in stream order
+                    hv_active = true;
+                    hv_depth = E;
+                }
+                TRY(launch_halves_pass(c, src, dst, E));
+                c->halo_valid = 0;   // (inside the mode; hv_drain restores the invariant)
+                c->cur = dst;
+                s += K;
+                continue;
+            }
+            TRY(hv_drain());
+            if (c->sharded() && c->halo_valid < H) TRY(ensure_halo(c, E));
+            if (c->sharded() && c->halo_valid >= 2 * H) {
                 const int ext = c->halo_valid - H; // ghost planes still valid after this pass
                 TRY(launch_pass(c->has_lo() ? lo - ext : lo, c->has_hi() ? hi + ext : hi, c->s_main, false));
                 c->halo_valid = ext;
@@ -1339,108 +1487,23 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 s += K;
                 continue;
             }
-            if (c->sharded() && c->overlap && c->halves && E == H && g.nzl >= 4 * H) {
-                // Mode 4.  The slab is updated as two half-slab launches, A = [lo, mid) and B = [mid, hi): full-size,
-                // efficient launches instead of two thin boundary launches (nine plane-iterations for three planes)
-                // and an interior.  After A its lowest E planes go down and the upper neighbour's arrive in the
-                // UPPER ghost planes (which only the next pass's B reads); after B the mirror image.  The order
-                // alternates -- A B | B A | A B ... -- so that the launch that follows an exchange never reads the
-                // ghost planes it fills: every exchange has one half-slab launch to hide behind.  Both halves read
-                // the pass's input buffer across their common face, so the split costs no redundant planes, only
-                // the pipeline fill of one more workgroup per tile.
-                if (!hv_active) {
-                    if (c->halo_valid < H) TRY(ensure_halo(c, E));
-                    hv_active = true;
-                    hv_first = 0;
-                    hv_pend[0] = hv_pend[1] = -1;
-                }
-                const int mid = lo + g.nzl / 2;
-                const int need[2] = {hv_pend[0], hv_pend[1]};   // the previous pass's exchanges
-                hv_pend[0] = hv_pend[1] = -1;
-                const int par = (int)(hv_pass & 1);
-                for (int i = 0; i < 2; ++i) {
-                    const int half = (hv_first + i) & 1;        // 0 = A (reads the lower ghost planes), 1 = B
-                    // A's ghost planes were filled by the exchange that followed the previous pass's B, and vice versa
-                    if (need[half ^ 1] >= 0) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[half ^ 1][need[half ^ 1]], 0));
-                    TRY(launch_pass(half == 0 ? lo : mid, half == 0 ? mid : hi, c->s_main, true));
-                    HIP_TRY(hipEventRecord(c->ev_half, c->s_main));
-                    HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_half, 0));
-                    HIP_TRY(hipEventRecord(c->ev_hop, c->s_aux));
-                    TRY(exchange_halo_side(c, dst, c->s_aux, E, half));
-                    HIP_TRY(hipEventRecord(c->ev_ex[half][par], c->s_aux));
-                    hv_pend[half] = par;
-                    // two event hops for the next launch against one for the exchange: its kernels reach the CUs first
-                    if (env_int("WAFER_HALVES_HOP", 1) != 0) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_hop, 0));
-                }
-                hv_first ^= 1;
-                ++hv_pass;
-                c->halo_valid = 0;   // (inside the mode; hv_drain restores the invariant)
-                c->cur = dst;
-                s += K;
-                if (!((fuse3 && steps - s >= 3) || (fuse && steps - s >= 2))) { // last fused pass of this call
-                    TRY(hv_drain());
-                    c->halo_valid = E;
-                }
-                continue;
-            }
-            TRY(hv_drain());
-            const bool split = c->sharded() && c->overlap && g.nzl > 2 * E;
-            if (split && c->alternate && K == 2 && E == 2 * R) {
-                // Mode 3: as below, but the two streams swap roles every pass.  The boundary kernels of this
-                // pass run on the stream that ran the interior of the previous one, so that dependency is
-                // stream order instead of an event hop (19 us in the kernel trace); the previous exchange,
-                // on the other stream, has long finished.  The hop that remains -- boundary kernels ->
-                // interior -- is the one that lets the exchange reach the CUs first.  Measured with the rank as
-                // its own neighbour: 0.369 -> 0.352 ms/step under the native RCCL hooks -- but the kernel
-                // trace shows RCCL's kernel starting 2 us AFTER the interior again (RCCL pays ~6 us more per
-                // call when the user stream changes between calls), i.e. the exchange is starved of CUs as in
-                // mode 2.  Not the default; bench.py times it with the other modes on the fabric it runs on.
-                const hipStream_t sE = intr_on_aux ? c->s_aux : c->s_main, sI = intr_on_aux ? c->s_main : c->s_aux;
-                if (have_join) HIP_TRY(hipStreamWaitEvent(sE, c->ev_join, 0)); // ghost planes of the previous exchange
-                if (c->has_lo()) TRY(launch_pass(lo, lo + E, sE, false));
-                if (c->has_hi()) TRY(launch_pass(hi - E, hi, sE, false));
-                HIP_TRY(hipEventRecord(c->ev_bdry, sE));
-                TRY(exchange_halo(c, dst, sE, E));
-                HIP_TRY(hipEventRecord(c->ev_join, sE));
-                have_join = true;
-                HIP_TRY(hipStreamWaitEvent(sI, c->ev_bdry, 0));
-                TRY(launch_pass(c->has_lo() ? lo + E : lo, c->has_hi() ? hi - E : hi, sI, true));
-                intr_on_aux = (sI == c->s_aux);
-                c->halo_valid = c->sharded() ? E : H;
-                c->cur = dst;
-                s += K;
-                if (!(fuse && steps - s >= 2)) { // last fused pass of this call: everything back onto the main stream
-                    if (intr_on_aux) {
-                        HIP_TRY(hipEventRecord(c->ev_intr, c->s_aux));
-                        HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_intr, 0));
-                    }
-                    HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
-                    intr_on_aux = false;
-                    have_join = false;
-                }
-                continue;
-            }
+            const bool split = c->sharded() && c->overlap_mode != 0 && g.nzl > 2 * E;
             if (split) {
-                // Second stream: boundary planes, then their exchange.  Main stream: the interior, released
+                // Mode 1.  Second stream: boundary planes, then their exchange.  Main stream: the interior, released
                 // by an event recorded after the boundary kernels.  The exchange is enqueued BEFORE the
                 // interior launch and needs no event hop, so its kernels reach the CUs first; the interior
                 // then fills what is left.  (Without the dependency the interior started first, filled
                 // every CU for a whole round, and the boundary kernels -- and the exchange behind them --
                 // finished only with the pass; with the exchange merely enqueued second, RCCL's
-                // workgroups waited 0.35 ms for CUs: profiles/r01_slab_overlap_timeline.txt.  See
-                // bdry_on_main for the in-stream variant.)
-                const hipStream_t sb = bdry_on_main(c) ? c->s_main : c->s_aux;
-                if (sb == c->s_aux) {
-                    HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
-                    HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
-                }
-                if (c->has_lo()) TRY(launch_pass(lo, lo + E, sb, false));
-                if (c->has_hi()) TRY(launch_pass(hi - E, hi, sb, false));
-                HIP_TRY(hipEventRecord(c->ev_bdry, sb));
-                if (sb == c->s_main) HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_bdry, 0));
+                // workgroups waited 0.35 ms for CUs: profiles/r01_slab_overlap_timeline.txt.)
+                HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
+                HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
+                if (c->has_lo()) TRY(launch_pass(lo, lo + E, c->s_aux, false));
+                if (c->has_hi()) TRY(launch_pass(hi - E, hi, c->s_aux, false));
+                HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux));
                 TRY(exchange_halo(c, dst, c->s_aux, E));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
-                if (sb == c->s_aux) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
+                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
                 // The exchange's kernels hold a few CUs for as long as the links need (RCCL's workgroups
                 // cannot share a CU with a stencil workgroup).  With one long workgroup per tile every
                 // displaced workgroup would add a whole extra round at the end of the pass (measured with
@@ -1459,23 +1522,20 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             s += K;
             continue;
         }
+        TRY(hv_drain());
         TRY(ensure_halo(c, R));
         if (wnum == 0) {
-            const bool split = c->sharded() && c->overlap && g.nzl > 2 * R;
+            const bool split = c->sharded() && c->overlap_mode != 0 && g.nzl > 2 * R;
             if (split) {
                 // boundary planes and their exchange on the second stream, the interior behind an event (as above)
-                const hipStream_t sb = bdry_on_main(c) ? c->s_main : c->s_aux;
-                if (sb == c->s_aux) {
-                    HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
-                    HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
-                }
-                if (c->has_lo()) TRY(launch_step(c, src, dst, lo, lo + R, false, sb));
-                if (c->has_hi()) TRY(launch_step(c, src, dst, hi - R, hi, false, sb));
-                HIP_TRY(hipEventRecord(c->ev_bdry, sb));
-                if (sb == c->s_main) HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_bdry, 0));
+                HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
+                HIP_TRY(hipStreamWaitEvent(c->s_aux, c->ev_fork, 0));
+                if (c->has_lo()) TRY(launch_step(c, src, dst, lo, lo + R, false, c->s_aux));
+                if (c->has_hi()) TRY(launch_step(c, src, dst, hi - R, hi, false, c->s_aux));
+                HIP_TRY(hipEventRecord(c->ev_bdry, c->s_aux));
                 TRY(exchange_halo(c, dst, c->s_aux, R));
                 HIP_TRY(hipEventRecord(c->ev_join, c->s_aux));
-                if (sb == c->s_aux) HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
+                HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_bdry, 0));
                 TRY(launch_step(c, src, dst, c->has_lo() ? lo + R : lo, c->has_hi() ? hi - R : hi, false, c->s_main));
                 HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
             } else {
@@ -1487,14 +1547,14 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             if (wnum <= WAFER_MAX_LOW && active_variant(c) >= 1) {
                 // one pass per step: the raw result travels to the next step, which normalises and
                 // projects it on load; phi is materialised once after the last step
-                const bool one_pass = env_int("WAFER_ONE_PASS", 1) != 0;
+                const bool one_pass = c->tune.one_pass != 0;
                 if (one_pass && s == 0) {
                     hipLaunchKernelGGL(wafer_k_identity_scalars, dim3(1), dim3(64), 0, c->s_main, c->scal, 1 + (int)wnum);
                     HIP_TRY(hipGetLastError());
                 }
                 // z-slabs, one-pass scheme, not the last step: the raw result's halo exchange hides behind
                 // the interior launch (the last step's phi is materialised first and exchanged on demand)
-                const bool split = one_pass && s + 1 < steps && c->sharded() && c->overlap && g.nzl > 2 * R;
+                const bool split = one_pass && s + 1 < steps && c->sharded() && c->overlap_mode != 0 && g.nzl > 2 * R;
                 if (split) {
                     TRY(excited_step_launch_overlapped(c, src, dst, wnum, one_pass));
                 } else {
@@ -1508,10 +1568,7 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 continue;
             }
             TRY(launch_step(c, src, dst, lo, hi, true, c->s_main));
-            long long nb = dispatch(c, [&](auto t, auto cc, auto r) {
-                return (int)step_partials_count<decltype(t), decltype(cc), decltype(r)::value>(c, lo, hi);
-            });
-            TRY(reduce_to_scal(c, 1, nb, 0, c->s_main));
+            TRY(reduce_to_scal(c, 1, step_partials_count(c, lo, hi), 0, c->s_main));
             TRY(launch_normalise(c, dst, c->scal + 0, 0.0, c->states[0], 1, c->s_main));
             TRY(gs_chain(c, dst, wnum, true, c->s_main));
             TRY(exchange_halo(c, dst, c->s_main, R));
@@ -1575,7 +1632,7 @@ int wafer_observables(wafer_ctx *c, wafer_observables_t *out)
     const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
     const double den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:314 / 337 / 367
     long long nb = 0;
-    if (env_int("WAFER_OBS_LDS", 1) != 0) {
+    if (c->tune.obs_lds != 0) {
         // the LDS pipeline of the step kernel in its observables mode: 16 B per lane from HBM
         WaferStepArgs sa{};
         sa.g = c->g;
@@ -1587,18 +1644,13 @@ int wafer_observables(wafer_ctx *c, wafer_observables_t *out)
         sa.potsub_kind = c->potsub_kind;
         sa.potsub_scalar = c->potsub_scalar;
         set_vg_args(c, sa);
-        TRY(dispatch(c, [&](auto t, auto, auto r) {
-            using T = decltype(t);
-            constexpr int RR = decltype(r)::value;
-            if (wafer_launch_observables_lds<T, RR>(sa, as<T>(c->phi[c->cur]), as<T>(c->v), as<T>(c->potsub), c->partials,
-                                                    c->partials_stride, c->s_main, &nb, closed_form_vg(c)) != hipSuccess)
-                return fail(WAFER_ERR_HIP, "observables launch failed: %s", hipGetErrorString(hipGetLastError()));
-            return (int)WAFER_OK;
-        }));
+        if (wafer_entry_observables_lds(type_combo(c, false), R, c->tune, sa, c->phi[c->cur], c->v, c->potsub, c->partials, c->partials_stride,
+                                        c->s_main, &nb, closed_form_vg(c)) != hipSuccess)
+            return fail(WAFER_ERR_HIP, "observables launch failed: %s", hipGetErrorString(hipGetLastError()));
     } else {
         WaferObsArgs a;
         a.g = c->g;
-        a.zchunk = pick_zchunk(c, c->g.nzl, env_int("WAFER_TARGET_BLOCKS", 4096));
+        a.zchunk = pick_zchunk(c, c->g.nzl, direct_target_blocks(c));
         const dim3 grid(c->bx, c->by, nchunks_of(c->g.nzl, a.zchunk));
         a.nblocks = (long long)c->partials_stride;
         nb = (long long)grid.x * grid.y * grid.z;
@@ -1782,39 +1834,7 @@ int wafer_solve_state(wafer_ctx *c, uint32_t wnum, double tolerance, uint64_t sc
     return wafer_push_state(c); // :239-242
 }
 
-// ---- diagnostics: device streaming ceilings ---------------------------------------------------
-int wafer_diag_stream_bw(wafer_ctx *c, int n_reads, int iters, double *gbps)
-{
-    if (!c || !gbps) return fail(WAFER_ERR_INVALID, "null argument");
-    if (n_reads < 1 || n_reads > 3 || iters < 1) return fail(WAFER_ERR_INVALID, "n_reads in 1..3, iters >= 1");
-    HIP_TRY(hipSetDevice(c->P.device));
-    if (n_reads > 1) TRY(ensure_ab(c)); // the second and third read streams
-    const long long n16 = (long long)c->g.total * (long long)c->esz / 16;
-    const wafer_f4 *r0 = as<const wafer_f4>(alloc_base(c, c->v)), *r1 = as<const wafer_f4>(alloc_base(c, c->a)),
-                   *r2 = as<const wafer_f4>(alloc_base(c, c->b));
-    wafer_f4 *w = as<wafer_f4>(alloc_base(c, c->phi[c->cur ^ 1])); // scratch between steps
-    const dim3 grid(256 * 8), block(256);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    for (int it = -2; it < iters; ++it) { // two warm-up launches
-        if (it == 0) HIP_TRY(hipEventRecord(e0, c->s_main));
-        if (n_reads == 1) hipLaunchKernelGGL((wafer_k_stream<1>), grid, block, 0, c->s_main, r0, r1, r2, w, n16);
-        else if (n_reads == 2) hipLaunchKernelGGL((wafer_k_stream<2>), grid, block, 0, c->s_main, r0, r1, r2, w, n16);
-        else hipLaunchKernelGGL((wafer_k_stream<3>), grid, block, 0, c->s_main, r0, r1, r2, w, n16);
-    }
-    HIP_TRY(hipEventRecord(e1, c->s_main));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    // the scratch buffer's frame must be zero again
-    HIP_TRY(hipMemsetAsync(alloc_base(c, c->phi[c->cur ^ 1]), 0, (size_t)c->g.total * c->esz, c->s_main));
-    *gbps = (double)n16 * 16.0 * (n_reads + 1) * iters / (ms * 1e-3) / 1e9;
-    return WAFER_OK;
-}
-
+// ---- diagnostics ---------------------------------------------------------------------------
 // the device's copy ceiling: 16 B per lane, `unroll` (1, 2, 4, 8) vectors in flight per lane, a
 // grid-stride loop over blocks_per_cu x CUs workgroups of 256 threads; V -> phi's scratch buffer
 int wafer_diag_copy_bw(wafer_ctx *c, int iters, int unroll, int blocks_per_cu, double *gbps)
@@ -1912,23 +1932,22 @@ int wafer_set_comm_hooks(wafer_ctx *c, wafer_halo_fn halo, wafer_allreduce_fn al
     return WAFER_OK;
 }
 
-int wafer_set_overlap(wafer_ctx *c, int enabled)
+int wafer_set_overlap(wafer_ctx *c, int mode)
 {
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
-    if (enabled < 0 || enabled > 4) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 4");
-    c->overlap = enabled != 0;
-    c->bdry_main = enabled == 2;
-    c->alternate = enabled == 3;
-    c->halves = enabled == 4;
+    if (mode < 0 || mode > 2) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 2");
+    c->overlap_mode = mode;
     return WAFER_OK;
 }
 
 int wafer_set_halo_cycle(wafer_ctx *c, int passes)
 {
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
-    if (passes < 1 || 2 * c->g.R * passes > c->g.G)
-        return fail(WAFER_ERR_INVALID, "halo cycle %d needs %d ghost planes, the context has %d (wafer_params.halo_depth)", passes,
-                    2 * c->g.R * passes, c->g.G);
+    // one fused pass consumes K * ext ghost planes per side: K = 3 where the three-step kernel applies, else 2
+    const int per_pass = (fuse3_applies(c) ? 3 : 2) * c->g.R;
+    if (passes < 1 || per_pass * passes > c->g.G)
+        return fail(WAFER_ERR_INVALID, "halo cycle %d needs %d ghost planes (%d per fused pass), the context has %d (wafer_params.halo_depth)",
+                    passes, per_pass * passes, per_pass, c->g.G);
     c->halo_cycle = passes;
     return WAFER_OK;
 }

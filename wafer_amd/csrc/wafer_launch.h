@@ -1,0 +1,50 @@
+// Non-template entry points of the kernel families.  Each family is compiled in its own translation unit
+// (wafer_tu_*.hip) so that the device code builds in parallel and an edit to one kernel rebuilds one unit; the engine
+// (wafer_engine.hip) holds the host logic and the small elementwise / set-up kernels.
+//
+// tc: storage / arithmetic types -- 0: fp64 / fp64, 1: fp32 storage / fp64 arithmetic, 2: fp32 / fp32 (ground-state
+// steps of WAFER_F32_FAST only).  R: CentralDifference::ext().  Array pointers are the engine's logical pointers
+// (plane 0, row 0) of that storage type.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wafer_stencil.hip.h"
+#include "wafer_tuning.h"
+
+struct WaferF3Block;
+struct WaferF3Sync;
+
+enum { WAFER_TC_F64 = 0, WAFER_TC_F32_F64 = 1, WAFER_TC_F32_F32 = 2 };
+
+// one ground-state step on the LDS pipeline (wafer_stencil_lds.hip.h)
+hipError_t wafer_entry_step_lds(int tc, int R, const WaferTuning &t, const WaferStepArgs &a, const void *phi, const void *pa,
+                                const void *pb, const void *pv, void *out, hipStream_t s, int vg);
+// one excited-state step with nlow raw overlaps (nlow == 0: the norm only); one translation unit per stencil order
+#define WAFER_DECL_EXCITED(R_)                                                                                                          \
+    hipError_t wafer_entry_step_lds_excited_r##R_(int tc, const WaferTuning &t, const WaferStepArgs &a, const void *phi, const void *pv, \
+                                                   void *out, double *partials, size_t partials_cap, int nlow, const WaferLowPtrs &low,   \
+                                                   hipStream_t s, const double *xscal, const double *xgram, int vg);
+WAFER_DECL_EXCITED(1)
+WAFER_DECL_EXCITED(2)
+WAFER_DECL_EXCITED(3)
+#undef WAFER_DECL_EXCITED
+static inline hipError_t wafer_entry_step_lds_excited(int tc, int R, const WaferTuning &t, const WaferStepArgs &a, const void *phi,
+                                                      const void *pv, void *out, double *partials, size_t partials_cap, int nlow,
+                                                      const WaferLowPtrs &low, hipStream_t s, const double *xscal, const double *xgram, int vg)
+{
+    switch (R) {
+    case 1: return wafer_entry_step_lds_excited_r1(tc, t, a, phi, pv, out, partials, partials_cap, nlow, low, s, xscal, xgram, vg);
+    case 2: return wafer_entry_step_lds_excited_r2(tc, t, a, phi, pv, out, partials, partials_cap, nlow, low, s, xscal, xgram, vg);
+    case 3: return wafer_entry_step_lds_excited_r3(tc, t, a, phi, pv, out, partials, partials_cap, nlow, low, s, xscal, xgram, vg);
+    default: return hipErrorInvalidValue;
+    }
+}
+// compute_observables on the LDS pipeline (storage type only: the sums are fp64)
+hipError_t wafer_entry_observables_lds(int tc, int R, const WaferTuning &t, const WaferStepArgs &a, const void *phi, const void *pv,
+                                       const void *potsub, double *partials, size_t partials_cap, hipStream_t s,
+                                       long long *nblocks_out, int vg);
+// two fused ground-state steps
+hipError_t wafer_entry_step2_fused(int tc, int R, const WaferTuning &t, const WaferStepArgs &a, const void *phi, const void *pa,
+                                   const void *pb, const void *pv, void *out, hipStream_t s);
+// three fused ground-state steps (ThreePoint fp64), table-driven
+hipError_t wafer_entry_step3_fused(const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
+                                   const WaferF3Sync &sy, const double *phi, const double *pv, double *out, hipStream_t s);

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "wafer_geom.h"
+#include "wafer_tuning.h"
 
 #define WAFER_WAVE 64
 

@@ -519,15 +519,13 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
 
 // planes per workgroup / launch size for the fused kernel
 template <typename T, int R, int NW2>
-static inline int wafer_f2_zchunk(const WaferGeom &g, int nplanes, int target_blocks)
+static inline int wafer_f2_zchunk(const WaferTuning &t, const WaferGeom &g, int nplanes, int target_blocks)
 {
     using Cfg = WaferF2Cfg<T, R, NW2>;
-    const char *f = getenv("WAFER_ZCHUNK");
-    if (f && atoi(f) > 0) return atoi(f);
+    if (t.zchunk > 0) return t.zchunk;
     if (target_blocks < 0) return -target_blocks < nplanes ? -target_blocks : nplanes; // the caller fixed the chunk length
     const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY);
-    const char *t = getenv("WAFER_TARGET_BLOCKS");
-    const long long target = (t && atoi(t) > 0) ? atoi(t) : (target_blocks > 0 ? target_blocks : 256);
+    const long long target = t.target_blocks > 0 ? t.target_blocks : (target_blocks > 0 ? target_blocks : 256);
     long long nch = (target + per_layer / 2) / per_layer;
     if (nch < 1) nch = 1;
     if (nch > nplanes) nch = nplanes;
@@ -536,7 +534,7 @@ static inline int wafer_f2_zchunk(const WaferGeom &g, int nplanes, int target_bl
 
 // Advances planes [lz_lo, lz_hi) by TWO steps: out = step(step(phi)).
 template <typename T, typename C, int R, int NW2>
-static inline hipError_t wafer_launch_step2_fused_nw(WaferStepArgs a, const WaferLdsOpts &o, const T *phi,
+static inline hipError_t wafer_launch_step2_fused_nw(const WaferTuning &t, WaferStepArgs a, const WaferLdsOpts &o, const T *phi,
                                                      const T *pa, const T *pb, const T *pv, T *out, hipStream_t s)
 {
     using Cfg = WaferF2Cfg<T, R, NW2>;
@@ -554,7 +552,7 @@ static inline hipError_t wafer_launch_step2_fused_nw(WaferStepArgs a, const Wafe
         nblocks = a.n_long + (long long)nshort_tiles * a.nsub;
         swz = 0; // the hardware's dispatch order is the point
     } else {
-        a.zchunk = wafer_f2_zchunk<T, R, NW2>(g, a.lz_hi - a.lz_lo, a.target_blocks);
+        a.zchunk = wafer_f2_zchunk<T, R, NW2>(t, g, a.lz_hi - a.lz_lo, a.target_blocks);
         nblocks = (long long)ntx * nty * ((a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk);
     }
     const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
@@ -562,8 +560,7 @@ static inline hipError_t wafer_launch_step2_fused_nw(WaferStepArgs a, const Wafe
     { // YR (register y neighbours in step 1), for the default variant only (ordinary loads, a and b from V).  Same-box
       // A/B at 512^3: FivePoint fp64 0.4390 against 0.4439 ms/step with it; ThreePoint fp64 no change; fp32 storage
       // 0.2674 against 0.2600 WITHOUT it -- so: on for FivePoint fp64, off elsewhere (WAFER_F2_YREG=0/1 overrides).
-        const char *ey = getenv("WAFER_F2_YREG");
-        const bool yr = (ey && *ey) ? atoi(ey) != 0 : (R == 2 && std::is_same<T, double>::value);
+        const bool yr = t.f2_yreg >= 0 ? t.f2_yreg != 0 : (R == 2 && std::is_same<T, double>::value);
         if (o.nt == 0 && o.abv != 0) {
             if (vir && yr) hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, true, true>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
             else if (vir) hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, true, false>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
@@ -587,10 +584,10 @@ static inline hipError_t wafer_launch_step2_fused_nw(WaferStepArgs a, const Wafe
 }
 
 template <typename T, typename C, int R>
-static inline hipError_t wafer_launch_step2_fused(WaferStepArgs a, const T *phi, const T *pa, const T *pb,
+static inline hipError_t wafer_launch_step2_fused(const WaferTuning &t, WaferStepArgs a, const T *phi, const T *pa, const T *pb,
                                                   const T *pv, T *out, hipStream_t s)
 {
-    WaferLdsOpts o = wafer_lds_opts();
+    WaferLdsOpts o = wafer_lds_opts(t);
     // Defaults measured at 512^3 fp64 (profiles/r01_sweep_f_512_fused.jsonl):
     //   ext 1: 128x16 tiles (8 main waves + halo-row + halo-column wave = 640 threads), a and b
     //          formed from V -- 0.369 ms/step; the taller tile halves the halo-row overhead
@@ -599,13 +596,11 @@ static inline hipError_t wafer_launch_step2_fused(WaferStepArgs a, const T *phi,
     //   ext 2: 128x8 tiles, a and b formed from V as well (0.53 ms/step against 0.66 with a, b
     //          streamed and 0.58 for the single-step kernel, since wafer_recip shortened b's reciprocal).
     // Ordinary (cache-retaining) loads: the halo-row wave re-reads rows its neighbour tile streams.
-    const char *e = getenv("WAFER_F2_NW2");
-    int nw2 = (e && *e) ? atoi(e) : ((R == 1 && a.g.ny >= 16) ? 8 : 4);
+    const int nw2 = t.f2_nw2 ? t.f2_nw2 : ((R == 1 && a.g.ny >= 16) ? 8 : 4);
     if (o.abv < 0) o.abv = 1;
-    e = getenv("WAFER_NT");
-    if (!(e && *e)) o.nt = 0;
+    if (t.nt < 0) o.nt = 0;
     if constexpr (R == 1) {
-        if (nw2 == 8) return wafer_launch_step2_fused_nw<T, C, R, 8>(a, o, phi, pa, pb, pv, out, s);
+        if (nw2 == 8) return wafer_launch_step2_fused_nw<T, C, R, 8>(t, a, o, phi, pa, pb, pv, out, s);
     }
-    return wafer_launch_step2_fused_nw<T, C, R, 4>(a, o, phi, pa, pb, pv, out, s);
+    return wafer_launch_step2_fused_nw<T, C, R, 4>(t, a, o, phi, pa, pb, pv, out, s);
 }

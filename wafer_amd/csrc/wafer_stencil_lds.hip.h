@@ -51,17 +51,11 @@ struct WaferLdsOpts {
 };
 // R: stencil reach of the kernel the options are for (the SevenPoint single-step kernel defaults to
 // 4 rows per lane: 6 halo rows per 16 instead of per 8 -- 0.60 vs 0.63 ms/step at 512^3)
-static inline WaferLdsOpts wafer_lds_opts(int R = 1)
+static inline WaferLdsOpts wafer_lds_opts(const WaferTuning &t, int R = 1)
 {
-    WaferLdsOpts o{R == 3 ? 4 : 2, 1, 1, 0, 1};
-    const char *e;
-    if ((e = getenv("WAFER_LDS_RY")) && *e) o.ry = atoi(e);
-    if ((e = getenv("WAFER_XCD_SWIZZLE")) && *e) o.swz = atoi(e);
-    if ((e = getenv("WAFER_NT")) && *e) o.nt = atoi(e);
-    if ((e = getenv("WAFER_LDS_PAD")) && *e) o.pad = atoi(e);
-    if ((e = getenv("WAFER_ABV")) && *e) o.abv = atoi(e);
-    else o.abv = -1; // kernel default (both the single-step and the fused kernel form a, b from V)
-    if (o.ry != 2 && o.ry != 4) o.ry = 2;
+    WaferLdsOpts o{R == 3 ? 4 : 2, t.swz, t.nt >= 0 ? t.nt : 1, t.lds_pad, t.abv};
+    if (t.lds_ry) o.ry = t.lds_ry;
+    // abv < 0: kernel default (both the single-step and the fused kernel form a, b from V)
     return o;
 }
 
@@ -72,18 +66,16 @@ static inline WaferLdsOpts wafer_lds_opts(int R = 1)
 // only add DRAM/L2 contention.  So z is chunked only as far as needed to give
 // every CU a workgroup.
 template <typename T, int R>
-static inline int wafer_lds_zchunk(const WaferGeom &g, int nplanes, int ry, int target_blocks)
+static inline int wafer_lds_zchunk(const WaferTuning &t, const WaferGeom &g, int nplanes, int ry, int target_blocks)
 {
     using Cfg = WaferLdsCfg<T, R, 1>;
     const int TY = Cfg::NW * ry;
-    const char *f = getenv("WAFER_ZCHUNK");
-    if (f && atoi(f) > 0) return atoi(f);
+    if (t.zchunk > 0) return t.zchunk;
     if (target_blocks < 0) return -target_blocks < nplanes ? -target_blocks : nplanes; // the caller fixed the chunk length
     const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + TY - 1) / TY);
-    const char *t = getenv("WAFER_TARGET_BLOCKS");
     // two workgroups per CU: with a, b formed from V the kernel does more arithmetic per byte and
     // a second resident workgroup hides it (0.539 vs 0.574 ms at 512^3, profiles/r01_sweep_e_512.jsonl)
-    const long long target = (t && atoi(t) > 0) ? atoi(t) : 2 * (target_blocks > 0 ? target_blocks : 256);
+    const long long target = t.target_blocks > 0 ? t.target_blocks : 2 * (target_blocks > 0 ? target_blocks : 256);
     long long nch = (target + per_layer / 2) / per_layer; // nearest
     if (nch < 1) nch = 1;
     if (nch > nplanes) nch = nplanes;
@@ -91,12 +83,12 @@ static inline int wafer_lds_zchunk(const WaferGeom &g, int nplanes, int ry, int 
 }
 
 template <typename T, int R>
-static inline long long wafer_step_lds_blocks(const WaferGeom &g, int lz_lo, int lz_hi, int target_blocks)
+static inline long long wafer_step_lds_blocks(const WaferTuning &t, const WaferGeom &g, int lz_lo, int lz_hi, int target_blocks)
 {
     using Cfg = WaferLdsCfg<T, R, 1>;
-    const int ry = wafer_lds_opts(R).ry;
+    const int ry = wafer_lds_opts(t, R).ry;
     const int TY = Cfg::NW * ry;
-    const int zc = wafer_lds_zchunk<T, R>(g, lz_hi - lz_lo, ry, target_blocks);
+    const int zc = wafer_lds_zchunk<T, R>(t, g, lz_hi - lz_lo, ry, target_blocks);
     return (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + TY - 1) / TY) *
            ((lz_hi - lz_lo + zc - 1) / zc);
 }
@@ -680,7 +672,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
 }
 
 template <typename T, typename C, int R, int RY, int NLOW, bool NT, bool ABV, bool XF = false, int NW = 4, int VG = 0, int VIRT = -1, bool DEEP = false>
-static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLdsOpts &o, const T *phi,
+static inline hipError_t wafer_launch_step_lds_ry(const WaferTuning &t, WaferStepArgs a, const WaferLdsOpts &o, const T *phi,
                                                   const T *pa, const T *pb, T *out, double *partials,
                                                   size_t partials_cap, hipStream_t s,
                                                   const WaferLowPtrs &low = WaferLowPtrs(),
@@ -688,7 +680,7 @@ static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLd
 {
     using Cfg = WaferLdsCfg<T, R, RY, NW>;
     const WaferGeom &g = a.g;
-    a.zchunk = wafer_lds_zchunk<T, R>(g, a.lz_hi - a.lz_lo, RY * (NW / 4), a.target_blocks); // tile height NW * RY
+    a.zchunk = wafer_lds_zchunk<T, R>(t, g, a.lz_hi - a.lz_lo, RY * (NW / 4), a.target_blocks); // tile height NW * RY
     const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX;
     const int nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
@@ -702,35 +694,32 @@ static inline hipError_t wafer_launch_step_lds_ry(WaferStepArgs a, const WaferLd
 // Waves per workgroup of the excited-state step kernels: with one to three stored states 8 waves on a
 // 128x16 tile, one workgroup per CU (half the halo rows of phi and of every stored state per tile: at
 // 512^3 k = 1 0.87 -> 0.83 ms, k = 2 1.13 -> 1.09, k = 3 1.40 -> 1.31); WAFER_XF_NW=4 restores the 128x8 tile.
-static inline int wafer_excited_nw(int nlow)
+static inline int wafer_excited_nw(const WaferTuning &t, int nlow)
 {
-    const char *e = getenv("WAFER_XF_NW");
-    const int want = (e && *e) ? atoi(e) : 8;
-    return (want == 8 && nlow >= 1 && nlow <= 3) ? 8 : 4;
+    return (t.xf_nw == 8 && nlow >= 1 && nlow <= 3) ? 8 : 4;
 }
 
 // excited-state step with `nlow` raw overlaps fused in (fixed tuning: RY 2, NT, a/b from V)
 template <typename T, typename C, int R>
-static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T *phi, const T *pv, T *out,
+static inline hipError_t wafer_launch_step_lds_excited(const WaferTuning &t, WaferStepArgs a, const T *phi, const T *pv, T *out,
                                                        double *partials, size_t partials_cap, int nlow,
                                                        const WaferLowPtrs &low, hipStream_t s,
                                                        const double *xscal = nullptr, const double *xgram = nullptr, int vg = 0)
 {
-    WaferLdsOpts o = wafer_lds_opts();
+    WaferLdsOpts o = wafer_lds_opts(t);
     o.ry = 2;
     if constexpr (std::is_same<T, double>::value && std::is_same<C, double>::value) {
         // closed-form V in the kernel (fp64, transform-on-load, 8-wave tiles): one HBM stream fewer
-        if (vg != 0 && xscal && a.v_in_range != 0 && wafer_excited_nw(nlow) == 8) {
+        if (vg != 0 && xscal && a.v_in_range != 0 && wafer_excited_nw(t, nlow) == 8) {
             // the raw staging pipeline (DEEP) where the registers allow it (FivePoint from k = 2 and SevenPoint spill); WAFER_XF_DEEP=0: off
-            const char *ed = getenv("WAFER_XF_DEEP");
-            const bool deep = (ed && *ed) ? atoi(ed) != 0 : true;
+            const bool deep = t.xf_deep != 0;
             // (two workgroups per CU for k = 1 -- 128 VGPRs, 28 B/lane of scratch -- measured: 0.797 against 0.686 ms;
             //  twice the concurrent footprint in the XCD's L2, as without the closed form)
 #define WAFER_VG_CASE(NLOW_, VG_)                                                                                          \
     if (nlow == NLOW_ && vg == VG_) {                                                                                      \
         if (deep && (R == 1 || (R == 2 && NLOW_ <= 1)))                                                                    \
-            return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1, (R == 1 || (R == 2 && NLOW_ <= 1))>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
-        return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
+            return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1, (R == 1 || (R == 2 && NLOW_ <= 1))>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
+        return wafer_launch_step_lds_ry<T, C, R, 2, NLOW_, true, true, true, 8, VG_, 1>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram); \
     }
             WAFER_VG_CASE(1, 4) WAFER_VG_CASE(2, 4) WAFER_VG_CASE(3, 4)
             WAFER_VG_CASE(1, 7) WAFER_VG_CASE(2, 7) WAFER_VG_CASE(3, 7)
@@ -739,44 +728,43 @@ static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T 
         }
     }
     if (xscal) { // transform-on-load: phi is the raw previous step
-        if (wafer_excited_nw(nlow) == 8) { // 128x16 tiles, 8 waves: half the halo rows per array
+        if (wafer_excited_nw(t, nlow) == 8) { // 128x16 tiles, 8 waves: half the halo rows per array
             if constexpr (R == 1 && std::is_same<T, double>::value) { // streamed V on the raw staging pipeline (DEEP) where it fits the registers
-                const char *ed = getenv("WAFER_XF_DEEP");
-                if (!(ed && *ed) || atoi(ed) != 0) {
-                    if (nlow == 1) return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true, 8, 0, -1, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
-                    if (nlow == 2) return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true, 8, 0, -1, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
-                    if (nlow == 3) return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, true, 8, 0, -1, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+                if (t.xf_deep != 0) {
+                    if (nlow == 1) return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true, 8, 0, -1, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+                    if (nlow == 2) return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true, 8, 0, -1, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+                    if (nlow == 3) return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, true, 8, 0, -1, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
                 }
             }
             switch (nlow) {
-            case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
-            case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
-            case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, true, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+            case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true, 8>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+            case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true, 8>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+            case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, true, 8>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
             default: return hipErrorInvalidValue;
             }
         }
         switch (nlow) {
-        case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
-        case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
-        case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
-        case 4: return wafer_launch_step_lds_ry<T, C, R, 2, 4, true, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+        case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+        case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+        case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
+        case 4: return wafer_launch_step_lds_ry<T, C, R, 2, 4, true, true, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
         default: return hipErrorInvalidValue;
         }
     }
-    if (wafer_excited_nw(nlow) == 8) { // the same tiles as the transform-on-load kernel: same partial sums, same bits
+    if (wafer_excited_nw(t, nlow) == 8) { // the same tiles as the transform-on-load kernel: same partial sums, same bits
         switch (nlow) {
-        case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, false, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
-        case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, false, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
-        case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, false, 8>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+        case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, false, 8>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+        case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, false, 8>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+        case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true, false, 8>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low);
         default: return hipErrorInvalidValue;
         }
     }
     switch (nlow) {
-    case 0: return wafer_launch_step_lds_ry<T, C, R, 2, 0, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
-    case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
-    case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
-    case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
-    case 4: return wafer_launch_step_lds_ry<T, C, R, 2, 4, true, true>(a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+    case 0: return wafer_launch_step_lds_ry<T, C, R, 2, 0, true, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+    case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+    case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+    case 3: return wafer_launch_step_lds_ry<T, C, R, 2, 3, true, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low);
+    case 4: return wafer_launch_step_lds_ry<T, C, R, 2, 4, true, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low);
     default: return hipErrorInvalidValue;
     }
 }
@@ -784,62 +772,58 @@ static inline hipError_t wafer_launch_step_lds_excited(WaferStepArgs a, const T 
 // compute_observables on the LDS pipeline: 8 waves on 128x16 tiles (ThreePoint / FivePoint), 4 waves on
 // 128x8 (SevenPoint).  *nblocks_out = partial sums written per quantity.
 template <typename T, int R>
-static inline hipError_t wafer_launch_observables_lds(WaferStepArgs a, const T *phi, const T *pv, const T *potsub,
+static inline hipError_t wafer_launch_observables_lds(const WaferTuning &t, WaferStepArgs a, const T *phi, const T *pv, const T *potsub,
                                                       double *partials, size_t partials_cap, hipStream_t s, long long *nblocks_out,
                                                       int vg = 0)
 {
-    WaferLdsOpts o = wafer_lds_opts();
+    WaferLdsOpts o = wafer_lds_opts(t);
     o.ry = 2;
     constexpr int NW = R <= 2 ? 8 : 4;
     using Cfg = WaferLdsCfg<T, R, 2, NW>;
     WaferLowPtrs low;
     low.p[0] = potsub;
     { // two workgroups per CU (110 VGPRs at 512 threads): 0.51 -> 0.37 ms at 512^3 incl. the host sync; WAFER_OBS_WGS=1: one
-        const char *e = getenv("WAFER_OBS_WGS");
-        if (NW == 8 && e && atoi(e) == 1) a.target_blocks = (a.target_blocks + 1) / 2;
+        if (NW == 8 && t.obs_wgs == 1) a.target_blocks = (a.target_blocks + 1) / 2;
     }
-    const int zc = wafer_lds_zchunk<T, R>(a.g, a.lz_hi - a.lz_lo, 2 * (NW / 4), a.target_blocks);
+    const int zc = wafer_lds_zchunk<T, R>(t, a.g, a.lz_hi - a.lz_lo, 2 * (NW / 4), a.target_blocks);
     *nblocks_out = (long long)((a.g.nx + Cfg::TX - 1) / Cfg::TX) * ((a.g.ny + Cfg::TY - 1) / Cfg::TY) * ((a.lz_hi - a.lz_lo + zc - 1) / zc);
     // (the closed-form V of the step kernels, template parameter VG, was measured here too: with two workgroups
     //  per CU the kernel is short of issue slots, not of bytes -- 0.40 against 0.37 ms at 512^3 -- so V is streamed)
     (void)vg;
-    return wafer_launch_step_lds_ry<T, double, R, 2, -2, true, true, false, NW>(a, o, phi, pv, pv, nullptr, partials, partials_cap, s, low);
+    return wafer_launch_step_lds_ry<T, double, R, 2, -2, true, true, false, NW>(t, a, o, phi, pv, pv, nullptr, partials, partials_cap, s, low);
 }
 
 template <typename T, int R>
-static inline long long wafer_step_lds_excited_blocks(const WaferGeom &g, int lz_lo, int lz_hi, int target_blocks,
+static inline long long wafer_step_lds_excited_blocks(const WaferTuning &t, const WaferGeom &g, int lz_lo, int lz_hi, int target_blocks,
                                                       int nlow = 0, bool xf = false)
 {
     using Cfg = WaferLdsCfg<T, R, 2>;
     (void)xf;
-    const int mul = (wafer_excited_nw(nlow) == 8) ? 2 : 1;
+    const int mul = (wafer_excited_nw(t, nlow) == 8) ? 2 : 1;
     const int TY = Cfg::TY * mul;
-    const int zc = wafer_lds_zchunk<T, R>(g, lz_hi - lz_lo, 2 * mul, target_blocks);
+    const int zc = wafer_lds_zchunk<T, R>(t, g, lz_hi - lz_lo, 2 * mul, target_blocks);
     return (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + TY - 1) / TY) * ((lz_hi - lz_lo + zc - 1) / zc);
 }
 
 template <typename T, typename C, int R>
-static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, const T *pa, const T *pb,
+static inline hipError_t wafer_launch_step_lds(const WaferTuning &t, WaferStepArgs a, const T *phi, const T *pa, const T *pb,
                                                const T *pv, T *out, hipStream_t s, int vg = 0)
 {
-    WaferLdsOpts o = wafer_lds_opts(R);
+    WaferLdsOpts o = wafer_lds_opts(t, R);
     if (o.abv < 0) o.abv = 1;
     double *partials = nullptr;
     const size_t partials_cap = 0;
     if constexpr (std::is_same<T, double>::value && std::is_same<C, double>::value) {
         // closed-form V (fp64, the default tuning of each stencil order): 16 B per update instead of 24
-        const char *e = getenv("WAFER_LDS_NW");
-        const char *ry = getenv("WAFER_LDS_RY");
-        const bool dflt = !(e && *e) && !(ry && *ry) && o.abv != 0 && o.nt != 0 && a.v_in_range != 0;
+        const bool dflt = t.lds_nw == 0 && t.lds_ry == 0 && o.abv != 0 && o.nt != 0 && a.v_in_range != 0;
         // (ThreePoint 0.546 -> 0.422 ms/step at 512^3, FivePoint 0.556 -> 0.475; SevenPoint, 4 rows per lane on 4
         //  waves, is short of issue slots: 0.617 -> 0.634 with Coulomb, so it keeps streaming V)
         {
-            const char *e7 = getenv("WAFER_SEVEN_VG");
-            if (vg != 0 && dflt && (R <= 2 || (e7 && atoi(e7) != 0))) {
+            if (vg != 0 && dflt && (R <= 2 || t.seven_vg != 0)) {
                 a.target_blocks = (a.target_blocks + 1) / 2; // one workgroup per CU, as below
-                if (vg == 4) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 4, 1>(a, o, phi, pv, pb, out, partials, partials_cap, s);
-                if (vg == 7) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 7, 1>(a, o, phi, pv, pb, out, partials, partials_cap, s);
-                if (vg == 9) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 9, 1>(a, o, phi, pv, pb, out, partials, partials_cap, s);
+                if (vg == 4) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 4, 1>(t, a, o, phi, pv, pb, out, partials, partials_cap, s);
+                if (vg == 7) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 7, 1>(t, a, o, phi, pv, pb, out, partials, partials_cap, s);
+                if (vg == 9) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 9, 1>(t, a, o, phi, pv, pb, out, partials, partials_cap, s);
                 return hipErrorInvalidValue;
             }
         }
@@ -847,22 +831,20 @@ static inline hipError_t wafer_launch_step_lds(WaferStepArgs a, const T *phi, co
     { // ThreePoint / FivePoint with a, b from V: 8 waves on a 128x16 tile, one workgroup per CU (half the
       // halo rows per tile: 0.56 -> 0.54 ms/step at 512^3); WAFER_LDS_NW=4 or an explicit WAFER_LDS_RY
       // select the 4-wave kernels
-        const char *e = getenv("WAFER_LDS_NW");
-        const char *ry = getenv("WAFER_LDS_RY");
         // SevenPoint as well (round 2): 8 waves x 2 rows on the 128x16 tile -- two waves per SIMD with half the
         // registers each -- against 4 waves x 4 rows (256 VGPRs + 54 AGPRs, one wave per SIMD): 0.561 against
         // 0.605 ms/step at 512^3.  (8 waves x 4 rows on 128x32 tiles spill 240 B/lane: 1.69 ms.)
-        const bool eight = (e && *e) ? atoi(e) == 8 : !(ry && *ry);
+        const bool eight = t.lds_nw ? t.lds_nw == 8 : t.lds_ry == 0;
         if (eight && o.abv != 0) {
             a.target_blocks = (a.target_blocks + 1) / 2; // one workgroup per CU
-            if (o.nt != 0) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8>(a, o, phi, pv, pb, out, partials, partials_cap, s);
-            return wafer_launch_step_lds_ry<T, C, R, 2, -1, false, true, false, 8>(a, o, phi, pv, pb, out, partials, partials_cap, s);
+            if (o.nt != 0) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8>(t, a, o, phi, pv, pb, out, partials, partials_cap, s);
+            return wafer_launch_step_lds_ry<T, C, R, 2, -1, false, true, false, 8>(t, a, o, phi, pv, pb, out, partials, partials_cap, s);
         }
     }
     // with ABV, V takes a's slot and b is not read
 #define WAFER_LDS_CASE(RY_, NT_, ABV_)                                                               \
     if (o.ry == RY_ && (o.nt != 0) == NT_ && (o.abv != 0) == ABV_)                                   \
-        return wafer_launch_step_lds_ry<T, C, R, RY_, -1, NT_, ABV_>(a, o, phi, ABV_ ? pv : pa, pb,   \
+        return wafer_launch_step_lds_ry<T, C, R, RY_, -1, NT_, ABV_>(t, a, o, phi, ABV_ ? pv : pa, pb,   \
                                                                        out, partials, partials_cap, s);
     WAFER_LDS_CASE(2, false, false)
     WAFER_LDS_CASE(2, true, false)

@@ -1,0 +1,3 @@
+// translation unit: excited-state step kernels, ext = 2 (one unit per stencil order: they are the bulk of the device code)
+#define WAFER_TU_EXCITED_R 2
+#include "wafer_tu_excited.inc"

@@ -1,0 +1,78 @@
+// Tuning knobs of the launch layer, read ONCE per context.
+//
+// wafer_ctx_create fills a WaferTuning from the WAFER_* environment variables (tools/stencil_sweep.py
+// and the tests drive A/B runs through them) and every launcher takes it by reference: nothing on a
+// launch path -- wafer_evolve, wafer_observables, the per-pass loop -- calls getenv.  A value of 0 / -1
+// means "the kernel's own default" unless stated otherwise.
+#pragma once
+#include <cstdlib>
+
+struct WaferTuning {
+    // launch geometry of the column-marching kernels
+    int zchunk = 0;         // WAFER_ZCHUNK: planes per workgroup (0: from the CU count)
+    int target_blocks = 0;  // WAFER_TARGET_BLOCKS: workgroups per launch (0: from the CU count)
+    int swz = 1;            // WAFER_XCD_SWIZZLE: XCD-aware workgroup -> tile map
+    int lds_pad = 0;        // WAFER_LDS_PAD: extra dynamic LDS bytes per workgroup (caps workgroups per CU)
+    // single-step LDS kernel
+    int lds_ry = 0;         // WAFER_LDS_RY: rows per lane, 2 or 4 (0: default per stencil order)
+    int lds_nw = 0;         // WAFER_LDS_NW: waves per workgroup, 4 or 8 (0: default)
+    int nt = -1;            // WAFER_NT: non-temporal streams (-1: default per kernel)
+    int abv = -1;           // WAFER_ABV: 0 = stream the stored a, b arrays instead of forming them from V
+    int seven_vg = 0;       // WAFER_SEVEN_VG: closed-form V in SevenPoint's single-step kernel (measured slower)
+    // excited-state step kernels
+    int xf_nw = 8;          // WAFER_XF_NW: 8 waves on 128 x 16 tiles (4: 128 x 8)
+    int xf_deep = 1;        // WAFER_XF_DEEP: the raw staging pipeline
+    int one_pass = 1;       // WAFER_ONE_PASS: transform-on-load (0: the two-pass scheme)
+    int vgen = 1;           // WAFER_VGEN: evaluate Coulomb / SimpleCornell / Harmonic per cell instead of streaming V
+    // observables
+    int obs_lds = 1;        // WAFER_OBS_LDS: 0 = the plain scalar-load kernel
+    int obs_wgs = 2;        // WAFER_OBS_WGS: workgroups per CU
+    // fused kernels
+    int f2_nw2 = 0;         // WAFER_F2_NW2: main waves of the two-step kernel (0: default)
+    int f2_yreg = -1;       // WAFER_F2_YREG
+    int fuse3 = 1;          // WAFER_FUSE3: 0 keeps ThreePoint fp64 on the two-step kernel
+    int fuse3_min_ny = -1;  // WAFER_FUSE3_MIN_NY (tests; lifts the cell threshold too)
+    long long fuse3_min_cells = 6000000; // WAFER_FUSE3_MIN_CELLS
+    int stencil_variant = -1; // WAFER_STENCIL_VARIANT
+    // z-slabs
+    int overlap = -1;       // WAFER_OVERLAP: initial wafer_set_overlap mode (-1: default)
+    int halo_cycle = 1;     // WAFER_HALO_CYCLE
+    int gate = 0;           // WAFER_GATE: how the single-launch pass releases its exchanges (0: stream memory operations, 1: gate kernels)
+};
+
+static inline int wafer_env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+static inline WaferTuning wafer_tuning_from_env()
+{
+    WaferTuning t;
+    t.zchunk = wafer_env_int("WAFER_ZCHUNK", t.zchunk);
+    t.target_blocks = wafer_env_int("WAFER_TARGET_BLOCKS", t.target_blocks);
+    t.swz = wafer_env_int("WAFER_XCD_SWIZZLE", t.swz);
+    t.lds_pad = wafer_env_int("WAFER_LDS_PAD", t.lds_pad);
+    t.lds_ry = wafer_env_int("WAFER_LDS_RY", t.lds_ry);
+    if (t.lds_ry != 2 && t.lds_ry != 4) t.lds_ry = 0;
+    t.lds_nw = wafer_env_int("WAFER_LDS_NW", t.lds_nw);
+    t.nt = wafer_env_int("WAFER_NT", t.nt);
+    t.abv = wafer_env_int("WAFER_ABV", t.abv);
+    t.seven_vg = wafer_env_int("WAFER_SEVEN_VG", t.seven_vg);
+    t.xf_nw = wafer_env_int("WAFER_XF_NW", t.xf_nw);
+    t.xf_deep = wafer_env_int("WAFER_XF_DEEP", t.xf_deep);
+    t.one_pass = wafer_env_int("WAFER_ONE_PASS", t.one_pass);
+    t.vgen = wafer_env_int("WAFER_VGEN", t.vgen);
+    t.obs_lds = wafer_env_int("WAFER_OBS_LDS", t.obs_lds);
+    t.obs_wgs = wafer_env_int("WAFER_OBS_WGS", t.obs_wgs);
+    t.f2_nw2 = wafer_env_int("WAFER_F2_NW2", t.f2_nw2);
+    t.f2_yreg = wafer_env_int("WAFER_F2_YREG", t.f2_yreg);
+    t.fuse3 = wafer_env_int("WAFER_FUSE3", t.fuse3);
+    t.fuse3_min_ny = wafer_env_int("WAFER_FUSE3_MIN_NY", t.fuse3_min_ny);
+    t.fuse3_min_cells = wafer_env_int("WAFER_FUSE3_MIN_CELLS", (int)t.fuse3_min_cells);
+    t.stencil_variant = wafer_env_int("WAFER_STENCIL_VARIANT", t.stencil_variant);
+    t.overlap = wafer_env_int("WAFER_OVERLAP", t.overlap);
+    t.halo_cycle = wafer_env_int("WAFER_HALO_CYCLE", t.halo_cycle);
+    t.gate = wafer_env_int("WAFER_GATE", t.gate);
+    return t;
+}

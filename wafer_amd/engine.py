@@ -37,7 +37,7 @@ EXPORTS = [
     "wafer_orthogonalise", "wafer_push_state", "wafer_load_state", "wafer_download_state",
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
-    "wafer_diag_stream_bw", "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
+    "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
     "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check",
     "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_set_halo_cycle",
 ]
@@ -159,7 +159,6 @@ def load_library():
     L.wafer_stencil_kernel_name.restype = C.c_char_p
     L.wafer_stencil_steps_per_launch.argtypes = [vp]
     L.wafer_set_stencil_variant.argtypes = [vp, C.c_int]
-    L.wafer_diag_stream_bw.argtypes = [vp, C.c_int, C.c_int, dp]
     L.wafer_set_comm_hooks.argtypes = [vp, HALO_FN, ALLREDUCE_FN, vp]
     L.wafer_set_overlap.argtypes = [vp, C.c_int]
     L.wafer_set_halo_cycle.argtypes = [vp, C.c_int]
@@ -420,12 +419,6 @@ class Context:
     def set_stencil_variant(self, variant: int) -> None:
         self._check(self._L.wafer_set_stencil_variant(self._h, variant))
 
-    def stream_bandwidth(self, n_reads: int = 3, iters: int = 20) -> float:
-        """measured GB/s of a flat streaming kernel (n_reads reads + 1 write)"""
-        v = C.c_double(0.0)
-        self._check(self._L.wafer_diag_stream_bw(self._h, n_reads, iters, C.byref(v)))
-        return v.value
-
     def copy_bandwidth(self, iters: int = 50, unroll: int = 4, blocks_per_cu: int = 1) -> float:
         """measured GB/s (read + written) of a 16 B-per-lane device copy: the device's own ceiling"""
         v = C.c_double(0.0)
@@ -463,11 +456,12 @@ class Context:
         self._check(self._L.wafer_set_comm_hooks(self._h, self._hooks[0], self._hooks[1], None))
 
     def set_overlap(self, enabled) -> None:
-        """halo schedule of a z-slab: False / 0, True / 1 (default), 2 or 3 (include/wafer_hip.h)"""
+        """halo schedule of a z-slab: False / 0 (exchange after the pass), True / 1 (default: boundary planes first),
+        2 (one launch per three-step pass, exchanges released by completion counters); include/wafer_hip.h"""
         self._check(self._L.wafer_set_overlap(self._h, int(enabled)))
 
     def set_halo_cycle(self, passes: int) -> None:
-        """fused passes per halo exchange of a z-slab (needs halo_depth >= 2 * ext * passes)"""
+        """fused passes per halo exchange of a z-slab (needs halo_depth >= K * ext * passes, K = steps per fused pass)"""
         self._check(self._L.wafer_set_halo_cycle(self._h, int(passes)))
 
     def set_stream(self, stream_ptr: int | None) -> None:

@@ -57,7 +57,7 @@ class SlabComm:
         ops = []
         # receives first, then sends; NCCL groups them, gloo posts them asynchronously
         # (a buffer may also be None on a side that HAS a neighbour: the engine's half-slab schedule,
-        #  wafer_set_overlap mode 4, exchanges one direction at a time)
+        #  wafer_set_overlap mode 2, exchanges one direction at a time)
         if self.lower is not None and recv_lo is not None:
             ops.append(dist.P2POp(dist.irecv, recv_lo, self.lower, self.group))
         if self.upper is not None and recv_hi is not None:
