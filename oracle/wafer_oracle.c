@@ -670,10 +670,13 @@ static inline double lerp1(double c0, double c1, double t) { return c0 * (1. - t
  * the `size` argument while the loop runs over `output`'s own dims -- the
  * production call passes the PADDED target size with the unpadded work view
  * (input.rs:156-173, 640-656), the unit test passes the view's own dims. */
-void wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
-                             int64_t sx, int64_t sy, int64_t sz, int64_t bx, int64_t by, int64_t bz)
+int wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
+                            int64_t sx, int64_t sy, int64_t sz, int64_t bx, int64_t by, int64_t bz)
 {
     const int64_t nx = vx - 1, ny = vy - 1, nz = vz - 1;
+    /* an axis of one point: (0..0).position(..) is None and the reference's (nx - 1, nx) underflows usize -- it panics
+     * on the index that follows (input.rs:687-698).  Refused here (found by `make asan`: this used to read v[-1]). */
+    if (nx < 1 || ny < 1 || nz < 1) return 1;
 #define VAT(x, y, z) v[(((size_t)(x)) * (size_t)vy + (size_t)(y)) * (size_t)vz + (size_t)(z)]
 #pragma omp parallel for schedule(static)
     for (int64_t x = 0; x < sx; ++x)
@@ -699,10 +702,11 @@ void wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz
                     lerp1(c0, c1, zd);
             }
 #undef VAT
+    return 0;
 }
 
-void wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
-                       int64_t sx, int64_t sy, int64_t sz)
+int wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
+                      int64_t sx, int64_t sy, int64_t sz)
 {
-    wo_trilerp_resize_basis(v, vx, vy, vz, out, sx, sy, sz, sx, sy, sz);
+    return wo_trilerp_resize_basis(v, vx, vy, vz, out, sx, sy, sz, sx, sy, sz);
 }

@@ -124,13 +124,14 @@ size_t wo_solve(const wo_config *c, int wnum, const double *v, const double *a, 
                 int has_max_steps, uint64_t max_steps, wo_block_record *records,
                 size_t max_records, int *converged);
 
-/* input.rs:667-716: v (vx,vy,vz) -> out (sx,sy,sz) dense arrays */
-void wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
-                       int64_t sx, int64_t sy, int64_t sz);
+/* input.rs:667-716: v (vx,vy,vz) -> out (sx,sy,sz) dense arrays.  Non-zero (nothing written) when an axis of v has
+ * a single point: the reference panics there (usize underflow of nx - 1, then an out-of-bounds index). */
+int wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
+                      int64_t sx, int64_t sy, int64_t sz);
 
 /* same, with the linspace basis built for (bx,by,bz) points (the production call, see .c) */
-void wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
-                             int64_t sx, int64_t sy, int64_t sz, int64_t bx, int64_t by, int64_t bz);
+int wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
+                            int64_t sx, int64_t sy, int64_t sz, int64_t bx, int64_t by, int64_t bz);
 
 void wo_set_threads(int n);
 int wo_get_threads(void);

@@ -98,10 +98,10 @@ def lib():
         L.wo_solve.argtypes = [cp, C.c_int, dp, dp, dp, C.c_int, C.c_double, dp, dp,
                                C.POINTER(dp), C.c_double, C.c_uint64, C.c_int, C.c_uint64,
                                C.POINTER(_Record), C.c_size_t, C.POINTER(C.c_int)]
-        L.wo_trilerp_resize.restype = None
+        L.wo_trilerp_resize.restype = C.c_int
         L.wo_trilerp_resize.argtypes = [dp, C.c_int64, C.c_int64, C.c_int64, dp,
                                         C.c_int64, C.c_int64, C.c_int64]
-        L.wo_trilerp_resize_basis.restype = None
+        L.wo_trilerp_resize_basis.restype = C.c_int
         L.wo_trilerp_resize_basis.argtypes = [dp] + [C.c_int64] * 3 + [dp] + [C.c_int64] * 6
         L.wo_set_threads.argtypes = [C.c_int]
         L.wo_get_threads.restype = C.c_int
@@ -278,6 +278,7 @@ def trilerp_resize(v: np.ndarray, size, basis=None) -> np.ndarray:
     v = np.ascontiguousarray(v, dtype=np.float64)
     out = np.zeros(tuple(size))
     basis = tuple(size) if basis is None else tuple(basis)
-    lib().wo_trilerp_resize_basis(_dp(v), v.shape[0], v.shape[1], v.shape[2], _dp(out),
-                                  size[0], size[1], size[2], basis[0], basis[1], basis[2])
+    if lib().wo_trilerp_resize_basis(_dp(v), v.shape[0], v.shape[1], v.shape[2], _dp(out),
+                                     size[0], size[1], size[2], basis[0], basis[1], basis[2]) != 0:
+        raise ValueError("trilerp_resize: every axis of the source needs at least two points (the reference panics)")
     return out

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLI = os.path.join(ROOT, "wafer_amd", "wafer-hip")
+CLI = os.environ.get("WAFER_CLI_BIN") or os.path.join(ROOT, "wafer_amd", "wafer-hip")   # (tests/test_sanitizers.py: the ASan build)
 EXT = ["mpk", "csv", "json", "yaml", "ron"]
 
 

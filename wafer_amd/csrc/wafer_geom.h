@@ -61,7 +61,8 @@ static inline WaferGeom wafer_make_geom(int nx, int ny, int nz, int R, int G, in
     const int nx_tiles = ((nx + tile - 1) / tile) * tile;
     g.pitch = ((g.xoff + R + nx_tiles + 2 * R + align - 1) / align) * align;
     g.gy = 16 + 2 * R + R;                        // tallest tile (16 rows) overhang + 2R halo rows
-    g.gz = 3 * R;                                 // the fused kernel reaches 2R planes past the slab
+    g.gz = 3 * R;                                 // the three-step kernel (ext 1) loads up to 3 planes past the slab's ghost planes
+                                                  // in either marching direction; the two-step kernel 2R
     g.plane = (long long)(g.py + 2 * g.gy) * g.pitch;
     g.total = (long long)(g.lz + 2 * g.gz) * g.plane;
     g.base_off = (long long)g.gz * g.plane + (long long)g.gy * g.pitch;

@@ -57,13 +57,21 @@ using Fabric = WaferRcclFabric;
 static auto &rccl_halo = wafer_rccl_halo;
 static auto &rccl_allreduce = wafer_rccl_allreduce;
 
-// the same exchange with itself as both neighbours, by device copies (what the self test expects
-// RCCL to deliver: first receive posted <- first send posted)
+// the same exchange with itself as both neighbours, by device copies: what the self test expects RCCL to deliver.  With one
+// rank as both neighbours RCCL pairs receives and sends in posting order (wafer_rccl_halo posts recv_lo, recv_hi, then
+// send_lo, send_hi).  The single-launch pass (wafer_set_overlap mode 2) calls the hook with ONE direction -- send_lo and
+// recv_hi, or send_hi and recv_lo, the other two NULL: the pairing by posting order covers that as well.
 static int copy_halo(void *, void *send_lo, void *send_hi, void *recv_lo, void *recv_hi, size_t bytes, void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemcpyAsync(recv_lo, send_lo, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
-    if (hipMemcpyAsync(recv_hi, send_hi, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+    void *recvs[2] = {recv_lo, recv_hi}, *sends[2] = {send_lo, send_hi};
+    int is = 0;
+    for (int ir = 0; ir < 2; ++ir) {
+        if (!recvs[ir]) continue;
+        while (is < 2 && !sends[is]) ++is;
+        if (is == 2) return 1; // a receive without a send: not a self-neighbour exchange
+        if (hipMemcpyAsync(recvs[ir], sends[is++], bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+    }
     return 0;
 }
 static int copy_allreduce(void *, void *, size_t, void *) { return 0; }
@@ -104,6 +112,7 @@ static int run_slab(const wafer_params &p, int potential, uint64_t steps, wafer_
 
 int main(int argc, char **argv)
 {
+    const auto started = std::chrono::system_clock::now(); // before anything slow (HIP initialisation of eight ranks at once)
     bool self = false;
     int a0 = 1;
     if (argc > 1 && std::string(argv[1]) == "--self") { self = true; a0 = 2; }
@@ -127,14 +136,15 @@ int main(int argc, char **argv)
         const char *path = getenv("WAFER_NCCL_ID_FILE");
         if (!path) { fprintf(stderr, "WAFER_NCCL_ID_FILE must name a file all ranks can reach\n"); return 2; }
         // The file carries a run nonce in front of the id so that a file left over from an earlier run is
-        // never mistaken for this one's: the launcher's TORCHELASTIC_RUN_ID / WAFER_RUN_ID when it sets
-        // one, else the file must be younger than this process (rank 0 removes any old file before it
-        // generates the id, writes to .tmp and renames; it removes the file again after ncclCommInitRank).
-        const char *nonce_env = getenv("WAFER_RUN_ID") ? getenv("WAFER_RUN_ID") : getenv("TORCHELASTIC_RUN_ID");
+        // never mistaken for this one's: WAFER_RUN_ID, else the launcher's TORCHELASTIC_RUN_ID, else MASTER_PORT (any
+        // value all ranks of ONE run share); without any of them the file must not be older than this process by
+        // more than the slack below (rank 0 removes any old file before it generates the id, writes to .tmp and
+        // renames; it removes the file again after ncclCommInitRank).
+        const char *nonce_env = getenv("WAFER_RUN_ID") ? getenv("WAFER_RUN_ID")
+                                : getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : getenv("MASTER_PORT");
         char nonce[64];
         memset(nonce, 0, sizeof nonce);
         if (nonce_env) strncpy(nonce, nonce_env, sizeof nonce - 1);
-        const auto started = std::chrono::system_clock::now();
         if (rank == 0) {
             remove(path);
             NCCLCHECK(ncclGetUniqueId(&id));
@@ -156,10 +166,10 @@ int main(int argc, char **argv)
                             got = memcmp(seen, nonce, sizeof nonce) == 0;
                             why = "its run id is not this run's (a file left over from another run?)";
                         } else {
-                            // no launcher nonce: accept only a file written after this process started (minus
-                            // clock slack between ranks of one node)
+                            // no nonce: accept only a file written after this process started, with slack for ranks
+                            // started by hand one after the other and the 1 s granularity of st_mtime
                             got = stat(path, &st) == 0 &&
-                                  std::chrono::system_clock::from_time_t(st.st_mtime) + std::chrono::seconds(2) >= started;
+                                  std::chrono::system_clock::from_time_t(st.st_mtime) + std::chrono::seconds(30) >= started;
                             why = "it is older than this run (a file left over from another run? set WAFER_RUN_ID)";
                         }
                     } else {
