@@ -580,21 +580,72 @@ def run_rank(args) -> int:
                 if not parity["timed_state_reproduced_by_single_step_kernel"]["identical"]:
                     rc = RC_PARITY
             result["parity"] = parity
-        # (informational, after everything the contract asks for) the excited-state step -- where a real run of
-        # BASELINE config #3 spends nine steps in ten: normalise + project on load, step, sum phi'^2 and the k raw
-        # overlaps in ONE pass (grid.rs:674-681 takes 2 + 2k) -- against k = 1..3 stored states on the same grid,
-        # priced at SURVEY.md 8(d)'s 80 / 112 / 144 B per update (the maximally fused multi-pass form)
+        # "kernel time via hipEvents; also end-to-end including the per-block observables": three blocks of
+        # the solve loop's body (grid.rs:126-221: observables, normalise, then screen_update = 1000 steps), wall clock
+        if not args.no_parity:
+            try:
+                ctx.set_stencil_variant(args.variant)
+                ctx.set_initial_condition("Boolean")
+                ctx.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(3):
+                    o_ = ctx.observables()
+                    ctx.normalise(o_["norm2"])
+                    ctx.evolve(0, 1000)
+                ctx.synchronize()
+                result["end_to_end"] = {"ms_per_step": (time.perf_counter() - t_) / 3000 * 1e3, "blocks": 3, "screen_update": 1000,
+                                        "note": "observables + normalise + 1000 steps per block (the body of grid.rs:126-221), wall clock"}
+            except Exception as e:
+                result["end_to_end"] = {"error": repr(e)}
+        # (after everything the contract asks for) the excited-state step -- where a real run of BASELINE config #3
+        # spends nine steps in ten: normalise + project on load, step, sum phi'^2 and the k raw overlaps in ONE pass
+        # (grid.rs:674-681 takes 2 + 2k) -- against k = 1..3 stored states on the same grid, priced at SURVEY.md 8(d)'s
+        # 80 / 112 / 144 B per update (the maximally fused multi-pass form).  The stored states are the three lowest
+        # modes of the empty box (deterministic, exactly orthonormal), and the block proves itself: the same kernels,
+        # from the same start, against the oracle over two k = 3 steps, every cell ("excited_parity"; > 1e-13 is exit
+        # code 3, like the ground-state check above).
         if args.dtype == "f64" and not args.no_excited:
             try:
+                n0, n1, n2_ = shape
+                e = ext
+
+                def sine(n, m):
+                    return np.sin(np.pi * m * np.arange(1, n + 1) / (n + 1)) * np.sqrt(2.0 / (n + 1))
+
+                def mode(mx, my, mz):
+                    out = np.zeros((n0 + 2 * e, n1 + 2 * e, n2_ + 2 * e))
+                    out[e:-e, e:-e, e:-e] = sine(n0, mx)[:, None, None] * sine(n1, my)[None, :, None] * sine(n2_, mz)[None, None, :]
+                    return out
+                lowers = [mode(1, 1, 1), mode(2, 1, 1), mode(1, 1, 2)]
                 ex = wafer_amd.Context(wafer_amd.Params(shape[0], shape[1], shape[2], dn=dn, dt=dt, mass=mass, sig=sig,
                                                         central_difference=ext, dtype=args.dtype, max_states=3, device=local_rank))
                 ex.set_potential(potential)
-                for i in range(3):
-                    ex.set_initial_condition("Gaussian", seed=i + 1)
-                    ex.normalise(ex.norm2())
-                    ex.push_state()
-                ex.set_initial_condition("Boolean")
+                for i, l in enumerate(lowers):
+                    ex.load_state(i, l)
+                phi0 = mode(1, 2, 1) + 0.3 * lowers[0] - 0.2 * lowers[2]
+                phi0[e:-e:2, e:-e:2, e:-e:2] += 1e-3     # (a rough component, as the Boolean grid is)
                 rec = {}
+                if not args.no_parity:
+                    from oracle import wafer_oracle as wo
+                    wo.set_threads(physical_cores())
+                    cfg = wo.Config(*shape, ext=ext, potential=potential, dn=dn, dt=dt, mass=mass, sig=sig)
+                    v_ = wo.potential_generate(cfg)
+                    a_, b_ = wo.ab(cfg, v_)
+                    del v_
+                    ex.upload_phi(phi0)
+                    ex.evolve(3, 2)
+                    got = ex.download_phi()
+                    want = phi0.copy()
+                    wo.evolve(cfg, 3, a_, b_, want, lowers, 2)
+                    del a_, b_
+                    worst = float(np.max(np.abs(got - want)))
+                    result["excited_parity"] = {"against": "oracle/wafer_oracle.c wo_evolve (grid.rs:544-687 with wnum = 3)", "k": 3, "steps": 2,
+                                                "max_abs": worst, "tolerance": 1e-13, "norm2_gpu": ex.norm2(), "norm2_oracle": wo.norm2(cfg, want)}
+                    del got, want
+                    if not (worst <= 1e-13):
+                        rc = RC_PARITY
+                ex.upload_phi(phi0)
+                del phi0, lowers
                 for k in (1, 2, 3):
                     ex.evolve(k, 10)
                     ex.evolve(k, 40)
@@ -604,8 +655,9 @@ def run_rank(args) -> int:
                                     "frac_of_hbm_peak": pts_total * bpu_k / (ms_k / st_k * 1e-3) / 1e9 / HBM_PEAK_GBPS}
                 ex.close()
                 result["excited_state_step"] = {"grid": list(shape), "potential": potential, **rec,
-                                                "note": "wafer_evolve(wnum = k) on the same grid, HIP events; informational"}
-            except Exception as e:  # informational
+                                                "stored_states": "box modes (1,1,1), (2,1,1), (1,1,2)",
+                                                "note": "wafer_evolve(wnum = k) on the same grid, HIP events; checked by excited_parity"}
+            except Exception as e:  # reported, never silently dropped
                 result["excited_state_step"] = {"error": repr(e)}
 
     if dist is not None:   # the process group goes first: its work objects refer to the engine's streams

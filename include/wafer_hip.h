@@ -275,9 +275,9 @@ int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn 
  * tolerate a NULL on a side that has a neighbour, and pair send_lo with the lower neighbour's recv_hi. */
 /* z-slabs, how the halo exchange is scheduled.  All modes give identical results.
  *  0 = the exchange follows the whole slab's update (nothing overlaps);
- *  1 (default) = boundary planes first, then their exchange, both on a second stream, beside the interior update:
+ *  1 = boundary planes first, then their exchange, both on a second stream, beside the interior update:
  *      three launches per pass;
- *  2 = ONE launch per three-step pass updates the whole slab as two halves marched outwards from the middle plane;
+ *  2 (default) = ONE launch per three-step pass updates the whole slab as two halves marched outwards from the middle plane;
  *      workgroups count themselves done and the second stream releases each half's exchange as soon as that half
  *      is complete; the ghost planes an exchange fills are announced by a device flag that only the workgroups
  *      reading them poll, shortly before the end of their column.  Ground-state three-step passes with one exchange

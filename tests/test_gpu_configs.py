@@ -88,13 +88,16 @@ def test_config2_256_cubed_harmonic_ten_steps_bit_exact(wo, wa):
 
 
 @BIG
-def test_config3_512_cubed_coulomb_three_stored_states_two_excited_steps(wo, wa):
-    """BASELINE config #3 where its wall time goes (93 % of its steps are excited-state steps): 512^3
-    Coulomb, THREE stored states, two steps of grid.rs:674-681 (step, renormalise, modified
-    Gram-Schmidt) against the oracle -- every cell to 1e-13, the sums to 1e-12.  The stored states are
-    the three lowest box modes (exactly orthogonal, normalised), phi a fourth one plus a Boolean grid."""
+@pytest.mark.parametrize("potential,k", [("Coulomb", 3), ("Coulomb", 1), ("Coulomb", 2), ("SimpleCornell", 1), ("SimpleCornell", 2),
+                                         ("SimpleCornell", 3)])
+def test_config3_512_cubed_stored_states_two_excited_steps(wo, wa, potential, k):
+    """BASELINE config #3 where its wall time goes (93 % of its steps are excited-state steps): 512^3, k stored
+    states, two steps of grid.rs:674-681 (step, renormalise, modified Gram-Schmidt) through the PRODUCTION kernels --
+    closed-form V evaluated per cell, raw staging pipeline -- against the oracle: every cell to 1e-13, the sums to
+    1e-12.  Coulomb (config #3's potential) and SimpleCornell (config #4's), k = 1, 2, 3.  The stored states are the
+    lowest box modes (exactly orthogonal, normalised), phi another one plus a Boolean grid and parts of the stored ones."""
     n = 512
-    cfg, par = make_pair((n, n, n), ext=1, potential="Coulomb", dn=0.05, dt=5e-4, mass=1.0, max_states=3)
+    cfg, par = make_pair((n, n, n), ext=1, potential=potential, dn=0.05, dt=5e-4, mass=1.0, sig=0.223, max_states=3)
     v = wo.potential_generate(cfg)
     a, b = wo.ab(cfg, v)
     s = [np.sin(np.pi * m * np.arange(1, n + 1) / (n + 1)) * np.sqrt(2.0 / (n + 1)) for m in (1, 2, 3)]
@@ -103,26 +106,50 @@ def test_config3_512_cubed_coulomb_three_stored_states_two_excited_steps(wo, wa)
         out = np.zeros(cfg.padded_shape)
         out[1:-1, 1:-1, 1:-1] = s[mx - 1][:, None, None] * s[my - 1][None, :, None] * s[mz - 1][None, None, :]
         return out
-    lowers = [mode(1, 1, 1), mode(2, 1, 1), mode(1, 1, 2)]
-    phi = wo.initial_condition(cfg, "Boolean") * 1e-3 + mode(1, 2, 1) + 0.3 * lowers[0] - 0.2 * lowers[2]
+    lowers = [mode(1, 1, 1), mode(2, 1, 1), mode(1, 1, 2)][:k]
+    phi = wo.initial_condition(cfg, "Boolean") * 1e-3 + mode(1, 2, 1) + 0.3 * lowers[0] - 0.2 * lowers[-1]
     with wa.Context(par) as ctx:
-        ctx.set_potential("Coulomb")
+        ctx.set_potential(potential)
         for i, l in enumerate(lowers):
             ctx.load_state(i, l)
         ctx.upload_phi(phi)
-        ctx.evolve(3, 2)
+        ctx.evolve(k, 2)
         got = ctx.download_phi()
         n2 = ctx.norm2()
         obs = ctx.observables()
-    wo.evolve(cfg, 3, a, b, phi, lowers, 2)
+    wo.evolve(cfg, k, a, b, phi, lowers, 2)
     assert np.max(np.abs(got - phi)) <= 1e-13
     assert n2 == pytest.approx(wo.norm2(cfg, phi), rel=1e-12)
     want = wo.observables(cfg, v, phi)
-    for k in ("energy", "norm2", "r2"):
-        assert obs[k] == pytest.approx(want[k], rel=1e-12)
+    for key in ("energy", "norm2", "r2"):
+        assert obs[key] == pytest.approx(want[key], rel=1e-12)
     for l in lowers:       # orthogonal to every stored state after the step's Gram-Schmidt
         assert abs(float(np.sum(l * got))) < 1e-13
     del got, phi, lowers, a, b, v
+
+
+@BIG
+@pytest.mark.parametrize("ext,kernel", [(2, "wafer_k_step2_fused"), (3, "wafer_k_step_lds")])
+def test_five_and_seven_point_256_cubed_four_steps_bit_exact(wo, wa, ext, kernel):
+    """the default kernels of the wider stencils at a size where every workgroup marches a long column: FivePoint on the
+    fused two-step kernel, SevenPoint on the single-step LDS kernel, 256^3 Coulomb x 4 steps, every cell's bits
+    against the oracle (grid.rs:593-663); dt = 0.2 dn^2 keeps both inside the true forward-Euler bound"""
+    n = 256
+    cfg, par = make_pair((n, n, n), ext=ext, potential="Coulomb", dn=0.05, dt=5e-4, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = wo.initial_condition(cfg, "Boolean")
+    wo.evolve(cfg, 0, a, b, phi, [], 4)
+    with wa.Context(par) as ctx:
+        assert ctx.stencil_kernel_name() == kernel
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 4)
+        got = ctx.download_phi()
+        assert np.array_equal(got, phi)
+        obs, want = ctx.observables(), wo.observables(cfg, v, phi)
+        for key in ("energy", "norm2", "r2"):
+            assert obs[key] == pytest.approx(want[key], rel=1e-12)
 
 
 @BIG

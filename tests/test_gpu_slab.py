@@ -249,14 +249,13 @@ def test_three_step_kernel_on_slabs_bit_exact(wa, world, shape, steps, cycle, ov
     assert all(n <= per_pass * passes // cycle + 6 for n in fabric.halo_calls), fabric.halo_calls
 
 
-@pytest.mark.parametrize("gate", ["0", "1"])   # stream memory operations / gate kernels on the exchange stream
-@pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 10), 12), (3, (140, 40, 13), 9), (2, (300, 70, 96), 15), (4, (130, 33, 17), 6)])
-def test_single_launch_pass_thin_and_uneven_slabs_bit_exact(wa, world, shape, steps, gate, monkeypatch):
+@pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 10), 12), (3, (140, 40, 13), 9), (2, (300, 70, 96), 15), (4, (130, 33, 17), 6),
+                                               (2, (1100, 300, 80), 9)])   # the last: more than 64 tiles, i.e. short pieces in the schedule
+def test_single_launch_pass_thin_and_uneven_slabs_bit_exact(wa, world, shape, steps, monkeypatch):
     """overlap mode 2 on slabs whose halves are thinner than the exchange depth (the side's boundary planes then reach
-    into the other half: its exchange waits for both counters), on uneven partitions, with both ways of releasing the
-    exchange stream; several evolve calls, so that the alternating order of the halves carries over between calls"""
+    into the other half: its exchange waits for both counters), on uneven partitions; several evolve calls, so that the
+    alternating order of the halves carries over between calls"""
     monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
-    monkeypatch.setenv("WAFER_GATE", gate)
     base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1, halo_depth=3)
     with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1)) as ctx:
         ctx.set_potential("Coulomb")

@@ -13,12 +13,46 @@ for step in "$@"; do
     tests_slab)   timeout 600 python -m pytest tests/test_gpu_slab.py -x -q > $O/tests_slab.log 2>&1; tail -5 $O/tests_slab.log ;;
     bench)        timeout 600 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-300 $O/bench_n1.json ;;
     bench_short)  timeout 600 python3 bench.py --steps 20 --warmup 5 > $O/bench_n1_short.json 2> $O/bench_n1_short.err; cut -c1-300 $O/bench_n1_short.json ;;
-    slab)         NCCL_MAX_P2P_NCHANNELS=8 timeout 600 python3 tools/slab_overhead.py --rccl --steps 60 --modes 2,1,0 > $O/slab_overhead.json 2> $O/slab_overhead.err; cat $O/slab_overhead.json ;;
-    slab_gate)    WAFER_GATE=1 NCCL_MAX_P2P_NCHANNELS=8 timeout 600 python3 tools/slab_overhead.py --rccl --steps 60 --modes 2 > $O/slab_overhead_gate.json 2> $O/slab_overhead_gate.err; cat $O/slab_overhead_gate.json ;;
+    slab)         NCCL_MAX_P2P_NCHANNELS=8 timeout 240 python3 tools/slab_overhead.py --rccl --steps 60 --modes 2,1,0 > $O/slab_overhead.json 2> $O/slab_overhead.err; cat $O/slab_overhead.json ;;
+    slab_noshort) WAFER_HV_DEBUG=8 NCCL_MAX_P2P_NCHANNELS=8 timeout 240 python3 tools/slab_overhead.py --rccl --steps 60 --modes 2 > $O/slab_overhead_noshort.json 2> $O/slab_overhead_noshort.err; cat $O/slab_overhead_noshort.json ;;
     trace2)       NCCL_MAX_P2P_NCHANNELS=8 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -o t -- python3 tools/slab_trace.py --rccl --mode 2 > $O/trace2.log 2>&1
                   python3 tools/slab_trace.py --parse $(find $O/trace2 -name "*kernel_trace.csv" | head -1) > $O/trace2_timeline.txt 2>&1; cat $O/trace2_timeline.txt; find $O/trace2 -name "*.csv" -size +2M -delete ;;
     trace1)       NCCL_MAX_P2P_NCHANNELS=8 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace1 -o t -- python3 tools/slab_trace.py --rccl --mode 1 > $O/trace1.log 2>&1
                   python3 tools/slab_trace.py --parse $(find $O/trace1 -name "*kernel_trace.csv" | head -1) > $O/trace1_timeline.txt 2>&1; cat $O/trace1_timeline.txt; find $O/trace1 -name "*.csv" -size +2M -delete ;;
+    hv_sweep)     timeout 240 python3 tools/hv_sweep.py > $O/hv_sweep.jsonl 2> $O/hv_sweep.err; cat $O/hv_sweep.jsonl; tail -3 $O/hv_sweep.err ;;
+    hv_sweep_rccl) timeout 240 python3 tools/hv_sweep.py --rccl > $O/hv_sweep_rccl.jsonl 2> $O/hv_sweep_rccl.err; cat $O/hv_sweep_rccl.jsonl; tail -3 $O/hv_sweep_rccl.err ;;
+    trace2lb)     timeout 300 rocprofv3 --kernel-trace --hip-trace --output-format csv -d $O/trace2lb -o t -- python3 tools/slab_trace.py --mode 2 > $O/trace2lb.log 2>&1
+                  python3 tools/trace_tail.py $(find $O/trace2lb -name "*kernel_trace.csv" | head -1) 70 > $O/trace2lb_kernels.txt 2>&1; cat $O/trace2lb_kernels.txt
+                  python3 - <<PY > $O/trace2lb_hip_api.txt 2>&1
+import csv, glob, collections
+f = glob.glob("$O/trace2lb/**/*hip_api_trace.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+agg = collections.defaultdict(lambda: [0, 0])
+for r in rows[len(rows) // 2:]:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    agg[r["Function"]][0] += 1
+    agg[r["Function"]][1] += d
+for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:20]:
+    print(f"{k:40s} calls {n:6d}  total {t / 1e3:10.1f} us  mean {t / n / 1e3:8.2f} us")
+PY
+                  cat $O/trace2lb_hip_api.txt; find $O/trace2lb -name "*.csv" -size +3M -delete ;;
+    slab_tune)    : > $O/slab_tune.jsonl
+                  while read -r envs; do
+                    [ -z "$envs" ] && continue
+                    echo "{\"env\": \"$envs\", \"result\": $(env $envs timeout 200 python3 tools/slab_overhead.py --rccl --steps 60 --modes 2 2>/dev/null | grep "^{" | tail -1)}" >> $O/slab_tune.jsonl
+                  done < $R/tools/slab_tune_envs.txt
+                  python3 - <<PY
+import json
+for line in open("$O/slab_tune.jsonl"):
+    try:
+        d = json.loads(line)
+        r = d["result"]
+        print(f"{d['env']:70s} undecomposed {r['undecomposed_ms_per_step']:.4f}  loopback {r['slab_ms_per_step_overlap_2']:.4f}  rccl-self {r['slab_native_rccl_self_ms_per_step_overlap_2']:.4f}  ratio {r['slab_native_rccl_self_ms_per_step_overlap_2'] / r['undecomposed_ms_per_step']:.3f}")
+    except Exception as e:
+        print("bad line", line[:200], e)
+PY
+                  ;;
+    rows)         timeout 1500 python3 tools/secondary_rows.py $O/rows > $O/rows.log 2>&1; cat $O/rows.log | cut -c1-600 ;;
     *)            echo "unknown step $step" ;;
   esac
 done

@@ -169,7 +169,7 @@ struct wafer_ctx {
     wafer_halo_fn halo_hook = nullptr;
     wafer_allreduce_fn allreduce_hook = nullptr;
     void *hook_user = nullptr;
-    int overlap_mode = 1;   // wafer_set_overlap: 0 exchange after the pass, 1 boundary-first split pass, 2 single-launch half-slab pass
+    int overlap_mode = 2;   // wafer_set_overlap: 0 exchange after the pass, 1 boundary-first split pass, 2 single-launch half-slab pass
     WaferTuning tune;       // WAFER_* knobs, read once in wafer_ctx_create
     // three-step kernel: workgroup tables by launch shape (device copies), and the words of the single-launch slab pass
     struct F3Table {
@@ -178,12 +178,11 @@ struct wafer_ctx {
         int nblocks, nbump[2];
     };
     std::vector<F3Table> f3_tables;
-    unsigned long long *hv_cnt[2] = {nullptr, nullptr}; // finished workgroups per half: signal memory (hipStreamWaitValue64) or coherent host memory (gate kernel)
-    unsigned long long *hv_flag = nullptr;  // [2] exchanges completed per ghost side, written by the exchange stream
-    unsigned *hv_err = nullptr;             // set by a workgroup whose wait gave up
+    unsigned long long *hv_words = nullptr; // device memory, four 64-byte lines: cnt[0], cnt[1] (finished workgroups per half), flag[0], flag[1]
+                                            // (exchanges completed per ghost side, written by the exchange stream)
+    unsigned *hv_err = nullptr;             // host memory: set by a workgroup or gate kernel whose wait gave up
     unsigned long long hv_cnt_target[2] = {0, 0}, hv_flag_epoch[2] = {0, 0};
     int hv_first = 0;                       // which half the next single-launch pass dispatches first
-    bool hv_use_memops = false;             // the exchange stream waits / signals with stream memory operations (else: gate kernels)
     hipEvent_t ev_ex[2] = {nullptr, nullptr}; // single-launch pass: the last exchange of each side
     int halo_valid = 0; // ghost planes of phi[cur] (counted from the owned region) known to be current
     int halo_cycle = 1; // fused passes per halo exchange: the exchange moves 2R * halo_cycle planes (<= G), see wafer_evolve
@@ -214,6 +213,10 @@ static inline int nchunks_of(int nplanes, int zchunk) { return (nplanes + zchunk
 
 template <typename T>
 static inline T *as(void *p) { return static_cast<T *>(p); }
+
+// single-launch slab pass: a workgroup or gate kernel that gave up waiting leaves a word in host memory; every call
+// that has just synchronised with the device reports it (defined with the pass, below)
+static int check_hv_err(wafer_ctx *c);
 
 // Arrays are held as LOGICAL pointers to (plane 0, row 0); the allocation starts
 // base_off elements earlier (guard planes / rows, wafer_geom.h).
@@ -307,6 +310,7 @@ static int read_scal(wafer_ctx *c, int slot, int n, double *out, hipStream_t s)
     HIP_TRY(hipMemcpyAsync(c->scal_host + slot, c->scal + slot, sizeof(double) * n,
                            hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    TRY(check_hv_err(c));
     for (int q = 0; q < n; ++q) out[q] = c->scal_host[slot + q];
     return WAFER_OK;
 }
@@ -558,7 +562,10 @@ static int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const
         // passes later has completed
         const bool need_wait[2] = {true, true};
         const int ntiles = ntx * nty;
-        wafer_f3_schedule_halves(host, ntx, nty, lz_lo, lz_hi, lz_lo + (lz_hi - lz_lo) / 2, aux, need_wait, ntiles >= 64 ? ntiles / 16 : 0, 4);
+        const int nshort = c->tune.hv_short_tiles >= 0 ? c->tune.hv_short_tiles : (ntiles >= 64 ? ntiles / 16 : 0);
+        wafer_f3_schedule_halves(host, ntx, nty, lz_lo, lz_hi, lz_lo + (lz_hi - lz_lo) / 2, aux & 1, need_wait,
+                                 (c->tune.hv_debug & 8) ? 0 : nshort, c->tune.hv_nsub, 3 * c->g.R /* planes per exchange */, !(aux & 2),
+                                 c->tune.hv_debug, c->tune.hv_layout);
     }
     wafer_ctx::F3Table t{};
     t.kind = kind; t.lz_lo = lz_lo; t.lz_hi = lz_hi; t.aux = aux;
@@ -590,6 +597,7 @@ static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
     const WaferStepArgs a = step_args(c, lz_lo, lz_hi);
     const wafer_ctx::F3Table *tab = nullptr;
     if (short_tail && lz_hi - lz_lo >= 8 * 4) TRY(f3_table(c, F3_MIXED, lz_lo, lz_hi, 4, &tab));
+    else if (c->tune.f3_sched == 1 && !c->sharded() && lz_hi - lz_lo >= 16) TRY(f3_table(c, F3_HALVES, lz_lo, lz_hi, 2 /* no flags, no counters */, &tab));
     else TRY(f3_table(c, F3_PLAIN, lz_lo, lz_hi, wafer_f3_zchunk(c->tune, ntx, nty, lz_hi - lz_lo, c->num_cus), &tab));
     if (wafer_entry_step3_fused(c->tune, a, tab->dev, tab->nblocks, WaferF3Sync(), as<double>(c->phi[src]), as<double>(c->v),
                                 as<double>(c->phi[dst]), s) != hipSuccess)
@@ -835,7 +843,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->bx = (c->g.px + 63) / 64; // covers both the work area and the padded extent
     c->by = (c->g.py + 3) / 4;
     c->tune = wafer_tuning_from_env(); // the only place the WAFER_* tuning variables are read
-    c->overlap_mode = (c->tune.overlap >= 0 && c->tune.overlap <= 2) ? c->tune.overlap : 1; // the modes of wafer_set_overlap
+    c->overlap_mode = (c->tune.overlap >= 0 && c->tune.overlap <= 2) ? c->tune.overlap : 2; // the modes of wafer_set_overlap
     // fused passes per halo exchange: 1 unless the host asks for deep halos (wafer_set_halo_cycle) -- a
     // concentrated exchange outlasts the interior launch it hides behind on anything but a very fast link
     c->halo_cycle = std::max(1, c->tune.halo_cycle);
@@ -857,7 +865,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     { // boundary planes and their exchange go ahead of the interior update: highest priority
         int prio_lo = 0, prio_hi = 0;
         HIP_TRYC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIP_TRYC(hipStreamCreateWithPriority(&c->s_aux, hipStreamNonBlocking, prio_hi));
+        HIP_TRYC(hipStreamCreateWithPriority(&c->s_aux, hipStreamNonBlocking, (c->tune.hv_debug & 64) ? prio_lo : prio_hi));
     }
     HIP_TRYC(hipEventCreate(&c->ev_start));
     HIP_TRYC(hipEventCreate(&c->ev_stop));
@@ -901,9 +909,7 @@ int wafer_ctx_destroy(wafer_ctx *c)
     for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join, c->ev_bdry, c->ev_ex[0], c->ev_ex[1]})
         if (e) (void)hipEventDestroy(e);
     for (auto &t : c->f3_tables) (void)hipFree(t.dev);
-    for (int h = 0; h < 2; ++h)
-        if (c->hv_cnt[h]) (void)(c->hv_use_memops ? hipFree(c->hv_cnt[h]) : hipHostFree(c->hv_cnt[h]));
-    if (c->hv_flag) (void)hipHostFree(c->hv_flag);
+    if (c->hv_words) (void)hipFree(c->hv_words);
     if (c->hv_err) (void)hipHostFree(c->hv_err);
     if (c->s_own) (void)hipStreamDestroy(c->s_own);
     if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
@@ -917,7 +923,7 @@ int wafer_synchronize(wafer_ctx *c)
     HIP_TRY(hipSetDevice(c->P.device));
     HIP_TRY(hipStreamSynchronize(c->s_aux));
     HIP_TRY(hipStreamSynchronize(c->s_main));
-    return WAFER_OK;
+    return check_hv_err(c);
 }
 
 } // extern "C"
@@ -1311,11 +1317,12 @@ int wafer_download_phi_owned(wafer_ctx *c, double *out)
 // ghost planes an exchange fills are announced by flag[side], which the workgroups that read them poll just before their
 // first load of a ghost plane, i.e. near the END of their column.  No thin boundary launches, no event hops between the
 // streams, one pipeline fill more per tile than an undecomposed slab.
-__global__ void wafer_k_gate(const unsigned long long *cnt, unsigned long long target, unsigned *err)
+__global__ __launch_bounds__(64) void wafer_k_gate(const unsigned long long *cnt, unsigned long long target, unsigned *err)
 {
+    // one wave, a handful of registers: it shares a CU with a resident stencil workgroup (which leaves 8 VGPRs per SIMD)
     if (threadIdx.x == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(32);
             if (++spins > (1u << 25)) {
                 __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1324,52 +1331,37 @@ __global__ void wafer_k_gate(const unsigned long long *cnt, unsigned long long t
         }
     }
 }
-__global__ void wafer_k_post(unsigned long long *flag, unsigned long long value)
+__global__ __launch_bounds__(64) void wafer_k_post(unsigned long long *flag, unsigned long long value)
 {
-    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 static int ensure_hv(wafer_ctx *c)
 {
-    if (c->hv_flag) return WAFER_OK;
-    int can = 0;
-    (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->P.device);
-    c->hv_use_memops = can != 0 && c->tune.gate == 0;
-    // flags (written by the exchange stream, polled by workgroups) and the give-up word: host memory every agent sees
-    // coherently; counters: signal memory for hipStreamWaitValue64, else the same kind of memory for the gate kernel
-    HIP_TRY(hipHostMalloc((void **)&c->hv_flag, 2 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped));
+    if (c->hv_words) return WAFER_OK;
     HIP_TRY(hipHostMalloc((void **)&c->hv_err, 64, hipHostMallocCoherent | hipHostMallocMapped));
-    c->hv_flag[0] = c->hv_flag[1] = 0;
     *c->hv_err = 0;
-    for (int h = 0; h < 2; ++h) {
-        if (c->hv_use_memops) HIP_TRY(hipExtMallocWithFlags((void **)&c->hv_cnt[h], 8, hipMallocSignalMemory));
-        else HIP_TRY(hipHostMalloc((void **)&c->hv_cnt[h], 64, hipHostMallocCoherent | hipHostMallocMapped));
-        *c->hv_cnt[h] = 0;
-    }
+    HIP_TRY(hipMalloc((void **)&c->hv_words, 4 * 64));
+    HIP_TRY(hipMemset(c->hv_words, 0, 4 * 64));
     return WAFER_OK;
 }
+static unsigned long long *hv_cnt(wafer_ctx *c, int half) { return c->hv_words + half * WAFER_F3_SYNC_STRIDE; }
+static unsigned long long *hv_flag(wafer_ctx *c, int side) { return c->hv_words + (2 + side) * WAFER_F3_SYNC_STRIDE; }
 
 // exchange stream: wait until every workgroup of `half` of the current launch has finished
 static int hv_gate(wafer_ctx *c, int half)
 {
-    if (c->hv_use_memops) {
-        HIP_TRY(hipStreamWaitValue64(c->s_aux, c->hv_cnt[half], c->hv_cnt_target[half], hipStreamWaitValueGte, ~0ull));
-    } else {
-        hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, c->s_aux, c->hv_cnt[half], c->hv_cnt_target[half], c->hv_err);
-        HIP_TRY(hipGetLastError());
-    }
+    hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, c->s_aux, hv_cnt(c, half), c->hv_cnt_target[half], c->hv_err);
+    HIP_TRY(hipGetLastError());
     return WAFER_OK;
 }
-// exchange stream: ghost side g has been filled once more
+// exchange stream: ghost side g has been filled once more (in stream order behind the exchange: its kernels have
+// completed, their writes are visible device-wide)
 static int hv_post(wafer_ctx *c, int g)
 {
     const unsigned long long v = ++c->hv_flag_epoch[g];
-    if (c->hv_use_memops) {
-        HIP_TRY(hipStreamWriteValue64(c->s_aux, c->hv_flag + g, v, 0));
-    } else {
-        hipLaunchKernelGGL(wafer_k_post, dim3(1), dim3(64), 0, c->s_aux, c->hv_flag + g, v);
-        HIP_TRY(hipGetLastError());
-    }
+    hipLaunchKernelGGL(wafer_k_post, dim3(1), dim3(64), 0, c->s_aux, hv_flag(c, g), v);
+    HIP_TRY(hipGetLastError());
     return WAFER_OK;
 }
 
@@ -1393,12 +1385,12 @@ static int launch_halves_pass(wafer_ctx *c, int src, int dst, int E)
     const wafer_ctx::F3Table *tab = nullptr;
     TRY(f3_table(c, F3_HALVES, lo, hi, first, &tab));
     WaferF3Sync sy;
-    sy.cnt[0] = c->hv_cnt[0];
-    sy.cnt[1] = c->hv_cnt[1];
-    sy.flag = c->hv_flag;
+    sy.cnt = hv_cnt(c, 0);
+    sy.flag = hv_flag(c, 0);
     sy.need[0] = c->hv_flag_epoch[0];   // every exchange enqueued so far
     sy.need[1] = c->hv_flag_epoch[1];
     sy.err = c->hv_err;
+    sy.debug = c->tune.hv_debug;
     const WaferStepArgs a = step_args(c, lo, hi);
     if (wafer_entry_step3_fused(c->tune, a, tab->dev, tab->nblocks, sy, as<double>(c->phi[src]), as<double>(c->v), as<double>(c->phi[dst]),
                                 c->s_main) != hipSuccess)
@@ -1407,7 +1399,7 @@ static int launch_halves_pass(wafer_ctx *c, int src, int dst, int E)
     c->hv_cnt_target[1] += (unsigned long long)tab->nbump[1];
     for (int i = 0; i < 2; ++i) {
         const int half = (first + i) & 1;
-        TRY(hv_gate(c, half));
+        if (!(c->tune.hv_debug & 32)) TRY(hv_gate(c, half));
         // a half thinner than the exchange depth: its side's boundary planes reach into the other half
         if ((half == 0 ? mid - lo : hi - mid) < E) TRY(hv_gate(c, half ^ 1));
         // side 0: the lowest owned planes go down, the upper ghost planes are filled (read by half B); side 1: the mirror image
@@ -1590,6 +1582,7 @@ int wafer_last_evolve_ms(wafer_ctx *c, float *ms, uint64_t *steps)
     if (!c->timing_valid) return fail(WAFER_ERR_STATE, "no evolve call to time");
     HIP_TRY(hipSetDevice(c->P.device));
     HIP_TRY(hipEventSynchronize(c->ev_stop));
+    TRY(check_hv_err(c));
     HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
     if (steps) *steps = c->last_steps;
     return WAFER_OK;

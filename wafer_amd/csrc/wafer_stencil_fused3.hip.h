@@ -73,35 +73,44 @@ struct WaferF3Block {
     int tile;        // ty * ntx + tx
     int zs, ze;      // output planes [zs, ze) (local plane indices)
     int down;        // 1: march from ze-1 down to zs
-    int wait_start;  // >= 0: wait for ghost flag [wait_start] before the prologue (its loads touch ghost planes)
     int wait_late;   // >= 0: wait for ghost flag [wait_late] at the top of iteration wait_it (the first prefetch of a ghost plane)
     int wait_it;
     int bump;        // >= 0: add 1 to completion counter [bump] after the last store
+    int wt;          // with bump: the last wt planes of the march are what the exchange sends: stored write-through
 };
 
-// Device words of the single-launch slab pass.  flag[i] is written by the exchange stream after the exchange that
-// fills ghost side i (0: lower ghost planes, 1: upper) has completed; need[i] is the value the blocks of THIS launch
-// wait for.  cnt[i] counts finished workgroups of half i; the exchange stream waits for it.  *err is set when a wait
-// gives up (a bounded spin: the host reports WAFER_ERR_COMM instead of hanging).
+// Device words of the single-launch slab pass, all in device memory and accessed at agent scope (relaxed atomics; the
+// payload is ordered by one release fence before a count and one acquire fence after a poll -- MI355X_MICROARCH.md,
+// "Workgroup dispatch, XCD placement & inter-workgroup visibility").  cnt[i] counts finished workgroups of half i; a
+// one-wave gate kernel on the exchange stream polls it.  flag[i] is written by a one-wave kernel on the exchange
+// stream after the exchange that fills ghost side i (0: lower ghost planes, 1: upper) has completed; need[i] is the
+// value the workgroups of THIS launch wait for.  *err (host memory) is set when a wait gives up (a bounded spin:
+// the host reports WAFER_ERR_COMM instead of hanging).
+// (Counters in host / signal memory -- what hipStreamWaitValue64 needs -- were measured first: a round of 256
+//  workgroups ends within microseconds, their 256 system-scope atomics queue up on the host link and every CU idles
+//  until its own has returned: 0.51 against 0.30 ms/step at the bench slab.)
 struct WaferF3Sync {
-    unsigned long long *cnt[2] = {nullptr, nullptr};   // (signal memory comes one 8-byte word per allocation)
-    const unsigned long long *flag = nullptr;
+    unsigned long long *cnt = nullptr;          // [0], [8]: one 64-byte line each
+    const unsigned long long *flag = nullptr;   // [0], [8]
     unsigned long long need[2] = {0, 0};
     unsigned *err = nullptr;
+    int debug = 0;   // WAFER_HV_DEBUG bit 4: no acquire fence (timing experiments)
 };
+enum { WAFER_F3_SYNC_STRIDE = 8 }; // 64-bit words between the two counters / flags
 
 __device__ __forceinline__ void wafer_f3_wait(const WaferF3Sync &sy, int idx, int tid)
 {
     if (tid == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(sy.flag + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < sy.need[idx]) {
-            __builtin_amdgcn_s_sleep(64);
-            if (++spins > (1u << 24)) { // seconds: the exchange never arrived
+        while (__hip_atomic_load(sy.flag + idx * WAFER_F3_SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.need[idx]) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1u << 25)) { // tens of seconds: the exchange never arrived
                 __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // system scope: the ghost planes were written by another kernel, possibly of another device
+        // system scope: the ghost planes were written by another kernel, possibly (through the fabric) of another device
+        if (!(sy.debug & 4)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -206,8 +215,6 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         wafer_ab_from_v<C>(vv, dt, vir, ca, cb);
         return (T)wafer_update<C>(w, ca, cb, dt, S, den);
     };
-
-    if (blk.wait_start >= 0) wafer_f3_wait(sy, blk.wait_start, tid);
 
     // ---- prologue: the first phi1 plane is z1 (two planes before the first output plane in marching order); the
     //      phi0 queue holds planes z1-SD, z1, z1+SD
@@ -382,9 +389,14 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                     if (INTERIOR || lvl2[r]) *reinterpret_cast<VT *>(w2 + (yrow[r] - (y0 - 1)) * LP2 + HX2 + xl) = res;
                 }
             };
-            if (is_main && all_rows && wplane2) level2(std::true_type{}, std::true_type{});
-            else if (is_main) level2(std::false_type{}, std::true_type{});
-            else level2(std::false_type{}, std::false_type{});
+            // (phi2 is needed on planes zs-1 .. ze: the first two iterations of a column produce planes outside that range --
+            //  zeros are as good there, level 3 never reads them)
+            const int zp2 = z - SD;
+            if (zp2 >= zs - 1 && zp2 <= ze) {
+                if (is_main && all_rows && wplane2) level2(std::true_type{}, std::true_type{});
+                else if (is_main) level2(std::false_type{}, std::true_type{});
+                else level2(std::false_type{}, std::false_type{});
+            }
             // ---- 5. level 3 (main waves): phi3 two planes behind from the phi2 queue, stored
             if (is_main) {
 #pragma unroll
@@ -394,6 +406,8 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                     q2[2][r] = p2new[r];
                 }
                 const int zo3 = z - 2 * SD;
+                // the planes the exchange sends once this workgroup has counted itself done: the last `wt` planes of the march
+                const bool wthrough = blk.bump >= 0 && (DOWN ? zo3 < zs + blk.wt : zo3 >= ze - blk.wt);
                 if (zo3 >= zs && zo3 < ze) {
                     auto level3 = [&](auto interior_tag) {
                         constexpr bool INTERIOR = decltype(interior_tag)::value;
@@ -422,7 +436,14 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                         for (int r = 0; r < RY; ++r) {
                             if (INTERIOR || rowwk[r]) {
                                 T *dst = (out + (long long)zo3 * g.plane + rowoff[r]) + xlu;
-                                if (INTERIOR || xi + VEC <= g.nx) {
+                                if (wthrough) {
+                                    // a plane the exchange will send: write-through stores (agent-scope relaxed atomics: sc1), so
+                                    // that the count after them needs no cache write-back (MI355X_MICROARCH.md, valid forms: sc1
+                                    // payload, every storing wave's vmcnt(0), the workgroup's barrier, then the counter)
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v)
+                                        if (INTERIOR || xi + v < g.nx) __hip_atomic_store(dst + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                } else if (INTERIOR || xi + VEC <= g.nx) {
                                     *reinterpret_cast<VT *>(dst) = res3[r];
                                 } else {
 #pragma unroll
@@ -467,7 +488,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             for (int q = 0; q < Cfg::CPL; ++q) {
                 if (c_l2[q]) {
                     T rs = T(0);
-                    if (wplane2 && c_wk[q]) {
+                    if (wplane2 && c_wk[q] && (z - SD) >= zs - 1 && (z - SD) <= ze) {
                         const int o1 = c_lds1[q];
                         const C w = (C)q1[1][q / VEC][q % VEC];
                         C xs[3], ys[3], zz[3];
@@ -496,15 +517,13 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         orow_nxt = orow_pre;
     }
     // ---- completion counter of the single-launch slab pass: every storing wave drains its stores, the workgroup
-    //      meets, one lane releases at system scope (the reader is another kernel: the exchange) and counts
+    //      meets, one lane counts
     if (blk.bump >= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(blk.bump ? sy.cnt[1] : sy.cnt[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        // (the planes the exchange reads were stored write-through; a half thinner than the exchange depth also sends planes
+        //  of the other half's workgroups, whose own write-through planes cover them: wt = the whole piece there)
+        if (tid == 0) __hip_atomic_fetch_add(sy.cnt + blk.bump * WAFER_F3_SYNC_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -547,8 +566,8 @@ static inline void wafer_f3_schedule_plain(std::vector<WaferF3Block> &out, int n
         k.zs = lz_lo + (id / (ntx * nty)) * zchunk;
         k.ze = k.zs + zchunk < lz_hi ? k.zs + zchunk : lz_hi;
         k.down = 0;
-        k.wait_start = k.wait_late = k.bump = -1;
-        k.wait_it = 0;
+        k.wait_late = k.bump = -1;
+        k.wait_it = k.wt = 0;
         out[(size_t)b] = k;
     }
 }
@@ -564,8 +583,8 @@ static inline void wafer_f3_schedule_mixed(std::vector<WaferF3Block> &out, int n
     auto push = [&](int tile, int zs, int ze) {
         WaferF3Block k{};
         k.tile = tile; k.zs = zs; k.ze = ze; k.down = 0;
-        k.wait_start = k.wait_late = k.bump = -1;
-        k.wait_it = 0;
+        k.wait_late = k.bump = -1;
+        k.wait_it = k.wt = 0;
         out.push_back(k);
     };
     for (int t = 0; t < nlong; ++t) push(t, lz_lo, lz_hi);
@@ -587,24 +606,28 @@ static inline void wafer_f3_schedule_mixed(std::vector<WaferF3Block> &out, int n
 // `nsub` short workgroups: dispatched at the head of the SECOND half they retire soon after the first half's exchange has
 // been released and hand it their CUs (the exchange's workgroups cannot share a CU with a stencil workgroup).
 static inline void wafer_f3_schedule_halves(std::vector<WaferF3Block> &out, int ntx, int nty, int lo, int hi, int mid, int first,
-                                            const bool need_wait[2], int nshort_tiles, int nsub)
+                                            const bool need_wait[2], int nshort_tiles, int nsub, int depth, bool sync = true, int debug = 0, int layout = 0)
 {
     const int ntiles = ntx * nty;
     out.clear();
-    auto push = [&](int half, int tile, int zs, int ze) {
+    auto push = [&](int half, int tile_, int zs, int ze) {
         WaferF3Block k{};
+        const int tile = (debug & 16) ? wafer_f3_xcd_slot(tile_, ntiles) : tile_;
         k.tile = tile; k.zs = zs; k.ze = ze;
         k.down = half == 0;
-        k.wait_start = k.wait_late = -1;
-        k.wait_it = 0;
-        k.bump = half;
+        k.wait_late = k.bump = -1;
+        k.wait_it = k.wt = 0;
+        if (!sync) { out.push_back(k); return; }
+        // only the piece that stores the half's boundary planes counts itself done: that is what the exchange waits for
+        const bool at_boundary = half == 0 ? zs == lo : ze == hi;
+        // (a half thinner than the exchange depth: its side's planes reach into the other half, so every plane of both is
+        //  stored write-through and the host waits for both counters)
+        const bool thin = mid - lo < depth || hi - mid < depth;
+        if (at_boundary && !(debug & 32)) { k.bump = half; k.wt = (thin || depth > ze - zs) ? ze - zs : depth; }
         // The first load that touches a ghost plane is the phi0 prefetch two planes ahead: half A (z = ze + 1 - it going
         // down) reaches plane lo - 1 at it = ze - lo; half B (z = zs - 2 + it going up) reaches plane hi at it = hi - zs.
         // The prologue stays within three planes of the piece's start, which lies on the side of the cut.
-        if (need_wait[half]) {
-            if (half == 0 && zs == lo) { k.wait_late = 0; k.wait_it = ze - lo; }
-            if (half == 1 && ze == hi) { k.wait_late = 1; k.wait_it = hi - zs; }
-        }
+        if (at_boundary && need_wait[half]) { k.wait_late = half; k.wait_it = half == 0 ? ze - lo : hi - zs; }
         out.push_back(k);
     };
     auto column = [&](int half, int tile, int pieces) {
@@ -619,12 +642,18 @@ static inline void wafer_f3_schedule_halves(std::vector<WaferF3Block> &out, int 
             if (zs < ze) push(half, tile, zs, ze);
         }
     };
-    const int nlong = ntiles - (nshort_tiles < ntiles ? nshort_tiles : 0);
+    const int ns = nshort_tiles < ntiles ? nshort_tiles : 0, nlong = ntiles - ns;
     for (int i = 0; i < 2; ++i) {
         const int half = (first + i) & 1;
-        if (i == 1) for (int t = nlong; t < ntiles; ++t) column(half, t, nsub); // short columns at the head of the second half
-        for (int t = 0; t < nlong; ++t) column(half, t, 1);
-        if (i == 0) for (int t = nlong; t < ntiles; ++t) column(half, t, nsub);
+        // layout 0: the short columns sit between the halves' long ones (tail of the first half, head of the second);
+        // layout 1: the second half's short columns are split between its head (CUs for the exchange) and its tail
+        // (the kernel's last round evens out)
+        // layout 2: only the second half has short columns, at its head
+        const int head = i == 0 ? 0 : (layout == 1 ? ns / 2 : ns);
+        const int nl = (layout == 2 && i == 0) ? ntiles : nlong;
+        for (int t = nl; t < nl + head && t < ntiles; ++t) column(half, t, nsub);
+        for (int t = 0; t < nl; ++t) column(half, t, 1);
+        for (int t = nl + head; t < ntiles; ++t) column(half, t, nsub);
     }
 }
 

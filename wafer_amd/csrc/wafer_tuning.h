@@ -37,7 +37,13 @@ struct WaferTuning {
     // z-slabs
     int overlap = -1;       // WAFER_OVERLAP: initial wafer_set_overlap mode (-1: default)
     int halo_cycle = 1;     // WAFER_HALO_CYCLE
-    int gate = 0;           // WAFER_GATE: how the single-launch pass releases its exchanges (0: stream memory operations, 1: gate kernels)
+    int hv_debug = 0;       // WAFER_HV_DEBUG: experiments on the single-launch pass (bits: 4 no acquire fence
+                            // (timing only), 8 no short pieces, 16 XCD-contiguous tile order inside each half, 32 no counters / gates (timing only),
+                            // 64 exchange stream at normal priority)
+    int hv_short_tiles = -1; // WAFER_HV_SHORT_TILES: tiles per half cut into short pieces (-1: 1/16 of the tiles)
+    int hv_nsub = 4;        // WAFER_HV_NSUB: pieces per short column
+    int hv_layout = 0;      // WAFER_HV_LAYOUT: where the short columns go (wafer_f3_schedule_halves)
+    int f3_sched = 0;       // WAFER_F3_SCHED: 1 = undecomposed launches use the two-halves schedule as well (timing experiments)
 };
 
 static inline int wafer_env_int(const char *name, int dflt)
@@ -73,6 +79,10 @@ static inline WaferTuning wafer_tuning_from_env()
     t.stencil_variant = wafer_env_int("WAFER_STENCIL_VARIANT", t.stencil_variant);
     t.overlap = wafer_env_int("WAFER_OVERLAP", t.overlap);
     t.halo_cycle = wafer_env_int("WAFER_HALO_CYCLE", t.halo_cycle);
-    t.gate = wafer_env_int("WAFER_GATE", t.gate);
+    t.hv_debug = wafer_env_int("WAFER_HV_DEBUG", t.hv_debug);
+    t.f3_sched = wafer_env_int("WAFER_F3_SCHED", t.f3_sched);
+    t.hv_short_tiles = wafer_env_int("WAFER_HV_SHORT_TILES", t.hv_short_tiles);
+    t.hv_nsub = wafer_env_int("WAFER_HV_NSUB", t.hv_nsub);
+    t.hv_layout = wafer_env_int("WAFER_HV_LAYOUT", t.hv_layout);
     return t;
 }
