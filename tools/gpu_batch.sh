@@ -10,6 +10,7 @@ for step in "$@"; do
   echo "=== $step ($(date +%T))"
   case $step in
     tests)        timeout 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; tail -5 $O/tests.log ;;
+    tests_cfg)    timeout 1200 python -m pytest tests/test_gpu_configs.py -x -q > $O/tests_cfg.log 2>&1; tail -5 $O/tests_cfg.log ;;
     tests_slab)   timeout 600 python -m pytest tests/test_gpu_slab.py -x -q > $O/tests_slab.log 2>&1; tail -5 $O/tests_slab.log ;;
     bench)        timeout 600 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-300 $O/bench_n1.json ;;
     bench_short)  timeout 600 python3 bench.py --steps 20 --warmup 5 > $O/bench_n1_short.json 2> $O/bench_n1_short.err; cut -c1-300 $O/bench_n1_short.json ;;

@@ -26,14 +26,28 @@ def parse_cfg(s):
     return d
 
 
-def apply_cfg(ctx, cfg):
-    ctx.set_stencil_variant(int(cfg.get("v", -1)))
-    for env, key in (("WAFER_ZCHUNK", "zchunk"), ("WAFER_TARGET_BLOCKS", "blocks"), ("WAFER_LDS_RY", "ry"),
-                     ("WAFER_XCD_SWIZZLE", "xcd"), ("WAFER_NT", "nt"), ("WAFER_LDS_PAD", "pad"), ("WAFER_ABV", "abv"), ("WAFER_F2_NW2", "nw2"), ("WAFER_F3_OPT", "f3opt"), ("WAFER_F2_YREG", "f2yreg"), ("WAFER_VGEN", "vgen"), ("WAFER_XF_NW", "xfnw"), ("WAFER_XF_DEEP", "deep"), ("WAFER_SEVEN_VG", "s8vg"), ("WAFER_LDS_NW", "nw")):
+ENV_KEYS = (("WAFER_ZCHUNK", "zchunk"), ("WAFER_TARGET_BLOCKS", "blocks"), ("WAFER_LDS_RY", "ry"), ("WAFER_XCD_SWIZZLE", "xcd"),
+            ("WAFER_NT", "nt"), ("WAFER_LDS_PAD", "pad"), ("WAFER_ABV", "abv"), ("WAFER_F2_NW2", "nw2"),
+            ("WAFER_F2_YREG", "f2yreg"), ("WAFER_VGEN", "vgen"), ("WAFER_XF_NW", "xfnw"), ("WAFER_XF_DEEP", "deep"),
+            ("WAFER_SEVEN_VG", "s8vg"), ("WAFER_LDS_NW", "nw"), ("WAFER_F3_SCHED", "sched"))
+
+
+def make_ctx(par, cfg, args):
+    """the tuning variables are read once, when a context is created (wafer_tuning.h): one context per configuration"""
+    for env, key in ENV_KEYS:
         if key in cfg:
             os.environ[env] = cfg[key]
         else:
             os.environ.pop(env, None)
+    ctx = wafer_amd.Context(par)
+    ctx.set_stencil_variant(int(cfg.get("v", -1)))
+    ctx.set_potential(args.potential)
+    for i in range(args.wnum):
+        ctx.set_initial_condition("Gaussian", seed=i + 1)
+        ctx.normalise(ctx.norm2())
+        ctx.push_state()
+    ctx.set_initial_condition("Boolean")
+    return ctx
 
 
 def main():
@@ -55,25 +69,20 @@ def main():
     par = wafer_amd.Params(nx, ny, nz, dn=args.dn, dt=args.dt, mass=args.mass, sig=args.sig,
                            central_difference=args.cd, dtype=args.dtype, max_states=max(1, args.wnum))
     bpu = {"f64": 32, "f32": 16, "f32fast": 16}[args.dtype]
-    with wafer_amd.Context(par) as ctx:
-        ctx.set_potential(args.potential)
-        ctx.set_initial_condition("Boolean")
-        for i in range(args.wnum):
-            ctx.set_initial_condition("Gaussian", seed=i + 1)
-            ctx.normalise(ctx.norm2())
-            ctx.push_state()
-        ctx.set_initial_condition("Boolean")
+    if True:
         cfgs = [parse_cfg(s) for s in args.configs]
+        ctxs = [make_ctx(par, cfg, args) for cfg in cfgs]
         times = [[] for _ in cfgs]
         for r in range(args.rounds + 1):
-            for i, cfg in enumerate(cfgs):
-                apply_cfg(ctx, cfg)
+            for i, ctx in enumerate(ctxs):
                 ctx.evolve(args.wnum, args.steps)
                 ms, steps = ctx.last_evolve_ms()
                 if r > 0:  # round 0 is warm-up
                     times[i].append(ms / steps)
-            if args.wnum == 0:
-                ctx.set_initial_condition("Boolean")  # keep values in range over long sweeps
+                if args.wnum == 0:
+                    ctx.set_initial_condition("Boolean")  # keep values in range over long sweeps
+        for ctx in ctxs:
+            ctx.close()
         pts = nx * ny * nz
         for s, t in zip(args.configs, times):
             med, mn = statistics.median(t), min(t)
