@@ -24,6 +24,11 @@ int wafer_rccl_attach(wafer_ctx *ctx, int rank, int world, const void *unique_id
 /* one small exchange and all-reduce so that channel set-up is outside any timed step;
  * scratch: >= 4 KiB of device memory, stream: any stream of the device */
 int wafer_rccl_warm_up(void *handle, void *scratch, void *stream);
+/* from now on the all-reduce hook is served by a connected wafer_mailbox (wafer_mailbox.h: device-side, no RCCL kernel on
+ * the critical path of an excited-state step); NULL restores ncclAllReduce */
+int wafer_rccl_use_mailbox(void *handle, void *mailbox);
+/* one in-place all-reduce of `count` doubles through whatever serves the hook (mailbox or ncclAllReduce), enqueued on stream */
+int wafer_rccl_allreduce_now(void *handle, void *dev_ptr, size_t count, void *stream);
 long wafer_rccl_halo_calls(void *handle);
 /* ncclCommCount, ncclCommUserRank, the z-neighbour ranks in use (-1 = none), ncclGetVersion */
 int wafer_rccl_comm_info(void *handle, int *nranks, int *rank, int *lower, int *upper, int *version);

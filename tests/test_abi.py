@@ -82,7 +82,7 @@ def test_rccl_hook_library_exports_its_header():
     lib = C.CDLL(build.RCCL_LIB)
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "wafer_rccl.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(wafer_rccl_[a-z0-9_]+)\s*\(", text)))
-    assert len(names) == 8
+    assert len(names) == 10
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/wafer_rccl.h but not exported"
     lib.wafer_rccl_unique_id_bytes.restype = C.c_int
@@ -126,3 +126,18 @@ def test_bench_bare_multi_gpu_call_refuses_without_the_devices():
 def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = _bench("--gpus", "8", "--steps", "4", "--warmup", "0", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     assert r.returncode == 2 and r.stdout.strip() == "" and "WORLD_SIZE=2" in r.stderr
+
+
+def test_mailbox_header_is_exported(lib):
+    """include/wafer_mailbox.h <-> libwafer_hip.so: every declared entry point is there (no compute calls without a GPU)"""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "wafer_mailbox.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(wafer_mailbox_[a-z0-9_]+)\s*\(", text)))
+    assert names == ["wafer_mailbox_allreduce", "wafer_mailbox_check", "wafer_mailbox_connect", "wafer_mailbox_create",
+                     "wafer_mailbox_destroy", "wafer_mailbox_handle"]
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/wafer_mailbox.h but not exported"
+    import torch
+    if not torch.cuda.is_available():   # no device: creation fails loudly, nothing is allocated
+        h = C.c_void_p()
+        assert lib.wafer_mailbox_create(0, 1, 0, C.byref(h)) != 0
+        assert lib.wafer_mailbox_create(0, 99, 0, C.byref(h)) != 0

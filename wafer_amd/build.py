@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libwafer_hip.so")
 # One translation unit per kernel family (wafer_launch.h): they compile in parallel and an edit to one kernel
 # rebuilds one unit.  The engine unit holds the host logic and the small elementwise / set-up kernels.
 SOURCES = ["wafer_engine.hip", "wafer_tu_lds.hip", "wafer_tu_excited_r1.hip", "wafer_tu_excited_r2.hip", "wafer_tu_excited_r3.hip",
-           "wafer_tu_fused2.hip", "wafer_tu_fused3.hip"]
+           "wafer_tu_fused2.hip", "wafer_tu_fused3.hip", "wafer_mailbox.hip"]
 HEADERS = ["wafer_geom.h", "wafer_tuning.h", "wafer_launch.h", "wafer_stencil.hip.h", "wafer_stencil_lds.hip.h",
            "wafer_stencil_fused2.hip.h", "wafer_stencil_fused3.hip.h", "wafer_elementwise.hip.h", "wafer_setup.hip.h",
            "wafer_tu_excited.inc"]
@@ -80,7 +80,7 @@ RCCL_LIB = os.path.join(HERE, "libwafer_rccl.so")
 def build_rccl_lib(force: bool = False, verbose: bool = False) -> str:
     """libwafer_rccl.so: the RCCL hooks for hosts that are not C++ (wafer_rccl_lib.cpp)."""
     srcs = [os.path.join(CSRC, "wafer_rccl_lib.cpp"), os.path.join(CSRC, "wafer_rccl_hooks.h"),
-            os.path.join(os.path.dirname(HERE), "include", "wafer_rccl.h")]
+            os.path.join(os.path.dirname(HERE), "include", "wafer_rccl.h"), os.path.join(os.path.dirname(HERE), "include", "wafer_mailbox.h")]
     if not force and os.path.exists(RCCL_LIB) and os.path.getmtime(RCCL_LIB) > max([os.path.getmtime(x) for x in srcs] + [os.path.getmtime(LIB)]):
         return RCCL_LIB
     cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", srcs[0], "-o", RCCL_LIB, "-L", HERE, "-lwafer_hip", "-lrccl",

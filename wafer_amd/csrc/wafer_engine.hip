@@ -47,6 +47,9 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// (other translation units of the library report through the same thread-local message: wafer_mailbox.hip)
+void wafer_set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
+
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include "../../include/wafer_mailbox.h"
+
 // RCCL's send / recv kernels take whole CUs away from the stencil for as long as the links are busy
 // (their workgroups cannot share a CU with a stencil workgroup) and RCCL launches 64 of them by
 // default for the four transfers of a pass.  Eight channels still move two 1024^2 planes faster than
@@ -21,6 +23,9 @@ struct WaferRcclFabric {
     ncclComm_t comm = nullptr;
     int lower = -1, upper = -1; // z-neighbour ranks, -1 = the global Dirichlet frame
     long halo_calls = 0, reduce_calls = 0;
+    // optional: the device-side all-reduce of libwafer_hip.so (include/wafer_mailbox.h) for the path's few doubles;
+    // ncclAllReduce stays the default and serves whatever the mailbox does not take
+    wafer_mailbox *mailbox = nullptr;
 };
 
 static inline int wafer_rccl_halo(void *user, void *send_lo, void *send_hi, void *recv_lo, void *recv_hi, size_t bytes,
@@ -44,5 +49,6 @@ static inline int wafer_rccl_allreduce(void *user, void *dev_ptr, size_t count, 
 {
     WaferRcclFabric *f = static_cast<WaferRcclFabric *>(user);
     ++f->reduce_calls;
+    if (f->mailbox && count <= WAFER_MAILBOX_MAX_COUNT) return wafer_mailbox_allreduce(f->mailbox, dev_ptr, count, stream);
     return ncclAllReduce(dev_ptr, dev_ptr, count, ncclDouble, ncclSum, f->comm, static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : 1;
 }

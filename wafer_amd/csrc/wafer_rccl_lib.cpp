@@ -66,6 +66,23 @@ int wafer_rccl_warm_up(void *handle, void *scratch, void *stream)
     return hipStreamSynchronize(static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : 1;
 }
 
+// the all-reduce hook served by a connected wafer_mailbox (include/wafer_mailbox.h) from now on; NULL: back to ncclAllReduce
+int wafer_rccl_use_mailbox(void *handle, void *mailbox)
+{
+    WaferRcclFabric *f = static_cast<WaferRcclFabric *>(handle);
+    if (!f) { g_err = "null handle"; return 1; }
+    f->mailbox = static_cast<wafer_mailbox *>(mailbox);
+    return 0;
+}
+
+// one all-reduce through the hook the handle serves (mailbox if one is in use, else ncclAllReduce): for hosts that need
+// a sum of their own on the same fabric, and for timing the two paths (tools/allreduce_latency.py)
+int wafer_rccl_allreduce_now(void *handle, void *dev_ptr, size_t count, void *stream)
+{
+    if (!handle) { g_err = "null handle"; return 1; }
+    return wafer_rccl_allreduce(handle, dev_ptr, count, stream);
+}
+
 long wafer_rccl_halo_calls(void *handle) { return static_cast<WaferRcclFabric *>(handle)->halo_calls; }
 
 // what RCCL itself says about the communicator: ncclCommCount / ncclCommUserRank, the z-neighbours in

@@ -157,6 +157,56 @@ class TorchSlabComm(SlabComm):
         return 0
 
 
+class MailboxAllReduce:
+    """include/wafer_mailbox.h through ctypes: the device-side all-reduce of libwafer_hip.so -- every rank's mailbox
+    mapped into every other rank through HIP IPC, one one-wave kernel per call, sums in rank order (the same bits on
+    every rank).  The IPC handles are gathered with torch.distributed (any backend).  Serves the all-reduce hook of
+    any of the comm classes below (`mailbox=True`); RCCL's ncclAllReduce stays the default."""
+
+    def __init__(self, rank: int, world: int, device_index: int, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from .engine import load_library
+        self._L = L = load_library()
+        L.wafer_mailbox_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.wafer_mailbox_handle.argtypes = [C.c_void_p, C.c_void_p]
+        L.wafer_mailbox_connect.argtypes = [C.c_void_p, C.c_void_p]
+        L.wafer_mailbox_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.wafer_mailbox_check.argtypes = [C.c_void_p]
+        L.wafer_mailbox_destroy.argtypes = [C.c_void_p]
+        L.wafer_last_error.restype = C.c_char_p
+        self._mb = C.c_void_p()
+        if L.wafer_mailbox_create(rank, world, device_index, C.byref(self._mb)) != 0:
+            raise RuntimeError(L.wafer_last_error().decode())
+        h = C.create_string_buffer(64)
+        if L.wafer_mailbox_handle(self._mb, h) != 0:
+            raise RuntimeError(L.wafer_last_error().decode())
+        handles = [None] * world
+        if world > 1:
+            dist.all_gather_object(handles, h.raw, group=group)
+        else:
+            handles = [h.raw]
+        blob = C.create_string_buffer(b"".join(handles), 64 * world)
+        if L.wafer_mailbox_connect(self._mb, blob) != 0:
+            raise RuntimeError(L.wafer_last_error().decode())
+
+    @property
+    def handle(self):
+        return self._mb
+
+    def allreduce(self, ptr: int, count: int, stream: int) -> int:
+        return int(self._L.wafer_mailbox_allreduce(self._mb, ptr, count, stream))
+
+    def check(self):
+        if self._L.wafer_mailbox_check(self._mb) != 0:
+            raise RuntimeError(self._L.wafer_last_error().decode())
+
+    def close(self):
+        if self._mb:
+            self._L.wafer_mailbox_destroy(self._mb)
+            self._mb = None
+
+
 class HostStagedSlabComm(TorchSlabComm):
     """The same hooks over a CPU process group (gloo): halo planes and scalars are
     staged through host buffers (plain pageable tensors and blocking copies:
@@ -167,9 +217,11 @@ class HostStagedSlabComm(TorchSlabComm):
     device.  The engine's arithmetic is untouched: only bytes move differently.
     """
 
-    def __init__(self, ctx, rank: int, world: int, device, group=None):
+    def __init__(self, ctx, rank: int, world: int, device, group=None, mailbox: bool = False):
         super().__init__(ctx, rank, world, device, group)
         self._host = {}
+        # the all-reduce hook served on the device (wafer_mailbox.h) instead of through host staging
+        self.mailbox = MailboxAllReduce(rank, world, device.index or 0, group) if mailbox else None
 
     def warm_up(self):
         torch = self.torch
@@ -207,6 +259,8 @@ class HostStagedSlabComm(TorchSlabComm):
         return 0
 
     def _allreduce_hook(self, ptr, count, stream):
+        if self.mailbox is not None:
+            return self.mailbox.allreduce(ptr, count, stream)
         torch = self.torch
         st = self._stream(stream)
         with torch.cuda.stream(st):
@@ -261,7 +315,8 @@ class NativeRcclSlabComm:
             raise RuntimeError("wafer_rccl_unique_id: " + L.wafer_rccl_last_error().decode())
         return L, uid
 
-    def __init__(self, ctx, rank: int, world: int, device, group=None, self_neighbours: bool = False, prechecked=None):
+    def __init__(self, ctx, rank: int, world: int, device, group=None, self_neighbours: bool = False, prechecked=None,
+                 mailbox: bool = False):
         """Phase 2, COLLECTIVE (broadcast of rank 0's id, ncclCommInitRank): every rank of `group` must
         call it, which make_slab_comm guarantees by agreeing on phase 1 first."""
         import ctypes as C
@@ -282,6 +337,12 @@ class NativeRcclSlabComm:
         if rc != 0:
             self._handle = None
             raise RuntimeError("wafer_rccl_attach: " + L.wafer_rccl_last_error().decode())
+        self.mailbox = None
+        if mailbox:   # the scalar all-reduces on the device (wafer_mailbox.h); halo planes stay with RCCL
+            self.mailbox = MailboxAllReduce(rank, 1 if self_neighbours else world, device.index or 0, group)
+            L.wafer_rccl_use_mailbox.argtypes = [C.c_void_p, C.c_void_p]
+            if L.wafer_rccl_use_mailbox(self._handle, self.mailbox.handle) != 0:
+                raise RuntimeError("wafer_rccl_use_mailbox: " + L.wafer_rccl_last_error().decode())
 
     def warm_up(self):
         torch = self.torch
@@ -309,6 +370,9 @@ class NativeRcclSlabComm:
             self.ctx.synchronize()
             self._L.wafer_rccl_detach(self.ctx.handle, self._handle)
             self._handle = None
+            if getattr(self, "mailbox", None) is not None:
+                self.mailbox.close()
+                self.mailbox = None
 
     def __del__(self):
         try:
@@ -353,7 +417,8 @@ def make_slab_comm(ctx, rank: int, world: int, device, transport: Optional[str] 
             # phase 2: id broadcast + ncclCommInitRank on every rank, then agree on the outcome
             comm = None
             try:
-                comm = NativeRcclSlabComm(ctx, rank, world, device, prechecked=pre)
+                comm = NativeRcclSlabComm(ctx, rank, world, device, prechecked=pre,
+                                          mailbox=os.environ.get("WAFER_MAILBOX", "0") not in ("", "0"))
             except Exception as e:  # noqa: BLE001
                 complain(e)
             if agreed(1 if comm is not None else 0):
