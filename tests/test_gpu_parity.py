@@ -859,6 +859,26 @@ def test_f32_path_tracks_f64(wo, wa):
     assert res["f32fast"][1] == pytest.approx(1.0, abs=1e-5)
 
 
+@pytest.mark.parametrize("ext", [1, 2])
+@pytest.mark.parametrize("dtype", ["f32", "f32fast"])
+def test_f32_storage_every_kernel_gives_the_same_bits(wa, dtype, ext):
+    """fp32 storage is not a bit-for-bit path against the fp64 oracle, but it must not depend on WHICH kernel advances the
+    steps: the fused two-step kernel against the single-step kernel, every cell's bits (round 3: the fused kernel used to
+    hand its second step fp32-rounded a, b).  (The plain kernel, variant 0, streams the STORED a, b arrays -- fp32 like every
+    stored array -- and is a different, equally legitimate reading of "fp32 storage"; it is not part of this comparison.)"""
+    shape = (200, 37, 29)
+    out = {}
+    for variant in (2, 1):
+        par = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.3, central_difference=ext, dtype=dtype)
+        with wa.Context(par) as ctx:
+            ctx.set_stencil_variant(variant)
+            ctx.set_potential("Coulomb")
+            ctx.set_initial_condition("Gaussian", seed=5)
+            ctx.evolve(0, 8)
+            out[variant] = ctx.download_phi()
+    assert np.array_equal(out[2], out[1])
+
+
 def test_config5_flow_file_potential_fp32_vs_fp64(wa):
     """BASELINE config #5 in miniature: a user potential given at low resolution (as a file would
     hold it), trilinearly upsampled on the device (input.rs:667-716), solved with fp32 storage and

@@ -13,6 +13,8 @@ for step in "$@"; do
     tests_cfg)    timeout 1200 python -m pytest tests/test_gpu_configs.py -x -q > $O/tests_cfg.log 2>&1; tail -5 $O/tests_cfg.log ;;
     tests_mp)     timeout 900 python -m pytest tests/test_gpu_multiprocess.py -x -q > $O/tests_mp.log 2>&1; tail -15 $O/tests_mp.log; cp gpurun_out/mailbox_latency_world*.txt $O/ 2>/dev/null ;;
     ar_latency)   timeout 300 python3 tools/allreduce_latency.py 2>/dev/null | grep "^{" > $O/allreduce_latency.json; cat $O/allreduce_latency.json ;;
+    tests_f32)    timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "f32 or fp32" > $O/tests_f32.log 2>&1; tail -5 $O/tests_f32.log ;;
+    sweep_f32)    for cd in 1 2; do for dt in f32 f32fast; do timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --cd $cd --dtype $dt --rounds 5 --steps 60 --configs "v=2" "v=1" "v=2" "v=1" 2>&1 | grep config | sed "s/^/cd=$cd $dt /"; done; done > $O/sweep_f32.jsonl; cat $O/sweep_f32.jsonl ;;
     tests_slab)   timeout 600 python -m pytest tests/test_gpu_slab.py -x -q > $O/tests_slab.log 2>&1; tail -5 $O/tests_slab.log ;;
     bench)        timeout 600 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-300 $O/bench_n1.json ;;
     bench_short)  timeout 600 python3 bench.py --steps 20 --warmup 5 > $O/bench_n1_short.json 2> $O/bench_n1_short.err; cut -c1-300 $O/bench_n1_short.json ;;

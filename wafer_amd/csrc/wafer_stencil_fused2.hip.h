@@ -242,7 +242,11 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
     // ABV: the a, b formed for step 1 at plane z serve step 2 at the same plane R iterations later -- for
     // ThreePoint / FivePoint.  SevenPoint's two seven-plane z-queues leave no room for an (R+1)-deep a, b
     // queue (64 VGPRs): step 2 forms them again from V (same expressions, same bits).
-    constexpr bool CARRY_AB = R < 3;
+    // Only where storage and arithmetic types agree: with fp32 storage and fp64 arithmetic a queue of storage type would
+    // hand step 2 fp32-rounded a, b where the single-step kernel (and step 1 here) use the fp64 values -- the two kernels'
+    // results would differ in the last fp32 bits (found by bench.py's cross-kernel check on the fp32 row, round 3) -- and a
+    // queue of arithmetic type spills 176 B/lane there: that combination forms a, b again at step 2.
+    constexpr bool CARRY_AB = R < 3 && std::is_same<T, C>::value;
     VT caq[CARRY_AB ? R + 1 : 1][RY], cbq[CARRY_AB ? R + 1 : 1][RY];
 #pragma unroll
     for (int m = 0; m <= (CARRY_AB ? R : 0); ++m)
