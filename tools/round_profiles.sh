@@ -1,12 +1,28 @@
-# The judged pair of the round: the bench line, the same command under rocprofv3 --kernel-trace --stats, and the
-# per-kernel stats / PMC passes of the whole path (tools/pmc_path_run.sh).  Writes under gpurun_out/final/.
+# The judged set of the round, written under gpurun_out/final/: the bench line, the same command under rocprofv3
+# --kernel-trace --stats, HBM-side traffic of its kernels (two --pmc passes), the slab overhead at the bench slab with the
+# kernel trace of the single-launch pass, the secondary rows.  Copy what is to be judged into profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+python3 bench.py --steps 20 --warmup 5 > $O/bench_n1_driver_form.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 bench.py > $O/bench_n1_under_rocprof.json 2> /dev/null
-find $O/bench_stats -name "*kernel_trace.csv" -delete
-bash tools/pmc_path_run.sh > $O/path_run.log 2>&1
-cat $O/bench_n1.json | cut -c1-400
+cp $(find $O/bench_stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench_512.csv
+rm -rf $O/bench_stats
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/fetch $O/write $O/pmc_traffic.json
+rm -rf $O/fetch $O/write
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1 -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/sq2 -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
+python3 tools/pmc_counters.py $O/sq1 $O/sq2 --match wafer_k_step3_fused > $O/sq_counters_fused3.json
+rm -rf $O/sq1 $O/sq2
+NCCL_MAX_P2P_NCHANNELS=8 python3 tools/slab_overhead.py --rccl --steps 60 --modes 2,1,0 2> /dev/null | grep "^{" > $O/slab_overhead.json
+NCCL_MAX_P2P_NCHANNELS=8 rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -o t -- python3 tools/slab_trace.py --rccl --mode 2 > /dev/null 2>&1
+python3 tools/slab_trace.py --parse $(find $O/trace2 -name "*kernel_trace.csv" | head -1) > $O/slab_single_launch_timeline.txt 2>&1
+rm -rf $O/trace2
+python3 tools/secondary_rows.py $O/rows > $O/rows.log 2>&1
+python3 tools/allreduce_latency.py 2> /dev/null | grep "^{" > $O/allreduce_latency.json
+cut -c1-300 $O/bench_n1.json; cat $O/slab_overhead.json; cat $O/sq_counters_fused3.json | head -40

@@ -1327,7 +1327,7 @@ __global__ __launch_bounds__(64) void wafer_k_gate(const unsigned long long *cnt
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(32);
-            if (++spins > (1u << 25)) {
+            if (++spins > (1u << 21)) {   // ~2 s: four times what a workgroup waits, so that a late exchange shows as the workgroups' error
                 __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }

@@ -104,7 +104,7 @@ __device__ __forceinline__ void wafer_f3_wait(const WaferF3Sync &sy, int idx, in
         unsigned spins = 0;
         while (__hip_atomic_load(sy.flag + idx * WAFER_F3_SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.need[idx]) {
             __builtin_amdgcn_s_sleep(32);
-            if (++spins > (1u << 25)) { // tens of seconds: the exchange never arrived
+            if (++spins > (1u << 19)) { // ~half a second (a legitimate wait is well under a millisecond): the exchange never arrived
                 __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
