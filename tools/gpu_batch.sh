@@ -15,8 +15,8 @@ for step in "$@"; do
     ar_latency)   timeout 300 python3 tools/allreduce_latency.py 2>/dev/null | grep "^{" > $O/allreduce_latency.json; cat $O/allreduce_latency.json ;;
     tests_f32)    timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "f32 or fp32" > $O/tests_f32.log 2>&1; tail -5 $O/tests_f32.log ;;
     sweep_f32)    for cd in 1 2; do for dt in f32 f32fast; do timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --cd $cd --dtype $dt --rounds 5 --steps 60 --configs "v=2" "v=1" "v=2" "v=1" 2>&1 | grep config | sed "s/^/cd=$cd $dt /"; done; done > $O/sweep_f32.jsonl; cat $O/sweep_f32.jsonl ;;
-    tests_f3c)    WAFER_F3_KERNEL=1 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_slab.py tests/test_gpu_configs.py -x -q -k "three_step or fused3 or single_launch or 512 or config2 or thousand" > $O/tests_f3c.log 2>&1; tail -5 $O/tests_f3c.log ;;
-    sweep_f3c)    timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 7 --steps 60 --configs "v=3" "v=3,f3k=1" "v=3" "v=3,f3k=1" > $O/sweep_f3c.jsonl 2>&1; cat $O/sweep_f3c.jsonl ;;
+    tests_f3c)    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_slab.py tests/test_gpu_configs.py -x -q -k "three_step or fused3 or single_launch or 512 or config2 or thousand" > $O/tests_f3c.log 2>&1; tail -5 $O/tests_f3c.log ;;
+    sweep_f3c)    timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 7 --steps 60 --configs "v=3" "v=2" "v=3" "v=2" > $O/sweep_f3c.jsonl 2>&1; cat $O/sweep_f3c.jsonl ;;
     sq_f3c)       for k in 0 1; do
                     WAFER_F3_KERNEL=$k timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1_$k -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
                     WAFER_F3_KERNEL=$k timeout 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/sq2_$k -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
@@ -28,7 +28,7 @@ for name, c in d.items():
     print("kernel $k", {k: round(v["avg"] / 1e6, 1) for k, v in c.items()})
 PY
                   done ;;
-    sweep_f3c_sizes) for grid in 256,256,256 384,384,384 1024,1024,128; do timeout 300 python3 tools/stencil_sweep.py --grid $grid --rounds 7 --steps 60 --configs "v=3" "v=3,f3k=1" "v=3" "v=3,f3k=1" 2>&1 | grep config | sed "s/^/$grid /"; done > $O/sweep_f3c_sizes.jsonl; cat $O/sweep_f3c_sizes.jsonl ;;
+    sweep_f3c_sizes) for grid in 256,256,256 384,384,384 1024,1024,128; do timeout 300 python3 tools/stencil_sweep.py --grid $grid --rounds 7 --steps 60 --configs "v=3" "v=2" "v=3" "v=2" 2>&1 | grep config | sed "s/^/$grid /"; done > $O/sweep_f3c_sizes.jsonl; cat $O/sweep_f3c_sizes.jsonl ;;
     tests_slab)   timeout 600 python -m pytest tests/test_gpu_slab.py -x -q > $O/tests_slab.log 2>&1; tail -5 $O/tests_slab.log ;;
     bench)        timeout 600 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-300 $O/bench_n1.json ;;
     bench_short)  timeout 600 python3 bench.py --steps 20 --warmup 5 > $O/bench_n1_short.json 2> $O/bench_n1_short.err; cut -c1-300 $O/bench_n1_short.json ;;

@@ -13,19 +13,18 @@
 // produced and stored.  phi1 and phi2 exist only in registers (own z-columns) and in two-slot LDS rings
 // (x / y neighbours).  One s_barrier per plane.
 //
-// Wave roles (12 waves, RY = 2 row slots per lane, three per SIMD; the helper waves are spread so that the four
-// SIMDs carry 14 / 14 / 14 / 13 row-updates per plane):
-//   waves 0..7   "main": own rows y0..y0+15 at all three levels;
-//   wave  8      "halo-row": row y0-1  (phi1, phi2);
-//   wave  9      "halo-row": row y0+16 (phi1, phi2);
-//   wave  10     "halo-row": rows y0-2 and y0+17 (phi1);
-//   wave  11     "halo-column": each lane keeps up to three phi0 halo-column cells (3 columns per side
-//                x 22 rows, z-queues in components of the row-slot registers) and produces phi1 on
-//                the inner two columns and phi2 on the innermost one.
-// phi0's outermost halo rows (y0-3, y0+18) are plain vector loads by main waves 0 and 1, staged through LDS.
+// Eight waves, two per SIMD, 214 VGPRs.  Every wave owns two rows of the tile at all three levels plus ONE extra slot:
+//   wave 0   row y0-1   (phi1 and phi2)          wave 7   row y0+16  (phi1 and phi2)
+//   wave 1   row y0-2   (phi1), stages row y0-3  wave 6   row y0+17  (phi1), stages row y0+18
+//   waves 2..5   33 of the 132 phi0 halo-column cells each, one per lane (z-queues in component 0 of the extra slot's
+//                registers): phi1 on the inner two columns, phi2 on the innermost
+// so that every global access stays 128-byte aligned and tiles need no overlap.
 //
-// a and b are formed from V in registers (potential.rs:104-110) at every level -- carrying them from
-// level to level as the two-step kernel does would cost the registers the third z-queue needs.
+// a and b of a cell (potential.rs:104-110) are formed ONCE per pass, at level 1, and ride in registers to levels 2 and 3 as
+// a and b * dt (b enters the update only through that product): 29 + 16 + 16 fp64 instructions per cell and pass instead of
+// 3 x 29 -- the reciprocal sequence is 12 of the 29.  (Round 2's kernel had twelve waves -- eight main, four helpers, three
+// per SIMD, 168-VGPR cap -- and formed a, b at every level because the registers to carry them did not exist there: 46.4
+// VALU instructions per update against 36.6 here; 0.284 against 0.262 ms/step at 512^3 on one box: profiles/NOTES.md.)
 // Per-update arithmetic is the single-step kernel's, so results are bit-identical to three single
 // steps (tests/test_gpu_parity.py::test_fused_three_step_kernel_bit_exact).  Cells of phi1 / phi2
 // outside the work area (Dirichlet frame, config.rs:597-622) and planes outside the global work range
@@ -51,11 +50,9 @@ template <typename T>
 struct WaferF3Cfg {
     static constexpr int VEC = WaferVec<T>::N;
     static constexpr int RY = 2;
-    static constexpr int NW2 = 8;                       // main waves: tile height 16
-    static constexpr int NWH = 3;                       // halo-row waves
-    static constexpr int NW = NW2 + NWH + 1;            // + halo-column wave
+    static constexpr int NW = 8;                        // waves: tile height 16, two rows per wave (+ one extra slot each)
     static constexpr int NT_ = NW * 64;
-    static constexpr int TX = 64 * VEC, TY = NW2 * RY;
+    static constexpr int TX = 64 * VEC, TY = NW * RY;
     static constexpr int HC0 = 3, HC1 = 2, HC2 = 1;     // halo columns per side of phi0 / phi1 / phi2
     static constexpr int HX0 = ((HC0 + VEC - 1) / VEC) * VEC;
     static constexpr int HX1 = ((HC1 + VEC - 1) / VEC) * VEC;
@@ -64,8 +61,9 @@ struct WaferF3Cfg {
     static constexpr int ROWS0 = TY + 6, ROWS1 = TY + 4, ROWS2 = TY + 2;
     static constexpr int TILE0 = ROWS0 * LP0, TILE1 = ROWS1 * LP1, TILE2 = ROWS2 * LP2;
     static constexpr int NCOL = 2 * HC0 * ROWS0;        // phi0 halo-column cells per plane
-    static constexpr int CPL = (NCOL + 63) / 64;        // cells per lane of the halo-column wave
-    static_assert(CPL <= RY * VEC, "halo-column cells per lane must fit the row-slot registers");
+    static constexpr int HCW0 = 2, HCWN = 4;            // waves HCW0 .. HCW0 + HCWN - 1 take the halo-column cells,
+    static constexpr int CPW = (NCOL + HCWN - 1) / HCWN; // one per lane: 33 each
+    static_assert(CPW <= 64, "one halo-column cell per lane");
 };
 
 // One workgroup's assignment.  32 bytes, read with scalar loads.
@@ -118,131 +116,112 @@ __device__ __forceinline__ void wafer_f3_wait(const WaferF3Sync &sy, int idx, in
 
 template <typename T, typename C, bool VIR, bool DOWN>
 __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const WaferF3Block &blk, int ntx, const WaferF3Sync &sy,
-                                                 const T *__restrict__ phi, const T *__restrict__ pv, T *__restrict__ out,
-                                                 T *lds0, T *lds1, T *lds2)
+                                                  const T *__restrict__ phi, const T *__restrict__ pv, T *__restrict__ out,
+                                                  T *lds0, T *lds1, T *lds2)
 {
     using Cfg = WaferF3Cfg<T>;
     using VT = typename WaferVec<T>::type;
     constexpr int R = 1;
     constexpr int VEC = Cfg::VEC, RY = Cfg::RY, TX = Cfg::TX, TY = Cfg::TY;
     constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, HX2 = Cfg::HX2, LP0 = Cfg::LP0, LP1 = Cfg::LP1, LP2 = Cfg::LP2;
-    constexpr int SD = DOWN ? -1 : 1;                    // marching direction along z
-    constexpr int ZLO = DOWN ? 2 : 0, ZHI = DOWN ? 0 : 2; // queue slots of the planes below / above the centre plane
+    constexpr int SD = DOWN ? -1 : 1;
+    constexpr int ZLO = DOWN ? 2 : 0, ZHI = DOWN ? 0 : 2;
 
     const WaferGeom &g = a.g;
     const int tx_i = blk.tile % ntx, ty_i = blk.tile / ntx;
     const int zs = blk.zs, ze = blk.ze;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: role tests become scalar branches
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = tx_i * TX, y0 = ty_i * TY;
     const C dt = (C)a.dt, den = (C)a.den;
     constexpr bool vir = VIR;
-    const bool is_main = wave < Cfg::NW2;
-    const bool is_hrow = wave >= Cfg::NW2 && wave < Cfg::NW2 + Cfg::NWH;
-    const bool is_hcol = wave == Cfg::NW - 1;
+    // the extra slot: a halo row (waves 0, 1, 6, 7) or halo-column cells (waves 2..5)
+    const bool x_row = wave < 2 || wave >= 6;
+    const bool x_l2 = wave == 0 || wave == 7;            // the halo row next to the tile: phi2 as well
+    const bool has_orow = wave == 1 || wave == 6;
 
     VT zero;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) zero[v] = T(0);
-
-    // ---- row slots of the main and halo-row waves (no bounds predicates on loads: whole tiles, three
-    //      halo rows / columns and three planes past the slab lie in the zero guard zone, wafer_geom.h)
     const int xl = lane * VEC, xi = x0 + xl;
-    int yrow[RY];
-    bool rowwk[RY], lvl2[RY], slot_on[RY];
-    // rowoff holds only the WAVE-UNIFORM part of a row's element offset (scalar registers) and the lane adds its
-    // 32-bit x offset at the access.  Per-lane 64-bit offsets cost six VGPRs in a kernel that sits at its 168-VGPR
-    // cap: the compiler spilled them, and reloading the store addresses from scratch put an s_waitcnt vmcnt(0) --
-    // scratch loads share the counter -- in front of each store of the plane.
-    long long rowoff[RY];
     const unsigned xlu = (unsigned)(lane * VEC);
+
+    // ---- main rows
+    int yrow[RY];
+    bool rowwk[RY];
+    long long rowoff[RY];
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-        int y;
-        bool l2 = true, on = true;
-        if (is_hrow) {
-            const int h = wave - Cfg::NW2;   // 0: row y0-1 (phi1, phi2);  1: row y0+16 (phi1, phi2);  2: rows y0-2, y0+17 (phi1)
-            if (h == 2) {
-                y = (r == 0) ? (y0 - 2) : (y0 + TY + 1);
-                l2 = false;
-            } else {
-                y = (h == 0) ? (y0 - 1) : (y0 + TY);   // the second slot repeats the row (its loads are the same values) and computes nothing
-                l2 = on = (r == 0);
-            }
-        } else {
-            y = y0 + wave * RY + r;                    // main (unused by the halo-column wave)
-        }
+        const int y = y0 + wave * RY + r;
         yrow[r] = y;
-        rowwk[r] = on && (y >= 0) && (y < g.ny);
-        lvl2[r] = l2;
-        slot_on[r] = on;
+        rowwk[r] = y < g.ny;
         rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + x0;
     }
-    // ---- outermost phi0 halo rows y0-3 and y0+18, fetched by main waves 0 and 1
-    const bool has_orow = is_main && wave < 2;
-    const int oy = (wave == 0) ? (y0 - 3) : (y0 + TY + 2);
-    const long long orow_off = (long long)(oy + R) * g.pitch + g.xoff + R + x0;   // as rowoff
+    // ---- the extra halo row
+    const int xy = wave == 0 ? y0 - 1 : wave == 1 ? y0 - 2 : wave == 6 ? y0 + TY + 1 : y0 + TY;
+    const bool xwk = x_row && xy >= 0 && xy < g.ny;
+    const long long xoff_row = (long long)(xy + R) * g.pitch + g.xoff + R + x0;
+    // ---- outermost phi0 halo rows y0-3 / y0+18 (plain vector loads staged through LDS)
+    const int oy = wave == 1 ? y0 - 3 : y0 + TY + 2;
+    const long long orow_off = (long long)(oy + R) * g.pitch + g.xoff + R + x0;
     const int orow_lds = (oy - (y0 - 3)) * LP0 + HX0 + xl;
-    // ---- halo-column cells of the last wave: cell c = lane + 64 q: row c / 6 of the phi0 tile, k = c % 6:
-    //      k < 3: column x0-1-k, else column x0+TX+(k-3)
-    bool c_ok[Cfg::CPL], c_l1[Cfg::CPL], c_l2[Cfg::CPL], c_wk[Cfg::CPL];
-    long long c_off[Cfg::CPL];
-    int c_lds0[Cfg::CPL], c_lds1[Cfg::CPL], c_lds2[Cfg::CPL];
-#pragma unroll
-    for (int q = 0; q < Cfg::CPL; ++q) {
-        const int cidx = min(lane + q * 64, Cfg::NCOL - 1);    // surplus lanes repeat the last cell
-        const int row = cidx / (2 * Cfg::HC0), k = cidx % (2 * Cfg::HC0);
-        const int kk = (k < Cfg::HC0) ? k : k - Cfg::HC0;       // distance - 1 from the tile edge
-        const int lc = (k < Cfg::HC0) ? (-1 - kk) : (TX + kk);
-        const int xw = x0 + lc, y = y0 - 3 + row;
-        c_ok[q] = is_hcol && lane + q * 64 < Cfg::NCOL;
-        c_wk[q] = (y >= 0) && (y < g.ny) && (xw >= 0) && (xw < g.nx);
-        c_l1[q] = c_ok[q] && kk < Cfg::HC1 && row >= 1 && row < Cfg::ROWS0 - 1;   // phi1: inner two columns, rows y0-2 .. y0+17
-        c_l2[q] = c_ok[q] && kk < Cfg::HC2 && row >= 2 && row < Cfg::ROWS0 - 2;   // phi2: innermost column, rows y0-1 .. y0+16
-        c_off[q] = (long long)(y + R) * g.pitch + g.xoff + R + xw;
-        c_lds0[q] = row * LP0 + HX0 + lc;
-        c_lds1[q] = (row - 1) * LP1 + HX1 + lc;
-        c_lds2[q] = (row - 2) * LP2 + HX2 + lc;
-    }
+    // ---- halo-column cell of this lane (waves 2..5): cell c: row c / 6 of the phi0 tile, k = c % 6: k < 3: column x0-1-k,
+    //      else column x0+TX+(k-3)
+    const int cidx = min((wave - Cfg::HCW0) * Cfg::CPW + lane, Cfg::NCOL - 1);
+    const int crow = cidx / (2 * Cfg::HC0), ck = cidx % (2 * Cfg::HC0);
+    const int ckk = (ck < Cfg::HC0) ? ck : ck - Cfg::HC0;
+    const int clc = (ck < Cfg::HC0) ? (-1 - ckk) : (TX + ckk);
+    const int cxw = x0 + clc, cy = y0 - 3 + crow;
+    const bool c_ok = !x_row && lane < Cfg::CPW && (wave - Cfg::HCW0) * Cfg::CPW + lane < Cfg::NCOL;
+    const bool c_wk = cy >= 0 && cy < g.ny && cxw >= 0 && cxw < g.nx;
+    const bool c_l1 = c_ok && ckk < Cfg::HC1 && crow >= 1 && crow < Cfg::ROWS0 - 1;
+    const bool c_l2 = c_ok && ckk < Cfg::HC2 && crow >= 2 && crow < Cfg::ROWS0 - 2;
+    const long long c_off = (long long)(cy + R) * g.pitch + g.xoff + R + cxw;
+    const int c_lds0 = crow * LP0 + HX0 + clc, c_lds1 = (crow - 1) * LP1 + HX1 + clc, c_lds2 = (crow - 2) * LP2 + HX2 + clc;
 
     auto work_plane = [&](int p) {
         const int kg = g.z_begin + (p - g.G);
         return kg >= 0 && kg < g.nz;
     };
-    // one update: a, b from V (potential.rs:104-110), then grid.rs:580-589
-    auto update = [&](C w, C vv, C S) -> T {
-        C ca, cb;
+    // level 1: a, b from V (potential.rs:104-110); what rides to levels 2 and 3 is a and the product b * dt -- b enters the
+    // update (grid.rs:580-589: w * a + b * dt * S / den, left to right) only through that product, which is the same number
+    // at every level
+    auto update_keep = [&](C w, C vv, C S, C &ca, C &cbdt) -> T {
+        C cb;
         wafer_ab_from_v<C>(vv, dt, vir, ca, cb);
-        return (T)wafer_update<C>(w, ca, cb, dt, S, den);
+        cbdt = cb * dt;
+        return (T)(w * ca + wafer_div_invariant<C>(cbdt * S, den));
     };
+    auto update_with = [&](C w, C ca, C cbdt, C S) -> T { return (T)(w * ca + wafer_div_invariant<C>(cbdt * S, den)); };
 
-    // ---- prologue: the first phi1 plane is z1 (two planes before the first output plane in marching order); the
-    //      phi0 queue holds planes z1-SD, z1, z1+SD
+    // ---- state.  Main rows: three z-queues, V of the level-1 plane, a / b of the planes of levels 2 and 3.
+    //      Extra slot (component 0 only for a halo-column cell): phi0 and phi1 queues, V, a / b of the level-2 plane.
     const int z1 = DOWN ? ze + 1 : zs - 2;
-    VT q0[3][RY], q1[3][RY], q2[3][RY];
-    VT vq[3][RY];   // V of the planes of levels 3, 2 and 1 of one iteration
-    // (the halo-column wave keeps cell q of its CPL cells in component q % VEC of row slot q / VEC)
+    VT q0[3][RY], q1[3][RY], q2[3][RY], vcur[RY], caq[2][RY], cbq[2][RY];
+    VT xq0[3], xq1[3], xv, xca, xcb;
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 3; ++m) {
 #pragma unroll
-        for (int r = 0; r < RY; ++r) q0[m][r] = q1[m][r] = q2[m][r] = vq[m][r] = zero;
+        for (int r = 0; r < RY; ++r) q0[m][r] = q1[m][r] = q2[m][r] = zero;
+        xq0[m] = xq1[m] = zero;
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r) vcur[r] = caq[0][r] = caq[1][r] = cbq[0][r] = cbq[1][r] = zero;
+    xv = xca = xcb = zero;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const long long po = (long long)(z1 + SD * (m - 1)) * g.plane;
-        if (!is_hcol) {
 #pragma unroll
-            for (int r = 0; r < RY; ++r) q0[m][r] = *reinterpret_cast<const VT *>((phi + po + rowoff[r]) + xlu);
-        } else {
-#pragma unroll
-            for (int q = 0; q < Cfg::CPL; ++q) q0[m][q / VEC][q % VEC] = phi[po + c_off[q]];
-        }
+        for (int r = 0; r < RY; ++r) q0[m][r] = *reinterpret_cast<const VT *>((phi + po + rowoff[r]) + xlu);
+        if (x_row) xq0[m] = *reinterpret_cast<const VT *>((phi + po + xoff_row) + xlu);
+        else xq0[m][0] = phi[po + c_off];
     }
-    if (!is_hcol) {
+    {
+        const long long po = (long long)z1 * g.plane;
 #pragma unroll
-        for (int r = 0; r < RY; ++r) vq[2][r] = *reinterpret_cast<const VT *>((pv + (long long)z1 * g.plane + rowoff[r]) + xlu);
-    } else {
-#pragma unroll
-        for (int q = 0; q < Cfg::CPL; ++q) vq[2][q / VEC][q % VEC] = pv[(long long)z1 * g.plane + c_off[q]];
+        for (int r = 0; r < RY; ++r) vcur[r] = *reinterpret_cast<const VT *>((pv + po + rowoff[r]) + xlu);
+        if (x_row) xv = *reinterpret_cast<const VT *>((pv + po + xoff_row) + xlu);
+        else xv[0] = pv[po + c_off];
     }
     for (int i = tid; i < 2 * Cfg::TILE0; i += Cfg::NT_) lds0[i] = T(0);
     for (int i = tid; i < 2 * Cfg::TILE1; i += Cfg::NT_) lds1[i] = T(0);
@@ -250,124 +229,156 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     __syncthreads();
     {
         T *t0 = lds0 + (z1 & 1) * Cfg::TILE0;
-        if (!is_hcol) {
 #pragma unroll
-            for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(t0 + (yrow[r] - (y0 - 3)) * LP0 + HX0 + xl) = q0[1][r];
-        } else {
-#pragma unroll
-            for (int q = 0; q < Cfg::CPL; ++q)
-                if (c_ok[q]) t0[c_lds0[q]] = q0[1][q / VEC][q % VEC];
-        }
+        for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(t0 + (yrow[r] - (y0 - 3)) * LP0 + HX0 + xl) = q0[1][r];
+        if (x_row) *reinterpret_cast<VT *>(t0 + (xy - (y0 - 3)) * LP0 + HX0 + xl) = xq0[1];
+        else if (c_ok) t0[c_lds0] = xq0[1][0];
         if (has_orow) *reinterpret_cast<VT *>(t0 + orow_lds) = *reinterpret_cast<const VT *>((phi + (long long)z1 * g.plane + orow_off) + xlu);
     }
     VT orow_nxt = zero;
     if (has_orow) orow_nxt = *reinterpret_cast<const VT *>((phi + (long long)(z1 + SD) * g.plane + orow_off) + xlu);
     __syncthreads();
 
-    const int niter = (ze - zs) + 4; // phi1 planes z1, z1+SD, ..., two past the last output plane
+    const int niter = (ze - zs) + 4;
     for (int it = 0; it < niter; ++it) {
         const int z = z1 + SD * it;
         const bool more = it + 1 < niter;
         const long long zo = (long long)z * g.plane;
         if (blk.wait_late >= 0 && it == blk.wait_it) wafer_f3_wait(sy, blk.wait_late, tid);
-        // ---- 1. prefetch: phi0 two planes ahead, V one plane ahead, outer halo rows two planes ahead
-        VT pre[RY], pre_v[RY], orow_pre = zero;
+        // ---- 1. prefetch: phi0 two planes ahead, V one plane ahead
+        VT pre[RY], pre_v[RY], xpre = zero, xpre_v = zero, orow_pre = zero;
 #pragma unroll
-        for (int r = 0; r < RY; ++r) pre[r] = pre_v[r] = zero;
-        if (!is_hcol) {
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                pre[r] = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + rowoff[r]) + xlu);
-                pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + SD * g.plane + rowoff[r]) + xlu);
-            }
+        for (int r = 0; r < RY; ++r) {
+            pre[r] = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + rowoff[r]) + xlu);
+            pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + SD * g.plane + rowoff[r]) + xlu);
+        }
+        if (x_row) {
+            xpre = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + xoff_row) + xlu);
+            xpre_v = *reinterpret_cast<const VT *>((pv + zo + SD * g.plane + xoff_row) + xlu);
             if (has_orow) orow_pre = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + orow_off) + xlu);
         } else {
-#pragma unroll
-            for (int q = 0; q < Cfg::CPL; ++q) {
-                pre[q / VEC][q % VEC] = phi[zo + SD * 2 * g.plane + c_off[q]];
-                pre_v[q / VEC][q % VEC] = pv[zo + SD * g.plane + c_off[q]];
-            }
+            xpre[0] = phi[zo + SD * 2 * g.plane + c_off];
+            xpre_v[0] = pv[zo + SD * g.plane + c_off];
         }
         // ---- 2. stage the next phi0 plane into the other buffer
         if (more) {
             T *nt = lds0 + ((z + 1) & 1) * Cfg::TILE0;
-            if (!is_hcol) {
 #pragma unroll
-                for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(nt + (yrow[r] - (y0 - 3)) * LP0 + HX0 + xl) = q0[2][r];
-            } else {
-#pragma unroll
-                for (int q = 0; q < Cfg::CPL; ++q)
-                    if (c_ok[q]) nt[c_lds0[q]] = q0[2][q / VEC][q % VEC];
-            }
-            if (has_orow) *reinterpret_cast<VT *>(nt + orow_lds) = orow_nxt;
+            for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(nt + (yrow[r] - (y0 - 3)) * LP0 + HX0 + xl) = q0[2][r];
+            if (x_row) {
+                *reinterpret_cast<VT *>(nt + (xy - (y0 - 3)) * LP0 + HX0 + xl) = xq0[2];
+                if (has_orow) *reinterpret_cast<VT *>(nt + orow_lds) = orow_nxt;
+            } else if (c_ok) nt[c_lds0] = xq0[2][0];
         }
         const T *c0 = lds0 + (z & 1) * Cfg::TILE0;
-        // rings: a plane lives in slot (plane & 1); the plane one step behind in marching order has the other parity
         T *w1 = lds1 + (z & 1) * Cfg::TILE1;
-        const T *c1 = lds1 + ((z + 1) & 1) * Cfg::TILE1;     // phi1 plane z - SD
-        T *w2 = lds2 + ((z + 1) & 1) * Cfg::TILE2;           // phi2 plane z - SD
-        const T *c2 = lds2 + (z & 1) * Cfg::TILE2;           // phi2 plane z - 2 SD
+        const T *c1 = lds1 + ((z + 1) & 1) * Cfg::TILE1;
+        T *w2 = lds2 + ((z + 1) & 1) * Cfg::TILE2;
+        const T *c2 = lds2 + (z & 1) * Cfg::TILE2;
         const bool wplane1 = work_plane(z), wplane2 = work_plane(z - SD);
-        VT p1new[RY], p2new[RY];
+        const int zp2 = z - SD;
+        const bool need2 = zp2 >= zs - 1 && zp2 <= ze;   // phi2 is read on planes zs-1 .. ze only
+        VT p1new[RY], p2new[RY], canew[RY], cbnew[RY];
 #pragma unroll
-        for (int r = 0; r < RY; ++r) p1new[r] = p2new[r] = zero;
+        for (int r = 0; r < RY; ++r) p1new[r] = p2new[r] = canew[r] = cbnew[r] = zero;
+        VT xp1 = zero, xcanew = zero, xcbnew = zero;
 
-        if (!is_hcol) {
-            bool all_rows = x0 + TX <= g.nx;   // INTERIOR also requires the tile's columns to be work columns: no per-cell x mask
+        bool all_rows = x0 + TX <= g.nx;
 #pragma unroll
-            for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];   // (rowwk is false for a slot that is off)
-            // ---- 3. level 1: phi1 plane z (main and halo-row waves).  INTERIOR: the plane and every row of this
-            //         wave are work cells -- no tests inside, so the RY x VEC updates form one basic block
-            // (the rows of a halo-row wave are not neighbours: their y neighbours come from LDS -- yreg_tag)
-            auto level1 = [&](auto interior_tag, auto yreg_tag) {
-                constexpr bool INTERIOR = decltype(interior_tag)::value;
-                constexpr bool YR = decltype(yreg_tag)::value;
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    VT res = zero;
-                    if (INTERIOR || (wplane1 && rowwk[r])) {
-                        const int ly = yrow[r] - (y0 - 3);
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            const C w = (C)q0[1][r][v];
-                            C xs[3], ys[3], zz[3];
-                            zz[0] = (C)q0[ZLO][r][v]; zz[1] = w; zz[2] = (C)q0[ZHI][r][v];
-                            xs[1] = ys[1] = w;
-                            xs[0] = (v >= 1) ? (C)q0[1][r][(v + VEC - 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v - 1];
-                            xs[2] = (v + 1 < VEC) ? (C)q0[1][r][(v + 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v + 1];
-                            ys[0] = (YR && r >= 1) ? (C)q0[1][r >= 1 ? r - 1 : 0][v] : (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
-                            ys[2] = (YR && r + 1 < RY) ? (C)q0[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
-                            const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                            const T rs = update(w, (C)vq[2][r][v], S);
-                            res[v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
-                        }
-                    }
-                    p1new[r] = res;
-                    if (INTERIOR || slot_on[r]) *reinterpret_cast<VT *>(w1 + (yrow[r] - (y0 - 2)) * LP1 + HX1 + xl) = res;
-                }
-            };
-            if (is_main) {
-                if (all_rows && wplane1) level1(std::true_type{}, std::true_type{});
-                else level1(std::false_type{}, std::true_type{});
-            } else {
-                if (all_rows && wplane1) level1(std::true_type{}, std::false_type{});
-                else level1(std::false_type{}, std::false_type{});
-            }
-            // ---- 4. level 2: phi2 of the plane behind from the phi1 queue; x / y neighbours from the phi1 ring slot
-            //         written one iteration ago
+        for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];
+        // ---- 3. level 1, main rows.  INTERIOR: the plane and both rows are work cells, the tile's columns too: no tests
+        //         inside, the RY x VEC updates form one basic block
+        auto level1 = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
-                q1[0][r] = q1[1][r];
-                q1[1][r] = q1[2][r];
-                q1[2][r] = p1new[r];
+                VT res = zero;
+                if (INTERIOR || (wplane1 && rowwk[r])) {
+                    const int ly = yrow[r] - (y0 - 3);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const C w = (C)q0[1][r][v];
+                        C xs[3], ys[3], zz[3];
+                        zz[0] = (C)q0[ZLO][r][v]; zz[1] = w; zz[2] = (C)q0[ZHI][r][v];
+                        xs[1] = ys[1] = w;
+                        xs[0] = (v >= 1) ? (C)q0[1][r][(v + VEC - 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v - 1];
+                        xs[2] = (v + 1 < VEC) ? (C)q0[1][r][(v + 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v + 1];
+                        ys[0] = (r >= 1) ? (C)q0[1][r >= 1 ? r - 1 : 0][v] : (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
+                        ys[2] = (r + 1 < RY) ? (C)q0[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
+                        const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
+                        C ka, kb;
+                        const T rs = update_keep(w, (C)vcur[r][v], S, ka, kb);
+                        canew[r][v] = (T)ka;
+                        cbnew[r][v] = (T)kb;
+                        res[v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
+                    }
+                }
+                p1new[r] = res;
+                *reinterpret_cast<VT *>(w1 + (yrow[r] - (y0 - 2)) * LP1 + HX1 + xl) = res;
             }
-            auto level2 = [&](auto interior_tag, auto yreg_tag) {
+        };
+        if (all_rows && wplane1) level1(std::true_type{});
+        else level1(std::false_type{});
+        // ---- 3x. level 1, the extra slot
+        if (x_row) {
+            VT res = zero;
+            if (wplane1 && xwk) {
+                const int ly = xy - (y0 - 3);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const C w = (C)xq0[1][v];
+                    C xs[3], ys[3], zz[3];
+                    zz[0] = (C)xq0[ZLO][v]; zz[1] = w; zz[2] = (C)xq0[ZHI][v];
+                    xs[1] = ys[1] = w;
+                    xs[0] = (v >= 1) ? (C)xq0[1][(v + VEC - 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v - 1];
+                    xs[2] = (v + 1 < VEC) ? (C)xq0[1][(v + 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v + 1];
+                    ys[0] = (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
+                    ys[2] = (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
+                    const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
+                    C ka, kb;
+                    const T rs = update_keep(w, (C)xv[v], S, ka, kb);
+                    xcanew[v] = (T)ka;
+                    xcbnew[v] = (T)kb;
+                    res[v] = (xi + v < g.nx) ? rs : T(0);
+                }
+            }
+            xp1 = res;
+            *reinterpret_cast<VT *>(w1 + (xy - (y0 - 2)) * LP1 + HX1 + xl) = res;
+        } else if (c_l1) {
+            T rs = T(0);
+            if (wplane1 && c_wk) {
+                const C w = (C)xq0[1][0];
+                C xs[3], ys[3], zz[3];
+                zz[0] = (C)xq0[ZLO][0]; zz[1] = w; zz[2] = (C)xq0[ZHI][0];
+                xs[1] = ys[1] = w;
+                xs[0] = (C)c0[c_lds0 - 1]; xs[2] = (C)c0[c_lds0 + 1];
+                ys[0] = (C)c0[c_lds0 - LP0]; ys[2] = (C)c0[c_lds0 + LP0];
+                const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
+                C ka, kb;
+                rs = update_keep(w, (C)xv[0], S, ka, kb);
+                xcanew[0] = (T)ka;
+                xcbnew[0] = (T)kb;
+            }
+            w1[c_lds1] = rs;
+            xp1[0] = rs;
+        }
+        // ---- 4. level 2: phi2 of the plane behind, from the phi1 queues; a, b as level 1 formed them one iteration ago
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            q1[0][r] = q1[1][r];
+            q1[1][r] = q1[2][r];
+            q1[2][r] = p1new[r];
+        }
+        xq1[0] = xq1[1];
+        xq1[1] = xq1[2];
+        xq1[2] = xp1;
+        if (need2) {
+            auto level2 = [&](auto interior_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
-                constexpr bool YR = decltype(yreg_tag)::value;
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     VT res = zero;
-                    if (INTERIOR || (lvl2[r] && wplane2 && rowwk[r])) {
+                    if (INTERIOR || (wplane2 && rowwk[r])) {
                         const int ly = yrow[r] - (y0 - 2);
                         const VT m1 = q1[1][r];
 #pragma unroll
@@ -378,168 +389,153 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                             xs[1] = ys[1] = w;
                             xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v - 1];
                             xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v + 1];
-                            ys[0] = (YR && r >= 1) ? (C)q1[1][r >= 1 ? r - 1 : 0][v] : (C)c1[(ly - 1) * LP1 + HX1 + xl + v];
-                            ys[2] = (YR && r + 1 < RY) ? (C)q1[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c1[(ly + 1) * LP1 + HX1 + xl + v];
+                            ys[0] = (r >= 1) ? (C)q1[1][r >= 1 ? r - 1 : 0][v] : (C)c1[(ly - 1) * LP1 + HX1 + xl + v];
+                            ys[2] = (r + 1 < RY) ? (C)q1[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c1[(ly + 1) * LP1 + HX1 + xl + v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                            const T rs = update(w, (C)vq[1][r][v], S);
+                            const T rs = update_with(w, (C)caq[1][r][v], (C)cbq[1][r][v], S);
                             res[v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
                         }
                     }
                     p2new[r] = res;
-                    if (INTERIOR || lvl2[r]) *reinterpret_cast<VT *>(w2 + (yrow[r] - (y0 - 1)) * LP2 + HX2 + xl) = res;
+                    *reinterpret_cast<VT *>(w2 + (yrow[r] - (y0 - 1)) * LP2 + HX2 + xl) = res;
                 }
             };
-            // (phi2 is needed on planes zs-1 .. ze: the first two iterations of a column produce planes outside that range --
-            //  zeros are as good there, level 3 never reads them)
-            const int zp2 = z - SD;
-            if (zp2 >= zs - 1 && zp2 <= ze) {
-                if (is_main && all_rows && wplane2) level2(std::true_type{}, std::true_type{});
-                else if (is_main) level2(std::false_type{}, std::true_type{});
-                else level2(std::false_type{}, std::false_type{});
-            }
-            // ---- 5. level 3 (main waves): phi3 two planes behind from the phi2 queue, stored
-            if (is_main) {
+            if (all_rows && wplane2) level2(std::true_type{});
+            else level2(std::false_type{});
+            if (x_row) {
+                if (x_l2) {
+                    VT res = zero;
+                    if (wplane2 && xwk) {
+                        const int ly = xy - (y0 - 2);
+                        const VT m1 = xq1[1];
 #pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    q2[0][r] = q2[1][r];
-                    q2[1][r] = q2[2][r];
-                    q2[2][r] = p2new[r];
-                }
-                const int zo3 = z - 2 * SD;
-                // the planes the exchange sends once this workgroup has counted itself done: the last `wt` planes of the march
-                const bool wthrough = blk.bump >= 0 && (DOWN ? zo3 < zs + blk.wt : zo3 >= ze - blk.wt);
-                if (zo3 >= zs && zo3 < ze) {
-                    auto level3 = [&](auto interior_tag) {
-                        constexpr bool INTERIOR = decltype(interior_tag)::value;
-                        VT res3[RY];
-#pragma unroll
-                        for (int r = 0; r < RY; ++r) {
-                            res3[r] = zero;
-                            if (INTERIOR || rowwk[r]) {
-                                const int ly = yrow[r] - (y0 - 1);
-#pragma unroll
-                                for (int v = 0; v < VEC; ++v) {
-                                    const C w = (C)q2[1][r][v];
-                                    C xs[3], ys[3], zz[3];
-                                    zz[0] = (C)q2[ZLO][r][v]; zz[1] = w; zz[2] = (C)q2[ZHI][r][v];
-                                    xs[1] = ys[1] = w;
-                                    xs[0] = (v >= 1) ? (C)q2[1][r][(v + VEC - 1) % VEC] : (C)c2[ly * LP2 + HX2 + xl + v - 1];
-                                    xs[2] = (v + 1 < VEC) ? (C)q2[1][r][(v + 1) % VEC] : (C)c2[ly * LP2 + HX2 + xl + v + 1];
-                                    ys[0] = (r >= 1) ? (C)q2[1][r - 1 < 0 ? 0 : r - 1][v] : (C)c2[(ly - 1) * LP2 + HX2 + xl + v];
-                                    ys[2] = (r + 1 < RY) ? (C)q2[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c2[(ly + 1) * LP2 + HX2 + xl + v];
-                                    const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                                    res3[r][v] = update(w, (C)vq[0][r][v], S);
-                                }
-                            }
+                        for (int v = 0; v < VEC; ++v) {
+                            const C w = (C)m1[v];
+                            C xs[3], ys[3], zz[3];
+                            zz[0] = (C)xq1[ZLO][v]; zz[1] = w; zz[2] = (C)xq1[ZHI][v];
+                            xs[1] = ys[1] = w;
+                            xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v - 1];
+                            xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v + 1];
+                            ys[0] = (C)c1[(ly - 1) * LP1 + HX1 + xl + v];
+                            ys[2] = (C)c1[(ly + 1) * LP1 + HX1 + xl + v];
+                            const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
+                            const T rs = update_with(w, (C)xca[v], (C)xcb[v], S);
+                            res[v] = (xi + v < g.nx) ? rs : T(0);
                         }
-#pragma unroll
-                        for (int r = 0; r < RY; ++r) {
-                            if (INTERIOR || rowwk[r]) {
-                                T *dst = (out + (long long)zo3 * g.plane + rowoff[r]) + xlu;
-                                if (wthrough) {
-                                    // a plane the exchange will send: write-through stores (agent-scope relaxed atomics: sc1), so
-                                    // that the count after them needs no cache write-back (MI355X_MICROARCH.md, valid forms: sc1
-                                    // payload, every storing wave's vmcnt(0), the workgroup's barrier, then the counter)
-#pragma unroll
-                                    for (int v = 0; v < VEC; ++v)
-                                        if (INTERIOR || xi + v < g.nx) __hip_atomic_store(dst + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                } else if (INTERIOR || xi + VEC <= g.nx) {
-                                    *reinterpret_cast<VT *>(dst) = res3[r];
-                                } else {
-#pragma unroll
-                                    for (int v = 0; v < VEC; ++v)
-                                        if (xi + v < g.nx) dst[v] = res3[r][v];
-                                }
-                            }
-                        }
-                    };
-                    if (all_rows) level3(std::true_type{});
-                    else level3(std::false_type{});
+                    }
+                    *reinterpret_cast<VT *>(w2 + (xy - (y0 - 1)) * LP2 + HX2 + xl) = res;
                 }
-            }
-        } else {
-            // ---- halo-column wave: phi1 on the inner two columns, phi2 on the innermost one
-#pragma unroll
-            for (int q = 0; q < Cfg::CPL; ++q) {
+            } else if (c_l2) {
                 T rs = T(0);
-                if (c_l1[q]) {
-                    if (wplane1 && c_wk[q]) {
-                        const int o0 = c_lds0[q];
-                        const C w = (C)q0[1][q / VEC][q % VEC];
-                        C xs[3], ys[3], zz[3];
-                        zz[0] = (C)q0[ZLO][q / VEC][q % VEC]; zz[1] = w; zz[2] = (C)q0[ZHI][q / VEC][q % VEC];
-                        xs[1] = ys[1] = w;
-                        xs[0] = (C)c0[o0 - 1]; xs[2] = (C)c0[o0 + 1];
-                        ys[0] = (C)c0[o0 - LP0]; ys[2] = (C)c0[o0 + LP0];
-                        const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                        rs = update(w, (C)vq[2][q / VEC][q % VEC], S);
-                    }
-                    w1[c_lds1[q]] = rs;
+                if (wplane2 && c_wk) {
+                    const C w = (C)xq1[1][0];
+                    C xs[3], ys[3], zz[3];
+                    zz[0] = (C)xq1[ZLO][0]; zz[1] = w; zz[2] = (C)xq1[ZHI][0];
+                    xs[1] = ys[1] = w;
+                    xs[0] = (C)c1[c_lds1 - 1]; xs[2] = (C)c1[c_lds1 + 1];
+                    ys[0] = (C)c1[c_lds1 - LP1]; ys[2] = (C)c1[c_lds1 + LP1];
+                    const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
+                    rs = update_with(w, (C)xca[0], (C)xcb[0], S);
                 }
-                p1new[q / VEC][q % VEC] = rs;
-            }
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                q1[0][r] = q1[1][r];
-                q1[1][r] = q1[2][r];
-                q1[2][r] = p1new[r];
-            }
-#pragma unroll
-            for (int q = 0; q < Cfg::CPL; ++q) {
-                if (c_l2[q]) {
-                    T rs = T(0);
-                    if (wplane2 && c_wk[q] && (z - SD) >= zs - 1 && (z - SD) <= ze) {
-                        const int o1 = c_lds1[q];
-                        const C w = (C)q1[1][q / VEC][q % VEC];
-                        C xs[3], ys[3], zz[3];
-                        zz[0] = (C)q1[ZLO][q / VEC][q % VEC]; zz[1] = w; zz[2] = (C)q1[ZHI][q / VEC][q % VEC];
-                        xs[1] = ys[1] = w;
-                        xs[0] = (C)c1[o1 - 1]; xs[2] = (C)c1[o1 + 1];
-                        ys[0] = (C)c1[o1 - LP1]; ys[2] = (C)c1[o1 + LP1];
-                        const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                        rs = update(w, (C)vq[1][q / VEC][q % VEC], S);
-                    }
-                    w2[c_lds2[q]] = rs;
-                }
+                w2[c_lds2] = rs;
             }
         }
+        // ---- 5. level 3: phi3 two planes behind from the phi2 queue, a, b as formed two iterations ago; stored
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            q2[0][r] = q2[1][r];
+            q2[1][r] = q2[2][r];
+            q2[2][r] = p2new[r];
+        }
+        const int zo3 = z - 2 * SD;
+        const bool wthrough = blk.bump >= 0 && (DOWN ? zo3 < zs + blk.wt : zo3 >= ze - blk.wt);
+        if (zo3 >= zs && zo3 < ze) {
+            auto level3 = [&](auto interior_tag) {
+                constexpr bool INTERIOR = decltype(interior_tag)::value;
+                VT res3[RY];
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    res3[r] = zero;
+                    if (INTERIOR || rowwk[r]) {
+                        const int ly = yrow[r] - (y0 - 1);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const C w = (C)q2[1][r][v];
+                            C xs[3], ys[3], zz[3];
+                            zz[0] = (C)q2[ZLO][r][v]; zz[1] = w; zz[2] = (C)q2[ZHI][r][v];
+                            xs[1] = ys[1] = w;
+                            xs[0] = (v >= 1) ? (C)q2[1][r][(v + VEC - 1) % VEC] : (C)c2[ly * LP2 + HX2 + xl + v - 1];
+                            xs[2] = (v + 1 < VEC) ? (C)q2[1][r][(v + 1) % VEC] : (C)c2[ly * LP2 + HX2 + xl + v + 1];
+                            ys[0] = (r >= 1) ? (C)q2[1][r - 1 < 0 ? 0 : r - 1][v] : (C)c2[(ly - 1) * LP2 + HX2 + xl + v];
+                            ys[2] = (r + 1 < RY) ? (C)q2[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c2[(ly + 1) * LP2 + HX2 + xl + v];
+                            const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
+                            res3[r][v] = update_with(w, (C)caq[0][r][v], (C)cbq[0][r][v], S);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    if (INTERIOR || rowwk[r]) {
+                        T *dst = (out + (long long)zo3 * g.plane + rowoff[r]) + xlu;
+                        if (wthrough) {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v)
+                                if (INTERIOR || xi + v < g.nx) __hip_atomic_store(dst + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else if (INTERIOR || xi + VEC <= g.nx) {
+                            *reinterpret_cast<VT *>(dst) = res3[r];
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v)
+                                if (xi + v < g.nx) dst[v] = res3[r][v];
+                        }
+                    }
+                }
+            };
+            if (all_rows) level3(std::true_type{});
+            else level3(std::false_type{});
+        }
         __syncthreads();
-        // ---- 6. rotate the phi0 / V pipelines
+        // ---- 6. rotate the phi0 / V / a, b pipelines
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             q0[0][r] = q0[1][r];
             q0[1][r] = q0[2][r];
             q0[2][r] = pre[r];
-            vq[0][r] = vq[1][r];
-            vq[1][r] = vq[2][r];
-            vq[2][r] = pre_v[r];
+            vcur[r] = pre_v[r];
+            caq[0][r] = caq[1][r];
+            cbq[0][r] = cbq[1][r];
+            caq[1][r] = canew[r];
+            cbq[1][r] = cbnew[r];
         }
+        xq0[0] = xq0[1];
+        xq0[1] = xq0[2];
+        xq0[2] = xpre;
+        xv = xpre_v;
+        xca = xcanew;
+        xcb = xcbnew;
         orow_nxt = orow_pre;
     }
-    // ---- completion counter of the single-launch slab pass: every storing wave drains its stores, the workgroup
-    //      meets, one lane counts
     if (blk.bump >= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // (the planes the exchange reads were stored write-through; a half thinner than the exchange depth also sends planes
-        //  of the other half's workgroups, whose own write-through planes cover them: wt = the whole piece there)
         if (tid == 0) __hip_atomic_fetch_add(sy.cnt + blk.bump * WAFER_F3_SYNC_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 template <typename T, typename C, bool VIR>
 __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(WaferStepArgs a, int ntx, const WaferF3Block *__restrict__ table,
-                                                                           WaferF3Sync sy, const T *__restrict__ phi,
-                                                                           const T *__restrict__ pv, T *__restrict__ out)
+                                                                              WaferF3Sync sy, const T *__restrict__ phi,
+                                                                              const T *__restrict__ pv, T *__restrict__ out)
 {
     using Cfg = WaferF3Cfg<T>;
     __shared__ __attribute__((aligned(16))) T lds0[2 * Cfg::TILE0];
     __shared__ __attribute__((aligned(16))) T lds1[2 * Cfg::TILE1];
     __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
-    const WaferF3Block blk = table[blockIdx.x];   // uniform address: scalar loads
+    const WaferF3Block blk = table[blockIdx.x];
     if (blk.down) wafer_step3_body<T, C, VIR, true>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
     else wafer_step3_body<T, C, VIR, false>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
 }
+
 
 // ---- schedules (host) ---------------------------------------------------------------------------------------------
 #include <vector>

@@ -43,7 +43,6 @@ struct WaferTuning {
     int hv_short_tiles = -1; // WAFER_HV_SHORT_TILES: tiles per half cut into short pieces (-1: 1/16 of the tiles)
     int hv_nsub = 4;        // WAFER_HV_NSUB: pieces per short column
     int hv_layout = 0;      // WAFER_HV_LAYOUT: where the short columns go (wafer_f3_schedule_halves)
-    int f3_kernel = 0;      // WAFER_F3_KERNEL: 0 = twelve waves, a / b formed at every level; 1 = eight waves, a / b carried (wafer_stencil_fused3c.hip.h)
     int f3_sched = 0;       // WAFER_F3_SCHED: 1 = undecomposed launches use the two-halves schedule as well (timing experiments)
 };
 
@@ -82,7 +81,6 @@ static inline WaferTuning wafer_tuning_from_env()
     t.halo_cycle = wafer_env_int("WAFER_HALO_CYCLE", t.halo_cycle);
     t.hv_debug = wafer_env_int("WAFER_HV_DEBUG", t.hv_debug);
     t.f3_sched = wafer_env_int("WAFER_F3_SCHED", t.f3_sched);
-    t.f3_kernel = wafer_env_int("WAFER_F3_KERNEL", t.f3_kernel);
     t.hv_short_tiles = wafer_env_int("WAFER_HV_SHORT_TILES", t.hv_short_tiles);
     t.hv_nsub = wafer_env_int("WAFER_HV_NSUB", t.hv_nsub);
     t.hv_layout = wafer_env_int("WAFER_HV_LAYOUT", t.hv_layout);
