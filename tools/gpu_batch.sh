@@ -17,6 +17,14 @@ for step in "$@"; do
     sweep_f32)    for cd in 1 2; do for dt in f32 f32fast; do timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --cd $cd --dtype $dt --rounds 5 --steps 60 --configs "v=2" "v=1" "v=2" "v=1" 2>&1 | grep config | sed "s/^/cd=$cd $dt /"; done; done > $O/sweep_f32.jsonl; cat $O/sweep_f32.jsonl ;;
     tests_f3c)    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_slab.py tests/test_gpu_configs.py -x -q -k "three_step or fused3 or single_launch or 512 or config2 or thousand" > $O/tests_f3c.log 2>&1; tail -5 $O/tests_f3c.log ;;
     sweep_f3c)    timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 7 --steps 60 --configs "v=3" "v=2" "v=3" "v=2" > $O/sweep_f3c.jsonl 2>&1; cat $O/sweep_f3c.jsonl ;;
+    ab_prev)      for i in 1 2 3; do
+                    WAFER_HIP_LIB=$PWD/wafer_amd/build/prev/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 5 --steps 60 --configs "v=3" 2>&1 | grep config | sed "s/^/prev /"
+                    timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 5 --steps 60 --configs "v=3" 2>&1 | grep config | sed "s/^/new  /"
+                  done > $O/ab_prev.jsonl; cat $O/ab_prev.jsonl ;;
+    ab_excited)   for i in 1 2; do for w in 1 2 3; do
+                    WAFER_HIP_LIB=$PWD/wafer_amd/build/prev/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 5 --steps 30 --configs "v=-1" 2>&1 | grep config | sed "s/^/prev k=$w /"
+                    timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 5 --steps 30 --configs "v=-1" 2>&1 | grep config | sed "s/^/new  k=$w /"
+                  done; done > $O/ab_excited.jsonl; cut -c1-120 $O/ab_excited.jsonl ;;
     sq_f3c)       for k in 0 1; do
                     WAFER_F3_KERNEL=$k timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1_$k -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
                     WAFER_F3_KERNEL=$k timeout 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/sq2_$k -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
@@ -71,6 +79,22 @@ for line in open("$O/slab_tune.jsonl"):
         print("bad line", line[:200], e)
 PY
                   ;;
+    pmc_halo)     rocprofv3 --list-avail 2>/dev/null | grep -o "TCC_[A-Z0-9_]*" | sort -u > $O/tcc_counters.txt
+                  for swz in ${HALO_SWZ:-1 3 5 7}; do
+                    WAFER_XCD_SWIZZLE=$swz timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/halo_f$swz -- python3 tools/path_bench.py --steps 10 > $O/halo_path_$swz.log 2>&1
+                    python3 - <<PY
+import csv, glob, collections
+for d in ("$O/halo_f$swz", "$O/halo_t$swz"):
+    v = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            v[(row["Kernel_Name"][:70], row["Counter_Name"])].append(float(row["Counter_Value"]))
+    for (k, c), x in sorted(v.items()):
+        if "step" in k or "observ" in k: print("swz=$swz", c, round(sum(x) / len(x)), len(x), k)
+PY
+                    grep evolve $O/halo_path_$swz.log | cut -c1-60
+                    rm -rf $O/halo_f$swz $O/halo_t$swz
+                  done > $O/pmc_halo.txt 2>&1; cat $O/pmc_halo.txt ;;
     rows)         timeout 1500 python3 tools/secondary_rows.py $O/rows > $O/rows.log 2>&1; cat $O/rows.log | cut -c1-600 ;;
     *)            echo "unknown step $step" ;;
   esac

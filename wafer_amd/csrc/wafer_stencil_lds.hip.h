@@ -244,7 +244,12 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + xi;
     }
 
-    // halo rows this wave fetches: halo row h in [0,2R): h<R is row y0-R+h, else row y0+TY+(h-R)
+    // halo rows this wave fetches: halo row h in [0,2R): h<R is row y0-R+h, else row y0+TY+(h-R).
+    // A wave without a halo row (h >= 2R) requests its own first row a second time instead: the request is a cache hit
+    // behind the wave's own request of that row, its value is never written to the tile, and every wave runs the same
+    // instruction stream (the staging pipeline's waits count requests).  Before round 3 these waves requested rows
+    // y0+TY+R.. of the tile BELOW, six whole rows per tile and plane with 8 waves: hits while that tile's workgroup was
+    // resident on the same XCD, HBM reads otherwise -- 4.7 % of the reads at 512^3 (profiles/r03_halo_attribution.json).
     long long hrow_off[Cfg::HALO_ROWS_PER_WAVE];
     int hrow_lds[Cfg::HALO_ROWS_PER_WAVE];
 #pragma unroll
@@ -252,20 +257,26 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         const int h = wave + q * Cfg::NW;
         const int ly = (h < R) ? h : TY + h;          // LDS row (0..R-1 above, TY+R.. below)
         const int yp = y0 + ly;                        // padded y (= work y - R + R)
-        hrow_off[q] = (long long)yp * g.pitch + g.xoff + R + xi;
+        hrow_off[q] = h < 2 * R ? (long long)yp * g.pitch + g.xoff + R + xi : rowoff[0];
         hrow_lds[q] = ly * LP + HX + xl;
     }
     // halo-column cells: cell c in [0, 2R*TY): row = c / (2R), k = c % (2R);
-    // k<R: column x0-1-k, else column x0+TX+(k-R)
+    // k<R: column x0-1-k, else column x0+TX+(k-R).
+    // A cell outside the work area (the Dirichlet frame and the pad cells behind it, zeros that no kernel writes) is not
+    // fetched: its 128-byte line holds nothing else anyone reads, so every such request was an HBM read of its own -- 32 lines
+    // per plane and row of tiles, 6.2 % of the reads at 512^3.  The lane requests the tile's own edge cell of that row instead
+    // (a hit) and the value is replaced by the zero it stands for.
     long long hcol_off[Cfg::HALO_X_ITERS];
     int hcol_lds[Cfg::HALO_X_ITERS];
+    bool hcol_frame[Cfg::HALO_X_ITERS];
 #pragma unroll
     for (int q = 0; q < Cfg::HALO_X_ITERS; ++q) {
         const int cidx = min(tid + q * Cfg::NT, Cfg::NHALO_X - 1);     // surplus lanes repeat the last cell
         const int row = cidx / (2 * R), k = cidx % (2 * R);
         const int xw = (k < R) ? (x0 - 1 - k) : (x0 + TX + (k - R)); // work x, may be -R..nx+R-1
         const int y = y0 + row;
-        hcol_off[q] = (long long)(y + R) * g.pitch + g.xoff + R + xw;
+        hcol_frame[q] = xw < 0 || xw >= g.nx;
+        hcol_off[q] = (long long)(y + R) * g.pitch + g.xoff + R + (hcol_frame[q] ? ((k < R) ? x0 : x0 + TX - 1) : xw);
         hcol_lds[q] = (row + R) * LP + ((k < R) ? (HX - 1 - k) : (HX + TX + (k - R)));
     }
 
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
             if (tid + qq * Cfg::NT < Cfg::NHALO_X)
-                tile[hcol_lds[qq]] = load_cell((long long)zs * g.plane + hcol_off[qq]);
+                tile[hcol_lds[qq]] = hcol_frame[qq] ? (T)0 : load_cell((long long)zs * g.plane + hcol_off[qq]);
     }
     // halo of plane zs+1, held in registers until it is written at iteration zs
     VT hrow_nxt[Cfg::HALO_ROWS_PER_WAVE];
@@ -385,7 +396,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
             hrow_nxt[qq] = load_vec((long long)(zs + 1) * g.plane + hrow_off[qq], nullptr);
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
-            hcol_nxt[qq] = load_cell((long long)(zs + 1) * g.plane + hcol_off[qq]);
+            hcol_nxt[qq] = hcol_frame[qq] ? (T)0 : load_cell((long long)(zs + 1) * g.plane + hcol_off[qq]);
     }
     // DEEP: the raw staging set
     [[maybe_unused]] VT raw_w[RY];
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
             hrow_pre[qq] = load_vec(zo + 2 * g.plane + hrow_off[qq], nullptr);
 #pragma unroll
         for (int qq = 0; qq < Cfg::HALO_X_ITERS; ++qq)
-            hcol_pre[qq] = load_cell(zo + 2 * g.plane + hcol_off[qq]);
+            hcol_pre[qq] = hcol_frame[qq] ? (T)0 : load_cell(zo + 2 * g.plane + hcol_off[qq]);
         }
 
         // stored states at this plane (only the cells this lane updates)
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                 T l[NL > 0 ? NL : 1];
 #pragma unroll
                 for (int j = 0; j < NL; ++j) l[j] = raw_cl[j][qq];
-                hcol_nxt[qq] = xform_cell(raw_cw[qq], l);
+                hcol_nxt[qq] = hcol_frame[qq] ? (T)0 : xform_cell(raw_cw[qq], l);
             }
             // (neither the optimiser may sink these transforms towards their uses nor the scheduler lift the
             //  requests below above them: the staging registers would then be live twice and the compiler falls

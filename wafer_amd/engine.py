@@ -14,7 +14,9 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libwafer_hip.so")
+# WAFER_HIP_LIB: another build of the same library (same-box A/B runs of two kernel versions, tools/gpu_batch.sh ab_prev);
+# it is still a HIP build of this engine -- there is no other implementation to point this at
+_LIB = os.environ.get("WAFER_HIP_LIB") or os.path.join(_HERE, "libwafer_hip.so")
 
 POTENTIALS = [
     "NoPotential", "Cube", "QuadWell", "Periodic", "Coulomb", "ComplexCoulomb",
