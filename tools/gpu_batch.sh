@@ -21,7 +21,7 @@ for step in "$@"; do
                     WAFER_HIP_LIB=$PWD/wafer_amd/build/prev/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 5 --steps 60 --configs "v=3" 2>&1 | grep config | sed "s/^/prev /"
                     timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 5 --steps 60 --configs "v=3" 2>&1 | grep config | sed "s/^/new  /"
                   done > $O/ab_prev.jsonl; cat $O/ab_prev.jsonl ;;
-    ab_excited)   for i in 1 2; do for w in 1 2 3; do
+    ab_excited)   for i in 1 2; do for w in ${AB_K:-1 2 3}; do
                     WAFER_HIP_LIB=$PWD/wafer_amd/build/prev/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 5 --steps 30 --configs "v=-1" 2>&1 | grep config | sed "s/^/prev k=$w /"
                     timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 5 --steps 30 --configs "v=-1" 2>&1 | grep config | sed "s/^/new  k=$w /"
                   done; done > $O/ab_excited.jsonl; cut -c1-120 $O/ab_excited.jsonl ;;

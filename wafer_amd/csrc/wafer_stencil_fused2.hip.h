@@ -164,7 +164,11 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
         orow_lds[q] = (y - (y0 - 2 * R)) * LP0 + HX0 + xl;
     }
     // ---- halo-column cells of the last wave ------------------------------------------------
-    bool c_p1[Cfg::CPL];
+    // (a cell outside the work area -- frame and pad columns, frame rows: zeros that no kernel writes -- is not fetched: its
+    //  128-byte line holds nothing anybody else reads, so each such request was an HBM read of its own.  The lane requests the
+    //  tile's own edge cell instead, a line the row's owner requests in the same iteration, and the value becomes the zero it
+    //  stands for where it is staged into the tile; the cell's queues are read nowhere else: c_p1.)
+    bool c_p1[Cfg::CPL], c_out[Cfg::CPL];
     long long c_off[Cfg::CPL];
     int c_lds0[Cfg::CPL], c_lds1[Cfg::CPL];
 #pragma unroll
@@ -178,7 +182,9 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
         // phi1 is produced on the inner R columns and rows y0-R .. y0+TY+R-1, work cells only
         c_p1[q] = valid && (kk < R) && (row >= R) && (row < Cfg::ROWS0 - R) && (y >= 0) && (y < g.ny) &&
                   (xw >= 0) && (xw < g.nx);
-        c_off[q] = (long long)(y + R) * g.pitch + g.xoff + R + xw;
+        c_out[q] = xw < 0 || xw >= g.nx || y < 0 || y >= g.ny;
+        c_off[q] = (long long)((y < 0 ? y0 : y >= g.ny ? y0 + TY - 1 : y) + R) * g.pitch + g.xoff + R +
+                   ((xw < 0 || xw >= g.nx) ? ((k < Cfg::HC0) ? x0 : x0 + TX - 1) : xw);
         c_lds0[q] = row * LP0 + HX0 + lc;
         c_lds1[q] = (row - R) * LP1 + HX1 + lc;
     }
@@ -270,7 +276,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                 *reinterpret_cast<VT *>(t0 + orow_lds[q]) = *reinterpret_cast<const VT *>(phi + (long long)z1 * g.plane + orow_off[q]);
 #pragma unroll
         for (int q = 0; q < Cfg::CPL; ++q)
-            if (is_hcol && lane + q * 64 < Cfg::NCOL) t0[c_lds0[q]] = q0[R][q / VEC][q % VEC];
+            if (is_hcol && lane + q * 64 < Cfg::NCOL) t0[c_lds0[q]] = c_out[q] ? T(0) : q0[R][q / VEC][q % VEC];
     }
     VT orow_nxt[Cfg::OPW];
 #pragma unroll
@@ -325,7 +331,7 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
                 if (is_main && wave + q * Cfg::NW2 < Cfg::OUTER) *reinterpret_cast<VT *>(nt + orow_lds[q]) = orow_nxt[q];
 #pragma unroll
             for (int q = 0; q < Cfg::CPL; ++q)
-                if (is_hcol && lane + q * 64 < Cfg::NCOL) nt[c_lds0[q]] = q0[R + 1][q / VEC][q % VEC];
+                if (is_hcol && lane + q * 64 < Cfg::NCOL) nt[c_lds0[q]] = c_out[q] ? T(0) : q0[R + 1][q / VEC][q % VEC];
         }
         // ---- 3. step 1: phi1 plane z ---------------------------------------------------------------------------
         const T *c0 = lds0 + (z & 1) * Cfg::TILE0;

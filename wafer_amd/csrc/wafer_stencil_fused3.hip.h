@@ -160,10 +160,14 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     // ---- the extra halo row
     const int xy = wave == 0 ? y0 - 1 : wave == 1 ? y0 - 2 : wave == 6 ? y0 + TY + 1 : y0 + TY;
     const bool xwk = x_row && xy >= 0 && xy < g.ny;
-    const long long xoff_row = (long long)(xy + R) * g.pitch + g.xoff + R + x0;
+    // (a halo row above / below the work area -- frame and guard rows, zeros -- is not fetched either: the wave requests its
+    //  own first row again and takes zeros)
+    const bool xy_out = xy < 0 || xy >= g.ny;
+    const long long xoff_row = xy_out ? rowoff[0] : (long long)(xy + R) * g.pitch + g.xoff + R + x0;
     // ---- outermost phi0 halo rows y0-3 / y0+18 (plain vector loads staged through LDS)
     const int oy = wave == 1 ? y0 - 3 : y0 + TY + 2;
-    const long long orow_off = (long long)(oy + R) * g.pitch + g.xoff + R + x0;
+    const bool oy_out = oy < 0 || oy >= g.ny;
+    const long long orow_off = oy_out ? rowoff[0] : (long long)(oy + R) * g.pitch + g.xoff + R + x0;
     const int orow_lds = (oy - (y0 - 3)) * LP0 + HX0 + xl;
     // ---- halo-column cell of this lane (waves 2..5): cell c: row c / 6 of the phi0 tile, k = c % 6: k < 3: column x0-1-k,
     //      else column x0+TX+(k-3)
@@ -176,7 +180,15 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     const bool c_wk = cy >= 0 && cy < g.ny && cxw >= 0 && cxw < g.nx;
     const bool c_l1 = c_ok && ckk < Cfg::HC1 && crow >= 1 && crow < Cfg::ROWS0 - 1;
     const bool c_l2 = c_ok && ckk < Cfg::HC2 && crow >= 2 && crow < Cfg::ROWS0 - 2;
-    const long long c_off = (long long)(cy + R) * g.pitch + g.xoff + R + cxw;
+    // a cell left or right of the work area (the Dirichlet frame column and the pad cells behind it: zeros that no kernel
+    // writes) is not fetched -- its 128-byte line holds nothing anybody else reads, so each such request was an HBM read of its
+    // own, 44 + 40 lines (phi0, V) per plane and row of tiles, 6 % of this kernel's reads at 512^3.  The lane requests the tile's
+    // own edge cell of that row instead (a line the row's owner requests in the same iteration) and phi0 becomes the zero it
+    // stands for; V of such a cell is never used (c_wk).  (Found with the halo-attribution runs of profiles/NOTES.md, round 3.
+    //  The same for a cell above / below the work area: the tile's own first / last row.)
+    const bool c_xout = cxw < 0 || cxw >= g.nx || cy < 0 || cy >= g.ny;
+    const long long c_off = (long long)((cy < 0 ? y0 : cy >= g.ny ? y0 + TY - 1 : cy) + R) * g.pitch + g.xoff + R +
+                            ((cxw < 0 || cxw >= g.nx) ? (ck < Cfg::HC0 ? x0 : x0 + TX - 1) : cxw);
     const int c_lds0 = crow * LP0 + HX0 + clc, c_lds1 = (crow - 1) * LP1 + HX1 + clc, c_lds2 = (crow - 2) * LP2 + HX2 + clc;
 
     auto work_plane = [&](int p) {
@@ -231,9 +243,9 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         T *t0 = lds0 + (z1 & 1) * Cfg::TILE0;
 #pragma unroll
         for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(t0 + (yrow[r] - (y0 - 3)) * LP0 + HX0 + xl) = q0[1][r];
-        if (x_row) *reinterpret_cast<VT *>(t0 + (xy - (y0 - 3)) * LP0 + HX0 + xl) = xq0[1];
-        else if (c_ok) t0[c_lds0] = xq0[1][0];
-        if (has_orow) *reinterpret_cast<VT *>(t0 + orow_lds) = *reinterpret_cast<const VT *>((phi + (long long)z1 * g.plane + orow_off) + xlu);
+        if (x_row) *reinterpret_cast<VT *>(t0 + (xy - (y0 - 3)) * LP0 + HX0 + xl) = xy_out ? zero : xq0[1];
+        else if (c_ok) t0[c_lds0] = c_xout ? T(0) : xq0[1][0];
+        if (has_orow) *reinterpret_cast<VT *>(t0 + orow_lds) = oy_out ? zero : *reinterpret_cast<const VT *>((phi + (long long)z1 * g.plane + orow_off) + xlu);
     }
     VT orow_nxt = zero;
     if (has_orow) orow_nxt = *reinterpret_cast<const VT *>((phi + (long long)(z1 + SD) * g.plane + orow_off) + xlu);
@@ -265,10 +277,14 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             T *nt = lds0 + ((z + 1) & 1) * Cfg::TILE0;
 #pragma unroll
             for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(nt + (yrow[r] - (y0 - 3)) * LP0 + HX0 + xl) = q0[2][r];
+            // (what was requested in place of a cell outside the work area becomes the zero it stands for HERE, where the value
+            //  is used, not where the request is waited for: a select on the prefetch registers before the barrier would put
+            //  the wait into the iteration that issued the request.  The queues of such a cell are never read otherwise:
+            //  xwk / c_wk.)
             if (x_row) {
-                *reinterpret_cast<VT *>(nt + (xy - (y0 - 3)) * LP0 + HX0 + xl) = xq0[2];
-                if (has_orow) *reinterpret_cast<VT *>(nt + orow_lds) = orow_nxt;
-            } else if (c_ok) nt[c_lds0] = xq0[2][0];
+                *reinterpret_cast<VT *>(nt + (xy - (y0 - 3)) * LP0 + HX0 + xl) = xy_out ? zero : xq0[2];
+                if (has_orow) *reinterpret_cast<VT *>(nt + orow_lds) = oy_out ? zero : orow_nxt;
+            } else if (c_ok) nt[c_lds0] = c_xout ? T(0) : xq0[2][0];
         }
         const T *c0 = lds0 + (z & 1) * Cfg::TILE0;
         T *w1 = lds1 + (z & 1) * Cfg::TILE1;
