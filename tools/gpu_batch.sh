@@ -36,6 +36,7 @@ for name, c in d.items():
     print("kernel $k", {k: round(v["avg"] / 1e6, 1) for k, v in c.items()})
 PY
                   done ;;
+    sweep_sizes)  for grid in 256,256,256 320,320,320 384,384,384 448,448,448 640,640,640 1024,1024,128; do timeout 300 python3 tools/stencil_sweep.py --grid $grid --rounds 5 --steps 60 --configs "v=-1" 2>&1 | grep config | sed "s/^/$grid /"; done > $O/sweep_sizes.jsonl; cut -c1-150 $O/sweep_sizes.jsonl ;;
     sweep_f3c_sizes) for grid in 256,256,256 384,384,384 1024,1024,128; do timeout 300 python3 tools/stencil_sweep.py --grid $grid --rounds 7 --steps 60 --configs "v=3" "v=2" "v=3" "v=2" 2>&1 | grep config | sed "s/^/$grid /"; done > $O/sweep_f3c_sizes.jsonl; cat $O/sweep_f3c_sizes.jsonl ;;
     tests_slab)   timeout 600 python -m pytest tests/test_gpu_slab.py -x -q > $O/tests_slab.log 2>&1; tail -5 $O/tests_slab.log ;;
     bench)        timeout 600 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-300 $O/bench_n1.json ;;
@@ -95,6 +96,22 @@ PY
                     grep evolve $O/halo_path_$swz.log | cut -c1-60
                     rm -rf $O/halo_f$swz $O/halo_t$swz
                   done > $O/pmc_halo.txt 2>&1; cat $O/pmc_halo.txt ;;
+    sq_path)      timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sqp1 -- python3 tools/path_bench.py --steps 10 > /dev/null 2>&1
+                  timeout 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/sqp2 -- python3 tools/path_bench.py --steps 10 > /dev/null 2>&1
+                  timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $O/sqp3 -- python3 tools/path_bench.py --steps 10 > /dev/null 2>&1
+                  python3 tools/pmc_counters.py $O/sqp1 $O/sqp2 $O/sqp3 --match wafer_k_step > $O/sq_path.json; rm -rf $O/sqp1 $O/sqp2 $O/sqp3
+                  python3 - <<PY
+import json
+d = json.load(open("$O/sq_path.json"))
+for name, c in d.items():
+    g = lambda k: c.get(k, {}).get("avg", 0.0)
+    wc = g("SQ_WAVE_CYCLES") or 1.0
+    print(name[:90])
+    print("   VALU %.1f M  LDS %.1f M  VMEM_RD %.2f M  VMEM_WR %.2f M  SALU %.1f M  active_valu %.3f  active_any %.3f  wait_inst %.3f  wait_any %.3f" % (
+        g("SQ_INSTS_VALU") / 1e6, g("SQ_INSTS_LDS") / 1e6, g("SQ_INSTS_VMEM_RD") / 1e6, g("SQ_INSTS_VMEM_WR") / 1e6, g("SQ_INSTS_SALU") / 1e6,
+        g("SQ_ACTIVE_INST_VALU") / wc, g("SQ_ACTIVE_INST_ANY") / wc, g("SQ_WAIT_INST_ANY") / wc, g("SQ_WAIT_ANY") / wc))
+PY
+                  ;;
     rows)         timeout 1500 python3 tools/secondary_rows.py $O/rows > $O/rows.log 2>&1; cat $O/rows.log | cut -c1-600 ;;
     *)            echo "unknown step $step" ;;
   esac

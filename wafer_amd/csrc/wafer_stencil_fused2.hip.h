@@ -536,10 +536,7 @@ static inline int wafer_f2_zchunk(const WaferTuning &t, const WaferGeom &g, int 
     if (target_blocks < 0) return -target_blocks < nplanes ? -target_blocks : nplanes; // the caller fixed the chunk length
     const long long per_layer = (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + Cfg::TY - 1) / Cfg::TY);
     const long long target = t.target_blocks > 0 ? t.target_blocks : (target_blocks > 0 ? target_blocks : 256);
-    long long nch = (target + per_layer / 2) / per_layer;
-    if (nch < 1) nch = 1;
-    if (nch > nplanes) nch = nplanes;
-    return (int)((nplanes + nch - 1) / nch);
+    return wafer_pick_zchunk(per_layer, nplanes, target, 2 * R + 3);
 }
 
 // Advances planes [lz_lo, lz_hi) by TWO steps: out = step(step(phi)).

@@ -676,10 +676,7 @@ static inline int wafer_f3_zchunk(const WaferTuning &t, int ntx, int nty, int np
     if (target_blocks < 0) return -target_blocks < nplanes ? -target_blocks : nplanes;
     const long long per_layer = (long long)ntx * nty;
     const long long target = t.target_blocks > 0 ? t.target_blocks : (target_blocks > 0 ? target_blocks : 256);
-    long long nch = (target + per_layer / 2) / per_layer;
-    if (nch < 1) nch = 1;
-    if (nch > nplanes) nch = nplanes;
-    return (int)((nplanes + nch - 1) / nch);
+    return wafer_pick_zchunk(per_layer, nplanes, target, 6);   // four iterations of pipeline fill + the prologue
 }
 
 // Advances the planes of `table` (device copy, nblocks entries) by THREE steps: out = step(step(step(phi))).  ThreePoint only.

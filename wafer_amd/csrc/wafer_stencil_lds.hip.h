@@ -76,10 +76,7 @@ static inline int wafer_lds_zchunk(const WaferTuning &t, const WaferGeom &g, int
     // two workgroups per CU: with a, b formed from V the kernel does more arithmetic per byte and
     // a second resident workgroup hides it (0.539 vs 0.574 ms at 512^3, profiles/r01_sweep_e_512.jsonl)
     const long long target = t.target_blocks > 0 ? t.target_blocks : 2 * (target_blocks > 0 ? target_blocks : 256);
-    long long nch = (target + per_layer / 2) / per_layer; // nearest
-    if (nch < 1) nch = 1;
-    if (nch > nplanes) nch = nplanes;
-    return (int)((nplanes + nch - 1) / nch);
+    return wafer_pick_zchunk(per_layer, nplanes, target, R + 2);
 }
 
 template <typename T, int R>

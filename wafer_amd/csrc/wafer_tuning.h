@@ -86,3 +86,27 @@ static inline WaferTuning wafer_tuning_from_env()
     t.hv_layout = wafer_env_int("WAFER_HV_LAYOUT", t.hv_layout);
     return t;
 }
+
+// Chunks per tile column of a column-marching kernel: the count that minimises the launch's makespan,
+//   rounds x (planes per chunk + fill),   rounds = ceil(workgroups / slots),
+// where `slots` workgroups are resident at once (CUs x workgroups per CU) and `fill` is what a chunk pays beyond its
+// own planes (pipeline fill and prologue, in plane iterations).  Rounds 1 and 2 rounded `slots / tiles per layer` to the
+// nearest integer instead, which is the same at 256^3, 512^3 and 1024^3 but not in between: 384^3 has 72 tiles per layer
+// of the three-step kernel, 3.55 rounded to 4 chunks = 288 workgroups = a full round and a second round of 32 -- two rounds
+// of 100 iterations where 7 chunks give two full rounds of 59 (325 against 449 G updates/s, profiles/NOTES.md).
+static inline int wafer_pick_zchunk(long long per_layer, int nplanes, long long slots, int fill)
+{
+    if (per_layer < 1) per_layer = 1;
+    if (slots < 1) slots = 1;
+    long long best_cost = -1;
+    int best_zc = nplanes;
+    const int nch_max = nplanes < 64 ? nplanes : 64;
+    for (int nch = 1; nch <= nch_max; ++nch) {
+        const int zc = (nplanes + nch - 1) / nch;
+        const int real = (nplanes + zc - 1) / zc;
+        const long long rounds = (per_layer * real + slots - 1) / slots;
+        const long long cost = rounds * (zc + fill);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_zc = zc; }
+    }
+    return best_zc;
+}
