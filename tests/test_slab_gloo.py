@@ -166,7 +166,7 @@ def _fallback_worker(rank, world, port, failing_rank, phase, out_dir):
         class Native(slab.NativeRcclSlabComm):
             precheck = staticmethod(pre)
 
-            def __init__(self, ctx, r, w, device, group=None, self_neighbours=False, prechecked=None):
+            def __init__(self, ctx, r, w, device, group=None, self_neighbours=False, prechecked=None, mailbox=False):
                 calls["phase2"] += 1
                 box = [b"id"]                   # the collective of the real phase 2: every rank must get here or none
                 dist.broadcast_object_list(box, src=0, group=group)
