@@ -646,17 +646,23 @@ def run_rank(args) -> int:
                         rc = RC_PARITY
                 ex.upload_phi(phi0)
                 del phi0, lowers
+                ex.evolve(3, 150)   # the device idled while the oracle ran on the host: bring the clocks back up before timing (as --preheat does for the headline)
                 for k in (1, 2, 3):
                     ex.evolve(k, 10)
-                    ex.evolve(k, 40)
-                    ms_k, st_k = ex.last_evolve_ms()
+                    ms_k, st_k = None, None
+                    for _ in range(3):   # median of three 40-step evolves
+                        ex.evolve(k, 40)
+                        m_, s_ = ex.last_evolve_ms()
+                        ms_k = sorted(([] if ms_k is None else ms_k) + [m_])
+                        st_k = s_
+                    ms_k = ms_k[1]
                     bpu_k = 80 + 32 * (k - 1)   # stencil + norm 32, normalise + dot 24, (k - 1) x (axpy + dot) 32, last axpy 24
                     rec[f"k{k}"] = {"ms_per_step": ms_k / st_k, "algorithmic_bytes_per_update": bpu_k,
                                     "frac_of_hbm_peak": pts_total * bpu_k / (ms_k / st_k * 1e-3) / 1e9 / HBM_PEAK_GBPS}
                 ex.close()
                 result["excited_state_step"] = {"grid": list(shape), "potential": potential, **rec,
                                                 "stored_states": "box modes (1,1,1), (2,1,1), (1,1,2)",
-                                                "note": "wafer_evolve(wnum = k) on the same grid, HIP events; checked by excited_parity"}
+                                                "note": "wafer_evolve(wnum = k) on the same grid, HIP events, median of three 40-step evolves after a 150-step warm-up; checked by excited_parity"}
             except Exception as e:  # reported, never silently dropped
                 result["excited_state_step"] = {"error": repr(e)}
 

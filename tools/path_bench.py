@@ -12,6 +12,7 @@ ap.add_argument("--grid", default="512,512,512")
 ap.add_argument("--cd", type=int, default=1)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--rounds", type=int, default=3, help="evolve calls per wnum; the median is reported")
 args = ap.parse_args()
 nx, ny, nz = (int(s) for s in args.grid.split(","))
 pts = nx * ny * nz
@@ -32,11 +33,16 @@ with wafer_amd.Context(par) as ctx:
         ctx.normalise(ctx.norm2())
         ctx.push_state()
     ctx.set_initial_condition("Boolean")
+    ctx.evolve(0, 600)   # clocks up (a cold device runs the first launches 10-40 % slow)
+    ctx.set_initial_condition("Boolean")
     for wnum, b in ((0, 4 * es), (1, 10 * es), (2, 14 * es), (3, 18 * es)):
         ctx.evolve(wnum, 4)
-        ctx.evolve(wnum, args.steps)
-        ms, steps = ctx.last_evolve_ms()
-        report(f"evolve wnum={wnum}", ms / steps, b)
+        per = []
+        for _ in range(args.rounds):
+            ctx.evolve(wnum, args.steps)
+            ms, steps = ctx.last_evolve_ms()
+            per.append(ms / steps)
+        report(f"evolve wnum={wnum}", sorted(per)[len(per) // 2], b)
         ctx.set_initial_condition("Boolean")
 
     def timed(fn, reps=10):

@@ -23,6 +23,15 @@ NCCL_MAX_P2P_NCHANNELS=8 python3 tools/slab_overhead.py --rccl --steps 60 --mode
 NCCL_MAX_P2P_NCHANNELS=8 rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -o t -- python3 tools/slab_trace.py --rccl --mode 2 > /dev/null 2>&1
 python3 tools/slab_trace.py --parse $(find $O/trace2 -name "*kernel_trace.csv" | head -1) > $O/slab_single_launch_timeline.txt 2>&1
 rm -rf $O/trace2
+# every kernel family of the path (excited-state steps k = 1..3, observables, reductions): times, --stats summary, traffic
+python3 tools/path_bench.py > $O/path_512.jsonl 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/path_stats -- python3 tools/path_bench.py > /dev/null 2>&1
+cp $(find $O/path_stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats_path_512.csv
+rm -rf $O/path_stats
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pfetch -- python3 tools/path_bench.py --steps 10 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pwrite -- python3 tools/path_bench.py --steps 10 > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/pfetch $O/pwrite $O/pmc_path_512.json
+rm -rf $O/pfetch $O/pwrite
 python3 tools/secondary_rows.py $O/rows > $O/rows.log 2>&1
 python3 tools/allreduce_latency.py 2> /dev/null | grep "^{" > $O/allreduce_latency.json
 cut -c1-300 $O/bench_n1.json; cat $O/slab_overhead.json; cat $O/sq_counters_fused3.json | head -40
