@@ -302,6 +302,31 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         bool all_rows = x0 + TX <= g.nx;
 #pragma unroll
         for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];
+        // ---- 2b. the x / y neighbours of the main rows, requested one level AHEAD: level 1's and level 2's here, level 3's
+        //          behind level 1's arithmetic.  What level L reads this iteration (phi0 plane z, phi1 plane z-1, phi2 plane z-2)
+        //          was written before the last barrier, and the ring slots the levels write are the other ones: reading early
+        //          changes no value.  In program order every level's reads sat behind the previous level's ring write (which the
+        //          compiler cannot tell apart from them), so each level paid its own LDS round trip with only one other wave on
+        //          the SIMD to hide it.  Per level: the cell left of the lane's first and right of its last on each row, the
+        //          row above the first row and the row below the last.  (All three levels at the top: 255 VGPRs and scratch.)
+        T nbl[3][RY], nbr[3][RY];
+        VT nbu[3], nbd[3];
+        auto nbload = [&](auto level_tag) {
+            constexpr int L = decltype(level_tag)::value;
+            const T *cc = L == 0 ? c0 : L == 1 ? c1 : c2;
+            constexpr int lp = L == 0 ? LP0 : L == 1 ? LP1 : LP2, hx = L == 0 ? HX0 : L == 1 ? HX1 : HX2;
+            const int yb = y0 - 3 + L;
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                const int o = (yrow[r] - yb) * lp + hx + xl;
+                nbl[L][r] = cc[o - 1];
+                nbr[L][r] = cc[o + VEC];
+            }
+            nbu[L] = *reinterpret_cast<const VT *>(cc + (yrow[0] - yb - 1) * lp + hx + xl);
+            nbd[L] = *reinterpret_cast<const VT *>(cc + (yrow[RY - 1] - yb + 1) * lp + hx + xl);
+        };
+        nbload(std::integral_constant<int, 0>{});
+        nbload(std::integral_constant<int, 1>{});
         // ---- 3. level 1, main rows.  INTERIOR: the plane and both rows are work cells, the tile's columns too: no tests
         //         inside, the RY x VEC updates form one basic block
         auto level1 = [&](auto interior_tag) {
@@ -310,17 +335,16 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             for (int r = 0; r < RY; ++r) {
                 VT res = zero;
                 if (INTERIOR || (wplane1 && rowwk[r])) {
-                    const int ly = yrow[r] - (y0 - 3);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         const C w = (C)q0[1][r][v];
                         C xs[3], ys[3], zz[3];
                         zz[0] = (C)q0[ZLO][r][v]; zz[1] = w; zz[2] = (C)q0[ZHI][r][v];
                         xs[1] = ys[1] = w;
-                        xs[0] = (v >= 1) ? (C)q0[1][r][(v + VEC - 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v - 1];
-                        xs[2] = (v + 1 < VEC) ? (C)q0[1][r][(v + 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v + 1];
-                        ys[0] = (r >= 1) ? (C)q0[1][r >= 1 ? r - 1 : 0][v] : (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
-                        ys[2] = (r + 1 < RY) ? (C)q0[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
+                        xs[0] = (v >= 1) ? (C)q0[1][r][(v + VEC - 1) % VEC] : (C)nbl[0][r];
+                        xs[2] = (v + 1 < VEC) ? (C)q0[1][r][(v + 1) % VEC] : (C)nbr[0][r];
+                        ys[0] = (r >= 1) ? (C)q0[1][r >= 1 ? r - 1 : 0][v] : (C)nbu[0][v];
+                        ys[2] = (r + 1 < RY) ? (C)q0[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[0][v];
                         const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
                         C ka, kb;
                         const T rs = update_keep(w, (C)vcur[r][v], S, ka, kb);
@@ -335,6 +359,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         };
         if (all_rows && wplane1) level1(std::true_type{});
         else level1(std::false_type{});
+        nbload(std::integral_constant<int, 2>{});
         // ---- 3x. level 1, the extra slot
         if (x_row) {
             VT res = zero;
@@ -395,7 +420,6 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                 for (int r = 0; r < RY; ++r) {
                     VT res = zero;
                     if (INTERIOR || (wplane2 && rowwk[r])) {
-                        const int ly = yrow[r] - (y0 - 2);
                         const VT m1 = q1[1][r];
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
@@ -403,10 +427,10 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                             C xs[3], ys[3], zz[3];
                             zz[0] = (C)q1[ZLO][r][v]; zz[1] = w; zz[2] = (C)q1[ZHI][r][v];
                             xs[1] = ys[1] = w;
-                            xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v - 1];
-                            xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v + 1];
-                            ys[0] = (r >= 1) ? (C)q1[1][r >= 1 ? r - 1 : 0][v] : (C)c1[(ly - 1) * LP1 + HX1 + xl + v];
-                            ys[2] = (r + 1 < RY) ? (C)q1[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c1[(ly + 1) * LP1 + HX1 + xl + v];
+                            xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)nbl[1][r];
+                            xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)nbr[1][r];
+                            ys[0] = (r >= 1) ? (C)q1[1][r >= 1 ? r - 1 : 0][v] : (C)nbu[1][v];
+                            ys[2] = (r + 1 < RY) ? (C)q1[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[1][v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
                             const T rs = update_with(w, (C)caq[1][r][v], (C)cbq[1][r][v], S);
                             res[v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
@@ -473,17 +497,16 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                 for (int r = 0; r < RY; ++r) {
                     res3[r] = zero;
                     if (INTERIOR || rowwk[r]) {
-                        const int ly = yrow[r] - (y0 - 1);
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
                             const C w = (C)q2[1][r][v];
                             C xs[3], ys[3], zz[3];
                             zz[0] = (C)q2[ZLO][r][v]; zz[1] = w; zz[2] = (C)q2[ZHI][r][v];
                             xs[1] = ys[1] = w;
-                            xs[0] = (v >= 1) ? (C)q2[1][r][(v + VEC - 1) % VEC] : (C)c2[ly * LP2 + HX2 + xl + v - 1];
-                            xs[2] = (v + 1 < VEC) ? (C)q2[1][r][(v + 1) % VEC] : (C)c2[ly * LP2 + HX2 + xl + v + 1];
-                            ys[0] = (r >= 1) ? (C)q2[1][r - 1 < 0 ? 0 : r - 1][v] : (C)c2[(ly - 1) * LP2 + HX2 + xl + v];
-                            ys[2] = (r + 1 < RY) ? (C)q2[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)c2[(ly + 1) * LP2 + HX2 + xl + v];
+                            xs[0] = (v >= 1) ? (C)q2[1][r][(v + VEC - 1) % VEC] : (C)nbl[2][r];
+                            xs[2] = (v + 1 < VEC) ? (C)q2[1][r][(v + 1) % VEC] : (C)nbr[2][r];
+                            ys[0] = (r >= 1) ? (C)q2[1][r - 1 < 0 ? 0 : r - 1][v] : (C)nbu[2][v];
+                            ys[2] = (r + 1 < RY) ? (C)q2[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[2][v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
                             res3[r][v] = update_with(w, (C)caq[0][r][v], (C)cbq[0][r][v], S);
                         }
