@@ -564,30 +564,15 @@ static inline hipError_t wafer_launch_step2_fused_nw(const WaferTuning &t, Wafer
     }
     const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
     const bool vir = a.v_in_range != 0;
-    { // YR (register y neighbours in step 1), for the default variant only (ordinary loads, a and b from V).  Same-box
-      // A/B at 512^3: FivePoint fp64 0.4390 against 0.4439 ms/step with it; ThreePoint fp64 no change; fp32 storage
-      // 0.2674 against 0.2600 WITHOUT it -- so: on for FivePoint fp64, off elsewhere (WAFER_F2_YREG=0/1 overrides).
-        const bool yr = t.f2_yreg >= 0 ? t.f2_yreg != 0 : (R == 2 && std::is_same<T, double>::value);
-        if (o.nt == 0 && o.abv != 0) {
-            if (vir && yr) hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, true, true>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
-            else if (vir) hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, true, false>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
-            else if (yr) hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, false, true>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
-            else hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, false, false>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
-            return hipGetLastError();
-        }
-    }
-#define WAFER_F2_CASE(NT_, ABV_, VIR_)                                                                          \
-    if ((o.nt != 0) == NT_ && (o.abv != 0) == ABV_ && (!ABV_ || vir == VIR_)) {                                 \
-        hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, NT_, ABV_, NW2, VIR_, false>), grid, block, (size_t)o.pad, s, \
-                           a, ntx, nty, swz, phi, ABV_ ? pv : pa, pb, out);                                      \
-        return hipGetLastError();                                                                               \
-    }
-    WAFER_F2_CASE(true, true, true)
-    WAFER_F2_CASE(true, true, false)
-    WAFER_F2_CASE(true, false, false)
-    WAFER_F2_CASE(false, false, false)
-#undef WAFER_F2_CASE
-    return hipErrorInvalidValue;
+    // One flavour per (types, ext, tile height): ordinary (cache-retaining) loads, a and b formed from V in registers.  The
+    // flavours that streamed a and b or used non-temporal loads were measured slower in round 1 (168+ VGPRs and scratch at
+    // ext 1) and had no test of their own; they are gone (96 -> 24 instantiations of this kernel in the library).
+    // YR (register y neighbours in step 1): same-box A/B at 512^3: FivePoint fp64 0.4390 against 0.4439 ms/step with it;
+    // ThreePoint fp64 no change; fp32 storage 0.2674 against 0.2600 WITHOUT it -- so: on for FivePoint fp64 only.
+    constexpr bool YR = R == 2 && std::is_same<T, double>::value;
+    if (vir) hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, true, YR>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
+    else hipLaunchKernelGGL((wafer_k_step2_fused<T, C, R, false, true, NW2, false, YR>), grid, block, (size_t)o.pad, s, a, ntx, nty, swz, phi, pv, pb, out);
+    return hipGetLastError();
 }
 
 template <typename T, typename C, int R>
