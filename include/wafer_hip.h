@@ -281,7 +281,8 @@ int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn 
  *      workgroups count themselves done and the second stream releases each half's exchange as soon as that half
  *      is complete; the ghost planes an exchange fills are announced by a device flag that only the workgroups
  *      reading them poll, shortly before the end of their column.  Ground-state three-step passes with one exchange
- *      per pass; every other kind of step runs as in mode 1.  The order of the halves alternates from pass to pass,
+ *      per pass; other ground-state passes run as in mode 1, excited-state steps (one plane per side and step) as in
+ *      mode 0, which measured faster for them.  The order of the halves alternates from pass to pass,
  *      so every rank must make the same sequence of wafer_evolve calls (as it must anyway). */
 int wafer_set_overlap(wafer_ctx *ctx, int mode);
 /* z-slabs, ground state: fused passes per halo exchange.  One fused pass advances K time steps and consumes

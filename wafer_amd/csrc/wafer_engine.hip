@@ -1549,7 +1549,11 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 }
                 // z-slabs, one-pass scheme, not the last step: the raw result's halo exchange hides behind
                 // the interior launch (the last step's phi is materialised first and exchanged on demand)
-                const bool split = one_pass && s + 1 < steps && c->sharded() && c->overlap_mode != 0 && g.nzl > 2 * R;
+                // (only when asked for by mode 1.  One plane per side and step is a short exchange, and its kernels take CUs
+                //  from an interior launch that packs the CUs exactly: the interior ends later by about the exchange's own
+                //  duration, and the two thin boundary launches come on top -- bench slab, native RCCL to the same rank,
+                //  k = 1: 0.772 ms/step split against 0.718 unsplit (undecomposed 0.643); k = 3: 1.210 against 1.121 (1.033).)
+                const bool split = one_pass && s + 1 < steps && c->sharded() && c->overlap_mode == 1 && g.nzl > 2 * R;
                 if (split) {
                     TRY(excited_step_launch_overlapped(c, src, dst, wnum, one_pass));
                 } else {
