@@ -241,6 +241,23 @@ def run_rank(args) -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
+    if world > 1:
+        # A rank that waits for a peer inside RCCL (communicator set-up, a send without its receive) waits for ever; the
+        # engine's own waits are bounded (WAFER_ERR_COMM) but the library's are not.  The transport has never run between
+        # two GPUs (tools/first_contact_8gpu.md), so a multi-rank run carries a deadline: say where it stands and leave with
+        # a code of its own instead of holding the node until somebody else's timeout.
+        import threading
+        import faulthandler
+        deadline = float(os.environ.get("WAFER_BENCH_DEADLINE_S", "900"))
+
+        def give_up():
+            print(f"bench.py: rank {rank}: no result after {deadline:.0f} s (WAFER_BENCH_DEADLINE_S); stacks follow",
+                  file=sys.stderr, flush=True)
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            os._exit(5)
+        watchdog = threading.Timer(deadline, give_up)
+        watchdog.daemon = True
+        watchdog.start()
 
     import numpy as np
     import torch
