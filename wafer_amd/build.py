@@ -20,7 +20,7 @@ HEADERS = ["wafer_geom.h", "wafer_tuning.h", "wafer_launch.h", "wafer_stencil.hi
            "wafer_stencil_fused2.hip.h", "wafer_stencil_fused3.hip.h", "wafer_elementwise.hip.h", "wafer_setup.hip.h",
            "wafer_tu_excited.inc"]
 # -ffp-contract=off: the stencil update must round exactly like the reference's
-# (rustc never fuses mul+add); see DESIGN.md "Arithmetic contract".
+# (rustc never fuses mul+add); see DESIGN.md "Parity contract".
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC"]
 OBJDIR = os.path.join(HERE, "build")
 
