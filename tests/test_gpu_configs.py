@@ -88,6 +88,28 @@ def test_config2_256_cubed_harmonic_ten_steps_bit_exact(wo, wa):
 
 
 @BIG
+@pytest.mark.parametrize("shape", [(384, 320, 448), (320, 384, 200)])
+def test_grids_between_the_powers_of_two_seven_steps_bit_exact(wo, wa, shape):
+    """tile counts that do not divide the CUs (72 / 60 tiles per layer): the z-chunk policy picks 7 / 4 chunks per column
+    (wafer_pick_zchunk; rounds 1-2 left a second round of 32 workgroups at 384^3), x- and y-ragged tiles, the frame cells
+    that are no longer fetched; two three-step passes and a single step against the oracle"""
+    cfg, par = make_pair(shape, ext=1, potential="Coulomb", dn=0.05, dt=5e-4, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = wo.initial_condition(cfg, "Boolean")
+    wo.evolve(cfg, 0, a, b, phi, [], 7)
+    with wa.Context(par) as ctx:
+        assert ctx.stencil_kernel_name() == "wafer_k_step3_fused"
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 7)
+        assert np.array_equal(ctx.download_phi(), phi)
+        obs, want = ctx.observables(), wo.observables(cfg, v, phi)
+        for k in ("energy", "norm2", "r2"):
+            assert obs[k] == pytest.approx(want[k], rel=1e-12)
+
+
+@BIG
 @pytest.mark.parametrize("potential,k", [("Coulomb", 3), ("Coulomb", 1), ("Coulomb", 2), ("SimpleCornell", 1), ("SimpleCornell", 2),
                                          ("SimpleCornell", 3)])
 def test_config3_512_cubed_stored_states_two_excited_steps(wo, wa, potential, k):
