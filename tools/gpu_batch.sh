@@ -26,6 +26,12 @@ for step in "$@"; do
                     timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 5 --steps 30 --configs "v=-1" 2>&1 | grep config | sed "s/^/new  k=$w /"
                   done; done > $O/ab_excited.jsonl; cut -c1-120 $O/ab_excited.jsonl ;;
     sweep_xf)     for w in 1 2 3; do timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 5 --steps 30 --configs ${XF_CONFIGS:-"xfnw=8" "xfnw=4"} 2>&1 | grep config | sed "s/^/k=$w /"; done > $O/sweep_xf.jsonl; cut -c1-130 $O/sweep_xf.jsonl ;;
+    ab_alt)       for i in 1 2 3; do
+                    timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 5 --steps 60 --configs "v=3" 2>&1 | grep config | sed "s/^/default /"
+                    for d in wafer_amd/build/alt_*; do
+                      WAFER_HIP_LIB=$PWD/$d/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 5 --steps 60 --configs "v=3" 2>&1 | grep config | sed "s/^/$(basename $d) /"
+                    done
+                  done > $O/ab_alt.jsonl; cut -c1-110 $O/ab_alt.jsonl ;;
     sq_f3c)       for k in 0 1; do
                     WAFER_F3_KERNEL=$k timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/sq1_$k -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
                     WAFER_F3_KERNEL=$k timeout 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/sq2_$k -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
