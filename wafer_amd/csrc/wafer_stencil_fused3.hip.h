@@ -13,7 +13,7 @@
 // produced and stored.  phi1 and phi2 exist only in registers (own z-columns) and in two-slot LDS rings
 // (x / y neighbours).  One s_barrier per plane.
 //
-// Eight waves, two per SIMD, 214 VGPRs.  Every wave owns two rows of the tile at all three levels plus ONE extra slot:
+// Eight waves, two per SIMD, 241 VGPRs, no scratch.  Every wave owns two rows of the tile at all three levels plus ONE extra slot:
 //   wave 0   row y0-1   (phi1 and phi2)          wave 7   row y0+16  (phi1 and phi2)
 //   wave 1   row y0-2   (phi1), stages row y0-3  wave 6   row y0+17  (phi1), stages row y0+18
 //   waves 2..5   33 of the 132 phi0 halo-column cells each, one per lane (z-queues in component 0 of the extra slot's
