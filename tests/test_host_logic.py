@@ -64,3 +64,109 @@ def test_zchunk_minimises_the_makespan(pick, slots, fill):
 def test_zchunk_degenerate_arguments(pick):
     zc = pick((0, 10, 256, 6), (5, 1, 256, 6), (5, 10, 0, 6))
     assert all(1 <= z <= n for z, n in zip(zc, (10, 1, 10)))
+
+
+# ---- workgroup schedules of the three-step kernel (wafer_stencil_fused3.hip.h, host code) ---------------------------------
+SCHED = r"""
+#include "wafer_stencil_fused3.hip.h"
+#include <cstdio>
+#include <cstdlib>
+int main(int argc, char **argv)
+{
+    std::vector<WaferF3Block> t;
+    const int kind = atoi(argv[1]), ntx = atoi(argv[2]), nty = atoi(argv[3]), lo = atoi(argv[4]), hi = atoi(argv[5]);
+    if (kind == 0) wafer_f3_schedule_plain(t, ntx, nty, lo, hi, atoi(argv[6]), atoi(argv[7]) != 0);
+    else if (kind == 1) wafer_f3_schedule_mixed(t, ntx, nty, lo, hi, atoi(argv[6]));
+    else {
+        const bool nw[2] = {atoi(argv[8]) != 0, atoi(argv[9]) != 0};
+        wafer_f3_schedule_halves(t, ntx, nty, lo, hi, atoi(argv[6]), atoi(argv[7]), nw, atoi(argv[10]), atoi(argv[11]), atoi(argv[12]), true, 0,
+                                 atoi(argv[13]));
+    }
+    for (const auto &b : t) printf("%d %d %d %d %d %d %d %d\n", b.tile, b.zs, b.ze, b.down, b.wait_late, b.wait_it, b.bump, b.wt);
+    return 0;
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def sched(tmp_path_factory):
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    d = tmp_path_factory.mktemp("sched")
+    src, exe = d / "sched.hip", d / "sched"
+    src.write_text(SCHED)
+    r = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", CSRC, str(src), "-o", str(exe)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+    def call(*args):
+        out = subprocess.run([str(exe), *[str(a) for a in args]], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr[-2000:]
+        keys = ("tile", "zs", "ze", "down", "wait_late", "wait_it", "bump", "wt")
+        return [dict(zip(keys, (int(x) for x in line.split()))) for line in out.stdout.splitlines()]
+    return call
+
+
+def covered_once(blocks, ntiles, lo, hi):
+    for t in range(ntiles):
+        planes = sorted(p for b in blocks if b["tile"] == t for p in range(b["zs"], b["ze"]))
+        assert planes == list(range(lo, hi)), f"tile {t}: planes {planes[:5]}.. of [{lo}, {hi})"
+
+
+@pytest.mark.parametrize("ntx,nty,lo,hi,zc,swz", [(4, 32, 0, 512, 256, 1), (3, 24, 3, 387, 55, 1), (1, 1, 0, 7, 3, 0), (2, 5, 3, 20, 100, 1),
+                                                  (8, 64, 3, 131, 128, 1)])
+def test_plain_schedule_covers_every_plane_of_every_tile_once(sched, ntx, nty, lo, hi, zc, swz):
+    b = sched(0, ntx, nty, lo, hi, zc, swz)
+    covered_once(b, ntx * nty, lo, hi)
+    assert all(x["down"] == 0 and x["bump"] == -1 and x["wait_late"] == -1 for x in b)
+    if swz:   # XCD-contiguous: the tiles dispatch slots b, b+8, b+16, ... (one XCD) work on are consecutive
+        ids = [x["tile"] + (x["zs"] - lo) // zc * ntx * nty for x in b]
+        assert sorted(ids) == list(range(len(b)))
+        per_xcd = ids[0::8]
+        assert per_xcd == list(range(per_xcd[0], per_xcd[0] + len(per_xcd)))
+
+
+def test_mixed_schedule_long_columns_then_short_pieces(sched):
+    b = sched(1, 8, 64, 6, 125, 4)
+    covered_once(b, 512, 6, 125)
+    n_long = sum(1 for x in b if (x["zs"], x["ze"]) == (6, 125))
+    assert n_long == 512 - 32 and all((x["zs"], x["ze"]) == (6, 125) for x in b[:n_long])
+
+
+@pytest.mark.parametrize("first", [0, 1])
+@pytest.mark.parametrize("need", [(1, 1), (0, 1), (1, 0)])
+@pytest.mark.parametrize("ntx,nty,lo,nzl,nshort,nsub,layout", [(8, 64, 3, 128, 32, 4, 0), (8, 64, 3, 128, 32, 4, 1), (8, 64, 3, 128, 32, 4, 2),
+                                                              (2, 3, 3, 16, 1, 2, 0), (1, 2, 3, 7, 0, 4, 0), (3, 5, 3, 37, 2, 3, 1),
+                                                              (2, 2, 3, 5, 1, 2, 0)])
+def test_halves_schedule_invariants(sched, ntx, nty, lo, nzl, nshort, nsub, layout, first, need):
+    """what the engine's single-launch pass relies on (wafer_engine.hip launch_halves_pass): both halves cover their planes
+    once; half A marches down to the lower boundary, half B up to the upper one; exactly one piece per tile and half stores
+    the boundary, counts itself done and -- where that side has a neighbour -- waits for the ghost flag at the iteration
+    whose prefetch first touches a ghost plane; the half named `first` is dispatched first"""
+    hi, mid, depth, ntiles = lo + nzl, lo + nzl // 2, 3, ntx * nty
+    b = sched(2, ntx, nty, lo, hi, mid, first, need[0], need[1], nshort, nsub, depth, layout)
+    covered_once(b, ntiles, lo, hi)
+    thin = mid - lo < depth or hi - mid < depth
+    for x in b:
+        half = 0 if x["down"] else 1
+        assert (lo <= x["zs"] < x["ze"] <= mid) if half == 0 else (mid <= x["zs"] < x["ze"] <= hi)
+        at_boundary = x["zs"] == lo if half == 0 else x["ze"] == hi
+        assert (x["bump"] == half) == at_boundary and (x["bump"] in (-1, half))
+        if at_boundary:
+            n = x["ze"] - x["zs"]
+            assert x["wt"] == (n if (thin or depth > n) else depth)
+            if need[half]:
+                assert x["wait_late"] == half
+                # marching z1 = ze + 1 - it (down) / zs - 2 + it (up), the prefetch reads plane z -+ 2: first ghost plane at
+                assert x["wait_it"] == (x["ze"] - lo if half == 0 else hi - x["zs"])
+                assert 0 <= x["wait_it"] < (x["ze"] - x["zs"]) + 4
+            else:
+                assert x["wait_late"] == -1
+        else:
+            assert x["wait_late"] == -1 and x["wt"] == 0
+    for half in (0, 1):
+        assert sum(1 for x in b if x["bump"] == half) == ntiles
+    halves_in_order = [0 if x["down"] else 1 for x in b]
+    assert halves_in_order[0] == first and halves_in_order == sorted(halves_in_order, reverse=bool(first))
