@@ -22,6 +22,7 @@ ROWS = {
     "threepoint_f32_storage_512": ["--dtype", "f32"],
     "config2_harmonic_256": ["--grid", "256,256,256", "--potential", "Harmonic"],
     "threepoint_f64_1024": ["--grid", "1024,1024,1024", "--potential", "SimpleCornell", "--no-parity"],
+    "threepoint_f64_384": ["--grid", "384,384,384"],   # 72 tiles per layer: the z-chunk policy's case (wafer_pick_zchunk)
 }
 COMMON = ["--no-cpu-baseline", "--no-excited"]
 SHORT = ["--steps", "60", "--warmup", "6", "--preheat", "0", "--no-parity"]
