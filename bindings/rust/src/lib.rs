@@ -112,7 +112,9 @@ extern "C" {
     pub fn wafer_load_state(ctx: *mut wafer_ctx, idx: u32, state: *const f64) -> c_int;
     pub fn wafer_clone_state_to_phi(ctx: *mut wafer_ctx, idx: u32) -> c_int;
     pub fn wafer_set_comm_hooks(ctx: *mut wafer_ctx, halo: wafer_halo_fn, allreduce: wafer_allreduce_fn, user: *mut c_void) -> c_int;
-    pub fn wafer_set_overlap(ctx: *mut wafer_ctx, enabled: c_int) -> c_int;
+    /// mode 0: exchange after the pass; 1: boundary planes first on a second stream; 2 (default): one launch per
+    /// three-step pass, the slab as two halves marched outwards (include/wafer_hip.h)
+    pub fn wafer_set_overlap(ctx: *mut wafer_ctx, mode: c_int) -> c_int;
     pub fn wafer_set_stream(ctx: *mut wafer_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn wafer_get_slab_info(ctx: *mut wafer_ctx, out: *mut wafer_slab_info) -> c_int;
     pub fn wafer_get_device_info(ctx: *mut wafer_ctx, out: *mut wafer_device_info) -> c_int;
