@@ -212,3 +212,40 @@ impl Drop for Engine {
         unsafe { wafer_ctx_destroy(self.ctx) };
     }
 }
+
+/// `libwafer_rccl.so` (include/wafer_rccl.h): the halo / all-reduce hooks of a multi-GPU run served by RCCL's C API, for a
+/// host that does not want to write them again, and the device-side all-reduce of the 1 + k sums
+/// (include/wafer_mailbox.h, part of `libwafer_hip.so`).
+#[repr(C)]
+pub struct wafer_mailbox {
+    _private: [u8; 0],
+}
+
+#[link(name = "wafer_rccl")]
+extern "C" {
+    pub fn wafer_rccl_last_error() -> *const c_char;
+    pub fn wafer_rccl_unique_id_bytes() -> c_int;
+    pub fn wafer_rccl_unique_id(out: *mut c_void) -> c_int;
+    pub fn wafer_rccl_attach(
+        ctx: *mut wafer_ctx, rank: c_int, world: c_int, unique_id: *const c_void, lower_override: c_int, upper_override: c_int,
+        handle_out: *mut *mut c_void,
+    ) -> c_int;
+    pub fn wafer_rccl_warm_up(handle: *mut c_void, scratch: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn wafer_rccl_use_mailbox(handle: *mut c_void, mailbox: *mut c_void) -> c_int;
+    pub fn wafer_rccl_allreduce_now(handle: *mut c_void, dev_ptr: *mut c_void, count: usize, stream: *mut c_void) -> c_int;
+    pub fn wafer_rccl_halo_calls(handle: *mut c_void) -> std::os::raw::c_long;
+    pub fn wafer_rccl_comm_info(
+        handle: *mut c_void, nranks: *mut c_int, rank: *mut c_int, lower: *mut c_int, upper: *mut c_int, version: *mut c_int,
+    ) -> c_int;
+    pub fn wafer_rccl_detach(ctx: *mut wafer_ctx, handle: *mut c_void) -> c_int;
+}
+
+#[link(name = "wafer_hip")]
+extern "C" {
+    pub fn wafer_mailbox_create(rank: c_int, world: c_int, device: c_int, out: *mut *mut wafer_mailbox) -> c_int;
+    pub fn wafer_mailbox_handle(mb: *mut wafer_mailbox, handle_out: *mut c_void) -> c_int;
+    pub fn wafer_mailbox_connect(mb: *mut wafer_mailbox, all_handles: *const c_void) -> c_int;
+    pub fn wafer_mailbox_allreduce(mailbox: *mut c_void, dev_ptr: *mut c_void, count: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn wafer_mailbox_check(mb: *mut wafer_mailbox) -> c_int;
+    pub fn wafer_mailbox_destroy(mb: *mut wafer_mailbox) -> c_int;
+}

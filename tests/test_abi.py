@@ -107,6 +107,25 @@ def test_rust_binding_declares_every_entry_point():
         assert n_c == n_rs, (name, n_c, n_rs)
 
 
+def test_rust_binding_declares_the_rccl_and_mailbox_entry_points():
+    """the same for include/wafer_rccl.h (libwafer_rccl.so) and include/wafer_mailbox.h"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rust = open(os.path.join(root, "bindings", "rust", "src", "lib.rs")).read()
+    total = 0
+    for h in ("wafer_rccl.h", "wafer_mailbox.h"):
+        header = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", h)).read(), flags=re.S)
+        decls = re.findall(r"\b(?:int|long|const char \*)\s*(wafer_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
+        total += len(decls)
+        for name, args in decls:
+            m = re.search(r"pub fn %s\s*\((.*?)\)\s*->" % name, rust, flags=re.S)
+            assert m, f"{name} missing from the Rust binding"
+            n_c = 0 if args.strip() in ("", "void") else args.count(",") + 1
+            n_rs = len([a for a in m.group(1).split(",") if a.strip()])
+            assert n_c == n_rs, (name, n_c, n_rs)
+    assert total == 16
+
+
 def _bench(*args, **env_extra):
     import subprocess
     import sys
