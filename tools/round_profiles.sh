@@ -19,7 +19,10 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES 
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/sq2 -- python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 > /dev/null 2>&1
 python3 tools/pmc_counters.py $O/sq1 $O/sq2 --match wafer_k_step3_fused > $O/sq_counters_fused3.json
 rm -rf $O/sq1 $O/sq2
-NCCL_MAX_P2P_NCHANNELS=8 python3 tools/slab_overhead.py --rccl --steps 60 --modes 2,1,0 2> /dev/null | grep "^{" > $O/slab_overhead.json
+for try in 1 2; do   # (once in this round the first attempt left an empty file: the c10d store's port was still in TIME_WAIT)
+  NCCL_MAX_P2P_NCHANNELS=8 MASTER_PORT=$((29455 + try)) python3 tools/slab_overhead.py --rccl --steps 60 --modes 2,1,0 2> $O/slab_overhead.err | grep "^{" > $O/slab_overhead.json
+  [ -s $O/slab_overhead.json ] && break
+done
 NCCL_MAX_P2P_NCHANNELS=8 rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -o t -- python3 tools/slab_trace.py --rccl --mode 2 > /dev/null 2>&1
 python3 tools/slab_trace.py --parse $(find $O/trace2 -name "*kernel_trace.csv" | head -1) > $O/slab_single_launch_timeline.txt 2>&1
 rm -rf $O/trace2
