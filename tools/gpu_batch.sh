@@ -87,6 +87,9 @@ for line in open("$O/slab_tune.jsonl"):
         print("bad line", line[:200], e)
 PY
                   ;;
+    # FETCH_SIZE per kernel of the path under WAFER_XCD_SWIZZLE = $HALO_SWZ (1 = the XCD-contiguous tile order, 0 = off).  The
+    # attribution runs of round 3 (profiles/r03_halo_attribution.json) used further bits of that variable in a scratch build of
+    # wafer_stencil_lds.hip.h (redirected / time-shifted halo requests); those bits do not exist in the committed kernels.
     pmc_halo)     rocprofv3 --list-avail 2>/dev/null | grep -o "TCC_[A-Z0-9_]*" | sort -u > $O/tcc_counters.txt
                   for swz in ${HALO_SWZ:-1 3 5 7}; do
                     WAFER_XCD_SWIZZLE=$swz timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/halo_f$swz -- python3 tools/path_bench.py --steps 10 > $O/halo_path_$swz.log 2>&1
