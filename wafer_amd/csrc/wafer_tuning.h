@@ -98,7 +98,7 @@ static inline int wafer_pick_zchunk(long long per_layer, int nplanes, long long 
     if (slots < 1) slots = 1;
     long long best_cost = -1;
     int best_zc = nplanes;
-    const int nch_max = nplanes < 64 ? nplanes : 64;
+    const int nch_max = nplanes < 64 ? nplanes : 64;   // (at most 64 chunks per column: the engine sizes its partial-sum rows for that)
     for (int nch = 1; nch <= nch_max; ++nch) {
         const int zc = (nplanes + nch - 1) / nch;
         const int real = (nplanes + zc - 1) / zc;
