@@ -322,7 +322,7 @@ def run_rank(args) -> int:
     # ghost planes: 3*ext (ThreePoint: three fused steps per exchange; otherwise 2*ext: two); twice that where the
     # slabs are thick enough, so that the set-up trial can also time one exchange per TWO fused passes
     # (wafer_set_halo_cycle)
-    per_pass = 3 * ext if (ext == 1 and args.dtype == "f64") else 2 * ext
+    per_pass = 3 * ext if (ext == 1 and args.dtype in ("f64", "f32fast")) else 2 * ext
     deep = world > 1 and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 4 * per_pass
     ctx = wafer_amd.Context(make_params(z_begin, z_count, (2 * per_pass if deep else per_pass) if world > 1 else 0))
     if args.variant >= 0:

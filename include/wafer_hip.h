@@ -81,7 +81,7 @@ typedef enum wafer_central_difference {
 
 /* WAFER_F64: the reference's arithmetic.  WAFER_F32: fp32 STORAGE of every array, arithmetic still
  * fp64 in registers (only storage rounding is added).  WAFER_F32_FAST: the ground-state stencil
- * steps also compute in fp32 (1.4x the step rate; sums, projections and observables stay fp64) --
+ * steps also compute in fp32 (1.5x the fp64 step rate, on the three-step kernel; sums, projections and observables stay fp64) --
  * the throughput setting of BASELINE config #5, to be cross-checked against fp64 as that config
  * prescribes. */
 typedef enum wafer_dtype { WAFER_F64 = 0, WAFER_F32 = 1, WAFER_F32_FAST = 2 } wafer_dtype;

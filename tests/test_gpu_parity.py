@@ -879,6 +879,31 @@ def test_f32_storage_every_kernel_gives_the_same_bits(wa, dtype, ext):
     assert np.array_equal(out[2], out[1])
 
 
+@pytest.mark.parametrize("shape,steps", [((200, 37, 29), 9), ((300, 20, 18), 7), ((257, 33, 40), 12), ((64, 16, 9), 6)])
+def test_all_fp32_three_step_kernel_gives_the_single_step_kernels_bits(wa, shape, steps, monkeypatch):
+    """f32fast (fp32 storage AND fp32 step arithmetic) on the three-step kernel -- 256 x 16 tiles, a and b carried between the
+    levels in fp32, which is this path's arithmetic type -- against the single-step fp32 kernel: every cell's bits, ragged
+    tiles, z-chunks, an odd step count (a trailing two-step pass / single step)"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    out = {}
+    for variant, zchunk in ((3, ""), (3, "5"), (1, "")):
+        if zchunk:
+            monkeypatch.setenv("WAFER_ZCHUNK", zchunk)
+        else:
+            monkeypatch.delenv("WAFER_ZCHUNK", raising=False)
+        par = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.3, central_difference=1, dtype="f32fast")
+        with wa.Context(par) as ctx:
+            ctx.set_stencil_variant(variant)
+            ctx.set_potential("Coulomb")
+            ctx.set_initial_condition("Gaussian", seed=5)
+            if variant == 3:
+                assert ctx.stencil_kernel_name() == "wafer_k_step3_fused"
+            ctx.evolve(0, steps)
+            out[(variant, zchunk)] = ctx.download_phi()
+    assert np.array_equal(out[(3, "")], out[(1, "")])
+    assert np.array_equal(out[(3, "5")], out[(1, "")])
+
+
 def test_config5_flow_file_potential_fp32_vs_fp64(wa):
     """BASELINE config #5 in miniature: a user potential given at low resolution (as a file would
     hold it), trilinearly upsampled on the device (input.rs:667-716), solved with fp32 storage and

@@ -299,6 +299,32 @@ def test_kernel_choice_on_slabs_does_not_depend_on_the_local_thickness(wa, monke
     assert ks == [3, 3]
 
 
+@pytest.mark.parametrize("overlap", [2, 1, 0])
+def test_all_fp32_three_step_kernel_on_slabs_bit_exact(wa, overlap, monkeypatch):
+    """f32fast with three ghost planes: the three-step kernel (256 x 16 tiles) on z-slabs, every schedule, against one context"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    shape, world, steps = (264, 40, 72), 3, 11
+    base = wa.Params(*shape, dn=0.2, dt=0.004, central_difference=1, dtype="f32fast", halo_depth=3)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=1, dtype="f32fast")) as ctx:
+        assert ctx.stencil_kernel_name() == "wafer_k_step3_fused"
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)
+        want = ctx.download_phi()
+
+    def body(ctx, rank):
+        ctx.set_overlap(overlap)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)
+        return ctx.download_phi(), None
+
+    res, _ = run_slabs(wa, base, world, body)
+    assert np.array_equal(assemble(base, world, [r[0] for r in res]), want)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f32fast"])
 def test_fp32_storage_on_slabs_bit_exact(wa, dtype):
     """fp32 storage (and fp32 step arithmetic) on z-slabs: the same bits as one context"""

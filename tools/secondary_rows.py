@@ -20,6 +20,7 @@ ROWS = {
     "fivepoint_f64_512": ["--cd", "2"],
     "sevenpoint_f64_512": ["--cd", "3"],
     "threepoint_f32_storage_512": ["--dtype", "f32"],
+    "threepoint_f32fast_512": ["--dtype", "f32fast"],   # fp32 storage and fp32 step arithmetic: config #5's throughput setting, on the three-step kernel
     "config2_harmonic_256": ["--grid", "256,256,256", "--potential", "Harmonic"],
     "threepoint_f64_1024": ["--grid", "1024,1024,1024", "--potential", "SimpleCornell", "--no-parity"],
     "threepoint_f64_384": ["--grid", "384,384,384"],   # 72 tiles per layer: the z-chunk policy's case (wafer_pick_zchunk)

@@ -396,8 +396,8 @@ static int default_variant(const wafer_ctx *c)
     // SevenPoint: the two-step kernel exists (variant 2, bit-exact, 128 x 8 tiles) but recomputes phi1 on 14 rows
     // per 8 and is issue-bound: 0.93 ms/step at 512^3 against 0.63 for the single-step kernel on 128 x 16 tiles
     if (c->g.R == 3) return 1;
-    // ThreePoint, fp64: three steps per pass (wafer_stencil_fused3.hip.h); everything else two
-    if (!c->f32 && c->g.R == 1 && c->tune.fuse3 != 0) return 3;
+    // ThreePoint, fp64 or all-fp32: three steps per pass (wafer_stencil_fused3.hip.h); everything else two
+    if ((!c->f32 || c->f32_arith) && c->g.R == 1 && c->tune.fuse3 != 0) return 3;
     return 2;
 }
 
@@ -528,7 +528,7 @@ static bool fuse3_applies(const wafer_ctx *c)
     const int ny_env = c->tune.fuse3_min_ny;
     const int min_ny = ny_env >= 0 ? ny_env : 16;
     const long long min_cells = ny_env >= 0 ? 0 : c->tune.fuse3_min_cells;
-    if (!(active_variant(c) == 3 && c->g.R == 1 && !c->f32 && c->g.ny >= min_ny)) return false;
+    if (!(active_variant(c) == 3 && c->g.R == 1 && (!c->f32 || c->f32_arith) && c->g.ny >= min_ny)) return false;
     if (c->sharded()) return c->g.G >= 3 * c->g.R;
     return (long long)c->g.nx * c->g.ny * c->g.nz >= min_cells;
 }
@@ -552,8 +552,9 @@ static int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const
             *out = &t;
             return WAFER_OK;
         }
-    using Cfg = WaferF3Cfg<double>;
-    const int ntx = (c->g.nx + Cfg::TX - 1) / Cfg::TX, nty = (c->g.ny + Cfg::TY - 1) / Cfg::TY;
+    int tx_, ty_;
+    wafer_step3_tile(type_combo(c, true), &tx_, &ty_);
+    const int ntx = (c->g.nx + tx_ - 1) / tx_, nty = (c->g.ny + ty_ - 1) / ty_;
     std::vector<WaferF3Block> host;
     if (kind == F3_PLAIN) {
         wafer_f3_schedule_plain(host, ntx, nty, lz_lo, lz_hi, aux /* planes per workgroup */, c->tune.swz != 0);
@@ -595,15 +596,15 @@ static int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const
 static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream_t s, bool short_tail = false)
 {
     if (lz_hi <= lz_lo) return WAFER_OK;
-    using Cfg = WaferF3Cfg<double>;
-    const int ntx = (c->g.nx + Cfg::TX - 1) / Cfg::TX, nty = (c->g.ny + Cfg::TY - 1) / Cfg::TY;
+    int tx_, ty_;
+    wafer_step3_tile(type_combo(c, true), &tx_, &ty_);
+    const int ntx = (c->g.nx + tx_ - 1) / tx_, nty = (c->g.ny + ty_ - 1) / ty_;
     const WaferStepArgs a = step_args(c, lz_lo, lz_hi);
     const wafer_ctx::F3Table *tab = nullptr;
     if (short_tail && lz_hi - lz_lo >= 8 * 4) TRY(f3_table(c, F3_MIXED, lz_lo, lz_hi, 4, &tab));
     else if (c->tune.f3_sched == 1 && !c->sharded() && lz_hi - lz_lo >= 16) TRY(f3_table(c, F3_HALVES, lz_lo, lz_hi, 2 /* no flags, no counters */, &tab));
     else TRY(f3_table(c, F3_PLAIN, lz_lo, lz_hi, wafer_f3_zchunk(c->tune, ntx, nty, lz_hi - lz_lo, c->num_cus), &tab));
-    if (wafer_entry_step3_fused(c->tune, a, tab->dev, tab->nblocks, WaferF3Sync(), as<double>(c->phi[src]), as<double>(c->v),
-                                as<double>(c->phi[dst]), s) != hipSuccess)
+    if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, WaferF3Sync(), c->phi[src], c->v, c->phi[dst], s) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
     return WAFER_OK;
 }
@@ -1395,8 +1396,7 @@ static int launch_halves_pass(wafer_ctx *c, int src, int dst, int E)
     sy.err = c->hv_err;
     sy.debug = c->tune.hv_debug;
     const WaferStepArgs a = step_args(c, lo, hi);
-    if (wafer_entry_step3_fused(c->tune, a, tab->dev, tab->nblocks, sy, as<double>(c->phi[src]), as<double>(c->v), as<double>(c->phi[dst]),
-                                c->s_main) != hipSuccess)
+    if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
     c->hv_cnt_target[0] += (unsigned long long)tab->nbump[0];
     c->hv_cnt_target[1] += (unsigned long long)tab->nbump[1];

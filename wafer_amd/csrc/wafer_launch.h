@@ -46,5 +46,6 @@ hipError_t wafer_entry_observables_lds(int tc, int R, const WaferTuning &t, cons
 hipError_t wafer_entry_step2_fused(int tc, int R, const WaferTuning &t, const WaferStepArgs &a, const void *phi, const void *pa,
                                    const void *pb, const void *pv, void *out, hipStream_t s);
 // three fused ground-state steps (ThreePoint fp64), table-driven
-hipError_t wafer_entry_step3_fused(const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
-                                   const WaferF3Sync &sy, const double *phi, const double *pv, double *out, hipStream_t s);
+hipError_t wafer_entry_step3_fused(int tc, const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
+                                   const WaferF3Sync &sy, const void *phi, const void *pv, void *out, hipStream_t s);
+void wafer_step3_tile(int tc, int *tx, int *ty);

@@ -1,9 +1,25 @@
-// translation unit: three fused ground-state steps (ThreePoint fp64)
+// translation unit: three fused ground-state steps (ThreePoint; fp64, and fp32 storage with fp32 step arithmetic)
 #include "wafer_launch.h"
 #include "wafer_stencil_fused3.hip.h"
 
-hipError_t wafer_entry_step3_fused(const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
-                                   const WaferF3Sync &sy, const double *phi, const double *pv, double *out, hipStream_t s)
+hipError_t wafer_entry_step3_fused(int tc, const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
+                                   const WaferF3Sync &sy, const void *phi, const void *pv, void *out, hipStream_t s)
 {
-    return wafer_launch_step3_fused<double, double>(t, a, table, nblocks, sy, phi, pv, out, s);
+    switch (tc) {
+    case WAFER_TC_F64:
+        return wafer_launch_step3_fused<double, double>(t, a, table, nblocks, sy, static_cast<const double *>(phi), static_cast<const double *>(pv),
+                                                        static_cast<double *>(out), s);
+    case WAFER_TC_F32_F32:   // a and b ride between the levels in the arithmetic type: fp32 here, as in the two-step kernel
+        return wafer_launch_step3_fused<float, float>(t, a, table, nblocks, sy, static_cast<const float *>(phi), static_cast<const float *>(pv),
+                                                      static_cast<float *>(out), s);
+    default:                 // fp32 storage with fp64 arithmetic: the carried a, b would need twice the registers
+        return hipErrorInvalidValue;
+    }
+}
+
+// tile of the kernel for a type combination (the host builds the workgroup tables from it)
+void wafer_step3_tile(int tc, int *tx, int *ty)
+{
+    if (tc == WAFER_TC_F64) { *tx = WaferF3Cfg<double>::TX; *ty = WaferF3Cfg<double>::TY; }
+    else { *tx = WaferF3Cfg<float>::TX; *ty = WaferF3Cfg<float>::TY; }
 }
