@@ -283,11 +283,15 @@ int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn 
  *      reading them poll, shortly before the end of their column.  Ground-state three-step passes with one exchange
  *      per pass; other ground-state passes run as in mode 1, excited-state steps (one plane per side and step) as in
  *      mode 0, which measured faster for them.  The order of the halves alternates from pass to pass,
- *      so every rank must make the same sequence of wafer_evolve calls (as it must anyway). */
+ *      so every rank must make the same sequence of wafer_evolve calls (as it must anyway).  A workgroup waits at most
+ *      WAFER_HV_WAIT_MS (default 20 s) for its ghost planes; one that gives up stores NaN from there on and the next
+ *      call that synchronises with the device returns WAFER_ERR_COMM.
+ * Setting a mode also resets the pass bookkeeping (which half goes first, which ghost planes are current): after a
+ * WAFER_ERR_COMM on any rank, call it on every rank before evolving again. */
 int wafer_set_overlap(wafer_ctx *ctx, int mode);
 /* z-slabs, ground state: fused passes per halo exchange.  One fused pass advances K time steps and consumes
- * K * ext ghost planes per side (K = 3 where the three-step kernel applies: ThreePoint fp64 with
- * halo_depth >= 3 * ext; else K = 2).  With `passes` > 1 the exchange moves K * ext * passes planes at once and
+ * K * ext ghost planes per side (K = 3 where the three-step kernel applies: ThreePoint, dtype WAFER_F64 or
+ * WAFER_F32_FAST, with halo_depth >= 3 * ext; else K = 2 -- every rank of a run must be created alike).  With `passes` > 1 the exchange moves K * ext * passes planes at once and
  * the passes in between run unsplit over the owned planes plus the ghost planes that are still valid -- fewer
  * boundary launches, exchanges and stream hops for a few redundant planes.  Needs wafer_params.halo_depth >=
  * K * ext * passes (WAFER_ERR_INVALID otherwise); the default is 1.  All settings give identical results. */

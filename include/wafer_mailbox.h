@@ -10,8 +10,10 @@
  * (system-scope stores, the epoch behind a release); the same lanes then poll this rank's own mailbox until
  * every sender's epoch has arrived, and the sums are formed in rank order -- the same bits on every rank --
  * and written in place.  Two buffers alternate by epoch parity: a rank can be at most one all-reduce ahead of
- * another (it needs the other's contribution to finish).  Waits are bounded; a wait that gives up leaves a word
- * that wafer_mailbox_check reports.
+ * another (it needs the other's contribution to finish).  Waits are bounded (WAFER_MAILBOX_WAIT_SPINS); a wait that
+ * gives up turns that call's results into NaN on the rank, makes every later call of the rank post and return NaN, and
+ * is reported by wafer_mailbox_check and by every later wafer_mailbox_allreduce (non-zero return): the failure is
+ * sticky, a mailbox that timed out once is not used again.
  *
  * The reference has no counterpart (one process); a Rust host would bind these five functions next to
  * wafer_set_comm_hooks.  wafer_mailbox_allreduce has the signature of wafer_allreduce_fn, `user` = the mailbox.
@@ -40,7 +42,7 @@ int wafer_mailbox_connect(wafer_mailbox *mb, const void *all_handles);
 /* in-place sum over ranks of `count` (<= WAFER_MAILBOX_MAX_COUNT) doubles at dev_ptr, enqueued on hip_stream;
  * every rank must make the same sequence of calls.  Signature of wafer_allreduce_fn (wafer_hip.h). */
 int wafer_mailbox_allreduce(void *mailbox, void *dev_ptr, size_t count, void *hip_stream);
-/* non-zero (and a message through wafer_last_error) if a kernel gave up waiting since the last check */
+/* WAFER_ERR_COMM (and a message through wafer_last_error) once a kernel has given up waiting; sticky */
 int wafer_mailbox_check(wafer_mailbox *mb);
 int wafer_mailbox_destroy(wafer_mailbox *mb);
 

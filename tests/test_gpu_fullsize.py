@@ -22,13 +22,17 @@ def free_gib():
     return free / 2**30
 
 
-def closed_forms(n, dn, dt, mass, store):
+def closed_forms(n, dn, dt, mass, store, arith32=False):
     k = dt / (2.0 * dn * dn * mass)
     half = n // 2
-    # the engine computes w*a + b*dt*S/den in fp64 and rounds to the storage type
-    c1 = float(store(1.0 * 1.0 + 1.0 * dt * -6.0 / (2.0 * dn * dn * mass)))
-    c2 = float(store(1.0 * dt * 2.0 / (2.0 * dn * dn * mass)))
-    c3 = float(store(1.0 * dt * 1.0 / (2.0 * dn * dn * mass)))
+    # the engine computes w*a + b*dt*S/den in fp64 and rounds to the storage type; f32fast computes in fp32 as well:
+    # every operand (dt, den) and every product / quotient / sum rounded to fp32 (grid.rs:580-589, left to right)
+    ar = np.float32 if arith32 else np.float64
+    den = ar(2.0 * dn * dn * mass)
+    upd = lambda w, S: ar(ar(w) * ar(1.0)) + ar(ar(ar(1.0) * ar(dt)) * ar(S)) / den
+    c1 = float(store(upd(1.0, -6.0)))
+    c2 = float(store(upd(0.0, 2.0)))
+    c3 = float(store(upd(0.0, 1.0)))
     norm2_0 = float(half) ** 3
     norm2_1 = half ** 3 * c1 ** 2 + 3 * half ** 2 * ((half - 1) * c2 ** 2 + c3 ** 2)
     # r^2 observable (grid.rs:428-437): WORK index i = 0, 2, 4, ... of the odd padded indices, centre (N+1)/2
@@ -41,8 +45,8 @@ def closed_forms(n, dn, dt, mass, store):
 
 def run_case(wa, n, dtype, dn, dt, mass):
     """(the single-step kernel run here is the LDS one with a, b from V: no stored a, b arrays)"""
-    store = np.float32 if dtype == "f32" else np.float64
-    k, n0, n1, r2, e0 = closed_forms(n, dn, dt, mass, store)
+    store = np.float64 if dtype == "f64" else np.float32
+    k, n0, n1, r2, e0 = closed_forms(n, dn, dt, mass, store, arith32=dtype == "f32fast")
     par = wa.Params(n, n, n, dn=dn, dt=dt, mass=mass, dtype=dtype, max_states=1)
     with wa.Context(par) as ctx:
         ctx.set_potential("NoPotential")
@@ -54,7 +58,8 @@ def run_case(wa, n, dtype, dn, dt, mass):
         ctx.set_stencil_variant(1)                                      # one single step
         ctx.evolve(0, 1)
         assert ctx.norm2() == pytest.approx(n1, rel=1e-12)
-        # the default path (two fused steps per pass) from the same start equals two single steps
+        # the default path from the same start equals two single steps (two steps cannot fill a three-step pass: the
+        # fused kernels' own remainder handling runs here)
         ctx.set_initial_condition("Boolean")
         ctx.evolve(0, 1)
         ctx.evolve(0, 1)
@@ -62,7 +67,7 @@ def run_case(wa, n, dtype, dn, dt, mass):
         ctx.set_stencil_variant(-1)
         ctx.set_initial_condition("Boolean")
         ctx.evolve(0, 2)
-        assert ctx.stencil_kernel_name() == ("wafer_k_step3_fused" if dtype == "f64" else "wafer_k_step2_fused")
+        assert ctx.stencil_kernel_name() == ("wafer_k_step2_fused" if dtype == "f32" else "wafer_k_step3_fused")
         assert ctx.norm2() == two_single
         # ... and three fused steps (fp64 ThreePoint: one pass of the three-step kernel) equal three single steps
         ctx.set_stencil_variant(1)
@@ -98,6 +103,15 @@ def test_config5_grid_2048_cubed_fp32(wa_mod):
     if free_gib() < 200:
         pytest.skip("needs 200 GiB of free device memory")
     ms = run_case(wa_mod, 2048, "f32", 0.01, 2e-5, 1.0)
+    assert ms < 200.0
+
+
+def test_config5_grid_2048_cubed_f32fast(wa_mod):
+    """the same grid with fp32 arithmetic in the stencil steps as well (`f32fast`, the three-step kernel on 256 x 16 tiles):
+    the closed forms hold with every product rounded to fp32"""
+    if free_gib() < 200:
+        pytest.skip("needs 200 GiB of free device memory")
+    ms = run_case(wa_mod, 2048, "f32fast", 0.01, 2e-5, 1.0)
     assert ms < 200.0
 
 

@@ -20,7 +20,7 @@ SAN_ENV = {"ASAN_OPTIONS": "detect_leaks=0:exitcode=99:abort_on_error=0", "UBSAN
 
 
 def test_oracle_under_asan_ubsan():
-    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run(["make", "-B", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SANITIZE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 

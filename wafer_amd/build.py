@@ -36,8 +36,9 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "wafer_hip.h"))
+    deps = {os.path.join(CSRC, f) for f in SOURCES + HEADERS}
+    for src in SOURCES:   # whatever the units really include (include/wafer_mailbox.h among them)
+        deps.update(_unit_deps(src))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -92,24 +93,23 @@ def build_rccl_lib(force: bool = False, verbose: bool = False) -> str:
 
 
 def _unit_deps(src: str) -> list:
-    """headers a unit includes (transitively, by name): a stale check without running the preprocessor"""
-    seen, todo = set(), [src]
+    """headers a unit includes (transitively; every #include "..." resolved relative to the including file, as the
+    preprocessor does): a stale check without running the preprocessor"""
+    seen, todo = set(), [os.path.join(CSRC, src)]
     while todo:
         f = todo.pop()
         try:
-            text = open(os.path.join(CSRC, f)).read()
+            text = open(f).read()
         except OSError:
             continue
         for line in text.splitlines():
             line = line.strip()
             if line.startswith('#include "'):
-                name = line.split('"')[1]
-                base = os.path.basename(name)
-                if base not in seen:
-                    seen.add(base)
-                    todo.append(base)
-    return [os.path.join(CSRC, h) for h in seen if os.path.exists(os.path.join(CSRC, h))] + \
-           [os.path.join(os.path.dirname(HERE), "include", "wafer_hip.h")]
+                path = os.path.normpath(os.path.join(os.path.dirname(f), line.split('"')[1]))
+                if path not in seen and os.path.exists(path):
+                    seen.add(path)
+                    todo.append(path)
+    return sorted(seen | {os.path.join(os.path.dirname(HERE), "include", "wafer_hip.h")})
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

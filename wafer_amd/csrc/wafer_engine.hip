@@ -1321,14 +1321,14 @@ int wafer_download_phi_owned(wafer_ctx *c, double *out)
 // ghost planes an exchange fills are announced by flag[side], which the workgroups that read them poll just before their
 // first load of a ghost plane, i.e. near the END of their column.  No thin boundary launches, no event hops between the
 // streams, one pipeline fill more per tile than an undecomposed slab.
-__global__ __launch_bounds__(64) void wafer_k_gate(const unsigned long long *cnt, unsigned long long target, unsigned *err)
+__global__ __launch_bounds__(64) void wafer_k_gate(const unsigned long long *cnt, unsigned long long target, unsigned *err, unsigned max_spins)
 {
     // one wave, a handful of registers: it shares a CU with a resident stencil workgroup (which leaves 8 VGPRs per SIMD)
     if (threadIdx.x == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(32);
-            if (++spins > (1u << 21)) {   // ~2 s: four times what a workgroup waits, so that a late exchange shows as the workgroups' error
+            if (++spins > max_spins) {   // four times what a workgroup waits, so that a late exchange shows as the workgroups' error
                 __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
@@ -1352,10 +1352,17 @@ static int ensure_hv(wafer_ctx *c)
 static unsigned long long *hv_cnt(wafer_ctx *c, int half) { return c->hv_words + half * WAFER_F3_SYNC_STRIDE; }
 static unsigned long long *hv_flag(wafer_ctx *c, int side) { return c->hv_words + (2 + side) * WAFER_F3_SYNC_STRIDE; }
 
+// WAFER_HV_WAIT_MS as a spin count (one spin = s_sleep 32 + a poll, about a microsecond)
+static unsigned hv_spins(const wafer_ctx *c, int mul)
+{
+    const long long n = (long long)c->tune.hv_wait_ms * 1000 * mul;
+    return (unsigned)(n < 0xffffffffll ? n : 0xffffffffll);
+}
+
 // exchange stream: wait until every workgroup of `half` of the current launch has finished
 static int hv_gate(wafer_ctx *c, int half)
 {
-    hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, c->s_aux, hv_cnt(c, half), c->hv_cnt_target[half], c->hv_err);
+    hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, c->s_aux, hv_cnt(c, half), c->hv_cnt_target[half], c->hv_err, hv_spins(c, 4));
     HIP_TRY(hipGetLastError());
     return WAFER_OK;
 }
@@ -1395,6 +1402,7 @@ static int launch_halves_pass(wafer_ctx *c, int src, int dst, int E)
     sy.need[1] = c->hv_flag_epoch[1];
     sy.err = c->hv_err;
     sy.debug = c->tune.hv_debug;
+    sy.max_spins = hv_spins(c, 1);
     const WaferStepArgs a = step_args(c, lo, hi);
     if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1937,6 +1945,10 @@ int wafer_set_overlap(wafer_ctx *c, int mode)
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
     if (mode < 0 || mode > 2) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 2");
     c->overlap_mode = mode;
+    // a fresh start for the single-launch pass: every rank dispatches the lower half first again and nothing in the ghost
+    // planes is taken for current (a host that has just seen WAFER_ERR_COMM on some rank calls this on all of them)
+    c->hv_first = 0;
+    c->halo_valid = 0;
     return WAFER_OK;
 }
 

@@ -13,6 +13,7 @@
 //       same rank, so halo planes really travel through ncclSend / ncclRecv (and scalars through
 //       ncclAllReduce); the run is repeated with plain device copies as hooks and must agree bit for
 //       bit.  Prints SELF-OK.  (tests/test_gpu_multiprocess.py)
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -23,6 +24,7 @@
 #include <vector>
 
 #include <sys/stat.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -140,8 +142,10 @@ int main(int argc, char **argv)
         // value all ranks of ONE run share); without any of them the file must not be older than this process by
         // more than the slack below (rank 0 removes any old file before it generates the id, writes to .tmp and
         // renames; it removes the file again after ncclCommInitRank).
-        const char *nonce_env = getenv("WAFER_RUN_ID") ? getenv("WAFER_RUN_ID")
-                                : getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : getenv("MASTER_PORT");
+        // MASTER_PORT is usually the same value run after run, so a file that a crashed run left behind carries the nonce of
+        // the next one: a nonce taken from MASTER_PORT narrows the match but does NOT lift the age check.
+        const char *strong_nonce = getenv("WAFER_RUN_ID") ? getenv("WAFER_RUN_ID") : getenv("TORCHELASTIC_RUN_ID");
+        const char *nonce_env = strong_nonce ? strong_nonce : getenv("MASTER_PORT");
         char nonce[64];
         memset(nonce, 0, sizeof nonce);
         if (nonce_env) strncpy(nonce, nonce_env, sizeof nonce - 1);
@@ -162,12 +166,14 @@ int main(int argc, char **argv)
                     char seen[64];
                     struct stat st;
                     if (fread(seen, sizeof seen, 1, f) == 1 && fread(&id, sizeof id, 1, f) == 1) {
-                        if (nonce_env) {
-                            got = memcmp(seen, nonce, sizeof nonce) == 0;
+                        got = true;
+                        if (nonce_env && memcmp(seen, nonce, sizeof nonce) != 0) {
+                            got = false;
                             why = "its run id is not this run's (a file left over from another run?)";
-                        } else {
-                            // no nonce: accept only a file written after this process started, with slack for ranks
-                            // started by hand one after the other and the 1 s granularity of st_mtime
+                        }
+                        if (got && !strong_nonce) {
+                            // no run id of its own: accept only a file written after this process started, with slack for
+                            // ranks started by hand one after the other and the 1 s granularity of st_mtime
                             got = stat(path, &st) == 0 &&
                                   std::chrono::system_clock::from_time_t(st.st_mtime) + std::chrono::seconds(30) >= started;
                             why = "it is older than this run (a file left over from another run? set WAFER_RUN_ID)";
@@ -185,7 +191,24 @@ int main(int argc, char **argv)
         NCCLCHECK(ncclGetUniqueId(&id));
     }
     wafer_rccl_default_env();
-    NCCLCHECK(ncclCommInitRank(&fab.comm, world, id, rank));
+    {
+        // ncclCommInitRank blocks for ever when a peer never arrives (or arrived with another id): a watchdog ends the
+        // process instead.  WAFER_COMM_INIT_TIMEOUT_S (default 300) bounds the call.
+        std::atomic<bool> init_done{false};
+        const int limit_s = env_int("WAFER_COMM_INIT_TIMEOUT_S", 300);
+        std::thread watchdog([&init_done, limit_s, rank]() {
+            for (int i = 0; i < limit_s * 10 && !init_done.load(); ++i) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            if (!init_done.load()) {
+                fprintf(stderr, "rank %d: ncclCommInitRank did not return within %d s (a rank missing, or a stale id file?)\n", rank, limit_s);
+                fflush(stderr);
+                _exit(3);
+            }
+        });
+        const ncclResult_t ir = ncclCommInitRank(&fab.comm, world, id, rank);
+        init_done.store(true);
+        watchdog.join();
+        NCCLCHECK(ir);
+    }
     if (world > 1 && rank == 0) remove(getenv("WAFER_NCCL_ID_FILE")); // every rank has read it: ncclCommInitRank is collective
 
     // ---- slab of this rank ----------------------------------------------------------------------------

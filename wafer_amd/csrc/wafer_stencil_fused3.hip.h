@@ -93,25 +93,35 @@ struct WaferF3Sync {
     unsigned long long need[2] = {0, 0};
     unsigned *err = nullptr;
     int debug = 0;   // WAFER_HV_DEBUG bit 4: no acquire fence (timing experiments)
+    unsigned max_spins = 1u << 24;   // bound of a ghost-flag wait, ~1 us per spin (WAFER_HV_WAIT_MS, default 20 s)
 };
 enum { WAFER_F3_SYNC_STRIDE = 8 }; // 64-bit words between the two counters / flags
 
-__device__ __forceinline__ void wafer_f3_wait(const WaferF3Sync &sy, int idx, int tid)
+// Returns true when the wait gave up (the whole workgroup sees the same answer).  The bound is generous -- a legitimate
+// wait is well under a millisecond inside a run of passes, but the FIRST pass of a wafer_evolve call waits for a neighbour
+// that may still be busy with host work between calls (file output, a table upload, RCCL channel set-up) -- and a
+// workgroup that gives up poisons everything it still stores (NaN), so that results built from stale ghost planes cannot
+// be mistaken for an answer; the host reports WAFER_ERR_COMM at its next synchronisation.
+__device__ __forceinline__ bool wafer_f3_wait(const WaferF3Sync &sy, int idx, int tid)
 {
+    __shared__ unsigned gave_up;
     if (tid == 0) {
-        unsigned spins = 0;
+        unsigned spins = 0, bad = 0;
         while (__hip_atomic_load(sy.flag + idx * WAFER_F3_SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.need[idx]) {
             __builtin_amdgcn_s_sleep(32);
-            if (++spins > (1u << 19)) { // ~half a second (a legitimate wait is well under a millisecond): the exchange never arrived
+            if (++spins > sy.max_spins) { // the exchange never arrived
                 __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                bad = 1;
                 break;
             }
         }
+        gave_up = bad;
         // system scope: the ghost planes were written by another kernel, possibly (through the fabric) of another device
         if (!(sy.debug & 4)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    return __builtin_amdgcn_readfirstlane(gave_up) != 0;
 }
 
 template <typename T, typename C, bool VIR, bool DOWN>
@@ -252,11 +262,12 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     __syncthreads();
 
     const int niter = (ze - zs) + 4;
+    bool poisoned = false;   // a ghost-flag wait gave up: everything stored from here on is NaN (wafer_f3_wait)
     for (int it = 0; it < niter; ++it) {
         const int z = z1 + SD * it;
         const bool more = it + 1 < niter;
         const long long zo = (long long)z * g.plane;
-        if (blk.wait_late >= 0 && it == blk.wait_it) wafer_f3_wait(sy, blk.wait_late, tid);
+        if (blk.wait_late >= 0 && it == blk.wait_it) poisoned = wafer_f3_wait(sy, blk.wait_late, tid);
         // ---- 1. prefetch: phi0 two planes ahead, V one plane ahead
         VT pre[RY], pre_v[RY], xpre = zero, xpre_v = zero, orow_pre = zero;
 #pragma unroll
@@ -508,7 +519,8 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                             ys[0] = (r >= 1) ? (C)q2[1][r - 1 < 0 ? 0 : r - 1][v] : (C)nbu[2][v];
                             ys[2] = (r + 1 < RY) ? (C)q2[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[2][v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                            res3[r][v] = update_with(w, (C)caq[0][r][v], (C)cbq[0][r][v], S);
+                            const T rs = update_with(w, (C)caq[0][r][v], (C)cbq[0][r][v], S);
+                            res3[r][v] = poisoned ? (T)__builtin_nanf("") : rs;
                         }
                     }
                 }

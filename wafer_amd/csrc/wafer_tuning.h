@@ -42,6 +42,8 @@ struct WaferTuning {
     int hv_short_tiles = -1; // WAFER_HV_SHORT_TILES: tiles per half cut into short pieces (-1: 1/16 of the tiles)
     int hv_nsub = 4;        // WAFER_HV_NSUB: pieces per short column
     int hv_layout = 0;      // WAFER_HV_LAYOUT: where the short columns go (wafer_f3_schedule_halves)
+    int hv_wait_ms = 20000; // WAFER_HV_WAIT_MS: how long a workgroup of the single-launch pass waits for its ghost planes before it gives up
+                            // (WAFER_ERR_COMM; the gate kernels wait four times as long)
     int f3_sched = 0;       // WAFER_F3_SCHED: 1 = undecomposed launches use the two-halves schedule as well (timing experiments)
 };
 
@@ -82,6 +84,8 @@ static inline WaferTuning wafer_tuning_from_env()
     t.hv_short_tiles = wafer_env_int("WAFER_HV_SHORT_TILES", t.hv_short_tiles);
     t.hv_nsub = wafer_env_int("WAFER_HV_NSUB", t.hv_nsub);
     t.hv_layout = wafer_env_int("WAFER_HV_LAYOUT", t.hv_layout);
+    t.hv_wait_ms = wafer_env_int("WAFER_HV_WAIT_MS", t.hv_wait_ms);
+    if (t.hv_wait_ms < 1) t.hv_wait_ms = 1;
     return t;
 }
 

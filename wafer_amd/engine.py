@@ -458,8 +458,9 @@ class Context:
         self._check(self._L.wafer_set_comm_hooks(self._h, self._hooks[0], self._hooks[1], None))
 
     def set_overlap(self, enabled) -> None:
-        """halo schedule of a z-slab: False / 0 (exchange after the pass), True / 1 (default: boundary planes first),
-        2 (one launch per three-step pass, exchanges released by completion counters); include/wafer_hip.h"""
+        """halo schedule of a z-slab: False / 0 (exchange after the pass), True / 1 (boundary planes first, three launches
+        per pass), 2 (the default: one launch per three-step pass, exchanges released by completion counters);
+        include/wafer_hip.h"""
         self._check(self._L.wafer_set_overlap(self._h, int(enabled)))
 
     def set_halo_cycle(self, passes: int) -> None:

@@ -176,19 +176,34 @@ class MailboxAllReduce:
         L.wafer_mailbox_destroy.argtypes = [C.c_void_p]
         L.wafer_last_error.restype = C.c_char_p
         self._mb = C.c_void_p()
+        # every rank reports how its own set-up went BEFORE anything depends on a peer: a rank whose mailbox cannot be
+        # created must not leave the others waiting in the gather
+        err, raw = "", b"\0" * 64
         if L.wafer_mailbox_create(rank, world, device_index, C.byref(self._mb)) != 0:
-            raise RuntimeError(L.wafer_last_error().decode())
-        h = C.create_string_buffer(64)
-        if L.wafer_mailbox_handle(self._mb, h) != 0:
-            raise RuntimeError(L.wafer_last_error().decode())
-        handles = [None] * world
-        if world > 1:
-            dist.all_gather_object(handles, h.raw, group=group)
+            err = L.wafer_last_error().decode()
         else:
-            handles = [h.raw]
-        blob = C.create_string_buffer(b"".join(handles), 64 * world)
-        if L.wafer_mailbox_connect(self._mb, blob) != 0:
-            raise RuntimeError(L.wafer_last_error().decode())
+            h = C.create_string_buffer(64)
+            if L.wafer_mailbox_handle(self._mb, h) != 0:
+                err = L.wafer_last_error().decode()
+            raw = h.raw
+        gathered = [None] * world
+        if world > 1:
+            dist.all_gather_object(gathered, (err, raw), group=group)
+        else:
+            gathered = [(err, raw)]
+        bad = [(r, e) for r, (e, _h) in enumerate(gathered) if e]
+        if not bad:
+            blob = C.create_string_buffer(b"".join(hh for _e, hh in gathered), 64 * world)
+            if L.wafer_mailbox_connect(self._mb, blob) != 0:
+                err = L.wafer_last_error().decode()
+            if world > 1:   # ... and nobody starts using mailboxes that a peer could not map
+                dist.all_gather_object(gathered, (err, b""), group=group)
+                bad = [(r, e) for r, (e, _h) in enumerate(gathered) if e]
+            elif err:
+                bad = [(rank, err)]
+        if bad:
+            self.close()
+            raise RuntimeError("wafer_mailbox set-up failed on rank(s) " + "; ".join(f"{r}: {e}" for r, e in bad))
 
     @property
     def handle(self):
