@@ -135,6 +135,7 @@ extern "C" {
     pub fn wafer_set_halo_cycle(ctx: *mut wafer_ctx, passes: c_int) -> c_int;
     pub fn wafer_diag_copy_bw(ctx: *mut wafer_ctx, iters: c_int, unroll: c_int, blocks_per_cu: c_int, gbps: *mut f64) -> c_int;
     pub fn wafer_diag_checksum(ctx: *mut wafer_ctx, z_begin: u32, z_count: u32, out: *mut u64) -> c_int;
+    pub fn wafer_diag_x2_passes(ctx: *mut wafer_ctx, out: *mut u64) -> c_int;
     pub fn wafer_diag_div_check(ctx: *mut wafer_ctx, den: f64, seed: u64, n_operands: u64, lo_exp: c_int, hi_exp: c_int, mismatches: *mut u64) -> c_int;
 }
 

@@ -247,6 +247,10 @@ int wafer_diag_copy_bw(wafer_ctx *ctx, int iters, int unroll, int blocks_per_cu,
  * ranges of an undecomposed run whenever the bits agree: bench.py's N > 1 parity check. */
 int wafer_diag_checksum(wafer_ctx *ctx, uint32_t z_begin, uint32_t z_count, uint64_t *out);
 
+/* Diagnostic: how many passes of the two-excited-steps-per-pass kernel (wafer_stencil_x2.hip.h: ThreePoint fp64, one to three
+ * stored states) this context has launched so far -- tests assert that the kernel they mean to test is the one that ran. */
+int wafer_diag_x2_passes(wafer_ctx *ctx, uint64_t *out);
+
 /* Diagnostic: the divisions by loop-invariant denominators (c*dn^2*m in the stencil update, the norm in
  * the excited-state transform) use a hoisted reciprocal with two exact remainders instead of the IEEE
  * sequence (wafer_div_invariant, wafer_stencil.hip.h).  Draws n_operands (rounded up to 2^18) doubles

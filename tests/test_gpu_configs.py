@@ -112,12 +112,15 @@ def test_grids_between_the_powers_of_two_seven_steps_bit_exact(wo, wa, shape):
 @BIG
 @pytest.mark.parametrize("potential,k", [("Coulomb", 3), ("Coulomb", 1), ("Coulomb", 2), ("SimpleCornell", 1), ("SimpleCornell", 2),
                                          ("SimpleCornell", 3)])
-def test_config3_512_cubed_stored_states_two_excited_steps(wo, wa, potential, k):
+def test_config3_512_cubed_stored_states_two_excited_steps(wo, wa, potential, k, monkeypatch):
     """BASELINE config #3 where its wall time goes (93 % of its steps are excited-state steps): 512^3, k stored
     states, two steps of grid.rs:674-681 (step, renormalise, modified Gram-Schmidt) through the PRODUCTION kernels --
     closed-form V evaluated per cell, raw staging pipeline -- against the oracle: every cell to 1e-13, the sums to
     1e-12.  Coulomb (config #3's potential) and SimpleCornell (config #4's), k = 1, 2, 3.  The stored states are the
-    lowest box modes (exactly orthogonal, normalised), phi another one plus a Boolean grid and parts of the stored ones."""
+    lowest box modes (exactly orthogonal, normalised), phi another one plus a Boolean grid and parts of the stored ones.
+    Then the same state through the two-steps-per-pass kernels (wafer_stencil_x2.hip.h): six more steps (two one-step, two
+    passes) and seven more (three one-step, two passes), each against the oracle at the same bar."""
+    monkeypatch.setenv("WAFER_X2_MAX_K", "3")   # (the default keeps k = 3 on the one-step kernel)
     n = 512
     cfg, par = make_pair((n, n, n), ext=1, potential=potential, dn=0.05, dt=5e-4, mass=1.0, sig=0.223, max_states=3)
     v = wo.potential_generate(cfg)
@@ -135,19 +138,23 @@ def test_config3_512_cubed_stored_states_two_excited_steps(wo, wa, potential, k)
         for i, l in enumerate(lowers):
             ctx.load_state(i, l)
         ctx.upload_phi(phi)
-        ctx.evolve(k, 2)
-        got = ctx.download_phi()
-        n2 = ctx.norm2()
-        obs = ctx.observables()
-    wo.evolve(cfg, k, a, b, phi, lowers, 2)
-    assert np.max(np.abs(got - phi)) <= 1e-13
-    assert n2 == pytest.approx(wo.norm2(cfg, phi), rel=1e-12)
-    want = wo.observables(cfg, v, phi)
-    for key in ("energy", "norm2", "r2"):
-        assert obs[key] == pytest.approx(want[key], rel=1e-12)
-    for l in lowers:       # orthogonal to every stored state after the step's Gram-Schmidt
-        assert abs(float(np.sum(l * got))) < 1e-13
-    del got, phi, lowers, a, b, v
+        for steps, passes in ((2, 0), (6, 2), (7, 2)):
+            before = ctx.x2_passes()
+            ctx.evolve(k, steps)
+            assert ctx.x2_passes() - before == passes
+            got = ctx.download_phi()
+            n2 = ctx.norm2()
+            obs = ctx.observables()
+            wo.evolve(cfg, k, a, b, phi, lowers, steps)
+            assert np.max(np.abs(got - phi)) <= 1e-13, steps
+            assert n2 == pytest.approx(wo.norm2(cfg, phi), rel=1e-12)
+            want = wo.observables(cfg, v, phi)
+            for key in ("energy", "norm2", "r2"):
+                assert obs[key] == pytest.approx(want[key], rel=1e-12)
+            for l in lowers:       # orthogonal to every stored state after the step's Gram-Schmidt
+                assert abs(float(np.sum(l * got))) < 1e-13
+            del got
+    del phi, lowers, a, b, v
 
 
 @BIG
@@ -175,13 +182,19 @@ def test_five_and_seven_point_256_cubed_four_steps_bit_exact(wo, wa, ext, kernel
 
 
 @BIG
+@pytest.mark.parametrize("x2", ["0", "1"])
 @pytest.mark.parametrize("potential", ["Coulomb", "SimpleCornell"])
-def test_512_cubed_excited_steps_closed_form_and_staging_pipeline_bit_identical(wa, potential, monkeypatch):
+def test_512_cubed_excited_steps_closed_form_and_staging_pipeline_bit_identical(wa, potential, x2, monkeypatch):
     """the production kernels of BASELINE config #3's excited states at full size -- potential evaluated per cell
     (VG), raw staging pipeline with full-vector stores (DEEP) -- against the kernels that stream the stored V on the
     plain prefetch: the checksum of every cell's bits after 5 steps against k = 1, 2, 3 stored states, and the sums"""
     n = 512
     got = {}
+    # x2 = 1: the same comparison through the two-steps-per-pass kernels (closed form against streamed V on the same tiles:
+    # WAFER_X2_RY=2 keeps one stored state on 128 x 16 tiles on both sides)
+    monkeypatch.setenv("WAFER_X2", x2)
+    monkeypatch.setenv("WAFER_X2_RY", "2")
+    monkeypatch.setenv("WAFER_X2_MAX_K", "3")
     for mode in ("plain", "production"):
         if mode == "plain":
             monkeypatch.setenv("WAFER_VGEN", "0")

@@ -634,6 +634,135 @@ def test_excited_state_evolve_nonorthogonal_store(wo, wa, wnum):
         assert ctx.norm2() == pytest.approx(wo.norm2(cfg, phi), rel=1e-11)
 
 
+def _orthonormal_store(wo, cfg, wnum, seed=30, correlated=0.0):
+    lowers = []
+    for i in range(wnum):
+        l = random_phi(cfg, seed=seed + i)
+        if correlated and lowers:
+            l = l + correlated * lowers[0]          # deliberately NOT orthogonal to the first
+        else:
+            wo.orthogonalise(i, l, lowers)
+        wo.normalise(l, wo.norm2(cfg, l))
+        lowers.append(np.ascontiguousarray(l))
+    return lowers
+
+
+X2_SHAPES = [(24, 20, 28), (150, 37, 29), (129, 17, 9), (65, 33, 20), (3, 2, 5), (260, 8, 40)]   # (more cells than stored states)
+
+
+@pytest.mark.parametrize("steps", [4, 7, 12])
+@pytest.mark.parametrize("potential", ["Harmonic", "Coulomb", "SimpleCornell", "Cube"])
+@pytest.mark.parametrize("wnum", [1, 2, 3])
+def test_two_excited_steps_per_pass_vs_oracle(wo, wa, wnum, potential, steps, monkeypatch):
+    """wafer_stencil_x2.hip.h against the reference's sequence (grid.rs:562-686, wnum > 0: step, norm^2, normalise, modified
+    Gram-Schmidt after EVERY step): the pass regroups the sums by linearity, so the bar is the excited-state one, 1e-13 per
+    cell.  Closed-form V (Harmonic, Coulomb, SimpleCornell) and streamed V (Cube); even and odd step counts; ragged tiles,
+    grids smaller than a tile.  (WAFER_X2_MAX_K=3: the default keeps three stored states on the one-step kernel.)"""
+    monkeypatch.setenv("WAFER_X2_MAX_K", "3")
+    for shape in X2_SHAPES:
+        cfg, par = make_pair(shape, ext=1, potential=potential, dn=0.3, dt=0.01, mass=1.3, sig=0.4)
+        v = wo.potential_generate(cfg)
+        a, b = wo.ab(cfg, v)
+        lowers = _orthonormal_store(wo, cfg, wnum)
+        phi = random_phi(cfg, seed=40)
+        with wa.Context(par) as ctx:
+            ctx.set_potential(potential)
+            for i, l in enumerate(lowers):
+                ctx.load_state(i, l)
+            ctx.upload_phi(phi)
+            ctx.evolve(wnum, steps)
+            assert ctx.x2_passes() == (steps - 2 - steps % 2) // 2, "the two-step kernel did not run"
+            wo.evolve(cfg, wnum, a, b, phi, lowers, steps)
+            got = ctx.download_phi()
+            assert np.allclose(got, phi, rtol=0, atol=1e-13), (shape, float(np.max(np.abs(got - phi))))
+            assert ctx.norm2() == pytest.approx(wo.norm2(cfg, phi), rel=1e-12)
+            # a second call continues from the materialised phi
+            ctx.evolve(wnum, 6)
+            wo.evolve(cfg, wnum, a, b, phi, lowers, 6)
+            assert np.allclose(ctx.download_phi(), phi, rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("ry", ["1", "2"])
+@pytest.mark.parametrize("zchunk", ["1", "2", "3", "5", "1000"])
+def test_two_excited_steps_per_pass_zchunking_and_tile_heights(wo, wa, zchunk, ry, monkeypatch):
+    """every z-chunking (the chunks overlap by a plane of Y1 on each side and split the sums differently) and both tile
+    heights for one stored state (128 x 16: RY = 2, 128 x 8: RY = 1)"""
+    monkeypatch.setenv("WAFER_ZCHUNK", zchunk)
+    monkeypatch.setenv("WAFER_X2_RY", ry)
+    cfg, par = make_pair((140, 35, 23), ext=1, potential="Coulomb", dn=0.25, dt=0.008)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    for wnum in (1, 2):
+        lowers = _orthonormal_store(wo, cfg, wnum, seed=50)
+        phi = random_phi(cfg, seed=57)
+        with wa.Context(par) as ctx:
+            ctx.set_potential("Coulomb")
+            for i, l in enumerate(lowers):
+                ctx.load_state(i, l)
+            ctx.upload_phi(phi)
+            ctx.evolve(wnum, 10)
+            assert ctx.x2_passes() == 4
+            wo.evolve(cfg, wnum, a, b, phi, lowers, 10)
+            assert np.allclose(ctx.download_phi(), phi, rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("wnum", [2, 3])
+def test_two_excited_steps_per_pass_nonorthogonal_store(wo, wa, wnum, monkeypatch):
+    """stored states that are NOT orthonormal (overlaps of order one in every step): the regrouped sums -- Gram matrix,
+    <l_j, A l_i>, <A l_i, A l_j> -- must still reproduce the reference's sequential modified Gram-Schmidt"""
+    monkeypatch.setenv("WAFER_X2_MAX_K", "3")
+    cfg, par = make_pair((40, 33, 26), ext=1, potential="SimpleCornell", dn=0.25, dt=0.006, mass=2.0, sig=0.3)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    lowers = _orthonormal_store(wo, cfg, wnum, seed=60, correlated=0.4)
+    phi = random_phi(cfg, seed=70)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("SimpleCornell")
+        for i, l in enumerate(lowers):
+            ctx.load_state(i, l)
+        ctx.upload_phi(phi)
+        ctx.evolve(wnum, 16)
+        assert ctx.x2_passes() == 7
+        wo.evolve(cfg, wnum, a, b, phi, lowers, 16)
+        assert np.allclose(ctx.download_phi(), phi, rtol=0, atol=2e-13)
+        assert ctx.norm2() == pytest.approx(wo.norm2(cfg, phi), rel=1e-11)
+
+
+def test_two_excited_steps_per_pass_follows_store_and_potential_changes(wo, wa):
+    """the images M_j = A l_j and their matrices are rebuilt when w_store or V changes; a start that IS a stored state (the
+    reference's clone, grid.rs:95) goes through the one-step head and stays finite; long run against the one-step path"""
+    cfg, par = make_pair((48, 40, 36), ext=1, potential="Harmonic", dn=0.3, dt=0.01)
+    lowers = _orthonormal_store(wo, cfg, 2, seed=80)
+    with wa.Context(par) as ctx:
+        ctx.set_potential("Harmonic")
+        ctx.load_state(0, lowers[0])
+        ctx.upload_phi(random_phi(cfg, seed=81))
+        ctx.evolve(1, 8)
+        n0 = ctx.x2_passes()
+        assert n0 == 3
+        # a second stored state, another potential: both must be picked up
+        ctx.load_state(1, lowers[1])
+        ctx.set_potential("Coulomb")
+        cfg2, _ = make_pair((48, 40, 36), ext=1, potential="Coulomb", dn=0.3, dt=0.01)
+        v = wo.potential_generate(cfg2)
+        a, b = wo.ab(cfg2, v)
+        phi = random_phi(cfg, seed=82)
+        ctx.upload_phi(phi)
+        ctx.evolve(2, 9)
+        assert ctx.x2_passes() == n0 + 3
+        wo.evolve(cfg2, 2, a, b, phi, lowers, 9)
+        assert np.allclose(ctx.download_phi(), phi, rtol=0, atol=1e-13)
+        # the clone start of solve (grid.rs:95, 130-135): normalised, projected to rounding noise, then evolved
+        ctx.clone_state_to_phi(1)
+        ctx.normalise(ctx.norm2())
+        ctx.orthogonalise(2)
+        ctx.evolve(2, 40)
+        got = ctx.download_phi()
+        assert np.all(np.isfinite(got)) and abs(ctx.norm2() - 1.0) < 1e-4   # 1 - sum s_j^2: normalise precedes the projection (grid.rs:679-680)
+        for l in lowers:
+            assert abs(np.sum(l * got)) < 1e-12
+
+
 @pytest.mark.parametrize("ext", [1, 2, 3])
 @pytest.mark.parametrize("wnum", [1, 3, 4])
 def test_one_pass_excited_step_equals_two_pass(wa, wnum, ext, monkeypatch):
@@ -641,6 +770,7 @@ def test_one_pass_excited_step_equals_two_pass(wa, wnum, ext, monkeypatch):
     performs the two-pass scheme's operations on the same operands: identical bits"""
     shape = (70, 21, 19)
     out = {}
+    monkeypatch.setenv("WAFER_X2", "0")   # (two STEPS per pass regroup the sums: compared with the oracle above, not bit for bit)
     for mode in ("0", "1"):
         monkeypatch.setenv("WAFER_ONE_PASS", mode)
         par = wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, max_states=4)
@@ -657,16 +787,24 @@ def test_one_pass_excited_step_equals_two_pass(wa, wnum, ext, monkeypatch):
     assert np.array_equal(out["0"][0], out["1"][0]) and out["0"][1] == out["1"][1]
 
 
+@pytest.mark.parametrize("x2", ["0", "1"])
 @pytest.mark.parametrize("potential", ["Coulomb", "SimpleCornell", "Harmonic", "ComplexCoulomb", "ComplexHarmonic"])
 @pytest.mark.parametrize("ext", [1, 2, 3])
 @pytest.mark.parametrize("wnum", [1, 2, 3])
-def test_closed_form_potential_evaluated_in_the_excited_step_kernel(wa, wnum, ext, potential, monkeypatch):
+def test_closed_form_potential_evaluated_in_the_excited_step_kernel(wa, wnum, ext, potential, x2, monkeypatch):
     """the excited-state step kernels evaluate Coulomb / SimpleCornell / Harmonic (potential.rs:221-229,
     241-249, 270-274) per cell instead of streaming the stored V: the same function that filled the
     array, so identical bits per cell and identical sums (WAFER_VGEN=0 streams V); odd axes put a cell
     at r = 0 (the r < dn clamp), the ragged shape leaves partial tiles"""
+    if x2 == "1" and ext != 1:
+        pytest.skip("two steps per pass: ThreePoint only")
     shape = (133, 21, 19)
     out = {}
+    # x2 = 0: one step per pass; x2 = 1: two (wafer_stencil_x2.hip.h) -- there the comparison needs the SAME tile height on
+    # both sides (the partial sums of a pass follow the tiles, and the default gives a streamed V the lower tile)
+    monkeypatch.setenv("WAFER_X2", x2)
+    monkeypatch.setenv("WAFER_X2_RY", "2")
+    monkeypatch.setenv("WAFER_X2_MAX_K", "3")
     for mode in ("0", "1"):
         monkeypatch.setenv("WAFER_VGEN", mode)
         par = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.3, sig=0.223, central_difference=ext, max_states=4)

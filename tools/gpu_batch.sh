@@ -25,6 +25,37 @@ for step in "$@"; do
                     WAFER_HIP_LIB=$PWD/wafer_amd/build/prev/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 5 --steps 30 --configs "v=-1" 2>&1 | grep config | sed "s/^/prev k=$w /"
                     timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 5 --steps 30 --configs "v=-1" 2>&1 | grep config | sed "s/^/new  k=$w /"
                   done; done > $O/ab_excited.jsonl; cut -c1-120 $O/ab_excited.jsonl ;;
+    tests_x2)     timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "two_excited or excited" > $O/tests_x2.log 2>&1; tail -15 $O/tests_x2.log ;;
+    sweep_x2)     for w in ${AB_K:-1 2 3}; do timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --potential ${X2_POT:-Coulomb} --rounds 4 --steps 62 --configs ${X2_CONFIGS:-x2=0 x2=1 x2=0 x2=1} 2>&1 | grep config | sed "s/^/k=$w /"; done > $O/sweep_x2.jsonl; cut -c1-140 $O/sweep_x2.jsonl ;;
+    ab_alt_x2)    # the excited-state steps of the default build against every wafer_amd/build/alt_*/ library, interleaved, same box
+                  for i in 1 2; do for w in ${AB_K:-1 2 3}; do
+                    timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 4 --steps 62 --configs "x2=1" 2>&1 | grep config | sed "s/^/default k=$w /"
+                    for d in wafer_amd/build/alt_*; do
+                      WAFER_HIP_LIB=$PWD/$d/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 4 --steps 62 --configs "x2=1" 2>&1 | grep config | sed "s/^/$(basename $d) k=$w /"
+                    done
+                  done; done > $O/ab_alt_x2.jsonl; cut -c1-130 $O/ab_alt_x2.jsonl ;;
+    prof_x2)      # the kernels of the whole path with the two-step excited kernels: --stats summary, HBM-side traffic, SQ counters
+                  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/px_stats -- python3 tools/path_bench.py --steps 22 > $O/path_x2.log 2>&1; grep op $O/path_x2.log
+                  cp $(find $O/px_stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats_path_512.csv; find $O/px_stats -name "*.csv" -size +2M -delete
+                  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/px_f -- python3 tools/path_bench.py --steps 22 > /dev/null 2>&1
+                  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/px_w -- python3 tools/path_bench.py --steps 22 > /dev/null 2>&1
+                  python3 tools/pmc_summary.py $O/px_f $O/px_w $O/pmc_path_512.json | grep -i "step\|apply"
+                  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/px_s1 -- python3 tools/path_bench.py --steps 22 > /dev/null 2>&1
+                  timeout 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/px_s2 -- python3 tools/path_bench.py --steps 22 > /dev/null 2>&1
+                  timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT --output-format csv -d $O/px_s3 -- python3 tools/path_bench.py --steps 22 > /dev/null 2>&1
+                  python3 tools/pmc_counters.py $O/px_s1 $O/px_s2 $O/px_s3 --match step > $O/sq_path.json; rm -rf $O/px_f $O/px_w $O/px_s1 $O/px_s2 $O/px_s3
+                  python3 - <<PY
+import json
+d = json.load(open("$O/sq_path.json"))
+for name, c in d.items():
+    g = lambda k: c.get(k, {}).get("avg", 0.0)
+    wc = g("SQ_WAVE_CYCLES") or 1.0
+    print(name[:100])
+    print("   VALU %.1f M  LDS %.1f M  VMEM_RD %.2f M  VMEM_WR %.2f M  SALU %.1f M  bank_conflict_cycles %.1f M  active_valu %.3f  active_any %.3f  wait_inst %.3f  wait_any %.3f" % (
+        g("SQ_INSTS_VALU") / 1e6, g("SQ_INSTS_LDS") / 1e6, g("SQ_INSTS_VMEM_RD") / 1e6, g("SQ_INSTS_VMEM_WR") / 1e6, g("SQ_INSTS_SALU") / 1e6, g("SQ_LDS_BANK_CONFLICT") / 1e6,
+        g("SQ_ACTIVE_INST_VALU") / wc, g("SQ_ACTIVE_INST_ANY") / wc, g("SQ_WAIT_INST_ANY") / wc, g("SQ_WAIT_ANY") / wc))
+PY
+                  ;;
     sweep_xf)     for w in 1 2 3; do timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 5 --steps 30 --configs ${XF_CONFIGS:-"xfnw=8" "xfnw=4"} 2>&1 | grep config | sed "s/^/k=$w /"; done > $O/sweep_xf.jsonl; cut -c1-130 $O/sweep_xf.jsonl ;;
     ab_alt)       for i in 1 2 3; do
                     timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 5 --steps 60 --configs "v=3" 2>&1 | grep config | sed "s/^/default /"

@@ -152,6 +152,12 @@ struct wafer_ctx {
     int cur = 0;
     void *v = nullptr, *a = nullptr, *b = nullptr, *potsub = nullptr;
     std::vector<void *> states;
+    // two excited-state steps per pass (wafer_stencil_x2.hip.h): M_j = A l_j of the first x2_ready stored states, the matrices
+    // <l_j, M_i> and <M_i, M_j> (device: amat[16], bmat[16]) and the load transform's coefficient block
+    std::vector<void *> mstates;
+    int x2_ready = 0;
+    double *x2mat = nullptr, *x2coef = nullptr;
+    uint64_t x2_passes = 0;
     int potsub_kind = WAFER_POTSUB_NONE;
     double potsub_scalar = 0.0;
     bool have_pot = false, have_phi = false;
@@ -692,6 +698,7 @@ static int gs_chain(wafer_ctx *c, int buf, uint32_t wnum, bool first_dot_done, h
 // Gram matrix of the stored states (lower triangle), recomputed whenever w_store changes.
 static int recompute_gram(wafer_ctx *c)
 {
+    c->x2_ready = 0;   // w_store changed: the images M_j and their matrices are rebuilt on demand (ensure_x2)
     const size_t n = c->states.size() < WAFER_MAX_LOW ? c->states.size() : WAFER_MAX_LOW;
     memset(c->gram_host, 0, sizeof c->gram_host);
     for (size_t j = 1; j < n; ++j)
@@ -771,6 +778,84 @@ static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32
                                nb_lo + nb_hi, c->s_main, &nb_in));
     HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_join, 0));
     return reduce_to_scal(c, 1 + (int)wnum, nb_lo + nb_hi + nb_in, 0, c->s_main);
+}
+
+// ---- two excited-state steps per pass (wafer_stencil_x2.hip.h) ------------------------------------------------------
+enum { X2_SUM_SLOT = 18 };   // scal[18 .. 18 + 2 + 3k): the sums of a two-step pass
+// ThreePoint fp64, one to three stored states, the potential inside the short reciprocal's range; undecomposed grids
+static bool x2_applies(const wafer_ctx *c, uint32_t wnum)
+{
+    return c->tune.x2 != 0 && c->tune.one_pass != 0 && !c->f32 && c->g.R == 1 && wnum >= 1 && wnum <= 3 && (int)wnum <= c->tune.x2_max_k &&
+           active_variant(c) >= 1 &&
+           c->v_in_range && !c->sharded();
+}
+
+// M_j = A l_j for the first wnum stored states (one ground-state step of each, grid.rs:568-592) and the matrices of the
+// coefficient kernel.  Rebuilt when w_store or the potential changed.
+static int ensure_x2(wafer_ctx *c, uint32_t wnum)
+{
+    if (c->x2_ready >= (int)wnum) return WAFER_OK;
+    const WaferGeom &g = c->g;
+    while (c->mstates.size() < wnum) {
+        void *slot = nullptr;
+        TRY(alloc_grid_array(c, &slot, c->s_main));
+        c->mstates.push_back(slot);
+    }
+    if (kernels_stream_ab(c, 1)) TRY(ensure_ab(c));
+    for (uint32_t j = 0; j < wnum; ++j) {
+        const WaferStepArgs a = step_args(c, g.G, g.G + g.nzl);
+        if (wafer_entry_step_lds(WAFER_TC_F64, g.R, c->tune, a, c->states[j], c->a, c->b, c->v, c->mstates[j], c->s_main, closed_form_vg(c)) != hipSuccess)
+            return fail(WAFER_ERR_HIP, "stencil launch (image of a stored state) failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    double host[2 * WAFER_MAX_LOW * WAFER_MAX_LOW];
+    memset(host, 0, sizeof host);
+    double *amat = host, *bmat = host + WAFER_MAX_LOW * WAFER_MAX_LOW;
+    for (uint32_t j = 0; j < wnum; ++j)
+        for (uint32_t i = 0; i < wnum; ++i) {   // <l_j, M_i>
+            TRY(launch_dot(c, c->mstates[i], c->states[j], 13, c->s_main));
+            TRY(read_scal(c, 13, 1, &amat[j * WAFER_MAX_LOW + i], c->s_main));
+        }
+    for (uint32_t i = 0; i < wnum; ++i)
+        for (uint32_t j = i; j < wnum; ++j) {   // <M_i, M_j>
+            TRY(launch_dot(c, c->mstates[i], c->mstates[j], 13, c->s_main));
+            TRY(read_scal(c, 13, 1, &bmat[i * WAFER_MAX_LOW + j], c->s_main));
+            bmat[j * WAFER_MAX_LOW + i] = bmat[i * WAFER_MAX_LOW + j];
+        }
+    HIP_TRY(hipMemcpyAsync(c->x2mat, host, sizeof host, hipMemcpyHostToDevice, c->s_main));
+    HIP_TRY(hipStreamSynchronize(c->s_main));
+    c->x2_ready = (int)wnum;
+    return WAFER_OK;
+}
+
+// `pairs` two-step passes from the raw result of a one-step kernel (phi[cur] = A x, its sums in scal[0 .. wnum]), then phi
+// materialised: 2 * pairs steps of grid.rs:562-686
+static int x2_run(wafer_ctx *c, uint32_t wnum, uint64_t pairs, hipStream_t s)
+{
+    const WaferGeom &g = c->g;
+    const int k = (int)wnum, nq = wafer_entry_x2_nsums(k);
+    const double *amat = c->x2mat, *bmat = c->x2mat + WAFER_MAX_LOW * WAFER_MAX_LOW;
+    const void *l[3] = {nullptr, nullptr, nullptr}, *m[3] = {nullptr, nullptr, nullptr};
+    for (int j = 0; j < k; ++j) { l[j] = c->states[j]; m[j] = c->mstates[j]; }
+    if (wafer_entry_x2_coeffs(1, k, c->scal, c->gram, amat, bmat, c->x2coef, s) != hipSuccess)
+        return fail(WAFER_ERR_HIP, "coefficient kernel launch failed");
+    const WaferStepArgs a = step_args(c, g.G, g.G + g.nzl);
+    const long long nb = wafer_entry_x2_blocks(c->tune, g, k, closed_form_vg(c), g.G, g.G + g.nzl, c->num_cus);
+    if (nb > (long long)c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
+    for (uint64_t p = 0; p < pairs; ++p) {
+        const int src = c->cur, dst = c->cur ^ 1;
+        if (wafer_entry_xstep2(c->tune, a, k, closed_form_vg(c), c->phi[src], c->v, c->phi[dst], c->partials, c->partials_stride, l, m,
+                               c->x2coef, s) != hipSuccess)
+            return fail(WAFER_ERR_HIP, "two-step excited-state stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+        ++c->x2_passes;
+        TRY(reduce_to_scal(c, nq, nb, X2_SUM_SLOT, s));
+        if (wafer_entry_x2_coeffs(2, k, c->scal + X2_SUM_SLOT, c->gram, amat, bmat, c->x2coef, s) != hipSuccess)
+            return fail(WAFER_ERR_HIP, "coefficient kernel launch failed");
+        c->cur = dst;
+    }
+    if (wafer_entry_x2_apply(g, g.G, g.G + g.nzl, k, c->phi[c->cur], l, m, c->x2coef, c->num_cus, s) != hipSuccess)
+        return fail(WAFER_ERR_HIP, "apply launch failed");
+    c->halo_valid = 0;
+    return WAFER_OK;
 }
 
 static int excited_apply(wafer_ctx *c, int buf, uint32_t wnum, hipStream_t s)
@@ -883,7 +968,10 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     for (void **arr : arrays)
         if (alloc_grid_array(c, arr, c->s_main) != WAFER_OK) return cleanup_fail(WAFER_ERR_HIP);
     c->partials_stride = std::max<size_t>((size_t)c->bx * c->by * 64 + 1024, (size_t)c->num_cus * 8); // column kernels / row kernels
-    HIP_TRYC(hipMalloc((void **)&c->partials, sizeof(double) * (WAFER_MAX_LOW + 1) * c->partials_stride));
+    // rows: 1 + WAFER_MAX_LOW sums of a one-step excited kernel, 2 + 3k (k <= 3) of a two-step pass
+    HIP_TRYC(hipMalloc((void **)&c->partials, sizeof(double) * (2 + 3 * WAFER_MAX_LOW) * c->partials_stride));
+    HIP_TRYC(hipMalloc((void **)&c->x2mat, sizeof(double) * 2 * WAFER_MAX_LOW * WAFER_MAX_LOW));
+    HIP_TRYC(hipMalloc((void **)&c->x2coef, sizeof(double) * 32));
     HIP_TRYC(hipMalloc((void **)&c->gram, sizeof(double) * WAFER_MAX_LOW * WAFER_MAX_LOW));
     HIP_TRYC(hipMemsetAsync(c->gram, 0, sizeof(double) * WAFER_MAX_LOW * WAFER_MAX_LOW, c->s_main));
     HIP_TRYC(hipMalloc((void **)&c->scal, sizeof(double) * SCAL_SLOTS));
@@ -906,6 +994,10 @@ int wafer_ctx_destroy(wafer_ctx *c)
         if (p) (void)hipFree(alloc_base(c, p));
     for (void *p : c->states)
         if (p) (void)hipFree(alloc_base(c, p));
+    for (void *p : c->mstates)
+        if (p) (void)hipFree(alloc_base(c, p));
+    if (c->x2mat) (void)hipFree(c->x2mat);
+    if (c->x2coef) (void)hipFree(c->x2coef);
     if (c->partials) (void)hipFree(c->partials);
     if (c->scal) (void)hipFree(c->scal);
     if (c->gram) (void)hipFree(c->gram);
@@ -1098,6 +1190,7 @@ int wafer_set_potential_builtin(wafer_ctx *c, int potential)
         }
     }
     c->have_pot = true;
+    c->x2_ready = 0;   // M_j = A l_j follows V
     // the excited-state kernels can evaluate these instead of reading V (wafer_k_step_lds, VG)
     c->vgen_type = (potential == WAFER_POT_COULOMB || potential == WAFER_POT_COMPLEXCOULOMB) ? WAFER_POT_COULOMB
                    : (potential == WAFER_POT_HARMONIC || potential == WAFER_POT_COMPLEXHARMONIC) ? WAFER_POT_HARMONIC
@@ -1122,6 +1215,7 @@ int wafer_set_potential_host(wafer_ctx *c, const double *v, int potsub_kind, dou
         TRY((convert_host_array<true>(c, const_cast<double *>(potsub), c->g.nx, c->g.ny, c->g.nz, c->g.R, c->g.R, c->g.R, c->potsub)));
     }
     c->have_pot = true;
+    c->x2_ready = 0;   // M_j = A l_j follows V
     return check_v_range(c);
 }
 
@@ -1278,6 +1372,7 @@ int wafer_set_potential_resampled(wafer_ctx *c, const double *src, uint32_t sx, 
     c->potsub_kind = WAFER_POTSUB_NONE; // potential.rs:357-358: FromFile has no pot_sub of its own
     c->potsub_scalar = 0.0;
     c->have_pot = true;
+    c->x2_ready = 0;   // M_j = A l_j follows V
     return check_v_range(c);
 }
 
@@ -1438,6 +1533,12 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     // is sharded, the slab carries 2R ghost planes
     const bool fuse = wnum == 0 && fuse2_applies(c);
     const bool fuse3 = wnum == 0 && fuse3_applies(c);
+    // Excited states, two steps per pass: the first two steps (three for an odd count) run one per pass -- whatever the
+    // caller hands over (a clone of a stored state, an un-normalised start) is normalised and projected by the reference's own
+    // sequence before the regrouped sums take over -- then pairs; phi is materialised after the last pass.
+    const bool x2 = wnum > 0 && steps >= 4 && x2_applies(c, wnum);
+    const uint64_t x2_head = x2 ? 2 + (steps & 1) : steps;
+    if (x2) TRY(ensure_x2(c, wnum));
     HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
     // single-launch passes in flight: their last exchanges have not been waited for by the main stream
     bool hv_active = false;
@@ -1547,10 +1648,16 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             }
         } else {
             // step + sum phi'^2 (grid.rs:675-678), normalise (:679), Gram-Schmidt (:680)
+            if (x2 && s == x2_head) {
+                TRY(x2_run(c, wnum, (steps - x2_head) / 2, c->s_main));
+                s = steps;
+                continue;
+            }
             if (wnum <= WAFER_MAX_LOW && active_variant(c) >= 1) {
                 // one pass per step: the raw result travels to the next step, which normalises and
                 // projects it on load; phi is materialised once after the last step
                 const bool one_pass = c->tune.one_pass != 0;
+                const bool last = s + 1 == steps;   // (never within the head of a two-steps-per-pass run)
                 if (one_pass && s == 0) {
                     hipLaunchKernelGGL(wafer_k_identity_scalars, dim3(1), dim3(64), 0, c->s_main, c->scal, 1 + (int)wnum);
                     HIP_TRY(hipGetLastError());
@@ -1561,15 +1668,15 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 //  from an interior launch that packs the CUs exactly: the interior ends later by about the exchange's own
                 //  duration, and the two thin boundary launches come on top -- bench slab, native RCCL to the same rank,
                 //  k = 1: 0.772 ms/step split against 0.718 unsplit (undecomposed 0.643); k = 3: 1.210 against 1.121 (1.033).)
-                const bool split = one_pass && s + 1 < steps && c->sharded() && c->overlap_mode == 1 && g.nzl > 2 * R;
+                const bool split = one_pass && !last && c->sharded() && c->overlap_mode == 1 && g.nzl > 2 * R;
                 if (split) {
                     TRY(excited_step_launch_overlapped(c, src, dst, wnum, one_pass));
                 } else {
                     TRY(excited_step_launch(c, src, dst, wnum, one_pass, c->s_main));
-                    if (!one_pass || s + 1 == steps) TRY(excited_apply(c, dst, wnum, c->s_main));
-                    if (s + 1 < steps || !one_pass) TRY(exchange_halo(c, dst, c->s_main, R));
+                    if (!one_pass || last) TRY(excited_apply(c, dst, wnum, c->s_main));
+                    if (!last || !one_pass) TRY(exchange_halo(c, dst, c->s_main, R));
                 }
-                c->halo_valid = (one_pass && s + 1 == steps) ? 0 : R;
+                c->halo_valid = (one_pass && last) ? 0 : R;
                 c->cur = dst;
                 s += 1;
                 continue;
@@ -1879,6 +1986,13 @@ int wafer_diag_copy_bw(wafer_ctx *c, int iters, int unroll, int blocks_per_cu, d
 
 // position-dependent integer checksum of the work cells of global work planes [z_begin, z_begin + z_count)
 // that this context owns (wafer_k_checksum): equal for equal bits, whatever the decomposition
+int wafer_diag_x2_passes(wafer_ctx *c, uint64_t *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    *out = c->x2_passes;
+    return WAFER_OK;
+}
+
 int wafer_diag_checksum(wafer_ctx *c, uint32_t z_begin, uint32_t z_count, uint64_t *out)
 {
     if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");

@@ -1,0 +1,829 @@
+// TWO excited-state steps per pass over HBM (ThreePoint, fp64): grid.rs:562-686 with wnum = k > 0.
+//
+// The reference renormalises and runs modified Gram-Schmidt against the k stored states after EVERY step
+// (grid.rs:674-681), which needs 1 + k global sums between two steps.  The step operator A (grid.rs:568-592) is linear, so
+// the sums of the first step need not be known while the second is computed:
+//
+//   x0                      the pass's input as the reference holds it (normalised, projected)
+//   Y1 = A x0               first raw step            n_b = sqrt(sum Y1^2),  s^b_j from t_j = sum l_j Y1      (:675-680)
+//   x1 = Y1 / n_b - sum_j s^b_j l_j                   the reference's state after step 1
+//   Y2 = A x1 = A(Y1) / n_b - sum_j s^b_j M_j         second raw step, with M_j = A l_j stored once per stored state
+//   x2 = Y2 / n_c - sum_j s^c_j l_j                   the reference's state after step 2
+//
+// The kernel computes Y1 = A x0 and Z = A Y1 in one pass (Y1 never leaves the CU) and stores the RAW Z; the NEXT pass forms
+//   x2 = (Z / n_b - sum_j s^b_j M_j) / n_c - sum_j s^c_j l_j
+// for every cell it loads (own cells, halo rows, halo columns), in the reference's per-cell operation order (a true
+// division, then k subtractions, twice).  The scalars come from sums taken during the pass -- sum Y1^2, sum l_j Y1 (they give
+// n_b, s^b) and sum Z^2, sum l_j Z, sum M_j Z, from which, with the constant matrices <l_j, M_i> and <M_i, M_j>,
+//   sum Y2^2 = sum Z^2 / n_b^2 - (2 / n_b) sum_j s^b_j sum M_j Z + sum_ij s^b_i s^b_j <M_i, M_j>
+//   sum l_j Y2 = sum l_j Z / n_b - sum_i s^b_i <l_j, M_i>
+// (wafer_k_x2_coeffs, one thread).  Exact in exact arithmetic; in fp64 the state stays within 1e-16 of the reference's
+// sequence per cell (tools/excited_two_step_feasibility.py; tests hold it to the 1e-13 of every excited-state test).
+// Streams per TWO updates: Z in, k x l_j, k x M_j, Z out (+ V unless its closed form is evaluated): (2 + 2k) * 8 B against
+// 2 * (2 + k) * 8 B for two one-step passes -- 16 / 24 / 32 B per update at k = 1 / 2 / 3 against 24 / 32 / 40.
+//
+// Structure: the three-step ground-state kernel's (wafer_stencil_fused3.hip.h) with one level less and a transform on load.
+// Eight waves on a 128 x (8 RY) tile marched up z; every wave owns RY rows at both levels plus ONE extra slot:
+//   wave 0   row y0-1   (x0 queue, Y1)           wave 7   row y0+TY   (x0 queue, Y1)
+//   wave 1   row y0-2   (x0 staged to LDS only)  wave 6   row y0+TY+1 (x0 staged to LDS only)
+//   waves 2..5   the 4 (TY + 4) x0 halo-column cells, one per lane: Y1 on the inner column
+// a, b of a cell are formed once per pass (level 1) and ride to level 2 as a and b dt.
+// The sums of a plane are all taken when its Z is produced (Y1 of that plane is still in its z-queue), which is three
+// planes after l_j, M_j of that plane were loaded for the transform: the stored states' values at the lane's own cells wait
+// in an LDS queue private to each lane (two slots per array, no barrier involved) plus one plane in registers.  That queue
+// is what sets the tile height: 128 x 16 tiles (RY = 2) fit k = 1 (145 KB of LDS); k = 2, 3 run on 128 x 8 tiles (RY = 1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wafer_geom.h"
+#include "wafer_stencil.hip.h"
+#include "wafer_stencil_lds.hip.h"
+#include "wafer_stencil_fused2.hip.h"
+#include "wafer_rowwalk.h"
+
+// the coefficient block the load transform reads (device memory, doubles)
+enum {
+    WAFER_X2_NB = 0,                      // n_b
+    WAFER_X2_NC = 1,                      // n_c
+    WAFER_X2_SB = 2,                      // s^b_j, j < WAFER_MAX_LOW
+    WAFER_X2_SC = 2 + WAFER_MAX_LOW,      // s^c_j
+    WAFER_X2_W0 = 2 + 2 * WAFER_MAX_LOW,  // 1 / (n_b n_c)
+    WAFER_X2_SBN = 3 + 2 * WAFER_MAX_LOW, // s^b_j / n_c
+    WAFER_X2_COEF_DOUBLES = 3 + 3 * WAFER_MAX_LOW
+};
+enum { WAFER_X2_MAX_LOW = 3 };
+
+struct WaferX2Ptrs {
+    const double *l[WAFER_X2_MAX_LOW] = {nullptr, nullptr, nullptr};   // stored states
+    const double *m[WAFER_X2_MAX_LOW] = {nullptr, nullptr, nullptr};   // M_j = A l_j
+};
+
+// sums a pass leaves: partials[q * pstride + workgroup], q in this order
+//   0: sum Y1^2   1 .. k: sum l_j Y1   k+1: sum Z^2   k+2 .. 2k+1: sum l_j Z   2k+2 .. 3k+1: sum M_j Z
+static inline int wafer_x2_nsums(int k) { return 2 + 3 * k; }
+
+template <int RY_>
+struct WaferX2Cfg {
+    static constexpr int VEC = 2;
+    static constexpr int RY = RY_;
+    static constexpr int NW = 8;
+    static constexpr int NT_ = NW * 64;
+    static constexpr int TX = 64 * VEC, TY = NW * RY;
+    static constexpr int HC0 = 2, HC1 = 1;              // halo columns per side of x0 / Y1
+    static constexpr int HX0 = 2, HX1 = 2;              // ... as kept in LDS (VEC aligned)
+    static constexpr int LP0 = TX + 2 * HX0, LP1 = TX + 2 * HX1;
+    static constexpr int ROWS0 = TY + 4, ROWS1 = TY + 2;
+    static constexpr int TILE0 = ROWS0 * LP0, TILE1 = ROWS1 * LP1;
+    static constexpr int NCOL = 2 * HC0 * ROWS0;        // x0 halo-column cells per plane
+    static constexpr int HCW0 = 2, HCWN = 4;            // waves HCW0 .. HCW0 + HCWN - 1 take them, one per lane
+    static constexpr int CPW = (NCOL + HCWN - 1) / HCWN;
+    static_assert(CPW <= 64, "one halo-column cell per lane");
+    static constexpr int QSLOT = TY * TX;               // elements of one array's plane in the LDS queue
+};
+
+// x = (w / n_b - sum_j m_j s^b_j) / n_c - sum_j l_j s^c_j        (grid.rs:467, 488-490, twice)
+// evaluated as  w * (1 / (n_b n_c)) - sum_j m_j (s^b_j / n_c) - sum_j l_j s^c_j : 1 + 4k instructions per cell instead of the
+// 12 + 4k of two true divisions.  The pass is not bit-comparable with the reference's sequence anyway (its sums are
+// regrouped); what is held is the excited-state bar, 1e-13 per cell, and each of these roundings is one ulp of a cell's
+// value.  kf.w0 = 1 / (n_b n_c), kf.sb[j] = s^b_j / n_c as loaded from the coefficient block (wafer_k_x2_coeffs writes both
+// forms).  Measured on one box, 512^3, k = 1 (tools/gpu_batch.sh ab_alt_x2): separate products and differences 0.461 ms per
+// step, the two divisions 0.480, fused multiply-adds 0.496 -- the independent products overlap, the fused chain does not --
+// so the products stay separate (-DWAFER_X2_DIV_XFORM / -DWAFER_X2_FMA_XFORM build the other two).
+template <int NL>
+struct WaferX2Coef {
+    double w0, sb[NL], sc[NL];
+#ifdef WAFER_X2_DIV_XFORM
+    double nb, nc, sbr[NL];
+#endif
+};
+template <int NL>
+__device__ __forceinline__ double wafer_x2_xform(const WaferX2Coef<NL> &k, double w, const double *l, const double *m)
+{
+#ifdef WAFER_X2_DIV_XFORM
+    double u = wafer_div_invariant<double>(w, k.nb);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) u = u - m[j] * k.sbr[j];
+    double x = wafer_div_invariant<double>(u, k.nc);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) x = x - l[j] * k.sc[j];
+    return x;
+#elif defined(WAFER_X2_FMA_XFORM)
+    double x = w * k.w0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) x = __builtin_fma(-m[j], k.sb[j], x);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) x = __builtin_fma(-l[j], k.sc[j], x);
+    return x;
+#else
+    double x = w * k.w0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) x = x - m[j] * k.sb[j];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) x = x - l[j] * k.sc[j];
+    return x;
+#endif
+}
+
+template <int RY, int NL, int VG, bool VIR>
+__global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, int nty, int swz, const double *__restrict__ phi,
+                                                       const double *__restrict__ pv, double *__restrict__ out,
+                                                       double *__restrict__ partials, long long pstride, WaferX2Ptrs st,
+                                                       const double *__restrict__ coef)
+{
+    using Cfg = WaferX2Cfg<RY>;
+    typedef double T;
+    typedef double C;
+    using VT = typename WaferVec<double>::type;
+    constexpr int R = 1;
+    constexpr int VEC = Cfg::VEC, TX = Cfg::TX, TY = Cfg::TY;
+    constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, LP0 = Cfg::LP0, LP1 = Cfg::LP1;
+    constexpr int QS = Cfg::QSLOT;
+    static_assert(NL >= 1 && NL <= WAFER_X2_MAX_LOW, "one to three stored states");
+    __shared__ __attribute__((aligned(16))) T lds0[2 * Cfg::TILE0];
+    __shared__ __attribute__((aligned(16))) T lds1[2 * Cfg::TILE1];
+    // L3: a third slot for the l_j where LDS allows it (RY = 2 with one stored state: 158 KB): a plane's l_j go to LDS right
+    // after the transform instead of waiting an iteration in registers (8 VGPRs per stored state); the two-slot queue then
+    // holds the m_j only
+    constexpr bool L3 = (RY == 2 && NL == 1);
+    constexpr int NA = L3 ? NL : 2 * NL;                               // arrays per slot of the two-slot queue
+    __shared__ __attribute__((aligned(16))) T ldsq[2 * NA * QS];       // [slot][array: l_0, m_0, l_1, m_1, ... (L3: m_0, ...)][row][x]
+    __shared__ __attribute__((aligned(16))) T ldsl3[L3 ? 3 * NL * QS : 2];
+    __shared__ double red[Cfg::NW];
+
+    const WaferGeom &g = a.g;
+    int bid = blockIdx.x;
+    if (swz) { // XCD-contiguous tile order (wafer_stencil_lds.hip.h)
+        const int n = gridDim.x, q = n >> 3, r = n & 7, k = bid & 7;
+        bid = k * q + min(k, r) + (bid >> 3);
+    }
+    const int tx_i = bid % ntx, ty_i = (bid / ntx) % nty, tz_i = bid / (ntx * nty);
+    const int zs = a.lz_lo + tz_i * a.zchunk;
+    const int ze = min(zs + a.zchunk, a.lz_hi);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = tx_i * TX, y0 = ty_i * TY;
+    const C dt = (C)a.dt, den = (C)a.den;
+    constexpr bool vir = VIR;
+    const bool x_row = wave < 2 || wave >= 6;
+    const bool x_l1 = wave == 0 || wave == 7;            // the halo row next to the tile: Y1 as well
+
+    WaferX2Coef<NL> kf;
+    kf.w0 = coef[WAFER_X2_W0];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        kf.sb[j] = coef[WAFER_X2_SBN + j];
+        kf.sc[j] = coef[WAFER_X2_SC + j];
+    }
+#ifdef WAFER_X2_DIV_XFORM
+    kf.nb = coef[WAFER_X2_NB];
+    kf.nc = coef[WAFER_X2_NC];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) kf.sbr[j] = coef[WAFER_X2_SB + j];
+#endif
+    [[maybe_unused]] WaferPotArgs vgen;
+    if constexpr (VG != 0) {
+        vgen.g = g;
+        vgen.type = VG;
+        vgen.dn = a.vg_dn; vgen.dt = a.dt; vgen.mass = a.vg_mass; vgen.sig = a.vg_sig;
+        vgen.mu_t = vgen.alphas_2pit = vgen.xi_coef = vgen.xi_fac = 0.0;
+    }
+
+    VT zero;
+    zero[0] = zero[1] = 0.0;
+    const int xl = lane * VEC, xi = x0 + xl;
+    const unsigned xlu = (unsigned)(lane * VEC);
+
+    // ---- main rows
+    int yrow[RY];
+    bool rowwk[RY];
+    long long rowoff[RY];
+    int qoff[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const int y = y0 + wave * RY + r;
+        yrow[r] = y;
+        rowwk[r] = y < g.ny;
+        rowoff[r] = (long long)(y + R) * g.pitch + g.xoff + R + x0;
+        qoff[r] = (wave * RY + r) * TX + xl;
+    }
+    // ---- the extra halo row (requests of rows outside the work area are redirected to the wave's own first row and the
+    //      value replaced by the zero it stands for, as in the three-step kernel)
+    const int xy = wave == 0 ? y0 - 1 : wave == 1 ? y0 - 2 : wave == 6 ? y0 + TY + 1 : y0 + TY;
+    const bool xwk = x_row && xy >= 0 && xy < g.ny;
+    const bool xy_out = xy < 0 || xy >= g.ny;
+    const long long xoff_row = xy_out ? rowoff[0] : (long long)(xy + R) * g.pitch + g.xoff + R + x0;
+    // ---- halo-column cell of this lane (waves 2..5): cell c: row c / 4 of the x0 tile, k = c % 4: k < 2: column x0-1-k,
+    //      else column x0+TX+(k-2)
+    const int cidx = min((wave - Cfg::HCW0) * Cfg::CPW + lane, Cfg::NCOL - 1);
+    const int crow = cidx / (2 * Cfg::HC0), ck = cidx % (2 * Cfg::HC0);
+    const int ckk = (ck < Cfg::HC0) ? ck : ck - Cfg::HC0;
+    const int clc = (ck < Cfg::HC0) ? (-1 - ckk) : (TX + ckk);
+    const int cxw = x0 + clc, cy = y0 - 2 + crow;
+    const bool c_ok = !x_row && lane < Cfg::CPW && (wave - Cfg::HCW0) * Cfg::CPW + lane < Cfg::NCOL;
+    const bool c_wk = cy >= 0 && cy < g.ny && cxw >= 0 && cxw < g.nx;
+    const bool c_l1 = c_ok && ckk < Cfg::HC1 && crow >= 2 && crow < Cfg::ROWS0 - 2;   // rows y0 .. y0+TY-1: what level 2 reads
+    const bool c_xout = cxw < 0 || cxw >= g.nx || cy < 0 || cy >= g.ny;
+    const long long c_off = (long long)((cy < 0 ? y0 : cy >= g.ny ? y0 + TY - 1 : cy) + R) * g.pitch + g.xoff + R +
+                            ((cxw < 0 || cxw >= g.nx) ? (ck < Cfg::HC0 ? x0 : x0 + TX - 1) : cxw);
+    const int c_lds0 = crow * LP0 + HX0 + clc, c_lds1 = (crow - 1) * LP1 + HX1 + clc;
+
+    auto work_plane = [&](int p) {
+        const int kg = g.z_begin + (p - g.G);
+        return kg >= 0 && kg < g.nz;
+    };
+    // level 1: a, b from V (potential.rs:104-110); what rides to level 2 is a and the product b * dt (grid.rs:580-589:
+    // w * a + b * dt * S / den, left to right)
+    auto update_keep = [&](C w, C vv, C S, C &ca, C &cbdt) -> T {
+        C cb;
+        wafer_ab_from_v<C>(vv, dt, vir, ca, cb);
+        cbdt = cb * dt;
+        return (T)(w * ca + wafer_div_invariant<C>(cbdt * S, den));
+    };
+    auto update_with = [&](C w, C ca, C cbdt, C S) -> T { return (T)(w * ca + wafer_div_invariant<C>(cbdt * S, den)); };
+    // V of a cell: streamed (vv) or its closed form at the padded global index
+    auto v_at = [&](C vv, int xw, int yw, int lzp) -> C {
+        if constexpr (VG != 0) return (C)wafer_vgen_at<VG>(vgen, xw + R, yw + R, g.zp_of(lzp));
+        else return vv;
+    };
+
+    // raw loads of one plane: the pass's input and the stored states / their images at the same cells
+    auto xform_vec = [&](VT w, const VT *l, const VT *m) -> VT {
+        VT x;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            double lv[NL], mv[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { lv[j] = l[j][v]; mv[j] = m[j][v]; }
+            x[v] = wafer_x2_xform<NL>(kf, w[v], lv, mv);
+        }
+        return x;
+    };
+
+    // ---- state
+    const int z1 = zs - 1;   // level 1 produces planes z1 .. ze, level 2 planes zs .. ze - 1
+    VT q0[3][RY], q1[3][RY], vcur[RY], caq[RY], cbq[RY];
+    VT hold_l[NL][RY], hold_m[NL][RY];      // stored states at the lane's own cells, plane z + 1 (transformed last iteration)
+    VT xq0[3], xv;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+        for (int r = 0; r < RY; ++r) q1[m][r] = zero;
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r) vcur[r] = caq[r] = cbq[r] = zero;
+    xv = zero;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const long long po = (long long)(z1 + (m - 1)) * g.plane;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            VT l[NL], mm[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                l[j] = *reinterpret_cast<const VT *>((st.l[j] + po + rowoff[r]) + xlu);
+                mm[j] = *reinterpret_cast<const VT *>((st.m[j] + po + rowoff[r]) + xlu);
+                if (m == 2) {
+                    hold_m[j][r] = mm[j];
+                    if constexpr (L3) *reinterpret_cast<VT *>(ldsl3 + (((z1 + 1) % 3) * NL + j) * QS + qoff[r]) = l[j];
+                    else hold_l[j][r] = l[j];
+                }
+            }
+            q0[m][r] = xform_vec(*reinterpret_cast<const VT *>((phi + po + rowoff[r]) + xlu), l, mm);
+        }
+        if (x_row) {
+            VT l[NL], mm[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                l[j] = *reinterpret_cast<const VT *>((st.l[j] + po + xoff_row) + xlu);
+                mm[j] = *reinterpret_cast<const VT *>((st.m[j] + po + xoff_row) + xlu);
+            }
+            xq0[m] = xform_vec(*reinterpret_cast<const VT *>((phi + po + xoff_row) + xlu), l, mm);
+        } else {
+            double l[NL], mm[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { l[j] = st.l[j][po + c_off]; mm[j] = st.m[j][po + c_off]; }
+            xq0[m] = zero;
+            xq0[m][0] = wafer_x2_xform<NL>(kf, phi[po + c_off], l, mm);
+        }
+    }
+    if constexpr (VG == 0) {
+        const long long po = (long long)z1 * g.plane;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) vcur[r] = *reinterpret_cast<const VT *>((pv + po + rowoff[r]) + xlu);
+        if (x_row) xv = *reinterpret_cast<const VT *>((pv + po + xoff_row) + xlu);
+        else xv[0] = pv[po + c_off];
+    }
+    for (int i = tid; i < 2 * Cfg::TILE0; i += Cfg::NT_) lds0[i] = T(0);
+    for (int i = tid; i < 2 * Cfg::TILE1; i += Cfg::NT_) lds1[i] = T(0);
+    __syncthreads();
+    {
+        T *t0 = lds0 + (z1 & 1) * Cfg::TILE0;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(t0 + (yrow[r] - (y0 - 2)) * LP0 + HX0 + xl) = q0[1][r];
+        if (x_row) *reinterpret_cast<VT *>(t0 + (xy - (y0 - 2)) * LP0 + HX0 + xl) = xy_out ? zero : xq0[1];
+        else if (c_ok) t0[c_lds0] = c_xout ? T(0) : xq0[1][0];
+    }
+    __syncthreads();
+
+    double acc_y = 0.0, acc_z = 0.0, acc_yl[NL], acc_zl[NL], acc_zm[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) acc_yl[j] = acc_zl[j] = acc_zm[j] = 0.0;
+
+    const int niter = (ze - zs) + 2;
+    for (int it = 0; it < niter; ++it) {
+        const int z = z1 + it;
+        const bool more = it + 1 < niter;
+        const long long zo = (long long)z * g.plane;
+        // ---- 1. prefetch, raw: input and stored states two planes ahead, V one plane ahead
+        VT pre[RY], pre_l[NL][RY], pre_m[NL][RY], pre_v[RY], xpre = zero, xpre_l[NL], xpre_m[NL], xpre_v = zero;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            pre[r] = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + rowoff[r]) + xlu);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                pre_l[j][r] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
+                pre_m[j][r] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
+            }
+            if constexpr (VG == 0) pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + g.plane + rowoff[r]) + xlu);
+            else pre_v[r] = zero;
+        }
+        if (x_row) {
+            xpre = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + xoff_row) + xlu);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                xpre_l[j] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + xoff_row) + xlu);
+                xpre_m[j] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + xoff_row) + xlu);
+            }
+            if constexpr (VG == 0) { if (x_l1) xpre_v = *reinterpret_cast<const VT *>((pv + zo + g.plane + xoff_row) + xlu); }
+        } else {
+            xpre[0] = phi[zo + 2 * g.plane + c_off];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                xpre_l[j] = zero;
+                xpre_m[j] = zero;
+                xpre_l[j][0] = st.l[j][zo + 2 * g.plane + c_off];
+                xpre_m[j][0] = st.m[j][zo + 2 * g.plane + c_off];
+            }
+            if constexpr (VG == 0) xpre_v[0] = pv[zo + g.plane + c_off];
+        }
+        // ---- 2. stage the next x0 plane into the other buffer
+        if (more) {
+            T *nt = lds0 + ((z + 1) & 1) * Cfg::TILE0;
+#pragma unroll
+            for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(nt + (yrow[r] - (y0 - 2)) * LP0 + HX0 + xl) = q0[2][r];
+            if (x_row) *reinterpret_cast<VT *>(nt + (xy - (y0 - 2)) * LP0 + HX0 + xl) = xy_out ? zero : xq0[2];
+            else if (c_ok) nt[c_lds0] = c_xout ? T(0) : xq0[2][0];
+        }
+        const T *c0 = lds0 + (z & 1) * Cfg::TILE0;
+        T *w1 = lds1 + (z & 1) * Cfg::TILE1;
+        const T *c1 = lds1 + ((z + 1) & 1) * Cfg::TILE1;
+        const bool wplane1 = work_plane(z), wplane2 = work_plane(z - 1);
+        const int zp2 = z - 1;
+        const bool act2 = zp2 >= zs && zp2 < ze;
+        VT p1new[RY], canew[RY], cbnew[RY];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) p1new[r] = canew[r] = cbnew[r] = zero;
+        VT xp1 = zero;
+
+        bool all_rows = x0 + TX <= g.nx;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];
+        // ---- 2b. x / y neighbours of the main rows at both levels, requested ahead of the arithmetic (what level L reads
+        //          this iteration was written before the last barrier; the slots written this iteration are the other ones)
+        T nbl[2][RY], nbr[2][RY];
+        VT nbu[2], nbd[2];
+        auto nbload = [&](auto level_tag) {
+            constexpr int L = decltype(level_tag)::value;
+            const T *cc = L == 0 ? c0 : c1;
+            constexpr int lp = L == 0 ? LP0 : LP1, hx = L == 0 ? HX0 : HX1;
+            const int yb = y0 - 2 + L;
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                const int o = (yrow[r] - yb) * lp + hx + xl;
+                nbl[L][r] = cc[o - 1];
+                nbr[L][r] = cc[o + VEC];
+            }
+            nbu[L] = *reinterpret_cast<const VT *>(cc + (yrow[0] - yb - 1) * lp + hx + xl);
+            nbd[L] = *reinterpret_cast<const VT *>(cc + (yrow[RY - 1] - yb + 1) * lp + hx + xl);
+        };
+        nbload(std::integral_constant<int, 0>{});
+        // ---- 3. level 1, main rows
+        auto level1 = [&](auto interior_tag) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                VT res = zero;
+                if (INTERIOR || (wplane1 && rowwk[r])) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const C w = (C)q0[1][r][v];
+                        C xs[3], ys[3], zz[3];
+                        zz[0] = (C)q0[0][r][v]; zz[1] = w; zz[2] = (C)q0[2][r][v];
+                        xs[1] = ys[1] = w;
+                        xs[0] = (v >= 1) ? (C)q0[1][r][(v + VEC - 1) % VEC] : (C)nbl[0][r];
+                        xs[2] = (v + 1 < VEC) ? (C)q0[1][r][(v + 1) % VEC] : (C)nbr[0][r];
+                        ys[0] = (r >= 1) ? (C)q0[1][r >= 1 ? r - 1 : 0][v] : (C)nbu[0][v];
+                        ys[2] = (r + 1 < RY) ? (C)q0[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[0][v];
+                        const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
+                        C ka, kb;
+                        const T rs = update_keep(w, v_at((C)vcur[r][v], xi + v, yrow[r], z), S, ka, kb);
+                        canew[r][v] = (T)ka;
+                        cbnew[r][v] = (T)kb;
+                        res[v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
+                    }
+                }
+                p1new[r] = res;
+                *reinterpret_cast<VT *>(w1 + (yrow[r] - (y0 - 1)) * LP1 + HX1 + xl) = res;
+            }
+        };
+        if (all_rows && wplane1) level1(std::true_type{});
+        else level1(std::false_type{});
+        // level 2's neighbours and the stored states of the plane it is about to produce (the lane's own LDS queue), requested
+        // behind level 1's arithmetic
+        VT lq[NL][RY], mq[NL][RY];
+        if (act2) {
+            nbload(std::integral_constant<int, 1>{});
+            const T *qs = ldsq + ((z - 1) & 1) * (NA * QS);
+#pragma unroll
+            for (int j = 0; j < NL; ++j)
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    if constexpr (L3) lq[j][r] = *reinterpret_cast<const VT *>(ldsl3 + (((z - 1) % 3) * NL + j) * QS + qoff[r]);
+                    else lq[j][r] = *reinterpret_cast<const VT *>(qs + (2 * j) * QS + qoff[r]);
+                    mq[j][r] = *reinterpret_cast<const VT *>(qs + (L3 ? j : 2 * j + 1) * QS + qoff[r]);
+                }
+        }
+        // ---- 3x. level 1, the extra slot
+        if (x_row) {
+            if (x_l1) {
+                VT res = zero;
+                if (wplane1 && xwk) {
+                    const int ly = xy - (y0 - 2);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const C w = (C)xq0[1][v];
+                        C xs[3], ys[3], zz[3];
+                        zz[0] = (C)xq0[0][v]; zz[1] = w; zz[2] = (C)xq0[2][v];
+                        xs[1] = ys[1] = w;
+                        xs[0] = (v >= 1) ? (C)xq0[1][(v + VEC - 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v - 1];
+                        xs[2] = (v + 1 < VEC) ? (C)xq0[1][(v + 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v + 1];
+                        ys[0] = (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
+                        ys[2] = (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
+                        const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
+                        C ka, kb;
+                        const T rs = update_keep(w, v_at((C)xv[v], xi + v, xy, z), S, ka, kb);
+                        res[v] = (xi + v < g.nx) ? rs : T(0);
+                    }
+                }
+                xp1 = res;
+                *reinterpret_cast<VT *>(w1 + (xy - (y0 - 1)) * LP1 + HX1 + xl) = res;
+            }
+        } else if (c_l1) {
+            T rs = T(0);
+            if (wplane1 && c_wk) {
+                const C w = (C)xq0[1][0];
+                C xs[3], ys[3], zz[3];
+                zz[0] = (C)xq0[0][0]; zz[1] = w; zz[2] = (C)xq0[2][0];
+                xs[1] = ys[1] = w;
+                xs[0] = (C)c0[c_lds0 - 1]; xs[2] = (C)c0[c_lds0 + 1];
+                ys[0] = (C)c0[c_lds0 - LP0]; ys[2] = (C)c0[c_lds0 + LP0];
+                const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
+                C ka, kb;
+                rs = update_keep(w, v_at((C)xv[0], cxw, cy, z), S, ka, kb);
+            }
+            w1[c_lds1] = rs;
+            xp1[0] = rs;
+        }
+        (void)xp1;
+        // ---- 4. level 2: Z of the plane behind from the Y1 queue, a, b as level 1 formed them one iteration ago; the sums
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            q1[0][r] = q1[1][r];
+            q1[1][r] = q1[2][r];
+            q1[2][r] = p1new[r];
+        }
+        if (act2) {
+            auto level2 = [&](auto interior_tag) {
+                constexpr bool INTERIOR = decltype(interior_tag)::value;
+                VT res2[RY];
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    res2[r] = zero;
+                    if (INTERIOR || (wplane2 && rowwk[r])) {
+                        const VT m1 = q1[1][r];
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const C w = (C)m1[v];
+                            C xs[3], ys[3], zz[3];
+                            zz[0] = (C)q1[0][r][v]; zz[1] = w; zz[2] = (C)q1[2][r][v];
+                            xs[1] = ys[1] = w;
+                            xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)nbl[1][r];
+                            xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)nbr[1][r];
+                            ys[0] = (r >= 1) ? (C)q1[1][r >= 1 ? r - 1 : 0][v] : (C)nbu[1][v];
+                            ys[2] = (r + 1 < RY) ? (C)q1[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[1][v];
+                            const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
+                            const T rs = update_with(w, (C)caq[r][v], (C)cbq[r][v], S);
+                            res2[r][v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
+                        }
+                    }
+                }
+                // the five kinds of sums of this plane: Y1 (still in its queue) and Z against themselves and against the
+                // stored states.  Cells outside the work area hold exact zeros at both levels, so nothing is masked here.
+#pragma unroll
+                for (int r = 0; r < RY; ++r)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double yv = q1[1][r][v], zv = res2[r][v];
+                        acc_y = __builtin_fma(yv, yv, acc_y);
+                        acc_z = __builtin_fma(zv, zv, acc_z);
+#pragma unroll
+                        for (int j = 0; j < NL; ++j) {
+                            acc_yl[j] = __builtin_fma(lq[j][r][v], yv, acc_yl[j]);
+                            acc_zl[j] = __builtin_fma(lq[j][r][v], zv, acc_zl[j]);
+                            acc_zm[j] = __builtin_fma(mq[j][r][v], zv, acc_zm[j]);
+                        }
+                    }
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    if (INTERIOR || rowwk[r]) {
+                        T *dst = (out + (long long)zp2 * g.plane + rowoff[r]) + xlu;
+                        if (INTERIOR || xi + VEC <= g.nx) {
+                            *reinterpret_cast<VT *>(dst) = res2[r];
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v)
+                                if (xi + v < g.nx) dst[v] = res2[r][v];
+                        }
+                    }
+                }
+            };
+            if (all_rows && wplane2) level2(std::true_type{});
+            else level2(std::false_type{});
+        }
+        // the plane transformed last iteration (z + 1) takes the queue slot just read (same lanes: program order suffices)
+        {
+            T *qd = ldsq + ((z + 1) & 1) * (NA * QS);
+#pragma unroll
+            for (int j = 0; j < NL; ++j)
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    if constexpr (!L3) *reinterpret_cast<VT *>(qd + (2 * j) * QS + qoff[r]) = hold_l[j][r];
+                    *reinterpret_cast<VT *>(qd + (L3 ? j : 2 * j + 1) * QS + qoff[r]) = hold_m[j][r];
+                }
+        }
+        __syncthreads();
+        // ---- 5. rotate the pipelines; the plane requested at the top of the iteration is transformed here -- BEHIND the
+        //         barrier: the wait for those loads then overlaps the wait for the other waves.  (With the transform down to a
+        //         handful of fused multiply-adds the compiler hoisted it above the barrier, and every wave waited for its loads
+        //         first and for the slowest wave second: 0.507 against 0.485 ms/step at k = 1.  The pins keep it here.)
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            asm volatile("" : "+v"(pre[r]));
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                asm volatile("" : "+v"(pre_l[j][r]));
+                asm volatile("" : "+v"(pre_m[j][r]));
+            }
+        }
+        asm volatile("" : "+v"(xpre));
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            asm volatile("" : "+v"(xpre_l[j]));
+            asm volatile("" : "+v"(xpre_m[j]));
+        }
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            q0[0][r] = q0[1][r];
+            q0[1][r] = q0[2][r];
+            VT l[NL], mm[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                l[j] = pre_l[j][r];
+                mm[j] = pre_m[j][r];
+                // plane z + 2: read at iteration z + 3, as plane (z + 3) - 1 -- its slot (z + 2) % 3 was last read at iteration z
+                if constexpr (L3) *reinterpret_cast<VT *>(ldsl3 + (((z + 2) % 3) * NL + j) * QS + qoff[r]) = l[j];
+                else hold_l[j][r] = l[j];
+                hold_m[j][r] = mm[j];
+            }
+            q0[2][r] = xform_vec(pre[r], l, mm);
+            vcur[r] = pre_v[r];
+            caq[r] = canew[r];
+            cbq[r] = cbnew[r];
+        }
+        xq0[0] = xq0[1];
+        xq0[1] = xq0[2];
+        if (x_row) {
+            xq0[2] = xform_vec(xpre, xpre_l, xpre_m);
+        } else {
+            double l[NL], mm[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { l[j] = xpre_l[j][0]; mm[j] = xpre_m[j][0]; }
+            xq0[2][0] = wafer_x2_xform<NL>(kf, xpre[0], l, mm);
+        }
+        xv = xpre_v;
+    }
+    // ---- the workgroup's partial sums
+    {
+        int q = 0;
+        auto put = [&](double v) {
+            const double s = wafer_block_sum<Cfg::NW>(v, red, tid);
+            if (tid == 0) partials[(size_t)q * pstride + blockIdx.x] = s;
+            ++q;
+        };
+        put(acc_y);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) put(acc_yl[j]);
+        put(acc_z);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) put(acc_zl[j]);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) put(acc_zm[j]);
+    }
+}
+
+// ---- the scalars between two passes (one thread) ------------------------------------------------------------------
+// kind 1: `sums` = what a ONE-step kernel left (sum Y^2, t_j = sum l_j Y): the buffer holds Y = A x, and the transform
+//         x = Y / n - sum_j s_j l_j is written as n_b = 1, s^b = 0, n_c = n, s^c = s (Y / 1 and - 0 * M_j are exact);
+// kind 2: `sums` = the 2 + 3k sums of a two-step pass (order: wafer_x2_nsums).
+// gram[j * WAFER_MAX_LOW + i] = <l_j, l_i> (i < j), amat[j * WAFER_MAX_LOW + i] = <l_j, M_i>, bmat[i * WAFER_MAX_LOW + j] = <M_i, M_j>.
+__global__ void wafer_k_x2_coeffs(int kind, int k, const double *__restrict__ sums, const double *__restrict__ gram,
+                                  const double *__restrict__ amat, const double *__restrict__ bmat, double *__restrict__ coef)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sb[WAFER_MAX_LOW] = {0, 0, 0, 0}, sc[WAFER_MAX_LOW] = {0, 0, 0, 0};
+    double nb = 1.0, nc = 1.0;
+    // the reference's sequential overlaps from raw ones: s_j = t_j / n - sum_{i<j} s_i G_ji  (wafer_k_gs_apply)
+    auto mgs = [&](double n, const double *t, double *s) {
+        for (int j = 0; j < k; ++j) {
+            double v = t[j] / n;
+            for (int i = 0; i < j; ++i) v -= s[i] * gram[j * WAFER_MAX_LOW + i];
+            s[j] = v;
+        }
+    };
+    if (kind == 1) {
+        nc = sqrt(sums[0]);
+        mgs(nc, sums + 1, sc);
+    } else {
+        const double *t1 = sums + 1, *zl = sums + k + 2, *zm = sums + 2 * k + 2;
+        const double zz = sums[k + 1];
+        nb = sqrt(sums[0]);
+        mgs(nb, t1, sb);
+        double sq = zz / (nb * nb), cross = 0.0, quad = 0.0;
+        for (int j = 0; j < k; ++j) cross += sb[j] * zm[j];
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) quad += sb[i] * sb[j] * bmat[i * WAFER_MAX_LOW + j];
+        sq = sq - 2.0 / nb * cross + quad;
+        double t2[WAFER_MAX_LOW];
+        for (int j = 0; j < k; ++j) {
+            double v = zl[j] / nb;
+            for (int i = 0; i < k; ++i) v -= sb[i] * amat[j * WAFER_MAX_LOW + i];
+            t2[j] = v;
+        }
+        nc = sqrt(sq);
+        mgs(nc, t2, sc);
+    }
+    coef[WAFER_X2_NB] = nb;
+    coef[WAFER_X2_NC] = nc;
+    coef[WAFER_X2_W0] = 1.0 / (nb * nc);
+    for (int j = 0; j < WAFER_MAX_LOW; ++j) {
+        coef[WAFER_X2_SB + j] = sb[j];
+        coef[WAFER_X2_SC + j] = sc[j];
+        coef[WAFER_X2_SBN + j] = sb[j] / nc;
+    }
+}
+
+// ---- phi materialised after the last pass: the load transform as an elementwise pass, in place ------------------------
+template <int NL>
+__global__ __launch_bounds__(256) void wafer_k_x2_apply(WaferRowArgs a, double *__restrict__ phi, WaferX2Ptrs st,
+                                                        const double *__restrict__ coef)
+{
+    using VT = typename WaferRowVec<double>::type;
+    constexpr int VEC = 2;
+    const WaferGeom &g = a.g;
+    WaferX2Coef<NL> kf;
+    kf.w0 = coef[WAFER_X2_W0];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        kf.sb[j] = coef[WAFER_X2_SBN + j];
+        kf.sc[j] = coef[WAFER_X2_SC + j];
+    }
+#ifdef WAFER_X2_DIV_XFORM
+    kf.nb = coef[WAFER_X2_NB];
+    kf.nc = coef[WAFER_X2_NC];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) kf.sbr[j] = coef[WAFER_X2_SB + j];
+#endif
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nsegx = (g.nx + 64 * VEC - 1) / (64 * VEC);
+    const int wlim = g.pitch - g.xoff - g.R;
+    WAFER_ROW_WALK_BEGIN(a, g)
+    for (int xs = 0; xs < nsegx; ++xs) {
+        const int xi = xs * 64 * VEC + lane * VEC;
+        if (xi >= wlim || xi >= g.nx) continue;
+        const long long p = rowp + xi;
+        const VT w = *reinterpret_cast<const VT *>(phi + p);
+        VT l[NL], m[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            l[j] = __builtin_nontemporal_load(reinterpret_cast<const VT *>(st.l[j] + p));
+            m[j] = __builtin_nontemporal_load(reinterpret_cast<const VT *>(st.m[j] + p));
+        }
+        VT r;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            double lv[NL], mv[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { lv[j] = l[j][v]; mv[j] = m[j][v]; }
+            r[v] = wafer_x2_xform<NL>(kf, w[v], lv, mv);
+        }
+        if (xi + VEC <= g.nx) {
+            *reinterpret_cast<VT *>(phi + p) = r;
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (xi + v < g.nx) phi[p + v] = r[v];
+        }
+    }
+    WAFER_ROW_WALK_END(g)
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------
+// rows per lane for k stored states: what the LDS queue allows (see the head of this file), and for k = 1 what the registers
+// allow: with V streamed (vg == 0: file / script potentials, the nine other built-ins) the 128 x 16 tile spills 80 B per lane,
+// so it runs on 128 x 8 tiles like k = 2, 3.  WAFER_X2_RY overrides (tests).
+static inline int wafer_x2_ry(const WaferTuning &t, int k, int vg)
+{
+    if (k > 1) return 1;
+    if (t.x2_ry == 1 || t.x2_ry == 2) return t.x2_ry;
+    return vg != 0 ? 2 : 1;
+}
+static inline void wafer_x2_tile(const WaferTuning &t, int k, int vg, int *tx, int *ty)
+{
+    *tx = 128;
+    *ty = 8 * wafer_x2_ry(t, k, vg);
+}
+static inline int wafer_x2_zchunk(const WaferTuning &t, const WaferGeom &g, int k, int vg, int nplanes, int target_blocks)
+{
+    int tx, ty;
+    wafer_x2_tile(t, k, vg, &tx, &ty);
+    if (t.zchunk > 0) return t.zchunk;
+    const long long per_layer = (long long)((g.nx + tx - 1) / tx) * ((g.ny + ty - 1) / ty);
+    const long long target = t.target_blocks > 0 ? t.target_blocks : (target_blocks > 0 ? target_blocks : 256);
+    return wafer_pick_zchunk(per_layer, nplanes, target, 5);   // two iterations of pipeline fill + the prologue's three planes
+}
+static inline long long wafer_x2_blocks(const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks)
+{
+    int tx, ty;
+    wafer_x2_tile(t, k, vg, &tx, &ty);
+    const int zc = wafer_x2_zchunk(t, g, k, vg, lz_hi - lz_lo, target_blocks);
+    return (long long)((g.nx + tx - 1) / tx) * ((g.ny + ty - 1) / ty) * ((lz_hi - lz_lo + zc - 1) / zc);
+}
+
+template <int RY, int NL, int VG>
+static inline hipError_t wafer_launch_xstep2_one(const WaferTuning &t, WaferStepArgs a, const double *phi, const double *pv, double *out,
+                                                 double *partials, size_t partials_cap, const WaferX2Ptrs &st, const double *coef,
+                                                 hipStream_t s)
+{
+    using Cfg = WaferX2Cfg<RY>;
+    const WaferGeom &g = a.g;
+    a.zchunk = wafer_x2_zchunk(t, g, NL, VG, a.lz_hi - a.lz_lo, a.target_blocks);
+    const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX, nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
+    const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
+    const long long nblocks = (long long)ntx * nty * ntz;
+    if ((size_t)nblocks > partials_cap) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((wafer_k_xstep2<RY, NL, VG, true>), dim3((unsigned)nblocks), dim3(Cfg::NT_), 0, s, a, ntx, nty, t.swz, phi, pv, out,
+                       partials, (long long)partials_cap, st, coef);
+    return hipGetLastError();
+}
+
+// out = A A x with x = the load transform of `phi` (coef); the 2 + 3k sums of the pass go to partials[q * partials_cap + wg].
+// Needs a.v_in_range (the short reciprocal); vg: the closed form V was generated from, or 0 (streamed).
+static inline hipError_t wafer_launch_xstep2(const WaferTuning &t, const WaferStepArgs &a, int k, int vg, const double *phi, const double *pv,
+                                             double *out, double *partials, size_t partials_cap, const WaferX2Ptrs &st, const double *coef,
+                                             hipStream_t s)
+{
+    const int ry = wafer_x2_ry(t, k, vg);
+#define WAFER_X2_CASE(RY_, NL_, VG_)                                                                                               \
+    if (ry == RY_ && k == NL_ && vg == VG_)                                                                                        \
+        return wafer_launch_xstep2_one<RY_, NL_, VG_>(t, a, phi, pv, out, partials, partials_cap, st, coef, s);
+#define WAFER_X2_CASES(RY_, NL_) WAFER_X2_CASE(RY_, NL_, 0) WAFER_X2_CASE(RY_, NL_, 4) WAFER_X2_CASE(RY_, NL_, 7) WAFER_X2_CASE(RY_, NL_, 9)
+    WAFER_X2_CASES(2, 1)
+    WAFER_X2_CASES(1, 1)
+    WAFER_X2_CASES(1, 2)
+    WAFER_X2_CASES(1, 3)
+#undef WAFER_X2_CASES
+#undef WAFER_X2_CASE
+    return hipErrorInvalidValue;
+}
+
+static inline hipError_t wafer_launch_x2_apply(const WaferRowArgs &ra, int k, double *phi, const WaferX2Ptrs &st, const double *coef,
+                                               int num_cus, hipStream_t s)
+{
+    const dim3 grid((unsigned)(num_cus * 8)), block(256);
+    switch (k) {
+    case 1: hipLaunchKernelGGL((wafer_k_x2_apply<1>), grid, block, 0, s, ra, phi, st, coef); break;
+    case 2: hipLaunchKernelGGL((wafer_k_x2_apply<2>), grid, block, 0, s, ra, phi, st, coef); break;
+    case 3: hipLaunchKernelGGL((wafer_k_x2_apply<3>), grid, block, 0, s, ra, phi, st, coef); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,46 @@
+// translation unit: two excited-state steps per pass (ThreePoint fp64; wafer_stencil_x2.hip.h)
+#include "wafer_launch.h"
+#include "wafer_stencil_x2.hip.h"
+
+static WaferX2Ptrs x2_ptrs(int k, const void *const *l, const void *const *m)
+{
+    WaferX2Ptrs st;
+    for (int j = 0; j < k && j < WAFER_X2_MAX_LOW; ++j) {
+        st.l[j] = static_cast<const double *>(l[j]);
+        st.m[j] = static_cast<const double *>(m[j]);
+    }
+    return st;
+}
+
+hipError_t wafer_entry_xstep2(const WaferTuning &t, const WaferStepArgs &a, int k, int vg, const void *phi, const void *pv, void *out,
+                              double *partials, size_t partials_cap, const void *const *l, const void *const *m, const double *coef,
+                              hipStream_t s)
+{
+    if (k < 1 || k > WAFER_X2_MAX_LOW || a.v_in_range == 0) return hipErrorInvalidValue;
+    return wafer_launch_xstep2(t, a, k, vg, static_cast<const double *>(phi), static_cast<const double *>(pv), static_cast<double *>(out),
+                               partials, partials_cap, x2_ptrs(k, l, m), coef, s);
+}
+
+hipError_t wafer_entry_x2_coeffs(int kind, int k, const double *sums, const double *gram, const double *amat, const double *bmat,
+                                 double *coef, hipStream_t s)
+{
+    hipLaunchKernelGGL(wafer_k_x2_coeffs, dim3(1), dim3(64), 0, s, kind, k, sums, gram, amat, bmat, coef);
+    return hipGetLastError();
+}
+
+hipError_t wafer_entry_x2_apply(const WaferGeom &g, int lz_lo, int lz_hi, int k, void *phi, const void *const *l, const void *const *m,
+                                const double *coef, int num_cus, hipStream_t s)
+{
+    WaferRowArgs ra;
+    ra.g = g;
+    ra.lz_lo = lz_lo;
+    ra.lz_hi = lz_hi;
+    return wafer_launch_x2_apply(ra, k, static_cast<double *>(phi), x2_ptrs(k, l, m), coef, num_cus, s);
+}
+
+long long wafer_entry_x2_blocks(const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks)
+{
+    return wafer_x2_blocks(t, g, k, vg, lz_lo, lz_hi, target_blocks);
+}
+
+int wafer_entry_x2_nsums(int k) { return wafer_x2_nsums(k); }

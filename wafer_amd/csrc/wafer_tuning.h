@@ -24,6 +24,10 @@ struct WaferTuning {
     int xf_deep = 1;        // WAFER_XF_DEEP: the raw staging pipeline
     int one_pass = 1;       // WAFER_ONE_PASS: transform-on-load (0: the two-pass scheme)
     int vgen = 1;           // WAFER_VGEN: evaluate Coulomb / SimpleCornell / Harmonic per cell instead of streaming V
+    int x2 = 1;             // WAFER_X2: two excited-state steps per pass (ThreePoint fp64, 1..3 stored states); 0: one step per pass
+    int x2_max_k = 2;       // WAFER_X2_MAX_K: most stored states the two-step kernel is used for (3 measures equal to one step per pass
+                            // at 512^3 -- 0.99 against 1.00 ms/step on 128 x 8 tiles -- and keeps the one-step kernel)
+    int x2_ry = 0;          // WAFER_X2_RY: rows per lane of that kernel (1: 128 x 8 tiles, 2: 128 x 16, k = 1 only; 0: default)
     // observables
     int obs_lds = 1;        // WAFER_OBS_LDS: 0 = the plain scalar-load kernel
     int obs_wgs = 2;        // WAFER_OBS_WGS: workgroups per CU
@@ -70,6 +74,9 @@ static inline WaferTuning wafer_tuning_from_env()
     t.xf_deep = wafer_env_int("WAFER_XF_DEEP", t.xf_deep);
     t.one_pass = wafer_env_int("WAFER_ONE_PASS", t.one_pass);
     t.vgen = wafer_env_int("WAFER_VGEN", t.vgen);
+    t.x2 = wafer_env_int("WAFER_X2", t.x2);
+    t.x2_ry = wafer_env_int("WAFER_X2_RY", t.x2_ry);
+    t.x2_max_k = wafer_env_int("WAFER_X2_MAX_K", t.x2_max_k);
     t.obs_lds = wafer_env_int("WAFER_OBS_LDS", t.obs_lds);
     t.obs_wgs = wafer_env_int("WAFER_OBS_WGS", t.obs_wgs);
     t.f2_nw2 = wafer_env_int("WAFER_F2_NW2", t.f2_nw2);

@@ -41,7 +41,7 @@ EXPORTS = [
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
     "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check",
-    "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_set_halo_cycle",
+    "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_set_halo_cycle", "wafer_diag_x2_passes",
 ]
 
 
@@ -136,6 +136,7 @@ def load_library():
     L.wafer_diag_div_check.argtypes = [vp, C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.wafer_diag_copy_bw.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     L.wafer_diag_checksum.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.wafer_diag_x2_passes.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.wafer_set_initial_condition.argtypes = [vp, C.c_int, C.c_uint64]
     L.wafer_upload_phi.argtypes = [vp, dp]
     L.wafer_download_phi.argtypes = [vp, dp]
@@ -426,6 +427,12 @@ class Context:
         v = C.c_double(0.0)
         self._check(self._L.wafer_diag_copy_bw(self._h, iters, unroll, blocks_per_cu, C.byref(v)))
         return v.value
+
+    def x2_passes(self) -> int:
+        """passes of the two-excited-steps-per-pass kernel launched so far (include/wafer_hip.h)"""
+        v = C.c_uint64(0)
+        self._check(self._L.wafer_diag_x2_passes(self._h, C.byref(v)))
+        return int(v.value)
 
     def checksum(self, z_begin: int = 0, z_count: int | None = None) -> int:
         """position-dependent integer checksum of the owned work cells of global planes
