@@ -417,6 +417,43 @@ def test_excited_state_steps_on_slabs(wa, world, shape, ext, wnum, overlap):
         assert n2 == pytest.approx(want_n2, rel=1e-12)
 
 
+@pytest.mark.parametrize("world,shape,wnum,depth", [(2, (40, 24, 32), 1, 2), (3, (140, 17, 30), 2, 2), (4, (130, 20, 40), 3, 3),
+                                                    (2, (24, 40, 9), 1, 2)])
+def test_two_excited_steps_per_pass_on_slabs(wa, world, shape, wnum, depth, monkeypatch):
+    """the two-steps-per-pass excited-state kernels (wafer_stencil_x2.hip.h) on z-slabs with two (or three) ghost planes:
+    the raw result's two boundary planes per side travel after every pass, the stored states and their images A l_j carry
+    two current ghost planes, the 2 + 3k sums are all-reduced -- against one context, 1e-12 per cell (sums associate per
+    slab); thin and uneven slabs included"""
+    import sys
+    sys.setswitchinterval(1e-4)
+    monkeypatch.setenv("WAFER_X2_MAX_K", "3")
+    base = wa.Params(*shape, dn=0.25, dt=0.006, mass=1.0, central_difference=1, max_states=wnum, halo_depth=depth)
+    single = wa.Params(*shape, dn=0.25, dt=0.006, mass=1.0, central_difference=1, max_states=wnum)
+
+    def body(ctx, rank=0):
+        ctx.set_potential("Coulomb")
+        for j in range(wnum):      # orthonormalised random stored states, identical on every slab
+            ctx.set_initial_condition("Gaussian", seed=40 + j)
+            ctx.normalise(ctx.norm2())
+            ctx.orthogonalise(j)
+            ctx.normalise(ctx.norm2())
+            ctx.push_state()
+        ctx.set_initial_condition("Gaussian", seed=7)
+        ctx.evolve(wnum, 8)
+        ctx.evolve(wnum, 5)
+        assert ctx.x2_passes() == 3 + 1
+        return ctx.download_phi(), ctx.norm2()
+
+    with wa.Context(single) as ctx:
+        want, want_n2 = body(ctx)
+    res, fabric = run_slabs(wa, base, world, body)
+    got = assemble(base, world, [r[0] for r in res])
+    err = float(np.max(np.abs(got - want))) / max(1.0, float(np.max(np.abs(want))))
+    assert err <= 1e-12, f"max error {err:.3e}, halo calls {fabric.halo_calls}"
+    for _, n2 in res:
+        assert n2 == pytest.approx(want_n2, rel=1e-12)
+
+
 def test_slab_without_hooks_fails_loudly(wa):
     par = wa.Params(16, 16, 16, dn=0.2, dt=0.004, z_begin=0, z_count=8)
     with wa.Context(par) as ctx:

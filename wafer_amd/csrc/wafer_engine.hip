@@ -162,6 +162,7 @@ struct wafer_ctx {
     double potsub_scalar = 0.0;
     bool have_pot = false, have_phi = false;
     bool v_in_range = false; // 2^-400 < |1 + dt*V/2| < 2^400 everywhere (wafer_recip's short form is exact)
+    int v_in_range_all = -1; // z-slabs: ... on EVERY rank (-1: not agreed yet; x2_agree)
     int vgen_type = 0;       // V was generated from this closed form (Coulomb / SimpleCornell / Harmonic), else 0: kernels may re-evaluate it instead of streaming it
 
     double *partials = nullptr; // [1 + WAFER_MAX_LOW][partials_stride]
@@ -298,6 +299,7 @@ static int check_v_range(wafer_ctx *c)
     memcpy(&lo, &got[0], 8);
     memcpy(&hi, &got[1], 8);
     c->v_in_range = (lo > 0x1p-400) && (hi < 0x1p400); // a NaN anywhere makes hi a NaN: false
+    c->v_in_range_all = -1;
     return WAFER_OK;
 }
 
@@ -327,14 +329,15 @@ static int read_scal(wafer_ctx *c, int slot, int n, double *out, hipStream_t s)
 // ---------------------------------------------------------------------------
 // halo exchange through the host-installed hook
 // ---------------------------------------------------------------------------
-static int exchange_halo(wafer_ctx *c, int buf, hipStream_t s, int planes)
+// the first / last `planes` owned planes of any grid array (logical pointer) to the z-neighbours' ghost planes
+static int exchange_halo_array(wafer_ctx *c, void *array, hipStream_t s, int planes)
 {
     if (!c->sharded()) return WAFER_OK;
     if (!c->halo_hook) return fail(WAFER_ERR_COMM, "context owns a z-slab but no halo hook is installed");
     RoctxRange range_("wafer_halo_exchange");
     const WaferGeom &g = c->g;
     if (planes > g.G || planes > g.nzl) return fail(WAFER_ERR_INVALID, "halo exchange deeper than the slab allows");
-    char *base = static_cast<char *>(c->phi[buf]);
+    char *base = static_cast<char *>(array);
     const size_t plane_b = (size_t)g.plane * c->esz;
     // from row 0 of the first plane to the last padded row of the last plane (guard rows in between ride along)
     const size_t bytes = ((size_t)(planes - 1) * (size_t)g.plane + (size_t)g.py * (size_t)g.pitch) * c->esz;
@@ -346,6 +349,8 @@ static int exchange_halo(wafer_ctx *c, int buf, hipStream_t s, int planes)
         return fail(WAFER_ERR_COMM, "halo hook failed");
     return WAFER_OK;
 }
+
+static int exchange_halo(wafer_ctx *c, int buf, hipStream_t s, int planes) { return exchange_halo_array(c, c->phi[buf], s, planes); }
 
 // One direction of the exchange (wafer_set_overlap mode 4).  side 0: the LOWEST owned planes go to the lower
 // neighbour, the upper neighbour's lowest planes arrive in the UPPER ghost planes; side 1: the mirror image.  Every
@@ -782,12 +787,33 @@ static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32
 
 // ---- two excited-state steps per pass (wafer_stencil_x2.hip.h) ------------------------------------------------------
 enum { X2_SUM_SLOT = 18 };   // scal[18 .. 18 + 2 + 3k): the sums of a two-step pass
-// ThreePoint fp64, one to three stored states, the potential inside the short reciprocal's range; undecomposed grids
+// ThreePoint fp64, one to three stored states, the potential inside the short reciprocal's range; z-slabs need two ghost
+// planes (a pass consumes two per side).  Every rank of a decomposed run takes the same decision: nothing here depends on
+// the local slab except v_in_range, on which the ranks agree in x2_agree.
 static bool x2_applies(const wafer_ctx *c, uint32_t wnum)
 {
     return c->tune.x2 != 0 && c->tune.one_pass != 0 && !c->f32 && c->g.R == 1 && wnum >= 1 && wnum <= 3 && (int)wnum <= c->tune.x2_max_k &&
-           active_variant(c) >= 1 &&
-           c->v_in_range && !c->sharded();
+           active_variant(c) >= 1 && c->v_in_range && (!c->sharded() || c->g.G >= 2);
+}
+
+// z-slabs: the two-step pass changes what the ranks exchange (two planes per pass, 2 + 3k sums), so every rank must take it
+// or none.  x2_applies depends on nothing local except v_in_range, which is a property of the local slab's V: the ranks
+// agree on it once per potential (a collective: every rank reaches its first excited-state wafer_evolve together).
+static int x2_agree(wafer_ctx *c, uint32_t wnum, bool *out)
+{
+    *out = false;
+    if (!c->sharded()) { *out = x2_applies(c, wnum); return WAFER_OK; }
+    if (!c->allreduce_hook) return WAFER_OK;
+    if (c->v_in_range_all < 0) {
+        c->scal_host[13] = c->v_in_range ? 0.0 : 1.0;
+        HIP_TRY(hipMemcpyAsync(c->scal + 13, c->scal_host + 13, sizeof(double), hipMemcpyHostToDevice, c->s_main));
+        if (c->allreduce_hook(c->hook_user, c->scal + 13, 1, (void *)c->s_main) != 0) return fail(WAFER_ERR_COMM, "allreduce hook failed");
+        double bad = 1.0;
+        TRY(read_scal(c, 13, 1, &bad, c->s_main));
+        c->v_in_range_all = bad == 0.0 ? 1 : 0;
+    }
+    *out = c->v_in_range_all == 1 && x2_applies(c, wnum);
+    return WAFER_OK;
 }
 
 // M_j = A l_j for the first wnum stored states (one ground-state step of each, grid.rs:568-592) and the matrices of the
@@ -803,9 +829,13 @@ static int ensure_x2(wafer_ctx *c, uint32_t wnum)
     }
     if (kernels_stream_ab(c, 1)) TRY(ensure_ab(c));
     for (uint32_t j = 0; j < wnum; ++j) {
+        // z-slabs: the pass transforms two ghost planes per side, so l_j and M_j must be current there (a stored state
+        // carries one ghost plane from wafer_push_state; the second, and M_j's two, come from the neighbours now)
+        TRY(exchange_halo_array(c, c->states[j], c->s_main, 2));
         const WaferStepArgs a = step_args(c, g.G, g.G + g.nzl);
         if (wafer_entry_step_lds(WAFER_TC_F64, g.R, c->tune, a, c->states[j], c->a, c->b, c->v, c->mstates[j], c->s_main, closed_form_vg(c)) != hipSuccess)
             return fail(WAFER_ERR_HIP, "stencil launch (image of a stored state) failed: %s", hipGetErrorString(hipGetLastError()));
+        TRY(exchange_halo_array(c, c->mstates[j], c->s_main, 2));
     }
     double host[2 * WAFER_MAX_LOW * WAFER_MAX_LOW];
     memset(host, 0, sizeof host);
@@ -841,12 +871,14 @@ static int x2_run(wafer_ctx *c, uint32_t wnum, uint64_t pairs, hipStream_t s)
     const WaferStepArgs a = step_args(c, g.G, g.G + g.nzl);
     const long long nb = wafer_entry_x2_blocks(c->tune, g, k, closed_form_vg(c), g.G, g.G + g.nzl, c->num_cus);
     if (nb > (long long)c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
+    TRY(ensure_halo(c, 2));   // z-slabs: two ghost planes of the raw input per side and pass
     for (uint64_t p = 0; p < pairs; ++p) {
         const int src = c->cur, dst = c->cur ^ 1;
         if (wafer_entry_xstep2(c->tune, a, k, closed_form_vg(c), c->phi[src], c->v, c->phi[dst], c->partials, c->partials_stride, l, m,
                                c->x2coef, s) != hipSuccess)
             return fail(WAFER_ERR_HIP, "two-step excited-state stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
         ++c->x2_passes;
+        if (p + 1 < pairs) TRY(exchange_halo(c, dst, s, 2));   // (unsplit: a short exchange takes CUs from a launch that packs them, as for one step per pass)
         TRY(reduce_to_scal(c, nq, nb, X2_SUM_SLOT, s));
         if (wafer_entry_x2_coeffs(2, k, c->scal + X2_SUM_SLOT, c->gram, amat, bmat, c->x2coef, s) != hipSuccess)
             return fail(WAFER_ERR_HIP, "coefficient kernel launch failed");
@@ -1536,7 +1568,8 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     // Excited states, two steps per pass: the first two steps (three for an odd count) run one per pass -- whatever the
     // caller hands over (a clone of a stored state, an un-normalised start) is normalised and projected by the reference's own
     // sequence before the regrouped sums take over -- then pairs; phi is materialised after the last pass.
-    const bool x2 = wnum > 0 && steps >= 4 && x2_applies(c, wnum);
+    bool x2 = false;
+    if (wnum > 0 && steps >= 4) TRY(x2_agree(c, wnum, &x2));
     const uint64_t x2_head = x2 ? 2 + (steps & 1) : steps;
     if (x2) TRY(ensure_x2(c, wnum));
     HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
