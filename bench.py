@@ -686,6 +686,23 @@ def run_rank(args) -> int:
                     del got, want
                     if not (worst <= 1e-13):
                         rc = RC_PARITY
+                    # ... and the two-steps-per-pass kernel (wafer_stencil_x2.hip.h: the default for one and two stored states)
+                    # over six k = 1 steps -- two one-step passes, then two passes of two steps -- at the same bar
+                    ex.upload_phi(phi0)
+                    p_before = ex.x2_passes()
+                    ex.evolve(1, 6)
+                    got = ex.download_phi()
+                    want = phi0.copy()
+                    a_, b_ = wo.ab(cfg, wo.potential_generate(cfg))
+                    wo.evolve(cfg, 1, a_, b_, want, lowers[:1], 6)
+                    del a_, b_
+                    worst2 = float(np.max(np.abs(got - want)))
+                    result["excited_parity_two_steps_per_pass"] = {"against": "oracle/wafer_oracle.c wo_evolve (grid.rs:544-687 with wnum = 1)", "k": 1,
+                                                                   "steps": 6, "two_step_passes": ex.x2_passes() - p_before, "max_abs": worst2,
+                                                                   "tolerance": 1e-13}
+                    del got, want
+                    if not (worst2 <= 1e-13):
+                        rc = RC_PARITY
                 ex.upload_phi(phi0)
                 del phi0, lowers
                 ex.evolve(3, 150)   # the device idled while the oracle ran on the host: bring the clocks back up before timing (as --preheat does for the headline)
@@ -698,13 +715,16 @@ def run_rank(args) -> int:
                         ms_k = sorted(([] if ms_k is None else ms_k) + [m_])
                         st_k = s_
                     ms_k = ms_k[1]
+                    p0_ = ex.x2_passes()
+                    ex.evolve(k, 4)
+                    spp_k = 2 if ex.x2_passes() > p0_ else 1
                     bpu_k = 80 + 32 * (k - 1)   # stencil + norm 32, normalise + dot 24, (k - 1) x (axpy + dot) 32, last axpy 24
-                    rec[f"k{k}"] = {"ms_per_step": ms_k / st_k, "algorithmic_bytes_per_update": bpu_k,
+                    rec[f"k{k}"] = {"ms_per_step": ms_k / st_k, "algorithmic_bytes_per_update": bpu_k, "steps_per_pass": spp_k,
                                     "frac_of_hbm_peak": pts_total * bpu_k / (ms_k / st_k * 1e-3) / 1e9 / HBM_PEAK_GBPS}
                 ex.close()
                 result["excited_state_step"] = {"grid": list(shape), "potential": potential, **rec,
                                                 "stored_states": "box modes (1,1,1), (2,1,1), (1,1,2)",
-                                                "note": "wafer_evolve(wnum = k) on the same grid, HIP events, median of three 40-step evolves after a 150-step warm-up; checked by excited_parity"}
+                                                "note": "wafer_evolve(wnum = k) on the same grid, HIP events, median of three 40-step evolves after a 150-step warm-up (steps_per_pass 2: two one-step passes, 19 two-step passes and the pass that materialises phi); checked by excited_parity and excited_parity_two_steps_per_pass"}
             except Exception as e:  # reported, never silently dropped
                 result["excited_state_step"] = {"error": repr(e)}
 

@@ -36,6 +36,29 @@ __device__ __forceinline__ double wafer_block_sum(double v, double *red, int tid
     return s;
 }
 
+// ---- a value of the neighbouring lane by DPP (gfx9 wave shifts), for x neighbours that the lane next door holds in registers.
+// wafer_lane_below(own, edge): lane i gets lane i-1's `own`, lane 0 keeps `edge`; wafer_lane_above: lane i gets lane i+1's,
+// lane 63 keeps `edge`.  Two v_mov_b32 with a DPP control per double (the shifts exist for 32-bit operands only).
+template <int CTRL>
+__device__ __forceinline__ double wafer_lane_shift(double own, double edge)
+{
+    int lo = __double2loint(own), hi = __double2hiint(own);
+    const int elo = __double2loint(edge), ehi = __double2hiint(edge);
+    lo = __builtin_amdgcn_update_dpp(elo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(ehi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wafer_lane_below(double own, double edge) { return wafer_lane_shift<0x138>(own, edge); } // wave_shr:1
+__device__ __forceinline__ double wafer_lane_above(double own, double edge) { return wafer_lane_shift<0x130>(own, edge); } // wave_shl:1
+__device__ __forceinline__ float wafer_lane_below(float own, float edge)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(own), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wafer_lane_above(float own, float edge)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(own), 0x130, 0xf, 0xf, false));
+}
+
 // ---- the bracketed central-difference sum S --------------------------------
 // xs/ys/zs hold the 2R+1 values along each axis, index R is the centre w.
 template <typename T, int R>

@@ -330,8 +330,18 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
                 const int o = (yrow[r] - yb) * lp + hx + xl;
+#ifdef WAFER_F3_DPP
+                // the x neighbours of the lane's first / last cell are the last / first cell of the lane next door, which holds
+                // them in registers: a DPP wave shift instead of an LDS read; only lanes 0 and 63 take the halo column from
+                // LDS (one read per row: each of the two reads its own side)
+                const VT ctr = L == 0 ? q0[1][r] : L == 1 ? q1[2][r] : q2[2][r];   // (levels 2, 3: the queues rotate after this)
+                const T edge = cc[o + (lane == 63 ? VEC : -1)];
+                nbl[L][r] = wafer_lane_below(ctr[VEC - 1], edge);
+                nbr[L][r] = wafer_lane_above(ctr[0], edge);
+#else
                 nbl[L][r] = cc[o - 1];
                 nbr[L][r] = cc[o + VEC];
+#endif
             }
             nbu[L] = *reinterpret_cast<const VT *>(cc + (yrow[0] - yb - 1) * lp + hx + xl);
             nbd[L] = *reinterpret_cast<const VT *>(cc + (yrow[RY - 1] - yb + 1) * lp + hx + xl);
