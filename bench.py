@@ -339,6 +339,15 @@ def run_rank(args) -> int:
                   "set WAFER_TRANSPORT=torch to measure the torch.distributed hooks on purpose", file=sys.stderr)
             return 4
         comm.warm_up()   # RCCL channel set-up is not part of any step
+        # peer stores (wafer_set_overlap mode 3): every rank maps its z-neighbours' buffers through HIP IPC; all ranks or none
+        peers_ok = False
+        # (not with the host-staged test transport: ranks folded onto ONE GPU would poll for each other's stores from workgroups
+        #  that hold the CUs the other rank's kernel needs)
+        if ext == 1 and args.dtype in ("f64", "f32fast") and not host_transport and os.environ.get("WAFER_BENCH_PEERS", "1") != "0":
+            try:
+                peers_ok = slab.connect_peers(ctx, rank, world) and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 6
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py: rank {rank}: peer connection failed: {e!r}", file=sys.stderr, flush=True)
     ctx.set_potential(potential)
     ctx.set_initial_condition("Boolean")   # deterministic, "good for benchmarks" (config.rs:168)
     ctx.synchronize()
@@ -380,7 +389,8 @@ def run_rank(args) -> int:
         device_info = {"error": repr(e)}
     ctx.set_initial_condition("Boolean")   # the copy used phi's second buffer as scratch
 
-    # N > 1: how the halo exchange is scheduled (wafer_set_overlap).  Mode 1: boundary planes and their exchange on a
+    # N > 1: how the halo exchange is scheduled (wafer_set_overlap).  Mode 3: mode 2's single launch with the boundary workgroups
+    # storing straight into the neighbours' ghost planes (HIP IPC / xGMI peer stores: no exchange kernels at all).  Mode 1: boundary planes and their exchange on a
     # second stream beside the interior update (three launches per pass); mode 2: ONE launch per three-step pass, the slab
     # as two halves marched outwards, each half's exchange released by its completion counter; mode 0: the exchange
     # follows the whole slab's update.  Which is fastest depends on the fabric, which this code has never seen: all are
@@ -391,7 +401,7 @@ def run_rank(args) -> int:
     DEFAULT_MODE = (2, 1)
     if dist is not None and os.environ.get("WAFER_OVERLAP", "") == "" and args.steps >= 8:
         trial = {}
-        for mode, cycle in [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []):
+        for mode, cycle in ([(3, 1)] if peers_ok else []) + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []):
             ctx.set_overlap(mode)
             ctx.set_halo_cycle(cycle)
             # a schedule whose bounded waits give up on this fabric (WAFER_ERR_COMM: a neighbour's planes never arrived)
@@ -424,7 +434,7 @@ def run_rank(args) -> int:
         best = min(trial, key=lambda k: trial[k] * (1.0 if k == DEFAULT_MODE else 1.02))
         ctx.set_overlap(best[0])
         ctx.set_halo_cycle(best[1])
-        names = {2: "2_single_launch_two_halves", 1: "1_boundary_first_three_launches", 0: "0_no_overlap"}
+        names = {3: "3_single_launch_peer_stores", 2: "2_single_launch_two_halves", 1: "1_boundary_first_three_launches", 0: "0_no_overlap"}
         overlap_choice = {"mode": best[0], "fused_passes_per_exchange": best[1],
                           "ms_per_step": {names[m] + ("" if cy == 1 else f"_exchange_every_{cy}_passes"): v for (m, cy), v in trial.items()}}
         ctx.set_initial_condition("Boolean")

@@ -59,6 +59,22 @@ pub struct wafer_observables_output {
     pub l_r: f64,
 }
 
+/// wafer_peer_info (peer stores, wafer_set_overlap mode 3): what a rank publishes to its z-neighbours
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct wafer_peer_info {
+    pub struct_size: u32,
+    pub z_begin: u32,
+    pub z_count: u32,
+    pub halo_depth: u32,
+    pub pid: u64,
+    pub phi_addr: [u64; 2],
+    pub flags_addr: u64,
+    pub phi_alloc_offset: [u64; 2],
+    pub phi_ipc: [[u8; 64]; 2],
+    pub flags_ipc: [u8; 64],
+}
+
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct wafer_slab_info {
@@ -136,6 +152,9 @@ extern "C" {
     pub fn wafer_diag_copy_bw(ctx: *mut wafer_ctx, iters: c_int, unroll: c_int, blocks_per_cu: c_int, gbps: *mut f64) -> c_int;
     pub fn wafer_diag_checksum(ctx: *mut wafer_ctx, z_begin: u32, z_count: u32, out: *mut u64) -> c_int;
     pub fn wafer_diag_x2_passes(ctx: *mut wafer_ctx, out: *mut u64) -> c_int;
+    pub fn wafer_peer_export(ctx: *mut wafer_ctx, out: *mut wafer_peer_info) -> c_int;
+    pub fn wafer_peer_connect(ctx: *mut wafer_ctx, lower: *const wafer_peer_info, upper: *const wafer_peer_info) -> c_int;
+    pub fn wafer_peer_disconnect(ctx: *mut wafer_ctx) -> c_int;
     pub fn wafer_diag_div_check(ctx: *mut wafer_ctx, den: f64, seed: u64, n_operands: u64, lo_exp: c_int, hi_exp: c_int, mismatches: *mut u64) -> c_int;
 }
 

@@ -293,6 +293,32 @@ int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn 
  * Setting a mode also resets the pass bookkeeping (which half goes first, which ghost planes are current): after a
  * WAFER_ERR_COMM on any rank, call it on every rank before evolving again. */
 int wafer_set_overlap(wafer_ctx *ctx, int mode);
+/*  3 = mode 2's single launch with PEER STORES instead of an exchange: the boundary workgroups of a pass store their last
+ *      planes into the z-neighbours' ghost planes themselves (the neighbour's buffers mapped here: directly within one process,
+ *      through HIP IPC between processes of one node, over xGMI between GPUs) and count themselves into the neighbour's arrival
+ *      counter; the neighbour's boundary workgroups poll that counter just before their first ghost-plane load.  No exchange
+ *      kernels (RCCL's need whole CUs), no gate kernels, no second stream, no short columns.  Needs wafer_peer_connect on every
+ *      rank first and at least 6 owned planes per rank; the host switches all ranks or none.  The first pass of a run of passes
+ *      still takes its ghost planes from the halo hook (it is the run's rendezvous).  Other passes as in mode 2. */
+/* Peer stores: what a rank publishes about itself, and the connection to its z-neighbours.  wafer_peer_export fills `out`
+ * (device addresses valid in this process + HIP IPC handles of the allocations for other processes); the host carries the
+ * records to the neighbours (any transport) and calls wafer_peer_connect with the lower / upper neighbour's record (NULL: no
+ * neighbour on that side; a record exported by this same process is used by address, without IPC -- several contexts in one
+ * process, or a slab whose neighbour is itself).  wafer_peer_disconnect unmaps; wafer_ctx_destroy does it too. */
+typedef struct wafer_peer_info {
+    uint32_t struct_size;
+    uint32_t z_begin, z_count, halo_depth;
+    uint64_t pid;                 /* of the exporting process */
+    uint64_t phi_addr[2];         /* the two ping-pong buffers (plane 0, row 0) */
+    uint64_t flags_addr;          /* arrival counters: [0] lower ghost side, [8] upper (64-bit words, one 64-byte line each) */
+    uint64_t phi_alloc_offset[2]; /* byte offset of phi_addr inside its allocation (IPC maps allocations) */
+    uint8_t phi_ipc[2][64];       /* hipIpcMemHandle_t */
+    uint8_t flags_ipc[64];
+} wafer_peer_info;
+int wafer_peer_export(wafer_ctx *ctx, wafer_peer_info *out);
+int wafer_peer_connect(wafer_ctx *ctx, const wafer_peer_info *lower, const wafer_peer_info *upper);
+int wafer_peer_disconnect(wafer_ctx *ctx);
+
 /* z-slabs, ground state: fused passes per halo exchange.  One fused pass advances K time steps and consumes
  * K * ext ghost planes per side (K = 3 where the three-step kernel applies: ThreePoint, dtype WAFER_F64 or
  * WAFER_F32_FAST, with halo_depth >= 3 * ext; else K = 2 -- every rank of a run must be created alike).  With `passes` > 1 the exchange moves K * ext * passes planes at once and

@@ -5,6 +5,8 @@ problem in one undecomposed context and compares:
 
   * ground-state evolve (fused two-step kernel, overlap on): bit for bit,
   * all-reduced observables: 1e-12,
+  * three-step passes with PEER STORES (overlap mode 3): every process maps its neighbours' buffers through HIP IPC and its
+    boundary workgroups store straight into their ghost planes: bit for bit,
   * solve of ground + first excited state from Gaussian starts: energies 5e-7.
 
 Prints "MP-OK <world>" on success."""
@@ -61,6 +63,40 @@ def main():
         for o in all_obs:
             for k, v in want_obs.items():
                 assert abs(o[k] - v) <= 1e-12 * max(1.0, abs(v)), (k, o[k], v)
+
+    # ---- peer stores (overlap mode 3): boundary workgroups write the neighbour PROCESS's ghost planes through HIP IPC ----
+    from wafer_amd.slab import connect_peers
+    os.environ["WAFER_FUSE3_MIN_NY"] = "1"
+    shape3 = (140, 40, 45)
+    whole3 = wa.Params(*shape3, dn=0.2, dt=0.004, central_difference=1)
+    zb, zc = partition(shape3[2], world, rank)
+    with wa.Context(dataclasses.replace(whole3, z_begin=zb, z_count=zc, halo_depth=3)) as ctx:
+        comm = HostStagedSlabComm(ctx, rank, world, dev)
+        assert connect_peers(ctx, rank, world), "peer connection (HIP IPC) failed"
+        ctx.set_overlap(3)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 12)
+        ctx.evolve(0, 4)
+        ctx.evolve(0, 9)
+        got = ctx.download_phi()
+        n2 = ctx.norm2()
+    pieces = [None] * world if rank == 0 else None
+    dist.gather_object((zb, zc, got[:, :, zb + 1:zb + zc + 1], n2), pieces, dst=0)
+    if rank == 0:
+        with wa.Context(whole3) as ctx:
+            ctx.set_potential("Coulomb")
+            ctx.set_initial_condition("Boolean")
+            ctx.evolve(0, 12)
+            ctx.evolve(0, 4)
+            ctx.evolve(0, 9)
+            want = ctx.download_phi()
+            want_n2 = ctx.norm2()
+        full = np.zeros_like(want)
+        for b, c, p, n2_ in pieces:
+            full[:, :, b + 1:b + c + 1] = p
+            assert abs(n2_ - want_n2) <= 1e-12 * want_n2
+        assert np.array_equal(full, want), "peer-store passes differ from the undecomposed run"
 
     # ---- ground + first excited state solve ----
     shape2 = (16, 16, 20)

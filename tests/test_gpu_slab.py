@@ -37,6 +37,15 @@ class FakeFabric:
         self.scal = [None] * world
         self.halo_calls = [0] * world
         self.reduce_calls = [0] * world
+        self.peer_recs = [None] * world
+
+    def connect_peers(self, ctx, rank):
+        """wafer_peer_export / wafer_peer_connect between the contexts of this process (the precondition of overlap mode 3:
+        boundary workgroups store into the neighbour's ghost planes themselves)"""
+        self.peer_recs[rank] = ctx.peer_export()
+        self.bar.wait()
+        ctx.peer_connect(self.peer_recs[rank - 1] if rank > 0 else None, self.peer_recs[rank + 1] if rank < self.world - 1 else None)
+        self.bar.wait()
 
     def hooks(self, rank):
         hip = self.hip
@@ -87,6 +96,8 @@ def run_slabs(wa, base, world, body):
             par = dataclasses.replace(base, z_begin=zb, z_count=zc)
             with wa.Context(par) as ctx:
                 ctx.set_comm_hooks(*fabric.hooks(rank))
+                if par.ext == 1 and par.halo_depth >= 3:
+                    fabric.connect_peers(ctx, rank)
                 results[rank] = body(ctx, rank)
         except BaseException as e:  # noqa: BLE001
             errors.append(e)
@@ -214,13 +225,15 @@ def test_deep_halo_cycles_bit_exact(wa, world, shape, ext, steps, cycle, overlap
         wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, z_begin=0, z_count=2 * ext, halo_depth=2 * ext + 1))
 
 
-@pytest.mark.parametrize("overlap", [True, False, 2])   # 2: ONE launch per pass, two halves marched outwards, exchanges released by counters
+@pytest.mark.parametrize("overlap", [True, False, 2, 3])   # 2: ONE launch per pass, two halves marched outwards, exchanges released by counters; 3: ... with peer stores instead of exchanges
 @pytest.mark.parametrize("cycle", [1, 2])
 @pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 32), 12), (3, (140, 17, 37), 7), (4, (130, 33, 48), 10), (2, (300, 70, 96), 11)])
 def test_three_step_kernel_on_slabs_bit_exact(wa, world, shape, steps, cycle, overlap, monkeypatch):
     """three fused ThreePoint steps per pass on z-slabs (3 ghost planes per pass and side; 6 with one exchange
     per two passes): boundary-first overlap, the mixed long / short interior launch, two-step and single-step
     remainders with their own exchange depths in between -- the same bits as one context"""
+    if overlap == 3 and world > 3:
+        pytest.skip("peer stores, four contexts on ONE GPU: two ranks' kernels share a hardware queue (see test_peer_store_four_slabs_in_a_subprocess)")
     monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
     base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1, halo_depth=3 * cycle)
     with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1)) as ctx:
@@ -247,6 +260,8 @@ def test_three_step_kernel_on_slabs_bit_exact(wa, world, shape, steps, cycle, ov
     passes = -(-steps // 3) + 2 + 3
     per_pass = 2 if (overlap == 2 and cycle == 1) else 1   # mode 2: one hook call per half of the slab
     assert all(n <= per_pass * passes // cycle + 6 for n in fabric.halo_calls), fabric.halo_calls
+    if overlap == 3 and cycle == 1:   # peer stores: the hook serves the first pass of each call and the remainders only
+        assert all(n <= 3 + 2 + 3 for n in fabric.halo_calls), fabric.halo_calls
 
 
 @pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 10), 12), (3, (140, 40, 13), 9), (2, (300, 70, 96), 15), (4, (130, 33, 17), 6),
@@ -279,6 +294,66 @@ def test_single_launch_pass_thin_and_uneven_slabs_bit_exact(wa, world, shape, st
     assert np.array_equal(assemble(base, world, [r[0] for r in res]), want)
     assert all(r[1] == pytest.approx(want_n2, rel=1e-12) for r in res)
     assert len(set(fabric.halo_calls)) == 1   # every rank made the same number of exchange calls
+
+
+@pytest.mark.parametrize("layout", ["3", "4"])   # the two halves marched outwards / whole columns, direction alternating per pass
+@pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 12), 12), (3, (140, 40, 19), 9), (2, (300, 70, 96), 15), (3, (130, 33, 20), 6),
+                                               (3, (260, 50, 40), 30)])
+def test_peer_store_pass_uneven_slabs_bit_exact(wa, world, shape, steps, layout, monkeypatch):
+    """overlap mode 3: the boundary workgroups of the single-launch pass store their planes into the neighbour's ghost planes
+    and count themselves into its arrival counter (no exchange, no gate kernel, no second stream); uneven partitions, slabs
+    down to the six planes the mode needs, several evolve calls (the order of the halves and the arrival counts carry over),
+    an operation in between that invalidates the ghost planes; norm through the all-reduce hook"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    monkeypatch.setenv("WAFER_HV_LAYOUT", layout)
+    base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1, halo_depth=3)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1)) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)
+        ctx.normalise(0.25)        # (a power of two: the slabs' all-reduced norm would differ from one context's in its last bits)
+        ctx.evolve(0, 7)
+        want = ctx.download_phi()
+        want_n2 = ctx.norm2()
+
+    def body(ctx, rank):
+        ctx.set_overlap(3)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)           # ONE single-launch pass: the order of the halves flips between calls
+        ctx.normalise(0.25)
+        ctx.evolve(0, 7)
+        return ctx.download_phi(), ctx.norm2()
+
+    res, fabric = run_slabs(wa, base, world, body)
+    assert np.array_equal(assemble(base, world, [r[0] for r in res]), want)
+    assert all(r[1] == pytest.approx(want_n2, rel=1e-12) for r in res)
+    # the halo hook ran for the first pass of each call and for the two-step / single-step remainders, never per pass
+    assert all(n <= 8 for n in fabric.halo_calls), fabric.halo_calls
+
+
+def test_peer_store_four_slabs_in_a_subprocess():
+    """four slabs (two middle ranks) need more hardware queues than the runtime hands one process by default: a kernel polling
+    for its neighbour's stores would otherwise sit in the same queue in front of that neighbour's kernel"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for layout in ("3", "4"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "peer_store_worker.py"), "4", "130,33,48", "10,5,9", "3", layout],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, GPU_MAX_HW_QUEUES="16"), cwd=root)
+        assert r.returncode == 0 and "PEER-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_peer_store_mode_needs_a_connection(wa):
+    par = wa.Params(64, 32, 40, dn=0.2, dt=0.004, central_difference=1, z_begin=0, z_count=20, halo_depth=3)
+    with wa.Context(par) as ctx:
+        with pytest.raises(wa.WaferError):
+            ctx.set_overlap(3)
+        with pytest.raises(wa.WaferError):
+            ctx.peer_connect(ctx.peer_export(), None)    # a record for a side without a neighbour
 
 
 def test_kernel_choice_on_slabs_does_not_depend_on_the_local_thickness(wa, monkeypatch):

@@ -71,6 +71,9 @@ def main():
                 comm.warm_up()
             else:
                 ctx.set_comm_hooks(hook or halo, lambda p, c, s: 0)
+            if mode == 3:   # peer stores, the slab as its own neighbour
+                rec = ctx.peer_export()
+                ctx.peer_connect(rec, rec)
             ctx.set_overlap(mode)
         ctx.set_potential("SimpleCornell")
         ctx.set_initial_condition("Boolean")
@@ -91,6 +94,9 @@ def main():
         ("mode0", {}, True, 0),
         ("mode2", {}, True, 2),
         ("mode2_no_acquire", {"WAFER_HV_DEBUG": "4"}, True, 2),
+        ("mode3", {}, True, 3),
+        ("mode3_halves", {"WAFER_HV_LAYOUT": "3"}, True, 3),
+        ("mode3_short_columns", {"WAFER_HV_SHORT_TILES": "32"}, True, 3),
         ("mode2_no_shorts", {"WAFER_HV_DEBUG": "8"}, True, 2),
         ("mode2_xcd_order_no_shorts", {"WAFER_HV_DEBUG": "24"}, True, 2),
     ]

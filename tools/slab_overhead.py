@@ -54,6 +54,9 @@ def main():
         with wafer_amd.Context(par) as ctx:
             if hooks:
                 ctx.set_comm_hooks(*hooks)
+                if int(overlap) == 3:   # peer stores, the slab as its own neighbour on both sides
+                    rec = ctx.peer_export()
+                    ctx.peer_connect(rec, rec)
                 ctx.set_overlap(overlap)
                 ctx.set_halo_cycle(max(1, par.halo_depth // (args.per_pass or (3 if ext == 1 else 2 * ext))))
             ctx.set_potential("SimpleCornell")
@@ -140,6 +143,9 @@ def main():
             with wafer_amd.Context(mid_params(cycle)) as ctx:
                 comm = NativeRcclSlabComm(ctx, 0, 1, dev, self_neighbours=True)
                 comm.warm_up()
+                if int(overlap) == 3:
+                    rec = ctx.peer_export()
+                    ctx.peer_connect(rec, rec)
                 ctx.set_overlap(overlap)
                 ctx.set_halo_cycle(cycle)
                 ctx.set_potential("SimpleCornell")

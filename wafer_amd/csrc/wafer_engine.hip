@@ -4,6 +4,7 @@
 // compute_observables/normalise/orthogonalise) with device-resident state.
 // No CPU fallback exists: every entry point fails loudly if HIP does.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <cfloat>
 #include <cstdarg>
@@ -193,6 +194,18 @@ struct wafer_ctx {
     unsigned *hv_err = nullptr;             // host memory: set by a workgroup or gate kernel whose wait gave up
     unsigned long long hv_cnt_target[2] = {0, 0}, hv_flag_epoch[2] = {0, 0};
     int hv_first = 0;                       // which half the next single-launch pass dispatches first
+    // peer stores (wafer_set_overlap mode 3): the z-neighbours' buffers and arrival counters as mapped here, this context's own
+    // counters (their own allocation: peers map it), and how many arrivals each ghost side has been promised so far
+    struct PeerSide {
+        bool connected = false;
+        void *phi[2] = {nullptr, nullptr};
+        unsigned long long *flags = nullptr;
+        int nzl = 0;
+        void *ipc_map[3] = {nullptr, nullptr, nullptr};   // what hipIpcOpenMemHandle returned (to close)
+    } peer[2];
+    bool peer_ready = false;
+    unsigned long long *peer_flags = nullptr;   // [0], [8]: arrivals into the lower / upper ghost planes
+    unsigned long long peer_expect[2] = {0, 0};
     hipEvent_t ev_ex[2] = {nullptr, nullptr}; // single-launch pass: the last exchange of each side
     int halo_valid = 0; // ghost planes of phi[cur] (counted from the owned region) known to be current
     int halo_cycle = 1; // fused passes per halo exchange: the exchange moves 2R * halo_cycle planes (<= G), see wafer_evolve
@@ -555,7 +568,7 @@ static bool fuse2_applies(const wafer_ctx *c)
 }
 
 // ---- workgroup tables of the three-step kernel (wafer_stencil_fused3.hip.h), built once per launch shape ---------
-enum { F3_PLAIN = 0, F3_MIXED = 1, F3_HALVES = 2 };
+enum { F3_PLAIN = 0, F3_MIXED = 1, F3_HALVES = 2, F3_WHOLE = 3 };
 static int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const wafer_ctx::F3Table **out)
 {
     for (const auto &t : c->f3_tables)
@@ -571,13 +584,20 @@ static int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const
         wafer_f3_schedule_plain(host, ntx, nty, lz_lo, lz_hi, aux /* planes per workgroup */, c->tune.swz != 0);
     } else if (kind == F3_MIXED) {
         wafer_f3_schedule_mixed(host, ntx, nty, lz_lo, lz_hi, aux /* short workgroups per tile */);
+    } else if (kind == F3_WHOLE) {
+        // peer-store pass without a cut: aux bit 0 = marching down, bits 8 / 16 = a neighbour below / above
+        const bool need_wait[2] = {(aux & 8) != 0, (aux & 16) != 0};
+        wafer_f3_schedule_whole(host, ntx, nty, lz_lo, lz_hi, aux & 1, need_wait, 3 * c->g.R, c->tune.swz != 0);
     } else {
         // the single-launch pass: aux = the half dispatched first.  Both sides wait for their flag whether or not a
         // neighbour exists there: the flag also says that this rank's SEND of the planes about to be overwritten two
         // passes later has completed
-        const bool need_wait[2] = {true, true};
+        // aux & 4: peer stores (mode 3) -- a side waits only where a neighbour delivers (bits 8: below, 16: above), and no column
+        // is cut short: there is no exchange kernel to hand CUs to (WAFER_HV_SHORT_TILES still applies if set)
+        const bool peer = (aux & 4) != 0;
+        const bool need_wait[2] = {peer ? (aux & 8) != 0 : true, peer ? (aux & 16) != 0 : true};
         const int ntiles = ntx * nty;
-        const int nshort = c->tune.hv_short_tiles >= 0 ? c->tune.hv_short_tiles : (ntiles >= 64 ? ntiles / 16 : 0);
+        const int nshort = c->tune.hv_short_tiles >= 0 ? c->tune.hv_short_tiles : (peer ? 0 : (ntiles >= 64 ? ntiles / 16 : 0));
         wafer_f3_schedule_halves(host, ntx, nty, lz_lo, lz_hi, lz_lo + (lz_hi - lz_lo) / 2, aux & 1, need_wait,
                                  (c->tune.hv_debug & 8) ? 0 : nshort, c->tune.hv_nsub, 3 * c->g.R /* planes per exchange */, !(aux & 2),
                                  c->tune.hv_debug, c->tune.hv_layout);
@@ -585,8 +605,10 @@ static int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const
     wafer_ctx::F3Table t{};
     t.kind = kind; t.lz_lo = lz_lo; t.lz_hi = lz_hi; t.aux = aux;
     t.nblocks = (int)host.size();
-    for (const auto &k : host)
+    for (const auto &k : host) {
         if (k.bump >= 0) ++t.nbump[k.bump];
+        if (((k.down >> 16) & 3) != 0) ++t.nbump[((k.down >> 16) & 3) - 1];   // whole-column peer passes count on both sides
+    }
     HIP_TRY(hipMalloc((void **)&t.dev, sizeof(WaferF3Block) * host.size()));
     hipError_t e = hipMemcpy(t.dev, host.data(), sizeof(WaferF3Block) * host.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -1037,6 +1059,8 @@ int wafer_ctx_destroy(wafer_ctx *c)
     for (hipEvent_t e : {c->ev_start, c->ev_stop, c->ev_fork, c->ev_join, c->ev_bdry, c->ev_ex[0], c->ev_ex[1]})
         if (e) (void)hipEventDestroy(e);
     for (auto &t : c->f3_tables) (void)hipFree(t.dev);
+    (void)wafer_peer_disconnect(c);
+    if (c->peer_flags) (void)hipFree(c->peer_flags);
     if (c->hv_words) (void)hipFree(c->hv_words);
     if (c->hv_err) (void)hipHostFree(c->hv_err);
     if (c->s_own) (void)hipStreamDestroy(c->s_own);
@@ -1448,18 +1472,21 @@ int wafer_download_phi_owned(wafer_ctx *c, double *out)
 // ghost planes an exchange fills are announced by flag[side], which the workgroups that read them poll just before their
 // first load of a ghost plane, i.e. near the END of their column.  No thin boundary launches, no event hops between the
 // streams, one pipeline fill more per tile than an undecomposed slab.
-__global__ __launch_bounds__(64) void wafer_k_gate(const unsigned long long *cnt, unsigned long long target, unsigned *err, unsigned max_spins)
+__global__ __launch_bounds__(64) void wafer_k_gate(const unsigned long long *cnt, unsigned long long target, unsigned *err, unsigned max_spins,
+                                                   int system_scope = 0)
 {
     // one wave, a handful of registers: it shares a CU with a resident stencil workgroup (which leaves 8 VGPRs per SIMD)
     if (threadIdx.x == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while ((system_scope ? __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                             : __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
             __builtin_amdgcn_s_sleep(32);
             if (++spins > max_spins) {   // four times what a workgroup waits, so that a late exchange shows as the workgroups' error
                 __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
+        if (system_scope) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // what the counted workgroups stored is visible to what follows in the stream
     }
 }
 __global__ __launch_bounds__(64) void wafer_k_post(unsigned long long *flag, unsigned long long value)
@@ -1489,7 +1516,7 @@ static unsigned hv_spins(const wafer_ctx *c, int mul)
 // exchange stream: wait until every workgroup of `half` of the current launch has finished
 static int hv_gate(wafer_ctx *c, int half)
 {
-    hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, c->s_aux, hv_cnt(c, half), c->hv_cnt_target[half], c->hv_err, hv_spins(c, 4));
+    hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, c->s_aux, hv_cnt(c, half), c->hv_cnt_target[half], c->hv_err, hv_spins(c, 4), 0);
     HIP_TRY(hipGetLastError());
     return WAFER_OK;
 }
@@ -1510,6 +1537,79 @@ static int check_hv_err(wafer_ctx *c)
         *c->hv_err = 0;
         return fail(WAFER_ERR_COMM, "single-launch slab pass: a %s gave up waiting (halo exchange never completed)",
                     e == 2 ? "gate kernel" : "workgroup");
+    }
+    return WAFER_OK;
+}
+
+// ---- peer stores (wafer_set_overlap mode 3) --------------------------------------------------------------------------
+static int ensure_peer_flags(wafer_ctx *c)
+{
+    if (c->peer_flags) return WAFER_OK;
+    // fine-grained where the runtime offers it (coherent for peers without cache maintenance); every access is a system-scope atomic
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, 2 * 64, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipMalloc(&p, 2 * 64));
+    }
+    HIP_TRY(hipMemset(p, 0, 2 * 64));
+    c->peer_flags = static_cast<unsigned long long *>(p);
+    return WAFER_OK;
+}
+
+// The same single launch as launch_halves_pass, but the boundary workgroups deliver their planes themselves (WaferF3Sync::peer).
+// need[h]: the arrivals promised to ghost side h by all earlier passes of this context's life; a pass adds one per tile and side.
+static int launch_peer_pass(wafer_ctx *c, int src, int dst, int E)
+{
+    const WaferGeom &g = c->g;
+    const int lo = g.G, hi = g.G + g.nzl;
+    (void)E;
+    const int first = c->hv_first;
+    const wafer_ctx::F3Table *tab = nullptr;
+    // Whole columns (no cut) where every CU gets a tile of its own; else the two halves (twice the workgroups).  Rank-invariant:
+    // the tile count follows nx, ny only.  WAFER_HV_LAYOUT=3 forces the halves.
+    int tx_, ty_;
+    wafer_step3_tile(type_combo(c, true), &tx_, &ty_);
+    const long long ntiles = (long long)((g.nx + tx_ - 1) / tx_) * ((g.ny + ty_ - 1) / ty_);
+    const bool whole = (ntiles >= c->num_cus && c->tune.hv_layout != 3) || c->tune.hv_layout == 4;   // (4: always, tests)
+    // aux bits: 1 the half dispatched first / the marching direction, 4 peer mode (no short columns), 8 / 16: a neighbour below / above (who waits)
+    TRY(f3_table(c, whole ? F3_WHOLE : F3_HALVES, lo, hi, first | 4 | (c->has_lo() ? 8 : 0) | (c->has_hi() ? 16 : 0), &tab));
+    WaferF3Sync sy;
+    sy.peer = 1;
+    sy.cnt = hv_cnt(c, 0);   // (unused in peer mode)
+    sy.flag = c->peer_flags;
+    sy.err = c->hv_err;
+    sy.debug = c->tune.hv_debug;
+    sy.max_spins = hv_spins(c, 1);
+    for (int h = 0; h < 2; ++h) {
+        const bool nb = h == 0 ? c->has_lo() : c->has_hi();
+        sy.need[h] = c->peer_expect[h];
+        if (!nb) continue;
+        const wafer_ctx::PeerSide &ps = c->peer[h];
+        sy.peer_out[h] = ps.phi[dst];
+        // my planes [lo, lo + E) are the lower neighbour's upper ghost planes [G + nzl_n, ...): shift by nzl_n (lo = G);
+        // my planes [hi - E, hi) are the upper neighbour's lower ghost planes [G - E, G): shift by -nzl
+        sy.peer_zshift[h] = h == 0 ? (long long)ps.nzl : -(long long)g.nzl;
+        sy.peer_flag[h] = ps.flags + (1 - h) * WAFER_F3_SYNC_STRIDE;   // what I send down fills the neighbour's UPPER side, and vice versa
+    }
+    const WaferStepArgs a = step_args(c, lo, hi);
+    if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main) != hipSuccess)
+        return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    // what this pass's neighbours will deliver: the lower neighbour's upper half (as many boundary workgroups as I have tiles)
+    if (c->has_lo()) c->peer_expect[0] += (unsigned long long)tab->nbump[1];
+    if (c->has_hi()) c->peer_expect[1] += (unsigned long long)tab->nbump[0];
+    c->hv_first ^= 1;
+    return WAFER_OK;
+}
+
+// main stream: the ghost planes the last peer pass's neighbours deliver have arrived
+static int peer_drain(wafer_ctx *c)
+{
+    for (int h = 0; h < 2; ++h) {
+        if (!(h == 0 ? c->has_lo() : c->has_hi())) continue;
+        hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, c->s_main, c->peer_flags + h * WAFER_F3_SYNC_STRIDE, c->peer_expect[h], c->hv_err,
+                           hv_spins(c, 4), 1);
+        HIP_TRY(hipGetLastError());
     }
     return WAFER_OK;
 }
@@ -1574,12 +1674,16 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
     if (x2) TRY(ensure_x2(c, wnum));
     HIP_TRY(hipEventRecord(c->ev_start, c->s_main));
     // single-launch passes in flight: their last exchanges have not been waited for by the main stream
-    bool hv_active = false;
+    bool hv_active = false, hv_peer = false;
     int hv_depth = 0;
     auto hv_drain = [&]() -> int {
         if (!hv_active) return WAFER_OK;
-        HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[0], 0));
-        HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[1], 0));
+        if (hv_peer) {
+            TRY(peer_drain(c));
+        } else {
+            HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[0], 0));
+            HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[1], 0));
+        }
         hv_active = false;
         c->halo_valid = hv_depth;
         return WAFER_OK;
@@ -1601,14 +1705,23 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             const int E = c->sharded() ? std::max(H, std::min(g.G, H * c->halo_cycle) / H * H) : H;
             // Mode 2: the whole slab in one launch (three-step passes with one exchange per pass; every rank takes this
             // branch or none: K, E and H depend on nothing local)
-            if (c->sharded() && c->overlap_mode == 2 && K == 3 && E == H) {
+            if (c->sharded() && (c->overlap_mode == 2 || c->overlap_mode == 3) && K == 3 && E == H) {
+                const bool peer = c->overlap_mode == 3;
                 if (!hv_active) {
                     TRY(ensure_hv(c));
-                    TRY(ensure_halo(c, E));   // the first pass's ghost planes: a plain exchange in stream order
+                    // the first pass's ghost planes: a plain exchange in stream order.  (Peer mode: always, also when they are
+                    // current -- the collective is the rendezvous that keeps a rank from storing into a neighbour's buffers while
+                    // that neighbour is still busy with whatever preceded this call.)
+                    // (stream order suffices: my first pass follows my exchange, which completes only when the neighbour's stream has
+                    //  reached its own)
+                    if (peer) c->halo_valid = 0;
+                    TRY(ensure_halo(c, E));
                     hv_active = true;
+                    hv_peer = peer;
                     hv_depth = E;
                 }
-                TRY(launch_halves_pass(c, src, dst, E));
+                if (peer) TRY(launch_peer_pass(c, src, dst, E));
+                else TRY(launch_halves_pass(c, src, dst, E));
                 c->halo_valid = 0;   // (inside the mode; hv_drain restores the invariant)
                 c->cur = dst;
                 s += K;
@@ -2090,12 +2203,100 @@ int wafer_set_comm_hooks(wafer_ctx *c, wafer_halo_fn halo, wafer_allreduce_fn al
 int wafer_set_overlap(wafer_ctx *c, int mode)
 {
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
-    if (mode < 0 || mode > 2) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 2");
+    if (mode < 0 || mode > 3) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 3");
+    if (mode == 3) {
+        if (c->sharded() && !c->peer_ready) return fail(WAFER_ERR_STATE, "overlap mode 3 (peer stores) needs wafer_peer_connect first");
+        if (c->sharded() && c->g.nzl < 6 * c->g.R) return fail(WAFER_ERR_INVALID, "overlap mode 3 needs at least %d owned planes", 6 * c->g.R);
+    }
     c->overlap_mode = mode;
     // a fresh start for the single-launch pass: every rank dispatches the lower half first again and nothing in the ghost
     // planes is taken for current (a host that has just seen WAFER_ERR_COMM on some rank calls this on all of them)
     c->hv_first = 0;
     c->halo_valid = 0;
+    return WAFER_OK;
+}
+
+int wafer_peer_export(wafer_ctx *c, wafer_peer_info *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->P.device));
+    TRY(ensure_hv(c));
+    TRY(ensure_peer_flags(c));
+    memset(out, 0, sizeof *out);
+    out->struct_size = (uint32_t)sizeof *out;
+    out->z_begin = (uint32_t)c->g.z_begin;
+    out->z_count = (uint32_t)c->g.nzl;
+    out->halo_depth = (uint32_t)c->g.G;
+    out->pid = (uint64_t)getpid();
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    for (int b = 0; b < 2; ++b) {
+        out->phi_addr[b] = (uint64_t)(uintptr_t)c->phi[b];
+        out->phi_alloc_offset[b] = (uint64_t)c->g.base_off * c->esz;
+        hipIpcMemHandle_t h;
+        // (a handle is only needed by another process; a runtime that cannot export one still serves neighbours in this process)
+        if (hipIpcGetMemHandle(&h, alloc_base(c, c->phi[b])) == hipSuccess) memcpy(out->phi_ipc[b], &h, sizeof h);
+        else (void)hipGetLastError();
+    }
+    out->flags_addr = (uint64_t)(uintptr_t)c->peer_flags;
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, c->peer_flags) == hipSuccess) memcpy(out->flags_ipc, &h, sizeof h);
+    else (void)hipGetLastError();
+    return WAFER_OK;
+}
+
+int wafer_peer_disconnect(wafer_ctx *c)
+{
+    if (!c) return WAFER_OK;
+    for (int h = 0; h < 2; ++h) {
+        for (void *&m : c->peer[h].ipc_map)
+            if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
+        c->peer[h] = wafer_ctx::PeerSide();
+    }
+    c->peer_ready = false;
+    if (c->overlap_mode == 3) c->overlap_mode = 2;
+    return WAFER_OK;
+}
+
+int wafer_peer_connect(wafer_ctx *c, const wafer_peer_info *lower, const wafer_peer_info *upper)
+{
+    if (!c) return fail(WAFER_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->P.device));
+    if ((lower != nullptr) != c->has_lo() || (upper != nullptr) != c->has_hi())
+        return fail(WAFER_ERR_INVALID, "wafer_peer_connect: a record is needed exactly for the sides that have a neighbour");
+    TRY(ensure_hv(c));
+    TRY(ensure_peer_flags(c));
+    (void)wafer_peer_disconnect(c);
+    const wafer_peer_info *rec[2] = {lower, upper};
+    for (int h = 0; h < 2; ++h) {
+        const wafer_peer_info *r = rec[h];
+        if (!r) continue;
+        if (r->struct_size != sizeof *r) return fail(WAFER_ERR_INVALID, "wafer_peer_info.struct_size mismatch");
+        if ((int)r->halo_depth != c->g.G) return fail(WAFER_ERR_INVALID, "neighbour was created with another halo_depth");
+        // the neighbour must own the planes next to mine
+        const bool adjacent = h == 0 ? (int)(r->z_begin + r->z_count) == c->g.z_begin || (int)r->z_begin == c->g.z_begin   // (itself: a self-loop)
+                                     : (int)r->z_begin == c->g.z_begin + c->g.nzl || (int)r->z_begin == c->g.z_begin;
+        if (!adjacent) return fail(WAFER_ERR_INVALID, "wafer_peer_connect: the %s record is not the z-neighbour's", h == 0 ? "lower" : "upper");
+        wafer_ctx::PeerSide &ps = c->peer[h];
+        ps.nzl = (int)r->z_count;
+        if (r->pid == (uint64_t)getpid()) {
+            ps.phi[0] = (void *)(uintptr_t)r->phi_addr[0];
+            ps.phi[1] = (void *)(uintptr_t)r->phi_addr[1];
+            ps.flags = (unsigned long long *)(uintptr_t)r->flags_addr;
+        } else {
+            for (int b = 0; b < 2; ++b) {
+                hipIpcMemHandle_t hd;
+                memcpy(&hd, r->phi_ipc[b], sizeof hd);
+                HIP_TRY(hipIpcOpenMemHandle(&ps.ipc_map[b], hd, hipIpcMemLazyEnablePeerAccess));
+                ps.phi[b] = static_cast<char *>(ps.ipc_map[b]) + r->phi_alloc_offset[b];
+            }
+            hipIpcMemHandle_t hd;
+            memcpy(&hd, r->flags_ipc, sizeof hd);
+            HIP_TRY(hipIpcOpenMemHandle(&ps.ipc_map[2], hd, hipIpcMemLazyEnablePeerAccess));
+            ps.flags = static_cast<unsigned long long *>(ps.ipc_map[2]);
+        }
+        ps.connected = true;
+    }
+    c->peer_ready = true;
     return WAFER_OK;
 }
 

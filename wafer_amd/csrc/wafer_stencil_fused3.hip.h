@@ -70,7 +70,9 @@ struct WaferF3Cfg {
 struct WaferF3Block {
     int tile;        // ty * ntx + tx
     int zs, ze;      // output planes [zs, ze) (local plane indices)
-    int down;        // 1: march from ze-1 down to zs
+    int down;        // bit 0: march from ze-1 down to zs.  Peer-store whole-column passes (wafer_f3_schedule_whole) also carry
+                     // bits 8-9: 1 + the ghost side to wait for BEFORE the prologue (the side the march starts at), bits 16-17: 1 + the
+                     // side whose neighbour gets the FIRST wt planes of the march (stored, then counted, early in the column)
     int wait_late;   // >= 0: wait for ghost flag [wait_late] at the top of iteration wait_it (the first prefetch of a ghost plane)
     int wait_it;
     int bump;        // >= 0: add 1 to completion counter [bump] after the last store
@@ -94,6 +96,15 @@ struct WaferF3Sync {
     unsigned *err = nullptr;
     int debug = 0;   // WAFER_HV_DEBUG bit 4: no acquire fence (timing experiments)
     unsigned max_spins = 1u << 24;   // bound of a ghost-flag wait, ~1 us per spin (WAFER_HV_WAIT_MS, default 20 s)
+    // Peer stores (wafer_set_overlap mode 3): a boundary workgroup of half h stores the planes the exchange would send ALSO into
+    // the z-neighbour's ghost planes -- peer_out[h] is the neighbour's output buffer as mapped here (same process: its pointer;
+    // another process: through HIP IPC), plane z of this slab is plane z + peer_zshift[h] there -- and then adds 1 to the
+    // neighbour's arrival counter peer_flag[h] (system scope).  flag[] then counts ARRIVED WORKGROUPS, need[] = workgroups per
+    // pass x passes so far, and both are accessed at system scope.  No gate kernel, no exchange kernel, no second stream.
+    void *peer_out[2] = {nullptr, nullptr};
+    long long peer_zshift[2] = {0, 0};
+    unsigned long long *peer_flag[2] = {nullptr, nullptr};
+    int peer = 0;
 };
 enum { WAFER_F3_SYNC_STRIDE = 8 }; // 64-bit words between the two counters / flags
 
@@ -107,7 +118,10 @@ __device__ __forceinline__ bool wafer_f3_wait(const WaferF3Sync &sy, int idx, in
     __shared__ unsigned gave_up;
     if (tid == 0) {
         unsigned spins = 0, bad = 0;
-        while (__hip_atomic_load(sy.flag + idx * WAFER_F3_SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.need[idx]) {
+        const unsigned long long *fw = sy.flag + idx * WAFER_F3_SYNC_STRIDE;
+        // (peer mode: the word is written by another device, or another process on this one: system scope)
+        while ((sy.peer ? __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                        : __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < sy.need[idx]) {
             __builtin_amdgcn_s_sleep(32);
             if (++spins > sy.max_spins) { // the exchange never arrived
                 __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -141,6 +155,10 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     const int tx_i = blk.tile % ntx, ty_i = blk.tile / ntx;
     const int zs = blk.zs, ze = blk.ze;
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wait_early = ((blk.down >> 8) & 3) - 1, bump_early = ((blk.down >> 16) & 3) - 1;
+    bool poisoned = false;   // a ghost-flag wait gave up: everything stored from here on is NaN (wafer_f3_wait)
+    // a whole-column pass starts at a ghost side: its planes are loaded by the prologue
+    if (wait_early >= 0) poisoned = wafer_f3_wait(sy, wait_early, tid);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = tx_i * TX, y0 = ty_i * TY;
     const C dt = (C)a.dt, den = (C)a.den;
@@ -262,7 +280,6 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     __syncthreads();
 
     const int niter = (ze - zs) + 4;
-    bool poisoned = false;   // a ghost-flag wait gave up: everything stored from here on is NaN (wafer_f3_wait)
     for (int it = 0; it < niter; ++it) {
         const int z = z1 + SD * it;
         const bool more = it + 1 < niter;
@@ -509,7 +526,14 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             q2[2][r] = p2new[r];
         }
         const int zo3 = z - 2 * SD;
-        const bool wthrough = blk.bump >= 0 && (DOWN ? zo3 < zs + blk.wt : zo3 >= ze - blk.wt);
+        const bool last_wt = blk.bump >= 0 && (DOWN ? zo3 < zs + blk.wt : zo3 >= ze - blk.wt);      // the last wt planes of the march
+        const bool first_wt = bump_early >= 0 && (DOWN ? zo3 >= ze - blk.wt : zo3 < zs + blk.wt);   // the first wt planes (whole-column peer passes)
+        // mode 2: the planes the exchange kernel reads while this kernel is still running go to memory at once; peer mode: nobody
+        // reads them before the kernel ends, what travels is the copy into the neighbour's ghost planes
+        const bool wthrough = last_wt && !sy.peer;
+        // the neighbour's buffer, shifted so that this slab's plane index addresses the ghost plane it fills (nullptr: no peer stores)
+        const int pside = first_wt ? bump_early : blk.bump & 1;
+        T *const peer_dst = ((last_wt || first_wt) && sy.peer_out[pside]) ? static_cast<T *>(sy.peer_out[pside]) + sy.peer_zshift[pside] * g.plane : nullptr;
         if (zo3 >= zs && zo3 < ze) {
             auto level3 = [&](auto interior_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
@@ -538,6 +562,12 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                 for (int r = 0; r < RY; ++r) {
                     if (INTERIOR || rowwk[r]) {
                         T *dst = (out + (long long)zo3 * g.plane + rowoff[r]) + xlu;
+                        if (peer_dst) {   // into the neighbour's ghost planes (wave-uniform), system scope, written through
+                            T *pd = (peer_dst + (long long)zo3 * g.plane + rowoff[r]) + xlu;
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v)
+                                if (INTERIOR || xi + v < g.nx) __hip_atomic_store(pd + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
                         if (wthrough) {
 #pragma unroll
                             for (int v = 0; v < VEC; ++v)
@@ -555,7 +585,12 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             if (all_rows) level3(std::true_type{});
             else level3(std::false_type{});
         }
+        // whole-column peer passes: the first wt planes are out after iteration wt + 3 -- acknowledged here, counted behind the barrier
+        const bool early_done = bump_early >= 0 && it == blk.wt + 3;
+        if (early_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (early_done && tid == 0 && sy.peer_flag[bump_early])
+            __hip_atomic_fetch_add(sy.peer_flag[bump_early], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // ---- 6. rotate the phi0 / V / a, b pipelines
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
@@ -579,7 +614,18 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     if (blk.bump >= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(sy.cnt + blk.bump * WAFER_F3_SYNC_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            if (sy.peer) {
+                // every wave's system-scope write-through stores have been acknowledged (vmcnt(0) + barrier), so the count that
+                // follows in program order cannot overtake them; the consumer's poll is followed by an acquire (wafer_f3_wait).
+                // (A release fence here writes back the whole L2 of the XCD once per workgroup: 0.2928 against %s ms/step at the
+                //  bench slab -- the lesson of round 3's mode 2 again.)
+                if (sy.peer_flag[blk.bump & 1])
+                    __hip_atomic_fetch_add(sy.peer_flag[blk.bump & 1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                __hip_atomic_fetch_add(sy.cnt + blk.bump * WAFER_F3_SYNC_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -593,7 +639,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     __shared__ __attribute__((aligned(16))) T lds1[2 * Cfg::TILE1];
     __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
     const WaferF3Block blk = table[blockIdx.x];
-    if (blk.down) wafer_step3_body<T, C, VIR, true>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    if (blk.down & 1) wafer_step3_body<T, C, VIR, true>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
     else wafer_step3_body<T, C, VIR, false>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
 }
 
@@ -711,6 +757,34 @@ static inline void wafer_f3_schedule_halves(std::vector<WaferF3Block> &out, int 
         for (int t = nl; t < nl + head && t < ntiles; ++t) column(half, t, nsub);
         for (int t = 0; t < nl; ++t) column(half, t, 1);
         for (int t = nl + head; t < ntiles; ++t) column(half, t, nsub);
+    }
+}
+
+// Peer-store passes without a cut (overlap mode 3 where there is at least a tile per CU): every tile's whole column [lo, hi) in
+// ONE workgroup, all marching in the same direction, which alternates from pass to pass.  Marching up, a workgroup reads its lower
+// ghost planes first (prologue: it waits for that side's arrivals before anything else) and its upper ghost planes last (the late
+// wait of the halves schedule); it stores its lowest `depth` planes first -- into the lower neighbour's upper ghost planes as well,
+// counted into that neighbour's arrival counter a few iterations into the column -- and its highest `depth` planes last.  The
+// neighbour's next pass marches DOWN: it reads those upper ghost planes first, half a pass (the second round of workgroups) to a
+// whole pass after they were stored, and its own lower ghost planes last.  Every wait precedes the stores to the same side's
+// neighbour, and an arrival from a neighbour implies that its workgroups have read the ghost planes the next stores overwrite
+// (they store boundary planes only after reading the ghost planes behind them): the ping-pong buffers need no other protection.
+static inline void wafer_f3_schedule_whole(std::vector<WaferF3Block> &out, int ntx, int nty, int lo, int hi, int down, const bool need_wait[2],
+                                           int depth, bool swz)
+{
+    const int n = ntx * nty;
+    out.resize((size_t)n);
+    const int first_side = down ? 1 : 0, last_side = down ? 0 : 1;
+    for (int b = 0; b < n; ++b) {
+        WaferF3Block k{};
+        k.tile = swz ? wafer_f3_xcd_slot(b, n) : b;
+        k.zs = lo; k.ze = hi;
+        k.down = (down ? 1 : 0) | ((need_wait[first_side] ? 1 + first_side : 0) << 8) | ((1 + first_side) << 16);
+        k.wait_late = need_wait[last_side] ? last_side : -1;
+        k.wait_it = hi - lo;          // the first prefetch that touches the far side's ghost planes (either direction)
+        k.bump = last_side;
+        k.wt = depth;
+        out[(size_t)b] = k;
     }
 }
 

@@ -45,7 +45,8 @@ struct WaferTuning {
                             // 64 exchange stream at normal priority)
     int hv_short_tiles = -1; // WAFER_HV_SHORT_TILES: tiles per half cut into short pieces (-1: 1/16 of the tiles)
     int hv_nsub = 4;        // WAFER_HV_NSUB: pieces per short column
-    int hv_layout = 0;      // WAFER_HV_LAYOUT: where the short columns go (wafer_f3_schedule_halves)
+    int hv_layout = 0;      // WAFER_HV_LAYOUT: where the short columns go (wafer_f3_schedule_halves); peer-store passes (mode 3): 3 = always
+                            // the two halves, 4 = always whole columns (default: whole columns where there is a tile per CU)
     int hv_wait_ms = 20000; // WAFER_HV_WAIT_MS: how long a workgroup of the single-launch pass waits for its ghost planes before it gives up
                             // (WAFER_ERR_COMM; the gate kernels wait four times as long)
     int f3_sched = 0;       // WAFER_F3_SCHED: 1 = undecomposed launches use the two-halves schedule as well (timing experiments)

@@ -42,6 +42,7 @@ EXPORTS = [
     "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
     "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check",
     "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_set_halo_cycle", "wafer_diag_x2_passes",
+    "wafer_peer_export", "wafer_peer_connect", "wafer_peer_disconnect",
 ]
 
 
@@ -49,6 +50,15 @@ class WaferError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"wafer_hip error {code}: {msg}")
         self.code = code
+
+
+class _PeerInfo(C.Structure):
+    """wafer_peer_info (include/wafer_hip.h)"""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("z_begin", C.c_uint32), ("z_count", C.c_uint32), ("halo_depth", C.c_uint32),
+        ("pid", C.c_uint64), ("phi_addr", C.c_uint64 * 2), ("flags_addr", C.c_uint64), ("phi_alloc_offset", C.c_uint64 * 2),
+        ("phi_ipc", (C.c_uint8 * 64) * 2), ("flags_ipc", C.c_uint8 * 64),
+    ]
 
 
 class _Params(C.Structure):
@@ -137,6 +147,9 @@ def load_library():
     L.wafer_diag_copy_bw.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     L.wafer_diag_checksum.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.wafer_diag_x2_passes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.wafer_peer_export.argtypes = [vp, C.POINTER(_PeerInfo)]
+    L.wafer_peer_connect.argtypes = [vp, C.POINTER(_PeerInfo), C.POINTER(_PeerInfo)]
+    L.wafer_peer_disconnect.argtypes = [vp]
     L.wafer_set_initial_condition.argtypes = [vp, C.c_int, C.c_uint64]
     L.wafer_upload_phi.argtypes = [vp, dp]
     L.wafer_download_phi.argtypes = [vp, dp]
@@ -464,9 +477,26 @@ class Context:
         self._hooks = (HALO_FN(_halo), ALLREDUCE_FN(_allreduce))  # keep alive
         self._check(self._L.wafer_set_comm_hooks(self._h, self._hooks[0], self._hooks[1], None))
 
+    def peer_export(self) -> bytes:
+        """this context's wafer_peer_info record (for the z-neighbours' peer_connect), as bytes any transport can carry"""
+        info = _PeerInfo()
+        self._check(self._L.wafer_peer_export(self._h, C.byref(info)))
+        return bytes(info)
+
+    def peer_connect(self, lower: bytes | None, upper: bytes | None) -> None:
+        """map the z-neighbours' buffers and arrival counters (records from their peer_export; None: no neighbour on that side):
+        the precondition of set_overlap(3)"""
+        recs = [_PeerInfo.from_buffer_copy(r) if r is not None else None for r in (lower, upper)]
+        self._check(self._L.wafer_peer_connect(self._h, C.byref(recs[0]) if recs[0] is not None else None,
+                                               C.byref(recs[1]) if recs[1] is not None else None))
+
+    def peer_disconnect(self) -> None:
+        self._check(self._L.wafer_peer_disconnect(self._h))
+
     def set_overlap(self, enabled) -> None:
         """halo schedule of a z-slab: False / 0 (exchange after the pass), True / 1 (boundary planes first, three launches
-        per pass), 2 (the default: one launch per three-step pass, exchanges released by completion counters);
+        per pass), 2 (the default: one launch per three-step pass, exchanges released by completion counters), 3 (the same
+        launch with peer stores into the neighbours' ghost planes instead of an exchange: after peer_connect);
         include/wafer_hip.h"""
         self._check(self._L.wafer_set_overlap(self._h, int(enabled)))
 

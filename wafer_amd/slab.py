@@ -157,6 +157,42 @@ class TorchSlabComm(SlabComm):
         return 0
 
 
+def connect_peers(ctx, rank: int, world: int, group=None) -> bool:
+    """Peer stores (wafer_set_overlap mode 3): every rank publishes its wafer_peer_info record (device addresses + HIP IPC
+    handles of its two phi buffers and its arrival counters), the records travel through torch.distributed (any backend), and
+    each rank maps its z-neighbours'.  Collective; returns True when EVERY rank connected (the mode is for all ranks or none)
+    -- False leaves the context as it was, e.g. where the runtime cannot export or map the handles."""
+    import torch.distributed as dist
+    err, rec = "", b""
+    try:
+        rec = ctx.peer_export()
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+    recs = [None] * world
+    if world > 1:
+        dist.all_gather_object(recs, (err, rec), group=group)
+    else:
+        recs = [(err, rec)]
+    ok = not any(e for e, _r in recs)
+    if ok:
+        try:
+            ctx.peer_connect(recs[rank - 1][1] if rank > 0 else None, recs[rank + 1][1] if rank + 1 < world else None)
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        outcome = [None] * world
+        if world > 1:
+            dist.all_gather_object(outcome, err, group=group)
+        else:
+            outcome = [err]
+        ok = not any(outcome)
+    if not ok:
+        try:
+            ctx.peer_disconnect()
+        except Exception:  # noqa: BLE001
+            pass
+    return ok
+
+
 class MailboxAllReduce:
     """include/wafer_mailbox.h through ctypes: the device-side all-reduce of libwafer_hip.so -- every rank's mailbox
     mapped into every other rank through HIP IPC, one one-wave kernel per call, sums in rank order (the same bits on
