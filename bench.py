@@ -339,6 +339,13 @@ def run_rank(args) -> int:
                   "set WAFER_TRANSPORT=torch to measure the torch.distributed hooks on purpose", file=sys.stderr)
             return 4
         comm.warm_up()   # RCCL channel set-up is not part of any step
+        # the scalar all-reduce (excited-state steps, observables): ncclAllReduce or the device-side mailboxes, by measurement
+        allreduce_choice = None
+        if hasattr(comm, "pick_allreduce") and os.environ.get("WAFER_MAILBOX", "") == "":
+            try:
+                allreduce_choice = comm.pick_allreduce()
+            except Exception as e:  # noqa: BLE001
+                allreduce_choice = {"error": repr(e)}
         # peer stores (wafer_set_overlap mode 3): every rank maps its z-neighbours' buffers through HIP IPC; all ranks or none
         peers_ok = False
         # (not with the host-staged test transport: ranks folded onto ONE GPU would poll for each other's stores from workgroups
@@ -488,6 +495,7 @@ def run_rank(args) -> int:
             comm_info.update(comm.info())   # ncclCommCount etc. of the communicator the hooks use
         comm_info["process_group_ranks"] = dist.get_world_size()
         comm_info["halo_overlap_mode"] = overlap_choice["mode"] if overlap_choice else None
+        comm_info["scalar_allreduce"] = allreduce_choice
 
     result = {
         "metric": "grid_point_updates_per_sec",

@@ -52,6 +52,11 @@ def main():
     def native(ctx):
         comm = NativeRcclSlabComm(ctx, 0, 1, dev, self_neighbours=True)
         comm.warm_up()
+        # the scalar all-reduce picked by measurement (ncclAllReduce against the device-side mailbox): whichever wins, the sums
+        # below must not change
+        choice = comm.pick_allreduce(calls=50)
+        assert choice["chosen"] in ("mailbox", "ncclAllReduce") and choice["ncclAllReduce_us"] > 0, choice
+        print("all-reduce:", choice, flush=True)
         return comm
 
     def copies(ctx):

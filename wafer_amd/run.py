@@ -233,6 +233,16 @@ def main(argv=None) -> int:
             comm, _name = slab.make_slab_comm(ctx, rank, world, torch.device("cuda", local_rank),
                                               "host" if host_transport else None)
             comm.warm_up()
+            # the 1 + k scalars of every excited-state step: ncclAllReduce or the device-side mailboxes, whichever the fabric
+            # serves faster (a solve spends most of its steps in excited states); WAFER_MAILBOX=0 / 1 fixes the choice
+            if hasattr(comm, "pick_allreduce") and os.environ.get("WAFER_MAILBOX", "") == "":
+                choice = comm.pick_allreduce()
+                if rank == 0:
+                    print(f"scalar all-reduce: {choice}", file=sys.stderr, flush=True)
+            # peer stores for the ground-state passes where every rank can map its neighbours (HIP IPC) and WAFER_PEER_STORES=1 asks for it
+            if not host_transport and os.environ.get("WAFER_PEER_STORES", "0") not in ("", "0"):
+                if slab.connect_peers(ctx, rank, world) and min(slab.partition(par.nz, world, r)[1] for r in range(world)) >= 6:
+                    ctx.set_overlap(3)
         def from_input(stem, pad, shape, what):
             a = staged_array(args.input_dir, stem, cfg["file_type"], pad, rank)
             if a is not None and (a.dtype != np.float64 or tuple(a.shape) != tuple(shape)):

@@ -405,6 +405,74 @@ class NativeRcclSlabComm:
     def halo_calls(self) -> int:
         return int(self._L.wafer_rccl_halo_calls(self._handle))
 
+    def pick_allreduce(self, group=None, calls: int = 200) -> dict:
+        """Which all-reduce serves the path's few doubles (1 + k per excited-state step, 2 + 3k per two-step pass, 4 per
+        observables) is decided by measurement on the fabric at hand: `calls` back-to-back 4-double all-reduces through
+        ncclAllReduce, then through the device-side mailboxes (include/wafer_mailbox.h: HIP-IPC-mapped, one one-wave kernel per
+        call) -- the slowest rank's time decides, and every rank switches or none.  Collective.  Returns the two timings (us
+        per call) and the choice; a mailbox that cannot be set up or does not sum correctly leaves ncclAllReduce in place."""
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        L = self._L
+        L.wafer_rccl_allreduce_now.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.wafer_rccl_use_mailbox.argtypes = [C.c_void_p, C.c_void_p]
+        world = 1 if self.world <= 1 else self.world
+        stream = torch.cuda.Stream(device=self.device)
+
+        def slowest(x: float) -> float:
+            if self.world <= 1:
+                return x
+            t = torch.tensor([x], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            return float(t[0])
+
+        def timed():
+            t = torch.ones(4, dtype=torch.float64, device=self.device)
+            with torch.cuda.stream(stream):
+                for _ in range(10):
+                    L.wafer_rccl_allreduce_now(self._handle, t.data_ptr(), 4, stream.cuda_stream)
+                stream.synchronize()
+                t.fill_(1.0)
+                L.wafer_rccl_allreduce_now(self._handle, t.data_ptr(), 4, stream.cuda_stream)
+                stream.synchronize()
+                good = bool(torch.all(t == float(world)).item())
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(calls):
+                    L.wafer_rccl_allreduce_now(self._handle, t.data_ptr(), 4, stream.cuda_stream)
+                e1.record(stream)
+                stream.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / calls, good
+
+        out = {}
+        had = self.mailbox
+        L.wafer_rccl_use_mailbox(self._handle, None)
+        us_nccl, good = timed()
+        out["ncclAllReduce_us"] = slowest(us_nccl)
+        mb = had
+        if mb is None:
+            try:
+                mb = MailboxAllReduce(self.rank, world, self.device.index or 0, group)
+            except Exception as e:  # noqa: BLE001 -- raised on every rank together (MailboxAllReduce gathers the outcome)
+                out["mailbox_error"] = repr(e)
+                mb = None
+        if mb is not None:
+            L.wafer_rccl_use_mailbox(self._handle, mb.handle)
+            us_mb, good = timed()
+            bad = slowest(0.0 if good else 1.0)
+            out["mailbox_us"] = slowest(us_mb)
+            if bad == 0.0 and out["mailbox_us"] < out["ncclAllReduce_us"]:
+                self.mailbox = mb
+                out["chosen"] = "mailbox"
+                return out
+            L.wafer_rccl_use_mailbox(self._handle, None)
+            if had is None:
+                mb.close()
+            self.mailbox = None
+        out["chosen"] = "ncclAllReduce"
+        return out
+
     def info(self) -> dict:
         """what RCCL reports for the communicator the hooks use (ncclCommCount, ncclCommUserRank,
         ncclGetVersion), the z-neighbours in use and the channel limit in force"""
