@@ -204,6 +204,7 @@ struct wafer_ctx {
         void *ipc_map[3] = {nullptr, nullptr, nullptr};   // what hipIpcOpenMemHandle returned (to close)
     } peer[2];
     bool peer_ready = false;
+    WaferF3Peer *peer_dev = nullptr;            // device copy of what the boundary workgroups need (written by wafer_peer_connect)
     unsigned long long *peer_flags = nullptr;   // [0], [8]: arrivals into the lower / upper ghost planes
     unsigned long long peer_expect[2] = {0, 0};
     hipEvent_t ev_ex[2] = {nullptr, nullptr}; // single-launch pass: the last exchange of each side
@@ -1061,6 +1062,7 @@ int wafer_ctx_destroy(wafer_ctx *c)
     for (auto &t : c->f3_tables) (void)hipFree(t.dev);
     (void)wafer_peer_disconnect(c);
     if (c->peer_flags) (void)hipFree(c->peer_flags);
+    if (c->peer_dev) (void)hipFree(c->peer_dev);
     if (c->hv_words) (void)hipFree(c->hv_words);
     if (c->hv_err) (void)hipHostFree(c->hv_err);
     if (c->s_own) (void)hipStreamDestroy(c->s_own);
@@ -1581,17 +1583,9 @@ static int launch_peer_pass(wafer_ctx *c, int src, int dst, int E)
     sy.err = c->hv_err;
     sy.debug = c->tune.hv_debug;
     sy.max_spins = hv_spins(c, 1);
-    for (int h = 0; h < 2; ++h) {
-        const bool nb = h == 0 ? c->has_lo() : c->has_hi();
-        sy.need[h] = c->peer_expect[h];
-        if (!nb) continue;
-        const wafer_ctx::PeerSide &ps = c->peer[h];
-        sy.peer_out[h] = ps.phi[dst];
-        // my planes [lo, lo + E) are the lower neighbour's upper ghost planes [G + nzl_n, ...): shift by nzl_n (lo = G);
-        // my planes [hi - E, hi) are the upper neighbour's lower ghost planes [G - E, G): shift by -nzl
-        sy.peer_zshift[h] = h == 0 ? (long long)ps.nzl : -(long long)g.nzl;
-        sy.peer_flag[h] = ps.flags + (1 - h) * WAFER_F3_SYNC_STRIDE;   // what I send down fills the neighbour's UPPER side, and vice versa
-    }
+    sy.peer_dev = c->peer_dev;
+    sy.peer_buf = dst;
+    for (int h = 0; h < 2; ++h) sy.need[h] = c->peer_expect[h];
     const WaferStepArgs a = step_args(c, lo, hi);
     if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -2296,6 +2290,20 @@ int wafer_peer_connect(wafer_ctx *c, const wafer_peer_info *lower, const wafer_p
         }
         ps.connected = true;
     }
+    WaferF3Peer host;
+    memset(&host, 0, sizeof host);
+    for (int h = 0; h < 2; ++h) {
+        const wafer_ctx::PeerSide &ps = c->peer[h];
+        if (!ps.connected) continue;
+        host.out[h][0] = ps.phi[0];
+        host.out[h][1] = ps.phi[1];
+        // my planes [lo, lo + E) are the lower neighbour's upper ghost planes [G + nzl_n, ...): shift by nzl_n (lo = G);
+        // my planes [hi - E, hi) are the upper neighbour's lower ghost planes [G - E, G): shift by -nzl
+        host.zshift[h] = h == 0 ? (long long)ps.nzl : -(long long)c->g.nzl;
+        host.flag[h] = ps.flags + (1 - h) * WAFER_F3_SYNC_STRIDE;   // what I send down fills the neighbour's UPPER side, and vice versa
+    }
+    if (!c->peer_dev) HIP_TRY(hipMalloc((void **)&c->peer_dev, sizeof(WaferF3Peer)));
+    HIP_TRY(hipMemcpy(c->peer_dev, &host, sizeof host, hipMemcpyHostToDevice));
     c->peer_ready = true;
     return WAFER_OK;
 }

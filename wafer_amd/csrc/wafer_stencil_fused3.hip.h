@@ -101,10 +101,18 @@ struct WaferF3Sync {
     // another process: through HIP IPC), plane z of this slab is plane z + peer_zshift[h] there -- and then adds 1 to the
     // neighbour's arrival counter peer_flag[h] (system scope).  flag[] then counts ARRIVED WORKGROUPS, need[] = workgroups per
     // pass x passes so far, and both are accessed at system scope.  No gate kernel, no exchange kernel, no second stream.
-    void *peer_out[2] = {nullptr, nullptr};
-    long long peer_zshift[2] = {0, 0};
-    unsigned long long *peer_flag[2] = {nullptr, nullptr};
+    // The three per-side values live in DEVICE memory (WaferF3Peer, written by wafer_peer_connect) and are read inside the few
+    // iterations that use them: as kernel arguments they stayed live in scalar registers through the whole plane loop, which
+    // cost the kernel 8 % (0.2840 against 0.2506 ms/step at the bench slab, the same effect that made the peer paths a
+    // separate instantiation).
+    const struct WaferF3Peer *peer_dev = nullptr;
+    int peer_buf = 0;   // which of the neighbour's two buffers this pass writes (its output buffer: the same index as mine)
     int peer = 0;
+};
+struct WaferF3Peer {
+    void *out[2][2];                 // [side][buffer]: the neighbour's phi buffers (nullptr: no neighbour on that side)
+    long long zshift[2];
+    unsigned long long *flag[2];
 };
 enum { WAFER_F3_SYNC_STRIDE = 8 }; // 64-bit words between the two counters / flags
 
@@ -138,7 +146,10 @@ __device__ __forceinline__ bool wafer_f3_wait(const WaferF3Sync &sy, int idx, in
     return __builtin_amdgcn_readfirstlane(gave_up) != 0;
 }
 
-template <typename T, typename C, bool VIR, bool DOWN>
+// PEER: the instantiation that serves overlap mode 3 (peer stores, the early wait and the early count of whole-column passes).
+// A separate instantiation because the mere presence of those paths costs the plain kernel 8 % (0.2789 against 0.2578 ms/step at
+// 512^3, same box: more live scalars and a longer loop body around the stores).
+template <typename T, typename C, bool VIR, bool DOWN, bool PEER>
 __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const WaferF3Block &blk, int ntx, const WaferF3Sync &sy,
                                                   const T *__restrict__ phi, const T *__restrict__ pv, T *__restrict__ out,
                                                   T *lds0, T *lds1, T *lds2)
@@ -155,10 +166,12 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     const int tx_i = blk.tile % ntx, ty_i = blk.tile / ntx;
     const int zs = blk.zs, ze = blk.ze;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wait_early = ((blk.down >> 8) & 3) - 1, bump_early = ((blk.down >> 16) & 3) - 1;
+    const int wait_early = PEER ? ((blk.down >> 8) & 3) - 1 : -1, bump_early = PEER ? ((blk.down >> 16) & 3) - 1 : -1;
     bool poisoned = false;   // a ghost-flag wait gave up: everything stored from here on is NaN (wafer_f3_wait)
     // a whole-column pass starts at a ghost side: its planes are loaded by the prologue
-    if (wait_early >= 0) poisoned = wafer_f3_wait(sy, wait_early, tid);
+    if constexpr (PEER) {
+        if (wait_early >= 0) poisoned = wafer_f3_wait(sy, wait_early, tid);
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = tx_i * TX, y0 = ty_i * TY;
     const C dt = (C)a.dt, den = (C)a.den;
@@ -527,13 +540,22 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         }
         const int zo3 = z - 2 * SD;
         const bool last_wt = blk.bump >= 0 && (DOWN ? zo3 < zs + blk.wt : zo3 >= ze - blk.wt);      // the last wt planes of the march
-        const bool first_wt = bump_early >= 0 && (DOWN ? zo3 >= ze - blk.wt : zo3 < zs + blk.wt);   // the first wt planes (whole-column peer passes)
+        const bool first_wt = PEER && bump_early >= 0 && (DOWN ? zo3 >= ze - blk.wt : zo3 < zs + blk.wt);   // the first wt planes (whole-column peer passes)
         // mode 2: the planes the exchange kernel reads while this kernel is still running go to memory at once; peer mode: nobody
         // reads them before the kernel ends, what travels is the copy into the neighbour's ghost planes
-        const bool wthrough = last_wt && !sy.peer;
-        // the neighbour's buffer, shifted so that this slab's plane index addresses the ghost plane it fills (nullptr: no peer stores)
-        const int pside = first_wt ? bump_early : blk.bump & 1;
-        T *const peer_dst = ((last_wt || first_wt) && sy.peer_out[pside]) ? static_cast<T *>(sy.peer_out[pside]) + sy.peer_zshift[pside] * g.plane : nullptr;
+        const bool wthrough = last_wt && !PEER;
+        // the neighbour's buffer, shifted so that this slab's plane index addresses the ghost plane it fills (nullptr: no peer stores).
+        // Stored from the registers, inside the loop's store path: a copy from memory after the fact (the planes read back at agent
+        // scope, two more barriers per boundary) measured 0.320 against 0.280 ms/step at the bench slab.
+        T *peer_dst = nullptr;
+        if constexpr (PEER) {
+            if (last_wt || first_wt) {
+                const int pside = first_wt ? bump_early : blk.bump & 1;
+                const volatile WaferF3Peer *pi = sy.peer_dev;   // (volatile: read here, not hoisted out of the plane loop)
+                T *const base = static_cast<T *>(pi->out[pside][sy.peer_buf]);
+                if (base) peer_dst = base + pi->zshift[pside] * g.plane;
+            }
+        }
         if (zo3 >= zs && zo3 < ze) {
             auto level3 = [&](auto interior_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
@@ -562,11 +584,13 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                 for (int r = 0; r < RY; ++r) {
                     if (INTERIOR || rowwk[r]) {
                         T *dst = (out + (long long)zo3 * g.plane + rowoff[r]) + xlu;
-                        if (peer_dst) {   // into the neighbour's ghost planes (wave-uniform), system scope, written through
-                            T *pd = (peer_dst + (long long)zo3 * g.plane + rowoff[r]) + xlu;
+                        if constexpr (PEER) {
+                            if (peer_dst) {   // into the neighbour's ghost planes (wave-uniform), system scope, written through
+                                T *pd = (peer_dst + (long long)zo3 * g.plane + rowoff[r]) + xlu;
 #pragma unroll
-                            for (int v = 0; v < VEC; ++v)
-                                if (INTERIOR || xi + v < g.nx) __hip_atomic_store(pd + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                for (int v = 0; v < VEC; ++v)
+                                    if (INTERIOR || xi + v < g.nx) __hip_atomic_store(pd + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
                         }
                         if (wthrough) {
 #pragma unroll
@@ -586,11 +610,17 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             else level3(std::false_type{});
         }
         // whole-column peer passes: the first wt planes are out after iteration wt + 3 -- acknowledged here, counted behind the barrier
-        const bool early_done = bump_early >= 0 && it == blk.wt + 3;
-        if (early_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool early_done = PEER && bump_early >= 0 && it == blk.wt + 3;
+        if constexpr (PEER) {
+            if (early_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
-        if (early_done && tid == 0 && sy.peer_flag[bump_early])
-            __hip_atomic_fetch_add(sy.peer_flag[bump_early], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if constexpr (PEER) {
+            if (early_done && tid == 0) {
+                unsigned long long *const pf = const_cast<const volatile WaferF3Peer *>(sy.peer_dev)->flag[bump_early];
+                if (pf) __hip_atomic_fetch_add(pf, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         // ---- 6. rotate the phi0 / V / a, b pipelines
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
@@ -615,13 +645,13 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            if (sy.peer) {
+            if constexpr (PEER) {
                 // every wave's system-scope write-through stores have been acknowledged (vmcnt(0) + barrier), so the count that
                 // follows in program order cannot overtake them; the consumer's poll is followed by an acquire (wafer_f3_wait).
                 // (A release fence here writes back the whole L2 of the XCD once per workgroup: 0.2928 against %s ms/step at the
                 //  bench slab -- the lesson of round 3's mode 2 again.)
-                if (sy.peer_flag[blk.bump & 1])
-                    __hip_atomic_fetch_add(sy.peer_flag[blk.bump & 1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                unsigned long long *const pf = const_cast<const volatile WaferF3Peer *>(sy.peer_dev)->flag[blk.bump & 1];
+                if (pf) __hip_atomic_fetch_add(pf, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
                 __hip_atomic_fetch_add(sy.cnt + blk.bump * WAFER_F3_SYNC_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -629,7 +659,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     }
 }
 
-template <typename T, typename C, bool VIR>
+template <typename T, typename C, bool VIR, bool PEER = false>
 __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(WaferStepArgs a, int ntx, const WaferF3Block *__restrict__ table,
                                                                               WaferF3Sync sy, const T *__restrict__ phi,
                                                                               const T *__restrict__ pv, T *__restrict__ out)
@@ -639,8 +669,8 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     __shared__ __attribute__((aligned(16))) T lds1[2 * Cfg::TILE1];
     __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
     const WaferF3Block blk = table[blockIdx.x];
-    if (blk.down & 1) wafer_step3_body<T, C, VIR, true>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
-    else wafer_step3_body<T, C, VIR, false>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    if (blk.down & 1) wafer_step3_body<T, C, VIR, true, PEER>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    else wafer_step3_body<T, C, VIR, false, PEER>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
 }
 
 
@@ -806,6 +836,13 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     using Cfg = WaferF3Cfg<T>;
     const int ntx = (a.g.nx + Cfg::TX - 1) / Cfg::TX;
     const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
+    if (sy.peer) {   // overlap mode 3: its own instantiation (see wafer_step3_body)
+        if (a.v_in_range != 0)
+            hipLaunchKernelGGL((wafer_k_step3_fused<T, C, true, true>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out);
+        else
+            hipLaunchKernelGGL((wafer_k_step3_fused<T, C, false, true>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out);
+        return hipGetLastError();
+    }
     if (a.v_in_range != 0)
         hipLaunchKernelGGL((wafer_k_step3_fused<T, C, true>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out);
     else
