@@ -153,8 +153,8 @@ struct wafer_ctx {
     int cur = 0;
     void *v = nullptr, *a = nullptr, *b = nullptr, *potsub = nullptr;
     std::vector<void *> states;
-    // two excited-state steps per pass (wafer_stencil_x2.hip.h): M_j = A l_j of the first x2_ready stored states, the matrices
-    // <l_j, M_i> and <M_i, M_j> (device: amat[16], bmat[16]) and the load transform's coefficient block
+    // two excited-state steps per pass (wafer_stencil_x2.hip.h): M_j = A l_j of the first x2_ready stored states, the matrix
+    // <l_j, M_i> (device) and the load transform's coefficient block
     std::vector<void *> mstates;
     int x2_ready = 0;
     double *x2mat = nullptr, *x2coef = nullptr;
@@ -809,7 +809,7 @@ static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32
 }
 
 // ---- two excited-state steps per pass (wafer_stencil_x2.hip.h) ------------------------------------------------------
-enum { X2_SUM_SLOT = 18 };   // scal[18 .. 18 + 2 + 3k): the sums of a two-step pass
+enum { X2_SUM_SLOT = 18 };   // scal[18 .. 18 + 1 + 2k): the sums of a two-step pass
 // ThreePoint fp64, one to three stored states, the potential inside the short reciprocal's range; z-slabs need two ghost
 // planes (a pass consumes two per side).  Every rank of a decomposed run takes the same decision: nothing here depends on
 // the local slab except v_in_range, on which the ranks agree in x2_agree.
@@ -839,8 +839,8 @@ static int x2_agree(wafer_ctx *c, uint32_t wnum, bool *out)
     return WAFER_OK;
 }
 
-// M_j = A l_j for the first wnum stored states (one ground-state step of each, grid.rs:568-592) and the matrices of the
-// coefficient kernel.  Rebuilt when w_store or the potential changed.
+// M_j = A l_j for the first wnum stored states (one ground-state step of each, grid.rs:568-592) and the matrix <l_j, M_i> of
+// the coefficient kernel.  Rebuilt when w_store or the potential changed.
 static int ensure_x2(wafer_ctx *c, uint32_t wnum)
 {
     if (c->x2_ready >= (int)wnum) return WAFER_OK;
@@ -860,19 +860,13 @@ static int ensure_x2(wafer_ctx *c, uint32_t wnum)
             return fail(WAFER_ERR_HIP, "stencil launch (image of a stored state) failed: %s", hipGetErrorString(hipGetLastError()));
         TRY(exchange_halo_array(c, c->mstates[j], c->s_main, 2));
     }
-    double host[2 * WAFER_MAX_LOW * WAFER_MAX_LOW];
+    double host[WAFER_MAX_LOW * WAFER_MAX_LOW];
     memset(host, 0, sizeof host);
-    double *amat = host, *bmat = host + WAFER_MAX_LOW * WAFER_MAX_LOW;
+    double *amat = host;
     for (uint32_t j = 0; j < wnum; ++j)
         for (uint32_t i = 0; i < wnum; ++i) {   // <l_j, M_i>
             TRY(launch_dot(c, c->mstates[i], c->states[j], 13, c->s_main));
             TRY(read_scal(c, 13, 1, &amat[j * WAFER_MAX_LOW + i], c->s_main));
-        }
-    for (uint32_t i = 0; i < wnum; ++i)
-        for (uint32_t j = i; j < wnum; ++j) {   // <M_i, M_j>
-            TRY(launch_dot(c, c->mstates[i], c->mstates[j], 13, c->s_main));
-            TRY(read_scal(c, 13, 1, &bmat[i * WAFER_MAX_LOW + j], c->s_main));
-            bmat[j * WAFER_MAX_LOW + i] = bmat[i * WAFER_MAX_LOW + j];
         }
     HIP_TRY(hipMemcpyAsync(c->x2mat, host, sizeof host, hipMemcpyHostToDevice, c->s_main));
     HIP_TRY(hipStreamSynchronize(c->s_main));
@@ -886,10 +880,10 @@ static int x2_run(wafer_ctx *c, uint32_t wnum, uint64_t pairs, hipStream_t s)
 {
     const WaferGeom &g = c->g;
     const int k = (int)wnum, nq = wafer_entry_x2_nsums(k);
-    const double *amat = c->x2mat, *bmat = c->x2mat + WAFER_MAX_LOW * WAFER_MAX_LOW;
+    const double *amat = c->x2mat;
     const void *l[3] = {nullptr, nullptr, nullptr}, *m[3] = {nullptr, nullptr, nullptr};
     for (int j = 0; j < k; ++j) { l[j] = c->states[j]; m[j] = c->mstates[j]; }
-    if (wafer_entry_x2_coeffs(1, k, c->scal, c->gram, amat, bmat, c->x2coef, s) != hipSuccess)
+    if (wafer_entry_x2_coeffs(1, k, c->scal, c->gram, amat, c->x2coef, s) != hipSuccess)
         return fail(WAFER_ERR_HIP, "coefficient kernel launch failed");
     const WaferStepArgs a = step_args(c, g.G, g.G + g.nzl);
     const long long nb = wafer_entry_x2_blocks(c->tune, g, k, closed_form_vg(c), g.G, g.G + g.nzl, c->num_cus);
@@ -903,12 +897,16 @@ static int x2_run(wafer_ctx *c, uint32_t wnum, uint64_t pairs, hipStream_t s)
         ++c->x2_passes;
         if (p + 1 < pairs) TRY(exchange_halo(c, dst, s, 2));   // (unsplit: a short exchange takes CUs from a launch that packs them, as for one step per pass)
         TRY(reduce_to_scal(c, nq, nb, X2_SUM_SLOT, s));
-        if (wafer_entry_x2_coeffs(2, k, c->scal + X2_SUM_SLOT, c->gram, amat, bmat, c->x2coef, s) != hipSuccess)
+        if (wafer_entry_x2_coeffs(2, k, c->scal + X2_SUM_SLOT, c->gram, amat, c->x2coef, s) != hipSuccess)
             return fail(WAFER_ERR_HIP, "coefficient kernel launch failed");
         c->cur = dst;
     }
-    if (wafer_entry_x2_apply(g, g.G, g.G + g.nzl, k, c->phi[c->cur], l, m, c->x2coef, c->num_cus, s) != hipSuccess)
+    // phi = x~ / n_c: the last step's normalisation (grid.rs:679), its norm taken directly as the sum of squares of Y2
+    int nap = 0;
+    if (wafer_entry_x2_apply(g, g.G, g.G + g.nzl, k, c->phi[c->cur], l, m, c->x2coef, c->partials, c->partials_stride, c->num_cus, s, &nap) != hipSuccess)
         return fail(WAFER_ERR_HIP, "apply launch failed");
+    TRY(reduce_to_scal(c, 1, nap, X2_SUM_SLOT, s));
+    TRY(launch_normalise(c, c->cur, c->scal + X2_SUM_SLOT, 0.0, nullptr, 0, s));
     c->halo_valid = 0;
     return WAFER_OK;
 }

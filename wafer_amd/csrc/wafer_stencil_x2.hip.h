@@ -4,21 +4,23 @@
 // (grid.rs:674-681), which needs 1 + k global sums between two steps.  The step operator A (grid.rs:568-592) is linear, so
 // the sums of the first step need not be known while the second is computed:
 //
-//   x0                      the pass's input as the reference holds it (normalised, projected)
+//   x0                      the pass's input as the reference holds it (normalised, projected) -- or any positive multiple
 //   Y1 = A x0               first raw step            n_b = sqrt(sum Y1^2),  s^b_j from t_j = sum l_j Y1      (:675-680)
-//   x1 = Y1 / n_b - sum_j s^b_j l_j                   the reference's state after step 1
+//   x1 = Y1 / n_b - sum_j s^b_j l_j                   the reference's state after step 1 (the scale of x0 has dropped out)
 //   Y2 = A x1 = A(Y1) / n_b - sum_j s^b_j M_j         second raw step, with M_j = A l_j stored once per stored state
-//   x2 = Y2 / n_c - sum_j s^c_j l_j                   the reference's state after step 2
+//   x2 = (Y2 - sum_j sigma_j l_j) / n_c               the reference's state after step 2: sigma_j = n_c s^c_j, n_c = |Y2|
 //
 // The kernel computes Y1 = A x0 and Z = A Y1 in one pass (Y1 never leaves the CU) and stores the RAW Z; the NEXT pass forms
-//   x2 = (Z / n_b - sum_j s^b_j M_j) / n_c - sum_j s^c_j l_j
-// for every cell it loads (own cells, halo rows, halo columns), in the reference's per-cell operation order (a true
-// division, then k subtractions, twice).  The scalars come from sums taken during the pass -- sum Y1^2, sum l_j Y1 (they give
-// n_b, s^b) and sum Z^2, sum l_j Z, sum M_j Z, from which, with the constant matrices <l_j, M_i> and <M_i, M_j>,
-//   sum Y2^2 = sum Z^2 / n_b^2 - (2 / n_b) sum_j s^b_j sum M_j Z + sum_ij s^b_i s^b_j <M_i, M_j>
-//   sum l_j Y2 = sum l_j Z / n_b - sum_i s^b_i <l_j, M_i>
+//   x~ = Z / n_b - sum_j s^b_j M_j - sum_j sigma_j l_j      ( = n_c x2 )
+// for every cell it loads (own cells, halo rows, halo columns).  It never divides by n_c: the first thing that happens to
+// the next pass's Y1 is the division by ITS norm, so a common positive factor of the input changes no later state -- and n_c,
+// the one scalar whose regrouped form would subtract nearly equal sums when the state lies close to the span of the stored
+// states, is not needed at all (n_c is 1 - O(dt): the magnitudes stay where the reference has them; the last pass's n_c is
+// taken directly, as a sum of squares, when phi is materialised).  The scalars come from 1 + 2k sums taken during the pass --
+// sum Y1^2, sum l_j Y1 (they give n_b, s^b by the recurrence of wafer_k_gs_apply) and sum l_j Z, from which, with the constant
+// matrix <l_j, M_i>,   sum l_j Y2 = sum l_j Z / n_b - sum_i s^b_i <l_j, M_i>   and sigma_j by the same recurrence
 // (wafer_k_x2_coeffs, one thread).  Exact in exact arithmetic; in fp64 the state stays within 1e-16 of the reference's
-// sequence per cell (tools/excited_two_step_feasibility.py; tests hold it to the 1e-13 of every excited-state test).
+// sequence per cell (tests hold it to the 1e-13 of every excited-state test).
 // Streams per TWO updates: Z in, k x l_j, k x M_j, Z out (+ V unless its closed form is evaluated): (2 + 2k) * 8 B against
 // 2 * (2 + k) * 8 B for two one-step passes -- 16 / 24 / 32 B per update at k = 1 / 2 / 3 against 24 / 32 / 40.
 //
@@ -29,9 +31,9 @@
 //   waves 2..5   the 4 (TY + 4) x0 halo-column cells, one per lane: Y1 on the inner column
 // a, b of a cell are formed once per pass (level 1) and ride to level 2 as a and b dt.
 // The sums of a plane are all taken when its Z is produced (Y1 of that plane is still in its z-queue), which is three
-// planes after l_j, M_j of that plane were loaded for the transform: the stored states' values at the lane's own cells wait
-// in an LDS queue private to each lane (two slots per array, no barrier involved) plus one plane in registers.  That queue
-// is what sets the tile height: 128 x 16 tiles (RY = 2) fit k = 1 (145 KB of LDS); k = 2, 3 run on 128 x 8 tiles (RY = 1).
+// planes after l_j of that plane was loaded for the transform: the stored states' values at the lane's own cells wait in an
+// LDS queue private to each lane (no barrier involved).  Registers set the tile height: 128 x 16 tiles (RY = 2) for one stored
+// state, 128 x 8 tiles (RY = 1) for two and three (wafer_x2_ry).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "wafer_geom.h"
@@ -40,15 +42,12 @@
 #include "wafer_stencil_fused2.hip.h"
 #include "wafer_rowwalk.h"
 
-// the coefficient block the load transform reads (device memory, doubles)
+// the coefficient block the load transform reads (device memory, doubles):  x~ = w * W0 - sum_j m_j SB_j - sum_j l_j SC_j
 enum {
-    WAFER_X2_NB = 0,                      // n_b
-    WAFER_X2_NC = 1,                      // n_c
-    WAFER_X2_SB = 2,                      // s^b_j, j < WAFER_MAX_LOW
-    WAFER_X2_SC = 2 + WAFER_MAX_LOW,      // s^c_j
-    WAFER_X2_W0 = 2 + 2 * WAFER_MAX_LOW,  // 1 / (n_b n_c)
-    WAFER_X2_SBN = 3 + 2 * WAFER_MAX_LOW, // s^b_j / n_c
-    WAFER_X2_COEF_DOUBLES = 3 + 3 * WAFER_MAX_LOW
+    WAFER_X2_W0 = 0,                      // 1 / n_b
+    WAFER_X2_SB = 1,                      // s^b_j, j < WAFER_MAX_LOW
+    WAFER_X2_SC = 1 + WAFER_MAX_LOW,      // sigma_j
+    WAFER_X2_COEF_DOUBLES = 1 + 2 * WAFER_MAX_LOW
 };
 enum { WAFER_X2_MAX_LOW = 3 };
 
@@ -58,8 +57,8 @@ struct WaferX2Ptrs {
 };
 
 // sums a pass leaves: partials[q * pstride + workgroup], q in this order
-//   0: sum Y1^2   1 .. k: sum l_j Y1   k+1: sum Z^2   k+2 .. 2k+1: sum l_j Z   2k+2 .. 3k+1: sum M_j Z
-static inline int wafer_x2_nsums(int k) { return 2 + 3 * k; }
+//   0: sum Y1^2   1 .. k: sum l_j Y1   k+1 .. 2k: sum l_j Z
+static inline int wafer_x2_nsums(int k) { return 1 + 2 * k; }
 
 template <int RY_>
 struct WaferX2Cfg {
@@ -80,47 +79,24 @@ struct WaferX2Cfg {
     static constexpr int QSLOT = TY * TX;               // elements of one array's plane in the LDS queue
 };
 
-// x = (w / n_b - sum_j m_j s^b_j) / n_c - sum_j l_j s^c_j        (grid.rs:467, 488-490, twice)
-// evaluated as  w * (1 / (n_b n_c)) - sum_j m_j (s^b_j / n_c) - sum_j l_j s^c_j : 1 + 4k instructions per cell instead of the
-// 12 + 4k of two true divisions.  The pass is not bit-comparable with the reference's sequence anyway (its sums are
-// regrouped); what is held is the excited-state bar, 1e-13 per cell, and each of these roundings is one ulp of a cell's
-// value.  kf.w0 = 1 / (n_b n_c), kf.sb[j] = s^b_j / n_c as loaded from the coefficient block (wafer_k_x2_coeffs writes both
-// forms).  Measured on one box, 512^3, k = 1 (tools/gpu_batch.sh ab_alt_x2): separate products and differences 0.461 ms per
-// step, the two divisions 0.480, fused multiply-adds 0.496 -- the independent products overlap, the fused chain does not --
-// so the products stay separate (-DWAFER_X2_DIV_XFORM / -DWAFER_X2_FMA_XFORM build the other two).
+// x~ = w / n_b - sum_j m_j s^b_j - sum_j l_j sigma_j, evaluated with the reciprocal of n_b and SEPARATE products and differences:
+// measured on one box, 512^3, k = 1 (profiles/r04_ab_x2_transform_k1.jsonl): 0.461 ms per step against 0.480 with a true
+// division and 0.496 with fused multiply-adds -- the independent products overlap, the fused chain is serial.  Each rounding
+// is one ulp of a cell's value; the pass is held to the excited-state bar, 1e-13 per cell.
 template <int NL>
 struct WaferX2Coef {
     double w0, sb[NL], sc[NL];
-#ifdef WAFER_X2_DIV_XFORM
-    double nb, nc, sbr[NL];
-#endif
 };
 template <int NL>
-__device__ __forceinline__ double wafer_x2_xform(const WaferX2Coef<NL> &k, double w, const double *l, const double *m)
+__device__ __forceinline__ double wafer_x2_xform(const WaferX2Coef<NL> &k, double w, const double *l, const double *m, double *u_out = nullptr)
 {
-#ifdef WAFER_X2_DIV_XFORM
-    double u = wafer_div_invariant<double>(w, k.nb);
-#pragma unroll
-    for (int j = 0; j < NL; ++j) u = u - m[j] * k.sbr[j];
-    double x = wafer_div_invariant<double>(u, k.nc);
-#pragma unroll
-    for (int j = 0; j < NL; ++j) x = x - l[j] * k.sc[j];
-    return x;
-#elif defined(WAFER_X2_FMA_XFORM)
-    double x = w * k.w0;
-#pragma unroll
-    for (int j = 0; j < NL; ++j) x = __builtin_fma(-m[j], k.sb[j], x);
-#pragma unroll
-    for (int j = 0; j < NL; ++j) x = __builtin_fma(-l[j], k.sc[j], x);
-    return x;
-#else
     double x = w * k.w0;
 #pragma unroll
     for (int j = 0; j < NL; ++j) x = x - m[j] * k.sb[j];
+    if (u_out) *u_out = x;   // Y2 up to the factor the pass carries: its norm is n_c (wafer_k_x2_apply)
 #pragma unroll
     for (int j = 0; j < NL; ++j) x = x - l[j] * k.sc[j];
     return x;
-#endif
 }
 
 template <int RY, int NL, int VG, bool VIR>
@@ -140,13 +116,13 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     static_assert(NL >= 1 && NL <= WAFER_X2_MAX_LOW, "one to three stored states");
     __shared__ __attribute__((aligned(16))) T lds0[2 * Cfg::TILE0];
     __shared__ __attribute__((aligned(16))) T lds1[2 * Cfg::TILE1];
-    // L3: a third slot for the l_j where LDS allows it (RY = 2 with one stored state: 158 KB): a plane's l_j go to LDS right
-    // after the transform instead of waiting an iteration in registers (8 VGPRs per stored state); the two-slot queue then
-    // holds the m_j only
-    constexpr bool L3 = (RY == 2 && NL == 1);
-    constexpr int NA = L3 ? NL : 2 * NL;                               // arrays per slot of the two-slot queue
-    __shared__ __attribute__((aligned(16))) T ldsq[2 * NA * QS];       // [slot][array: l_0, m_0, l_1, m_1, ... (L3: m_0, ...)][row][x]
-    __shared__ __attribute__((aligned(16))) T ldsl3[L3 ? 3 * NL * QS : 2];
+    // The stored states' values at the lane's own cells wait three planes between the transform and the sums: in an LDS queue of
+    // three slots per state (written right after the transform, read when that plane's Z is produced; private to each lane, no
+    // barrier), or -- 128 x 16 tiles with two stored states, where LDS has room for two slots only -- two slots plus one plane
+    // in registers (HOLD).  Only the l_j wait: the M_j are used by the transform alone (see the head of this file).
+    constexpr bool HOLD = (RY == 2 && NL == 2);
+    constexpr int NSLOT = HOLD ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) T ldsq[NSLOT * NL * QS];   // [slot][state][row][x]
     __shared__ double red[Cfg::NW];
 
     const WaferGeom &g = a.g;
@@ -170,15 +146,9 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     kf.w0 = coef[WAFER_X2_W0];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-        kf.sb[j] = coef[WAFER_X2_SBN + j];
+        kf.sb[j] = coef[WAFER_X2_SB + j];
         kf.sc[j] = coef[WAFER_X2_SC + j];
     }
-#ifdef WAFER_X2_DIV_XFORM
-    kf.nb = coef[WAFER_X2_NB];
-    kf.nc = coef[WAFER_X2_NC];
-#pragma unroll
-    for (int j = 0; j < NL; ++j) kf.sbr[j] = coef[WAFER_X2_SB + j];
-#endif
     [[maybe_unused]] WaferPotArgs vgen;
     if constexpr (VG != 0) {
         vgen.g = g;
@@ -261,7 +231,9 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     // ---- state
     const int z1 = zs - 1;   // level 1 produces planes z1 .. ze, level 2 planes zs .. ze - 1
     VT q0[3][RY], q1[3][RY], vcur[RY], caq[RY], cbq[RY];
-    VT hold_l[NL][RY], hold_m[NL][RY];      // stored states at the lane's own cells, plane z + 1 (transformed last iteration)
+    [[maybe_unused]] VT hold_l[NL][RY];     // HOLD: the stored states at the lane's own cells, plane z + 1 (transformed last iteration)
+    // queue slot of plane p (HOLD: two slots by parity, written one iteration late from hold_l)
+    auto qslot = [&](int p) -> T * { return ldsq + ((HOLD ? (p & 1) : (p % 3)) * NL) * QS; };
     VT xq0[3], xv;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -282,9 +254,8 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
                 l[j] = *reinterpret_cast<const VT *>((st.l[j] + po + rowoff[r]) + xlu);
                 mm[j] = *reinterpret_cast<const VT *>((st.m[j] + po + rowoff[r]) + xlu);
                 if (m == 2) {
-                    hold_m[j][r] = mm[j];
-                    if constexpr (L3) *reinterpret_cast<VT *>(ldsl3 + (((z1 + 1) % 3) * NL + j) * QS + qoff[r]) = l[j];
-                    else hold_l[j][r] = l[j];
+                    if constexpr (HOLD) hold_l[j][r] = l[j];
+                    else *reinterpret_cast<VT *>(qslot(z1 + 1) + j * QS + qoff[r]) = l[j];
                 }
             }
             q0[m][r] = xform_vec(*reinterpret_cast<const VT *>((phi + po + rowoff[r]) + xlu), l, mm);
@@ -324,9 +295,9 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     }
     __syncthreads();
 
-    double acc_y = 0.0, acc_z = 0.0, acc_yl[NL], acc_zl[NL], acc_zm[NL];
+    double acc_y = 0.0, acc_yl[NL], acc_zl[NL];
 #pragma unroll
-    for (int j = 0; j < NL; ++j) acc_yl[j] = acc_zl[j] = acc_zm[j] = 0.0;
+    for (int j = 0; j < NL; ++j) acc_yl[j] = acc_zl[j] = 0.0;
 
     const int niter = (ze - zs) + 2;
     for (int it = 0; it < niter; ++it) {
@@ -439,18 +410,14 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
         else level1(std::false_type{});
         // level 2's neighbours and the stored states of the plane it is about to produce (the lane's own LDS queue), requested
         // behind level 1's arithmetic
-        VT lq[NL][RY], mq[NL][RY];
+        VT lq[NL][RY];
         if (act2) {
             nbload(std::integral_constant<int, 1>{});
-            const T *qs = ldsq + ((z - 1) & 1) * (NA * QS);
+            const T *qs = qslot(z - 1);
 #pragma unroll
             for (int j = 0; j < NL; ++j)
 #pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    if constexpr (L3) lq[j][r] = *reinterpret_cast<const VT *>(ldsl3 + (((z - 1) % 3) * NL + j) * QS + qoff[r]);
-                    else lq[j][r] = *reinterpret_cast<const VT *>(qs + (2 * j) * QS + qoff[r]);
-                    mq[j][r] = *reinterpret_cast<const VT *>(qs + (L3 ? j : 2 * j + 1) * QS + qoff[r]);
-                }
+                for (int r = 0; r < RY; ++r) lq[j][r] = *reinterpret_cast<const VT *>(qs + j * QS + qoff[r]);
         }
         // ---- 3x. level 1, the extra slot
         if (x_row) {
@@ -526,20 +493,18 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
                         }
                     }
                 }
-                // the five kinds of sums of this plane: Y1 (still in its queue) and Z against themselves and against the
-                // stored states.  Cells outside the work area hold exact zeros at both levels, so nothing is masked here.
+                // the sums of this plane: Y1 (still in its queue) against itself and the stored states, Z against the stored
+                // states.  Cells outside the work area hold exact zeros at both levels, so nothing is masked here.
 #pragma unroll
                 for (int r = 0; r < RY; ++r)
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         const double yv = q1[1][r][v], zv = res2[r][v];
                         acc_y = __builtin_fma(yv, yv, acc_y);
-                        acc_z = __builtin_fma(zv, zv, acc_z);
 #pragma unroll
                         for (int j = 0; j < NL; ++j) {
                             acc_yl[j] = __builtin_fma(lq[j][r][v], yv, acc_yl[j]);
                             acc_zl[j] = __builtin_fma(lq[j][r][v], zv, acc_zl[j]);
-                            acc_zm[j] = __builtin_fma(mq[j][r][v], zv, acc_zm[j]);
                         }
                     }
 #pragma unroll
@@ -559,16 +524,13 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
             if (all_rows && wplane2) level2(std::true_type{});
             else level2(std::false_type{});
         }
-        // the plane transformed last iteration (z + 1) takes the queue slot just read (same lanes: program order suffices)
-        {
-            T *qd = ldsq + ((z + 1) & 1) * (NA * QS);
+        // HOLD: the plane transformed last iteration (z + 1) takes the queue slot just read (same lanes: program order suffices)
+        if constexpr (HOLD) {
+            T *qd = qslot(z + 1);
 #pragma unroll
             for (int j = 0; j < NL; ++j)
 #pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    if constexpr (!L3) *reinterpret_cast<VT *>(qd + (2 * j) * QS + qoff[r]) = hold_l[j][r];
-                    *reinterpret_cast<VT *>(qd + (L3 ? j : 2 * j + 1) * QS + qoff[r]) = hold_m[j][r];
-                }
+                for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(qd + j * QS + qoff[r]) = hold_l[j][r];
         }
         __syncthreads();
         // ---- 5. rotate the pipelines; the plane requested at the top of the iteration is transformed here -- BEHIND the
@@ -600,9 +562,8 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
                 l[j] = pre_l[j][r];
                 mm[j] = pre_m[j][r];
                 // plane z + 2: read at iteration z + 3, as plane (z + 3) - 1 -- its slot (z + 2) % 3 was last read at iteration z
-                if constexpr (L3) *reinterpret_cast<VT *>(ldsl3 + (((z + 2) % 3) * NL + j) * QS + qoff[r]) = l[j];
-                else hold_l[j][r] = l[j];
-                hold_m[j][r] = mm[j];
+                if constexpr (HOLD) hold_l[j][r] = l[j];
+                else *reinterpret_cast<VT *>(qslot(z + 2) + j * QS + qoff[r]) = l[j];
             }
             q0[2][r] = xform_vec(pre[r], l, mm);
             vcur[r] = pre_v[r];
@@ -632,25 +593,21 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
         put(acc_y);
 #pragma unroll
         for (int j = 0; j < NL; ++j) put(acc_yl[j]);
-        put(acc_z);
 #pragma unroll
         for (int j = 0; j < NL; ++j) put(acc_zl[j]);
-#pragma unroll
-        for (int j = 0; j < NL; ++j) put(acc_zm[j]);
     }
 }
 
 // ---- the scalars between two passes (one thread) ------------------------------------------------------------------
-// kind 1: `sums` = what a ONE-step kernel left (sum Y^2, t_j = sum l_j Y): the buffer holds Y = A x, and the transform
-//         x = Y / n - sum_j s_j l_j is written as n_b = 1, s^b = 0, n_c = n, s^c = s (Y / 1 and - 0 * M_j are exact);
-// kind 2: `sums` = the 2 + 3k sums of a two-step pass (order: wafer_x2_nsums).
-// gram[j * WAFER_MAX_LOW + i] = <l_j, l_i> (i < j), amat[j * WAFER_MAX_LOW + i] = <l_j, M_i>, bmat[i * WAFER_MAX_LOW + j] = <M_i, M_j>.
+// kind 1: `sums` = what a ONE-step kernel left (sum Y^2, t_j = sum l_j Y): the buffer holds Y = A x and the transform is the
+//         reference's x = Y / n - sum_j s_j l_j: W0 = 1 / n, SB = 0, SC = s (0 * M_j is exact);
+// kind 2: `sums` = the 1 + 2k sums of a two-step pass (order: wafer_x2_nsums).
+// gram[j * WAFER_MAX_LOW + i] = <l_j, l_i> (i < j), amat[j * WAFER_MAX_LOW + i] = <l_j, M_i>.
 __global__ void wafer_k_x2_coeffs(int kind, int k, const double *__restrict__ sums, const double *__restrict__ gram,
-                                  const double *__restrict__ amat, const double *__restrict__ bmat, double *__restrict__ coef)
+                                  const double *__restrict__ amat, double *__restrict__ coef)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double sb[WAFER_MAX_LOW] = {0, 0, 0, 0}, sc[WAFER_MAX_LOW] = {0, 0, 0, 0};
-    double nb = 1.0, nc = 1.0;
     // the reference's sequential overlaps from raw ones: s_j = t_j / n - sum_{i<j} s_i G_ji  (wafer_k_gs_apply)
     auto mgs = [&](double n, const double *t, double *s) {
         for (int j = 0; j < k; ++j) {
@@ -659,62 +616,48 @@ __global__ void wafer_k_x2_coeffs(int kind, int k, const double *__restrict__ su
             s[j] = v;
         }
     };
+    const double n = sqrt(sums[0]);
     if (kind == 1) {
-        nc = sqrt(sums[0]);
-        mgs(nc, sums + 1, sc);
+        mgs(n, sums + 1, sc);
     } else {
-        const double *t1 = sums + 1, *zl = sums + k + 2, *zm = sums + 2 * k + 2;
-        const double zz = sums[k + 1];
-        nb = sqrt(sums[0]);
-        mgs(nb, t1, sb);
-        double sq = zz / (nb * nb), cross = 0.0, quad = 0.0;
-        for (int j = 0; j < k; ++j) cross += sb[j] * zm[j];
-        for (int i = 0; i < k; ++i)
-            for (int j = 0; j < k; ++j) quad += sb[i] * sb[j] * bmat[i * WAFER_MAX_LOW + j];
-        sq = sq - 2.0 / nb * cross + quad;
+        const double *t1 = sums + 1, *zl = sums + k + 1;
+        mgs(n, t1, sb);
         double t2[WAFER_MAX_LOW];
-        for (int j = 0; j < k; ++j) {
-            double v = zl[j] / nb;
+        for (int j = 0; j < k; ++j) {   // sum l_j Y2 (in the pass's scale)
+            double v = zl[j] / n;
             for (int i = 0; i < k; ++i) v -= sb[i] * amat[j * WAFER_MAX_LOW + i];
             t2[j] = v;
         }
-        nc = sqrt(sq);
-        mgs(nc, t2, sc);
+        mgs(1.0, t2, sc);               // sigma_j = n_c s^c_j: the same recurrence, not divided by the norm
     }
-    coef[WAFER_X2_NB] = nb;
-    coef[WAFER_X2_NC] = nc;
-    coef[WAFER_X2_W0] = 1.0 / (nb * nc);
+    coef[WAFER_X2_W0] = 1.0 / n;
     for (int j = 0; j < WAFER_MAX_LOW; ++j) {
         coef[WAFER_X2_SB + j] = sb[j];
         coef[WAFER_X2_SC + j] = sc[j];
-        coef[WAFER_X2_SBN + j] = sb[j] / nc;
     }
 }
 
-// ---- phi materialised after the last pass: the load transform as an elementwise pass, in place ------------------------
+// ---- phi materialised after the last pass: x~ written in place, sum Y2^2 (= n_c^2 in the pass's scale) to partials[workgroup];
+//      the caller divides by its square root (wafer_k_row_op<2>: grid.rs:467) ------------------------------------------------
 template <int NL>
 __global__ __launch_bounds__(256) void wafer_k_x2_apply(WaferRowArgs a, double *__restrict__ phi, WaferX2Ptrs st,
-                                                        const double *__restrict__ coef)
+                                                        const double *__restrict__ coef, double *__restrict__ partials)
 {
     using VT = typename WaferRowVec<double>::type;
     constexpr int VEC = 2;
+    __shared__ double red[4];
     const WaferGeom &g = a.g;
     WaferX2Coef<NL> kf;
     kf.w0 = coef[WAFER_X2_W0];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-        kf.sb[j] = coef[WAFER_X2_SBN + j];
+        kf.sb[j] = coef[WAFER_X2_SB + j];
         kf.sc[j] = coef[WAFER_X2_SC + j];
     }
-#ifdef WAFER_X2_DIV_XFORM
-    kf.nb = coef[WAFER_X2_NB];
-    kf.nc = coef[WAFER_X2_NC];
-#pragma unroll
-    for (int j = 0; j < NL; ++j) kf.sbr[j] = coef[WAFER_X2_SB + j];
-#endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nsegx = (g.nx + 64 * VEC - 1) / (64 * VEC);
     const int wlim = g.pitch - g.xoff - g.R;
+    double acc = 0.0;
     WAFER_ROW_WALK_BEGIN(a, g)
     for (int xs = 0; xs < nsegx; ++xs) {
         const int xi = xs * 64 * VEC + lane * VEC;
@@ -730,10 +673,11 @@ __global__ __launch_bounds__(256) void wafer_k_x2_apply(WaferRowArgs a, double *
         VT r;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            double lv[NL], mv[NL];
+            double lv[NL], mv[NL], u;
 #pragma unroll
             for (int j = 0; j < NL; ++j) { lv[j] = l[j][v]; mv[j] = m[j][v]; }
-            r[v] = wafer_x2_xform<NL>(kf, w[v], lv, mv);
+            r[v] = wafer_x2_xform<NL>(kf, w[v], lv, mv, &u);
+            if (xi + v < g.nx) acc += u * u;
         }
         if (xi + VEC <= g.nx) {
             *reinterpret_cast<VT *>(phi + p) = r;
@@ -744,17 +688,21 @@ __global__ __launch_bounds__(256) void wafer_k_x2_apply(WaferRowArgs a, double *
         }
     }
     WAFER_ROW_WALK_END(g)
+    const double sum = wafer_block_sum<4>(acc, red, threadIdx.x);
+    if (threadIdx.x == 0) partials[blockIdx.x] = sum;
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
-// rows per lane for k stored states: what the LDS queue allows (see the head of this file), and for k = 1 what the registers
-// allow: with V streamed (vg == 0: file / script potentials, the nine other built-ins) the 128 x 16 tile spills 80 B per lane,
-// so it runs on 128 x 8 tiles like k = 2, 3.  WAFER_X2_RY overrides (tests).
+// rows per lane for k stored states: the registers decide.  128 x 16 tiles (RY = 2) for one stored state (230-246 VGPRs, closed-form
+// and streamed V alike); for two the tall tile needs 256 VGPRs + 72 B of scratch per lane and loses to the lower one (512^3
+// Coulomb, same box: 0.793 against 0.755 ms/step; one step per pass 0.817), so two and three run on 128 x 8 tiles (RY = 1).
+// WAFER_X2_RY overrides for k <= 2 (tests, sweeps).
 static inline int wafer_x2_ry(const WaferTuning &t, int k, int vg)
 {
-    if (k > 1) return 1;
+    (void)vg;
+    if (k > 2) return 1;
     if (t.x2_ry == 1 || t.x2_ry == 2) return t.x2_ry;
-    return vg != 0 ? 2 : 1;
+    return k == 1 ? 2 : 1;
 }
 static inline void wafer_x2_tile(const WaferTuning &t, int k, int vg, int *tx, int *ty)
 {
@@ -807,6 +755,7 @@ static inline hipError_t wafer_launch_xstep2(const WaferTuning &t, const WaferSt
         return wafer_launch_xstep2_one<RY_, NL_, VG_>(t, a, phi, pv, out, partials, partials_cap, st, coef, s);
 #define WAFER_X2_CASES(RY_, NL_) WAFER_X2_CASE(RY_, NL_, 0) WAFER_X2_CASE(RY_, NL_, 4) WAFER_X2_CASE(RY_, NL_, 7) WAFER_X2_CASE(RY_, NL_, 9)
     WAFER_X2_CASES(2, 1)
+    WAFER_X2_CASES(2, 2)
     WAFER_X2_CASES(1, 1)
     WAFER_X2_CASES(1, 2)
     WAFER_X2_CASES(1, 3)
@@ -815,14 +764,17 @@ static inline hipError_t wafer_launch_xstep2(const WaferTuning &t, const WaferSt
     return hipErrorInvalidValue;
 }
 
+// x~ in place and the partial sums of Y2^2 (one per workgroup; *nblocks_out of them)
 static inline hipError_t wafer_launch_x2_apply(const WaferRowArgs &ra, int k, double *phi, const WaferX2Ptrs &st, const double *coef,
-                                               int num_cus, hipStream_t s)
+                                               double *partials, size_t partials_cap, int num_cus, hipStream_t s, int *nblocks_out)
 {
     const dim3 grid((unsigned)(num_cus * 8)), block(256);
+    if ((size_t)grid.x > partials_cap) return hipErrorInvalidValue;
+    *nblocks_out = (int)grid.x;
     switch (k) {
-    case 1: hipLaunchKernelGGL((wafer_k_x2_apply<1>), grid, block, 0, s, ra, phi, st, coef); break;
-    case 2: hipLaunchKernelGGL((wafer_k_x2_apply<2>), grid, block, 0, s, ra, phi, st, coef); break;
-    case 3: hipLaunchKernelGGL((wafer_k_x2_apply<3>), grid, block, 0, s, ra, phi, st, coef); break;
+    case 1: hipLaunchKernelGGL((wafer_k_x2_apply<1>), grid, block, 0, s, ra, phi, st, coef, partials); break;
+    case 2: hipLaunchKernelGGL((wafer_k_x2_apply<2>), grid, block, 0, s, ra, phi, st, coef, partials); break;
+    case 3: hipLaunchKernelGGL((wafer_k_x2_apply<3>), grid, block, 0, s, ra, phi, st, coef, partials); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

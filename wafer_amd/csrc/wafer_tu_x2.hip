@@ -21,21 +21,20 @@ hipError_t wafer_entry_xstep2(const WaferTuning &t, const WaferStepArgs &a, int 
                                partials, partials_cap, x2_ptrs(k, l, m), coef, s);
 }
 
-hipError_t wafer_entry_x2_coeffs(int kind, int k, const double *sums, const double *gram, const double *amat, const double *bmat,
-                                 double *coef, hipStream_t s)
+hipError_t wafer_entry_x2_coeffs(int kind, int k, const double *sums, const double *gram, const double *amat, double *coef, hipStream_t s)
 {
-    hipLaunchKernelGGL(wafer_k_x2_coeffs, dim3(1), dim3(64), 0, s, kind, k, sums, gram, amat, bmat, coef);
+    hipLaunchKernelGGL(wafer_k_x2_coeffs, dim3(1), dim3(64), 0, s, kind, k, sums, gram, amat, coef);
     return hipGetLastError();
 }
 
 hipError_t wafer_entry_x2_apply(const WaferGeom &g, int lz_lo, int lz_hi, int k, void *phi, const void *const *l, const void *const *m,
-                                const double *coef, int num_cus, hipStream_t s)
+                                const double *coef, double *partials, size_t partials_cap, int num_cus, hipStream_t s, int *nblocks_out)
 {
     WaferRowArgs ra;
     ra.g = g;
     ra.lz_lo = lz_lo;
     ra.lz_hi = lz_hi;
-    return wafer_launch_x2_apply(ra, k, static_cast<double *>(phi), x2_ptrs(k, l, m), coef, num_cus, s);
+    return wafer_launch_x2_apply(ra, k, static_cast<double *>(phi), x2_ptrs(k, l, m), coef, partials, partials_cap, num_cus, s, nblocks_out);
 }
 
 long long wafer_entry_x2_blocks(const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks)
