@@ -787,17 +787,14 @@ def test_one_pass_excited_step_equals_two_pass(wa, wnum, ext, monkeypatch):
     assert np.array_equal(out["0"][0], out["1"][0]) and out["0"][1] == out["1"][1]
 
 
-@pytest.mark.parametrize("x2", ["0", "1"])
 @pytest.mark.parametrize("potential", ["Coulomb", "SimpleCornell", "Harmonic", "ComplexCoulomb", "ComplexHarmonic"])
-@pytest.mark.parametrize("ext", [1, 2, 3])
+@pytest.mark.parametrize("ext,x2", [(1, "0"), (2, "0"), (3, "0"), (1, "1")])   # two steps per pass: ThreePoint only
 @pytest.mark.parametrize("wnum", [1, 2, 3])
 def test_closed_form_potential_evaluated_in_the_excited_step_kernel(wa, wnum, ext, potential, x2, monkeypatch):
     """the excited-state step kernels evaluate Coulomb / SimpleCornell / Harmonic (potential.rs:221-229,
     241-249, 270-274) per cell instead of streaming the stored V: the same function that filled the
     array, so identical bits per cell and identical sums (WAFER_VGEN=0 streams V); odd axes put a cell
     at r = 0 (the r < dn clamp), the ragged shape leaves partial tiles"""
-    if x2 == "1" and ext != 1:
-        pytest.skip("two steps per pass: ThreePoint only")
     shape = (133, 21, 19)
     out = {}
     # x2 = 0: one step per pass; x2 = 1: two (wafer_stencil_x2.hip.h) -- there the comparison needs the SAME tile height on

@@ -225,15 +225,17 @@ def test_deep_halo_cycles_bit_exact(wa, world, shape, ext, steps, cycle, overlap
         wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, z_begin=0, z_count=2 * ext, halo_depth=2 * ext + 1))
 
 
-@pytest.mark.parametrize("overlap", [True, False, 2, 3])   # 2: ONE launch per pass, two halves marched outwards, exchanges released by counters; 3: ... with peer stores instead of exchanges
-@pytest.mark.parametrize("cycle", [1, 2])
-@pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 32), 12), (3, (140, 17, 37), 7), (4, (130, 33, 48), 10), (2, (300, 70, 96), 11)])
+F3_SLAB_CASES = [(2, (40, 24, 32), 12), (3, (140, 17, 37), 7), (4, (130, 33, 48), 10), (2, (300, 70, 96), 11)]
+
+
+# overlap 2: ONE launch per pass, two halves marched outwards, exchanges released by counters; 3: ... with peer stores instead of
+# exchanges (four contexts on ONE GPU share hardware queues: that case runs in test_peer_store_four_slabs_in_a_subprocess)
+@pytest.mark.parametrize("world,shape,steps,cycle,overlap",
+                         [(w, sh, st, cy, ov) for (w, sh, st) in F3_SLAB_CASES for cy in (1, 2) for ov in (True, False, 2, 3) if not (ov == 3 and w > 3)])
 def test_three_step_kernel_on_slabs_bit_exact(wa, world, shape, steps, cycle, overlap, monkeypatch):
     """three fused ThreePoint steps per pass on z-slabs (3 ghost planes per pass and side; 6 with one exchange
     per two passes): boundary-first overlap, the mixed long / short interior launch, two-step and single-step
     remainders with their own exchange depths in between -- the same bits as one context"""
-    if overlap == 3 and world > 3:
-        pytest.skip("peer stores, four contexts on ONE GPU: two ranks' kernels share a hardware queue (see test_peer_store_four_slabs_in_a_subprocess)")
     monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
     base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1, halo_depth=3 * cycle)
     with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1)) as ctx:
