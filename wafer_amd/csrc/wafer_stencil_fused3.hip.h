@@ -121,35 +121,59 @@ enum { WAFER_F3_SYNC_STRIDE = 8 }; // 64-bit words between the two counters / fl
 // that may still be busy with host work between calls (file output, a table upload, RCCL channel set-up) -- and a
 // workgroup that gives up poisons everything it still stores (NaN), so that results built from stale ghost planes cannot
 // be mistaken for an answer; the host reports WAFER_ERR_COMM at its next synchronisation.
-__device__ __forceinline__ bool wafer_f3_wait(const WaferF3Sync &sy, int idx, int tid)
+__device__ __forceinline__ bool wafer_f3_wait(const volatile WaferF3Sync *sy, int idx, int tid)
 {
     __shared__ unsigned gave_up;
     if (tid == 0) {
         unsigned spins = 0, bad = 0;
-        const unsigned long long *fw = sy.flag + idx * WAFER_F3_SYNC_STRIDE;
+        const unsigned long long *fw = const_cast<const unsigned long long *>(sy->flag) + idx * WAFER_F3_SYNC_STRIDE;
+        const unsigned long long need = sy->need[idx];
+        const unsigned max_spins = sy->max_spins;
+        const bool peer = sy->peer != 0;
         // (peer mode: the word is written by another device, or another process on this one: system scope)
-        while ((sy.peer ? __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                        : __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < sy.need[idx]) {
+        while ((peer ? __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                     : __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
             __builtin_amdgcn_s_sleep(32);
-            if (++spins > sy.max_spins) { // the exchange never arrived
-                __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (++spins > max_spins) { // the exchange never arrived
+                __hip_atomic_store(const_cast<unsigned *>(sy->err), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 bad = 1;
                 break;
             }
         }
         gave_up = bad;
         // system scope: the ghost planes were written by another kernel, possibly (through the fabric) of another device
-        if (!(sy.debug & 4)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (!(sy->debug & 4)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     return __builtin_amdgcn_readfirstlane(gave_up) != 0;
 }
 
+// The kernel's arguments as they lie in the kernarg segment (by-value aggregates follow the C layout rules).  The
+// synchronising instantiations read WaferF3Sync THERE, at the two or three places that need it, instead of through the
+// parameter: as a parameter its sixteen scalars are live across the plane loop of a kernel that is out of scalar registers
+// (106 SGPRs; 42 of them spilled to vector lanes with mode 2's paths, 76 with the peer paths, 2 without either).
+struct WaferF3KernArgs {
+    WaferStepArgs a;
+    int ntx;
+    const WaferF3Block *table;
+    WaferF3Sync sy;
+    const void *phi, *pv;
+    void *out;
+};
+__device__ __forceinline__ const volatile WaferF3Sync *wafer_f3_sync_in_kernarg()
+{
+    return &((const volatile WaferF3KernArgs *)__builtin_amdgcn_kernarg_segment_ptr())->sy;
+}
+
 // PEER: the instantiation that serves overlap mode 3 (peer stores, the early wait and the early count of whole-column passes).
 // A separate instantiation because the mere presence of those paths costs the plain kernel 8 % (0.2789 against 0.2578 ms/step at
 // 512^3, same box: more live scalars and a longer loop body around the stores).
-template <typename T, typename C, bool VIR, bool DOWN, bool PEER>
+// MODE: 0 = no synchronisation at all (undecomposed grids, unsplit passes: the benchmark's kernel) -- the table's wait / bump
+// fields are ignored and WaferF3Sync is dead, which takes its sixteen scalars out of a kernel that spills scalar registers
+// (106 SGPRs, 42 spilled to vector lanes with the sync paths compiled in); 1 = the single-launch pass of overlap mode 2;
+// 2 = peer stores (overlap mode 3).
+template <typename T, typename C, bool VIR, bool DOWN, int MODE>
 __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const WaferF3Block &blk, int ntx, const WaferF3Sync &sy,
                                                   const T *__restrict__ phi, const T *__restrict__ pv, T *__restrict__ out,
                                                   T *lds0, T *lds1, T *lds2)
@@ -166,11 +190,14 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     const int tx_i = blk.tile % ntx, ty_i = blk.tile / ntx;
     const int zs = blk.zs, ze = blk.ze;
     const int tid = threadIdx.x, lane = tid & 63;
+    constexpr bool PEER = MODE == 2, SYNC = MODE != 0;
+    (void)sy;   // (never read through the parameter: see WaferF3KernArgs)
+    [[maybe_unused]] const volatile WaferF3Sync *const syv = SYNC ? wafer_f3_sync_in_kernarg() : nullptr;
     const int wait_early = PEER ? ((blk.down >> 8) & 3) - 1 : -1, bump_early = PEER ? ((blk.down >> 16) & 3) - 1 : -1;
     bool poisoned = false;   // a ghost-flag wait gave up: everything stored from here on is NaN (wafer_f3_wait)
     // a whole-column pass starts at a ghost side: its planes are loaded by the prologue
     if constexpr (PEER) {
-        if (wait_early >= 0) poisoned = wafer_f3_wait(sy, wait_early, tid);
+        if (wait_early >= 0) poisoned = wafer_f3_wait(syv, wait_early, tid);
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = tx_i * TX, y0 = ty_i * TY;
@@ -231,6 +258,9 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     const long long c_off = (long long)((cy < 0 ? y0 : cy >= g.ny ? y0 + TY - 1 : cy) + R) * g.pitch + g.xoff + R +
                             ((cxw < 0 || cxw >= g.nx) ? (ck < Cfg::HC0 ? x0 : x0 + TX - 1) : cxw);
     const int c_lds0 = crow * LP0 + HX0 + clc, c_lds1 = (crow - 1) * LP1 + HX1 + clc, c_lds2 = (crow - 2) * LP2 + HX2 + clc;
+    // per-lane element offsets of the extra slot's requests inside a plane (see the prefetch at the top of the plane loop)
+    const long long xslot_off = x_row ? xoff_row + (long long)xlu : c_off;
+    const long long orow_slot_off = has_orow ? orow_off + (long long)xlu : xslot_off;
 
     auto work_plane = [&](int p) {
         const int kg = g.z_begin + (p - g.G);
@@ -292,12 +322,32 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     if (has_orow) orow_nxt = *reinterpret_cast<const VT *>((phi + (long long)(z1 + SD) * g.plane + orow_off) + xlu);
     __syncthreads();
 
+    // Peer stores: where the first / last wt planes of the march go in the neighbours' buffers, read ONCE from the device copy
+    // of the connection and held in VECTOR registers (the pin): as scalars they stay live across a plane loop that has none to
+    // spare (6-8 % in round 4's first version), and read inside the loop the loads of a rarely taken branch make the wait-count
+    // pass pessimistic about every prefetch in flight (0.325 against 0.273 ms/step at the bench slab).
+    [[maybe_unused]] T *peer_first = nullptr, *peer_last = nullptr;
+    if constexpr (PEER) {
+        const volatile WaferF3Peer *pi = syv->peer_dev;
+        const int buf = syv->peer_buf;
+        if (bump_early >= 0) {
+            T *const base = static_cast<T *>(pi->out[bump_early][buf]);
+            if (base) peer_first = base + pi->zshift[bump_early] * g.plane;
+        }
+        if (blk.bump >= 0) {
+            T *const base = static_cast<T *>(pi->out[blk.bump & 1][buf]);
+            if (base) peer_last = base + pi->zshift[blk.bump & 1] * g.plane;
+        }
+        asm volatile("" : "+v"(peer_first), "+v"(peer_last));
+    }
     const int niter = (ze - zs) + 4;
     for (int it = 0; it < niter; ++it) {
         const int z = z1 + SD * it;
         const bool more = it + 1 < niter;
         const long long zo = (long long)z * g.plane;
-        if (blk.wait_late >= 0 && it == blk.wait_it) poisoned = wafer_f3_wait(sy, blk.wait_late, tid);
+        if constexpr (SYNC) {
+            if (blk.wait_late >= 0 && it == blk.wait_it) poisoned = wafer_f3_wait(syv, blk.wait_late, tid);
+        }
         // ---- 1. prefetch: phi0 two planes ahead, V one plane ahead
         VT pre[RY], pre_v[RY], xpre = zero, xpre_v = zero, orow_pre = zero;
 #pragma unroll
@@ -305,14 +355,16 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             pre[r] = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + rowoff[r]) + xlu);
             pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + SD * g.plane + rowoff[r]) + xlu);
         }
-        if (x_row) {
-            xpre = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + xoff_row) + xlu);
-            xpre_v = *reinterpret_cast<const VT *>((pv + zo + SD * g.plane + xoff_row) + xlu);
-            if (has_orow) orow_pre = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + orow_off) + xlu);
-        } else {
-            xpre[0] = phi[zo + SD * 2 * g.plane + c_off];
-            xpre_v[0] = pv[zo + SD * g.plane + c_off];
-        }
+        // The extra slot's requests are the SAME three instructions in every wave, the address chosen per lane (a halo row's
+        // 16 bytes, or the 16 bytes that start at the lane's halo-column cell: component 0 is the cell; a wave without an outer
+        // row asks for its slot's line again).  As two branches with loads of their own -- row waves / column waves -- the
+        // compiler let the branches share destination registers, and its wait-count pass, which cannot know that a wave takes
+        // one branch for life, then made the row waves wait for every request in flight before they issued theirs: the four row
+        // waves of every workgroup sat out the memory latency at the top of each iteration (0.279 against 0.258 ms/step at
+        // 512^3; which builds fell into it depended on the register allocator's mood).
+        xpre = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + xslot_off);
+        xpre_v = *reinterpret_cast<const VT *>(pv + zo + SD * g.plane + xslot_off);
+        orow_pre = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + orow_slot_off);
         // ---- 2. stage the next phi0 plane into the other buffer
         if (more) {
             T *nt = lds0 + ((z + 1) & 1) * Cfg::TILE0;
@@ -539,7 +591,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             q2[2][r] = p2new[r];
         }
         const int zo3 = z - 2 * SD;
-        const bool last_wt = blk.bump >= 0 && (DOWN ? zo3 < zs + blk.wt : zo3 >= ze - blk.wt);      // the last wt planes of the march
+        const bool last_wt = SYNC && blk.bump >= 0 && (DOWN ? zo3 < zs + blk.wt : zo3 >= ze - blk.wt);      // the last wt planes of the march
         const bool first_wt = PEER && bump_early >= 0 && (DOWN ? zo3 >= ze - blk.wt : zo3 < zs + blk.wt);   // the first wt planes (whole-column peer passes)
         // mode 2: the planes the exchange kernel reads while this kernel is still running go to memory at once; peer mode: nobody
         // reads them before the kernel ends, what travels is the copy into the neighbour's ghost planes
@@ -548,14 +600,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         // Stored from the registers, inside the loop's store path: a copy from memory after the fact (the planes read back at agent
         // scope, two more barriers per boundary) measured 0.320 against 0.280 ms/step at the bench slab.
         T *peer_dst = nullptr;
-        if constexpr (PEER) {
-            if (last_wt || first_wt) {
-                const int pside = first_wt ? bump_early : blk.bump & 1;
-                const volatile WaferF3Peer *pi = sy.peer_dev;   // (volatile: read here, not hoisted out of the plane loop)
-                T *const base = static_cast<T *>(pi->out[pside][sy.peer_buf]);
-                if (base) peer_dst = base + pi->zshift[pside] * g.plane;
-            }
-        }
+        if constexpr (PEER) peer_dst = first_wt ? peer_first : last_wt ? peer_last : nullptr;
         if (zo3 >= zs && zo3 < ze) {
             auto level3 = [&](auto interior_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
@@ -576,7 +621,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                             ys[2] = (r + 1 < RY) ? (C)q2[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[2][v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
                             const T rs = update_with(w, (C)caq[0][r][v], (C)cbq[0][r][v], S);
-                            res3[r][v] = poisoned ? (T)__builtin_nanf("") : rs;
+                            res3[r][v] = (SYNC && poisoned) ? (T)__builtin_nanf("") : rs;
                         }
                     }
                 }
@@ -617,11 +662,22 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         __syncthreads();
         if constexpr (PEER) {
             if (early_done && tid == 0) {
-                unsigned long long *const pf = const_cast<const volatile WaferF3Peer *>(sy.peer_dev)->flag[bump_early];
+                unsigned long long *const pf = const_cast<const volatile WaferF3Peer *>(syv->peer_dev)->flag[bump_early];
                 if (pf) __hip_atomic_fetch_add(pf, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-        // ---- 6. rotate the phi0 / V / a, b pipelines
+        // ---- 6. rotate the phi0 / V / a, b pipelines.  The prefetched values are pinned HERE, behind the barrier: left to itself the
+        //         compiler sometimes consumes a prefetch where it was issued (the halo-column waves then wait out the whole memory
+        //         latency at the top of every iteration) or ahead of the barrier (every wave waits for its loads first and for the
+        //         slowest wave second) -- which of the two 8 % apart "states" a build landed in used to depend on unrelated edits.
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            asm volatile("" : "+v"(pre[r]));
+            asm volatile("" : "+v"(pre_v[r]));
+        }
+        asm volatile("" : "+v"(xpre));
+        asm volatile("" : "+v"(xpre_v));
+        asm volatile("" : "+v"(orow_pre));
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             q0[0][r] = q0[1][r];
@@ -641,7 +697,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         xcb = xcbnew;
         orow_nxt = orow_pre;
     }
-    if (blk.bump >= 0) {
+    if (SYNC && blk.bump >= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -650,16 +706,16 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                 // follows in program order cannot overtake them; the consumer's poll is followed by an acquire (wafer_f3_wait).
                 // (A release fence here writes back the whole L2 of the XCD once per workgroup: 0.2928 against %s ms/step at the
                 //  bench slab -- the lesson of round 3's mode 2 again.)
-                unsigned long long *const pf = const_cast<const volatile WaferF3Peer *>(sy.peer_dev)->flag[blk.bump & 1];
+                unsigned long long *const pf = const_cast<const volatile WaferF3Peer *>(syv->peer_dev)->flag[blk.bump & 1];
                 if (pf) __hip_atomic_fetch_add(pf, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
-                __hip_atomic_fetch_add(sy.cnt + blk.bump * WAFER_F3_SYNC_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(const_cast<unsigned long long *>(syv->cnt) + blk.bump * WAFER_F3_SYNC_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
 }
 
-template <typename T, typename C, bool VIR, bool PEER = false>
+template <typename T, typename C, bool VIR, int MODE = 0>
 __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(WaferStepArgs a, int ntx, const WaferF3Block *__restrict__ table,
                                                                               WaferF3Sync sy, const T *__restrict__ phi,
                                                                               const T *__restrict__ pv, T *__restrict__ out)
@@ -669,8 +725,8 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     __shared__ __attribute__((aligned(16))) T lds1[2 * Cfg::TILE1];
     __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
     const WaferF3Block blk = table[blockIdx.x];
-    if (blk.down & 1) wafer_step3_body<T, C, VIR, true, PEER>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
-    else wafer_step3_body<T, C, VIR, false, PEER>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    if (blk.down & 1) wafer_step3_body<T, C, VIR, true, MODE>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    else wafer_step3_body<T, C, VIR, false, MODE>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
 }
 
 
@@ -836,16 +892,19 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     using Cfg = WaferF3Cfg<T>;
     const int ntx = (a.g.nx + Cfg::TX - 1) / Cfg::TX;
     const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
-    if (sy.peer) {   // overlap mode 3: its own instantiation (see wafer_step3_body)
-        if (a.v_in_range != 0)
-            hipLaunchKernelGGL((wafer_k_step3_fused<T, C, true, true>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out);
-        else
-            hipLaunchKernelGGL((wafer_k_step3_fused<T, C, false, true>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out);
-        return hipGetLastError();
+    // the synchronisation a launch needs picks the instantiation (see wafer_step3_body): none, mode 2's flags and counters, peer stores
+    const int mode = sy.peer ? 2 : (sy.flag != nullptr ? 1 : 0);
+#define WAFER_F3_LAUNCH(VIR_, MODE_) \
+    hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out)
+    if (a.v_in_range != 0) {
+        if (mode == 2) WAFER_F3_LAUNCH(true, 2);
+        else if (mode == 1) WAFER_F3_LAUNCH(true, 1);
+        else WAFER_F3_LAUNCH(true, 0);
+    } else {
+        if (mode == 2) WAFER_F3_LAUNCH(false, 2);
+        else if (mode == 1) WAFER_F3_LAUNCH(false, 1);
+        else WAFER_F3_LAUNCH(false, 0);
     }
-    if (a.v_in_range != 0)
-        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, true>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out);
-    else
-        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, false>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out);
+#undef WAFER_F3_LAUNCH
     return hipGetLastError();
 }
