@@ -324,7 +324,9 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
                 xpre_l[j] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + xoff_row) + xlu);
                 xpre_m[j] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + xoff_row) + xlu);
             }
-            if constexpr (VG == 0) { if (x_l1) xpre_v = *reinterpret_cast<const VT *>((pv + zo + g.plane + xoff_row) + xlu); }
+            // (every row wave, also the two that only stage their row: a request inside one more branch makes the wait-count pass
+            //  wait for the requests issued before it)
+            if constexpr (VG == 0) xpre_v = *reinterpret_cast<const VT *>((pv + zo + g.plane + xoff_row) + xlu);
         } else {
             xpre[0] = phi[zo + 2 * g.plane + c_off];
 #pragma unroll
