@@ -251,6 +251,34 @@ def test_fused3_zchunk_independence(wo, wa, zchunk, monkeypatch):
         assert ulp_diff(ctx.download_phi(), phi) == 0
 
 
+@pytest.mark.parametrize("sched", ["0", "1"])
+@pytest.mark.parametrize("xs", ["0", "1"])
+@pytest.mark.parametrize("zchunk", ["1", "2", "5", "1000"])
+@pytest.mark.parametrize("shape", [(128, 16, 5), (256, 32, 11), (128, 48, 23)])
+def test_fused3_exact_store_count_variant(wo, wa, shape, zchunk, xs, sched, monkeypatch):
+    """grids made of whole 128 x 16 tiles run the three-step kernel that issues two stores in EVERY plane iteration (while the
+    pipeline fills they go to the column's first plane, which the first real store overwrites; WAFER_F3_XS=0: the stores
+    inside conditions): the oracle's bits either way, for every z-chunking, marching up and (WAFER_F3_SCHED=1: the
+    two-halves schedule on an undecomposed grid) down"""
+    monkeypatch.setenv("WAFER_ZCHUNK", zchunk)
+    monkeypatch.setenv("WAFER_F3_XS", xs)
+    monkeypatch.setenv("WAFER_F3_SCHED", sched)
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    cfg, par = make_pair(shape, ext=1, potential="Coulomb", dn=0.2, dt=0.004, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=31)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(3)
+        ctx.set_potential("Coulomb")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 9)
+        wo.evolve(cfg, 0, a, b, phi, [], 9)
+        got = ctx.download_phi()
+        assert ulp_diff(got, phi) == 0
+        assert not got[0].any() and not got[-1].any() and not got[:, 0].any() and not got[:, :, -1].any()
+
+
 def test_fused3_thousand_steps_64cubed_and_default_dispatch(wo, wa, monkeypatch):
     """1000 steps (333 three-step passes + one single step) at 64^3 (forced onto the kernel) against the
     oracle; the three-step kernel is what a ThreePoint fp64 context of 6 M cells or more runs by default,

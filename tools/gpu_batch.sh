@@ -58,9 +58,9 @@ PY
                   ;;
     sweep_xf)     for w in 1 2 3; do timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 5 --steps 30 --configs ${XF_CONFIGS:-"xfnw=8" "xfnw=4"} 2>&1 | grep config | sed "s/^/k=$w /"; done > $O/sweep_xf.jsonl; cut -c1-130 $O/sweep_xf.jsonl ;;
     ab_alt)       for i in 1 2 3; do
-                    timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 5 --steps 60 --configs "v=3" 2>&1 | grep config | sed "s/^/default /"
+                    timeout 200 python3 tools/stencil_sweep.py --grid ${AB_GRID:-512,512,512} --rounds 5 --steps 60 --configs ${AB_CFGS:-v=3} 2>&1 | grep config | sed "s/^/default /"
                     for d in wafer_amd/build/alt_*; do
-                      WAFER_HIP_LIB=$PWD/$d/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --rounds 5 --steps 60 --configs "v=3" 2>&1 | grep config | sed "s/^/$(basename $d) /"
+                      WAFER_HIP_LIB=$PWD/$d/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid ${AB_GRID:-512,512,512} --rounds 5 --steps 60 --configs ${AB_CFGS:-v=3} 2>&1 | grep config | sed "s/^/$(basename $d) /"
                     done
                   done > $O/ab_alt.jsonl; cut -c1-110 $O/ab_alt.jsonl ;;
     sq_f3c)       for k in 0 1; do

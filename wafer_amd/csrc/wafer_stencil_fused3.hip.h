@@ -46,9 +46,17 @@
 #include "wafer_stencil_lds.hip.h"
 #include "wafer_stencil_fused2.hip.h"
 
+// Cells per lane.  -DWAFER_F3_VEC1: one fp64 cell per lane (a 64 x 16 tile, half the registers and half the LDS per workgroup:
+// two workgroups per CU) -- an experiment, see profiles/NOTES.md.
+#ifdef WAFER_F3_VEC1
+template <typename T> struct WaferF3Vec : WaferVec<T> {};
+template <> struct WaferF3Vec<double> { static constexpr int N = 1; typedef double __attribute__((ext_vector_type(1))) type; };
+#else
+template <typename T> struct WaferF3Vec : WaferVec<T> {};
+#endif
 template <typename T>
 struct WaferF3Cfg {
-    static constexpr int VEC = WaferVec<T>::N;
+    static constexpr int VEC = WaferF3Vec<T>::N;
     static constexpr int RY = 2;
     static constexpr int NW = 8;                        // waves: tile height 16, two rows per wave (+ one extra slot each)
     static constexpr int NT_ = NW * 64;
@@ -173,13 +181,20 @@ __device__ __forceinline__ const volatile WaferF3Sync *wafer_f3_sync_in_kernarg(
 // fields are ignored and WaferF3Sync is dead, which takes its sixteen scalars out of a kernel that spills scalar registers
 // (106 SGPRs, 42 spilled to vector lanes with the sync paths compiled in); 1 = the single-launch pass of overlap mode 2;
 // 2 = peer stores (overlap mode 3).
-template <typename T, typename C, bool VIR, bool DOWN, int MODE>
+// XS ("exact stores"; plain launches over grids made of whole tiles): every plane iteration issues exactly two stores -- one full
+// vector per main row -- on every path, so that the compiler's wait for the prefetched planes, behind the loop's barrier, is an
+// exact count that leaves the stores in flight.  With the stores inside conditions (pipeline fill, ragged tiles) the wait-count
+// pass has to assume the path without them, the last prefetch is then waited for with vmcnt(0), and in the steady state that
+// makes every wave sit out the completion of the two stores it issued a few hundred cycles earlier, once per plane (the
+// ablations of profiles/NOTES.md: the kernel without its stores 0.202 ms/step, without its loads 0.215, with both 0.253, without
+// either 0.192).  While the pipeline fills, the two stores go to the column's first plane, which the first real store overwrites.
+template <typename T, typename C, bool VIR, bool DOWN, int MODE, bool XS = false>
 __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const WaferF3Block &blk, int ntx, const WaferF3Sync &sy,
                                                   const T *__restrict__ phi, const T *__restrict__ pv, T *__restrict__ out,
                                                   T *lds0, T *lds1, T *lds2)
 {
     using Cfg = WaferF3Cfg<T>;
-    using VT = typename WaferVec<T>::type;
+    using VT = typename WaferF3Vec<T>::type;
     constexpr int R = 1;
     constexpr int VEC = Cfg::VEC, RY = Cfg::RY, TX = Cfg::TX, TY = Cfg::TY;
     constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, HX2 = Cfg::HX2, LP0 = Cfg::LP0, LP1 = Cfg::LP1, LP2 = Cfg::LP2;
@@ -191,6 +206,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     const int zs = blk.zs, ze = blk.ze;
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr bool PEER = MODE == 2, SYNC = MODE != 0;
+    static_assert(!XS || MODE == 0, "exact store counts: plain launches only");
     (void)sy;   // (never read through the parameter: see WaferF3KernArgs)
     [[maybe_unused]] const volatile WaferF3Sync *const syv = SYNC ? wafer_f3_sync_in_kernarg() : nullptr;
     const int wait_early = PEER ? ((blk.down >> 8) & 3) - 1 : -1, bump_early = PEER ? ((blk.down >> 16) & 3) - 1 : -1;
@@ -344,7 +360,11 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     for (int it = 0; it < niter; ++it) {
         const int z = z1 + SD * it;
         const bool more = it + 1 < niter;
+#ifdef WAFER_F3_ABL_NOLOAD   // timing experiment: every prefetch asks for the column's first planes again (cache hits)
+        const long long zo = (long long)(z1 + (it & 1)) * g.plane;
+#else
         const long long zo = (long long)z * g.plane;
+#endif
         if constexpr (SYNC) {
             if (blk.wait_late >= 0 && it == blk.wait_it) poisoned = wafer_f3_wait(syv, blk.wait_late, tid);
         }
@@ -601,7 +621,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         // scope, two more barriers per boundary) measured 0.320 against 0.280 ms/step at the bench slab.
         T *peer_dst = nullptr;
         if constexpr (PEER) peer_dst = first_wt ? peer_first : last_wt ? peer_last : nullptr;
-        if (zo3 >= zs && zo3 < ze) {
+        if (XS || (zo3 >= zs && zo3 < ze)) {
             auto level3 = [&](auto interior_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
                 VT res3[RY];
@@ -628,7 +648,15 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     if (INTERIOR || rowwk[r]) {
-                        T *dst = (out + (long long)zo3 * g.plane + rowoff[r]) + xlu;
+#ifdef WAFER_F3_ABL_NOSTORE  // timing experiment: nothing is stored (the compiler cannot know)
+                        if (a.dt > -1.0) continue;
+#endif
+                        const int zst = !XS ? zo3 : DOWN ? (zo3 < ze - 1 ? zo3 : ze - 1) : (zo3 > zs ? zo3 : zs);
+                        T *dst = (out + (long long)zst * g.plane + rowoff[r]) + xlu;
+                        if constexpr (XS) {
+                            *reinterpret_cast<VT *>(dst) = res3[r];
+                            continue;
+                        }
                         if constexpr (PEER) {
                             if (peer_dst) {   // into the neighbour's ghost planes (wave-uniform), system scope, written through
                                 T *pd = (peer_dst + (long long)zo3 * g.plane + rowoff[r]) + xlu;
@@ -651,7 +679,8 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                     }
                 }
             };
-            if (all_rows) level3(std::true_type{});
+            if constexpr (XS) level3(std::true_type{});   // (grids of whole tiles only: the launcher)
+            else if (all_rows) level3(std::true_type{});
             else level3(std::false_type{});
         }
         // whole-column peer passes: the first wt planes are out after iteration wt + 3 -- acknowledged here, counted behind the barrier
@@ -659,7 +688,11 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         if constexpr (PEER) {
             if (early_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#ifdef WAFER_F3_ABL_NOBAR      // timing experiment: no workgroup barrier in the plane loop (LDS contents race)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         __syncthreads();
+#endif
         if constexpr (PEER) {
             if (early_done && tid == 0) {
                 unsigned long long *const pf = const_cast<const volatile WaferF3Peer *>(syv->peer_dev)->flag[bump_early];
@@ -670,14 +703,21 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         //         compiler sometimes consumes a prefetch where it was issued (the halo-column waves then wait out the whole memory
         //         latency at the top of every iteration) or ahead of the barrier (every wave waits for its loads first and for the
         //         slowest wave second) -- which of the two 8 % apart "states" a build landed in used to depend on unrelated edits.
+        auto pin = [](VT &x) {
+            if constexpr (VEC == 1) {
+                T t = x[0];
+                asm volatile("" : "+v"(t));
+                x[0] = t;
+            } else asm volatile("" : "+v"(x));
+        };
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            asm volatile("" : "+v"(pre[r]));
-            asm volatile("" : "+v"(pre_v[r]));
+            pin(pre[r]);
+            pin(pre_v[r]);
         }
-        asm volatile("" : "+v"(xpre));
-        asm volatile("" : "+v"(xpre_v));
-        asm volatile("" : "+v"(orow_pre));
+        pin(xpre);
+        pin(xpre_v);
+        pin(orow_pre);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             q0[0][r] = q0[1][r];
@@ -715,8 +755,13 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     }
 }
 
-template <typename T, typename C, bool VIR, int MODE = 0>
-__global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(WaferStepArgs a, int ntx, const WaferF3Block *__restrict__ table,
+#if defined(WAFER_F3_VEC1) && defined(WAFER_F3_VEC1_OCC2)
+#define WAFER_F3_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define WAFER_F3_OCC
+#endif
+template <typename T, typename C, bool VIR, int MODE = 0, bool XS = false>
+__global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) WAFER_F3_OCC void wafer_k_step3_fused(WaferStepArgs a, int ntx, const WaferF3Block *__restrict__ table,
                                                                               WaferF3Sync sy, const T *__restrict__ phi,
                                                                               const T *__restrict__ pv, T *__restrict__ out)
 {
@@ -725,8 +770,8 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) void wafer_k_step3_fused(Wafe
     __shared__ __attribute__((aligned(16))) T lds1[2 * Cfg::TILE1];
     __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
     const WaferF3Block blk = table[blockIdx.x];
-    if (blk.down & 1) wafer_step3_body<T, C, VIR, true, MODE>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
-    else wafer_step3_body<T, C, VIR, false, MODE>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    if (blk.down & 1) wafer_step3_body<T, C, VIR, true, MODE, XS>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    else wafer_step3_body<T, C, VIR, false, MODE, XS>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
 }
 
 
@@ -894,16 +939,20 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
     // the synchronisation a launch needs picks the instantiation (see wafer_step3_body): none, mode 2's flags and counters, peer stores
     const int mode = sy.peer ? 2 : (sy.flag != nullptr ? 1 : 0);
-#define WAFER_F3_LAUNCH(VIR_, MODE_) \
-    hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out)
+    // exact store counts (XS): plain launches over grids made of whole tiles (every store a full vector of work cells)
+    const bool xs = t.f3_xs != 0 && mode == 0 && a.g.nx % Cfg::TX == 0 && a.g.ny % Cfg::TY == 0;
+#define WAFER_F3_LAUNCH(VIR_, MODE_, XS_) \
+    hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out)
     if (a.v_in_range != 0) {
-        if (mode == 2) WAFER_F3_LAUNCH(true, 2);
-        else if (mode == 1) WAFER_F3_LAUNCH(true, 1);
-        else WAFER_F3_LAUNCH(true, 0);
+        if (mode == 2) WAFER_F3_LAUNCH(true, 2, false);
+        else if (mode == 1) WAFER_F3_LAUNCH(true, 1, false);
+        else if (xs) WAFER_F3_LAUNCH(true, 0, true);
+        else WAFER_F3_LAUNCH(true, 0, false);
     } else {
-        if (mode == 2) WAFER_F3_LAUNCH(false, 2);
-        else if (mode == 1) WAFER_F3_LAUNCH(false, 1);
-        else WAFER_F3_LAUNCH(false, 0);
+        if (mode == 2) WAFER_F3_LAUNCH(false, 2, false);
+        else if (mode == 1) WAFER_F3_LAUNCH(false, 1, false);
+        else if (xs) WAFER_F3_LAUNCH(false, 0, true);
+        else WAFER_F3_LAUNCH(false, 0, false);
     }
 #undef WAFER_F3_LAUNCH
     return hipGetLastError();
