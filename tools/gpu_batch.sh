@@ -29,9 +29,9 @@ for step in "$@"; do
     sweep_x2)     for w in ${AB_K:-1 2 3}; do timeout 300 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --potential ${X2_POT:-Coulomb} --rounds 4 --steps 62 --configs ${X2_CONFIGS:-x2=0 x2=1 x2=0 x2=1} 2>&1 | grep config | sed "s/^/k=$w /"; done > $O/sweep_x2.jsonl; cut -c1-140 $O/sweep_x2.jsonl ;;
     ab_alt_x2)    # the excited-state steps of the default build against every wafer_amd/build/alt_*/ library, interleaved, same box
                   for i in 1 2; do for w in ${AB_K:-1 2 3}; do
-                    timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 4 --steps 62 --configs "x2=1" 2>&1 | grep config | sed "s/^/default k=$w /"
+                    timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 4 --steps 62 --configs ${AB_CFGS:-x2=1} 2>&1 | grep config | sed "s/^/default k=$w /"
                     for d in wafer_amd/build/alt_*; do
-                      WAFER_HIP_LIB=$PWD/$d/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 4 --steps 62 --configs "x2=1" 2>&1 | grep config | sed "s/^/$(basename $d) k=$w /"
+                      WAFER_HIP_LIB=$PWD/$d/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 4 --steps 62 --configs ${AB_CFGS:-x2=1} 2>&1 | grep config | sed "s/^/$(basename $d) k=$w /"
                     done
                   done; done > $O/ab_alt_x2.jsonl; cut -c1-130 $O/ab_alt_x2.jsonl ;;
     prof_x2)      # the kernels of the whole path with the two-step excited kernels: --stats summary, HBM-side traffic, SQ counters

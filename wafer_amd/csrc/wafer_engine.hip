@@ -815,7 +815,11 @@ enum { X2_SUM_SLOT = 18 };   // scal[18 .. 18 + 1 + 2k): the sums of a two-step 
 // the local slab except v_in_range, on which the ranks agree in x2_agree.
 static bool x2_applies(const wafer_ctx *c, uint32_t wnum)
 {
-    return c->tune.x2 != 0 && c->tune.one_pass != 0 && !c->f32 && c->g.R == 1 && wnum >= 1 && wnum <= 3 && (int)wnum <= c->tune.x2_max_k &&
+    // three stored states: the 128 x 8-tile kernel wins where a plane is small enough for the halo rows to stay in the XCDs' L2
+    // (-4 % per step at 512 x 512, -2 ... -4 % at 256^2 / 384^2) and loses on 1024 x 1024 planes (+3 ... +5 %,
+    // profiles/r04_x2_shapes.log).  The plane extent is the same on every rank of a decomposed run.
+    const int kmax = c->tune.x2_max_k > 0 ? c->tune.x2_max_k : ((long long)c->g.nx * c->g.ny <= 300000 ? 3 : 2);
+    return c->tune.x2 != 0 && c->tune.one_pass != 0 && !c->f32 && c->g.R == 1 && wnum >= 1 && wnum <= 3 && (int)wnum <= kmax &&
            active_variant(c) >= 1 && c->v_in_range && (!c->sharded() || c->g.G >= 2);
 }
 

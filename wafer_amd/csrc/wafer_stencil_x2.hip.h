@@ -99,7 +99,11 @@ __device__ __forceinline__ double wafer_x2_xform(const WaferX2Coef<NL> &k, doubl
     return x;
 }
 
-template <int RY, int NL, int VG, bool VIR>
+// XS (grids made of whole tiles): one full-vector store per main row in EVERY plane iteration (the two iterations that fill the
+// pipeline store into the column's first plane, which the first real store overwrites; their sums are not taken), so that the
+// wait for the prefetched planes behind the loop's barrier is an exact count that leaves the stores in flight -- with the stores
+// inside conditions it was vmcnt(0): every wave sat out the completion of the store it had issued just before the barrier.
+template <int RY, int NL, int VG, bool VIR, bool XS = false>
 __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, int nty, int swz, const double *__restrict__ phi,
                                                        const double *__restrict__ pv, double *__restrict__ out,
                                                        double *__restrict__ partials, long long pstride, WaferX2Ptrs st,
@@ -303,7 +307,11 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     for (int it = 0; it < niter; ++it) {
         const int z = z1 + it;
         const bool more = it + 1 < niter;
+#ifdef WAFER_X2_ABL_NOLOAD    // timing experiment: every prefetch asks for the column's first planes again (cache hits)
+        const long long zo = (long long)(z1 + (it & 1)) * g.plane;
+#else
         const long long zo = (long long)z * g.plane;
+#endif
         // ---- 1. prefetch, raw: input and stored states two planes ahead, V one plane ahead
         VT pre[RY], pre_l[NL][RY], pre_m[NL][RY], pre_v[RY], xpre = zero, xpre_l[NL], xpre_m[NL], xpre_v = zero;
 #pragma unroll
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
         // level 2's neighbours and the stored states of the plane it is about to produce (the lane's own LDS queue), requested
         // behind level 1's arithmetic
         VT lq[NL][RY];
-        if (act2) {
+        if (XS || act2) {
             nbload(std::integral_constant<int, 1>{});
             const T *qs = qslot(z - 1);
 #pragma unroll
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
             q1[1][r] = q1[2][r];
             q1[2][r] = p1new[r];
         }
-        if (act2) {
+        if (XS || act2) {
             auto level2 = [&](auto interior_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
                 VT res2[RY];
@@ -497,6 +505,7 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
                 }
                 // the sums of this plane: Y1 (still in its queue) against itself and the stored states, Z against the stored
                 // states.  Cells outside the work area hold exact zeros at both levels, so nothing is masked here.
+                if (!XS || act2)
 #pragma unroll
                 for (int r = 0; r < RY; ++r)
 #pragma unroll
@@ -512,7 +521,10 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     if (INTERIOR || rowwk[r]) {
-                        T *dst = (out + (long long)zp2 * g.plane + rowoff[r]) + xlu;
+#ifdef WAFER_X2_ABL_NOSTORE   // timing experiment: nothing is stored (the compiler cannot know)
+                        if (a.dt > -1.0) continue;
+#endif
+                        T *dst = (out + (long long)(XS && zp2 < zs ? zs : zp2) * g.plane + rowoff[r]) + xlu;
                         if (INTERIOR || xi + VEC <= g.nx) {
                             *reinterpret_cast<VT *>(dst) = res2[r];
                         } else {
@@ -523,7 +535,8 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
                     }
                 }
             };
-            if (all_rows && wplane2) level2(std::true_type{});
+            if constexpr (XS) level2(std::true_type{});   // (whole tiles, work planes only: the launcher)
+            else if (all_rows && wplane2) level2(std::true_type{});
             else level2(std::false_type{});
         }
         // HOLD: the plane transformed last iteration (z + 1) takes the queue slot just read (same lanes: program order suffices)
@@ -740,8 +753,12 @@ static inline hipError_t wafer_launch_xstep2_one(const WaferTuning &t, WaferStep
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
     const long long nblocks = (long long)ntx * nty * ntz;
     if ((size_t)nblocks > partials_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((wafer_k_xstep2<RY, NL, VG, true>), dim3((unsigned)nblocks), dim3(Cfg::NT_), 0, s, a, ntx, nty, t.swz, phi, pv, out,
-                       partials, (long long)partials_cap, st, coef);
+    if (t.f3_xs != 0 && g.nx % Cfg::TX == 0 && g.ny % Cfg::TY == 0)
+        hipLaunchKernelGGL((wafer_k_xstep2<RY, NL, VG, true, true>), dim3((unsigned)nblocks), dim3(Cfg::NT_), 0, s, a, ntx, nty, t.swz, phi, pv,
+                           out, partials, (long long)partials_cap, st, coef);
+    else
+        hipLaunchKernelGGL((wafer_k_xstep2<RY, NL, VG, true, false>), dim3((unsigned)nblocks), dim3(Cfg::NT_), 0, s, a, ntx, nty, t.swz, phi, pv,
+                           out, partials, (long long)partials_cap, st, coef);
     return hipGetLastError();
 }
 

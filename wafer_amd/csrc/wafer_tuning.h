@@ -25,7 +25,7 @@ struct WaferTuning {
     int one_pass = 1;       // WAFER_ONE_PASS: transform-on-load (0: the two-pass scheme)
     int vgen = 1;           // WAFER_VGEN: evaluate Coulomb / SimpleCornell / Harmonic per cell instead of streaming V
     int x2 = 1;             // WAFER_X2: two excited-state steps per pass (ThreePoint fp64, 1..3 stored states); 0: one step per pass
-    int x2_max_k = 2;       // WAFER_X2_MAX_K: most stored states the two-step kernel is used for.  512^3 Coulomb against one step per pass,
+    int x2_max_k = 0;       // WAFER_X2_MAX_K: most stored states the two-step kernel takes (1 .. 3); 0 = by plane size: 3 up to 300 000 cells per plane, else 2 (wafer_engine.hip, x2_applies)
                             // two boxes: k = 1 0.463-0.485 / 0.609-0.634, k = 2 0.730-0.755 / 0.786-0.817, k = 3 0.984-0.990 / 0.981-1.018 ms
                             // per step: three stored states are a wash on the lower tile and keep the one-step kernel (and its memory)
     int x2_ry = 0;          // WAFER_X2_RY: rows per lane of that kernel (1: 128 x 8 tiles, 2: 128 x 16, k = 1 only; 0: default)
