@@ -54,6 +54,24 @@ template <> struct WaferF3Vec<double> { static constexpr int N = 1; typedef doub
 #else
 template <typename T> struct WaferF3Vec : WaferVec<T> {};
 #endif
+// -DWAFER_F3_STAMP: a diagnostic build (cdna_hip_programming.md, "In-kernel stamps") -- one workgroup adds up, per wave, the
+// shader-clock cycles between fixed points of the plane iteration and leaves the sums in a buffer of their own
+// (wafer_debug_f3_stamps reads it; tools/f3_stamps.py prints the shares).  Never timed, never shipped.
+#ifdef WAFER_F3_STAMP
+enum { WAFER_F3_NSTAMP = 8 };
+__device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
+#define WAFER_F3_STAMP_AT(k)                                                                        \
+    do {                                                                                            \
+        unsigned long long t_;                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        stamp_sum[k] += t_ - stamp_last;                                                            \
+        stamp_last = t_;                                                                            \
+    } while (0)
+#else
+#define WAFER_F3_STAMP_AT(k) do { } while (0)
+#endif
 template <typename T>
 struct WaferF3Cfg {
     static constexpr int VEC = WaferF3Vec<T>::N;
@@ -357,6 +375,10 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         asm volatile("" : "+v"(peer_first), "+v"(peer_last));
     }
     const int niter = (ze - zs) + 4;
+#ifdef WAFER_F3_STAMP
+    unsigned long long stamp_sum[WAFER_F3_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     for (int it = 0; it < niter; ++it) {
         const int z = z1 + SD * it;
         const bool more = it + 1 < niter;
@@ -399,6 +421,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                 if (has_orow) *reinterpret_cast<VT *>(nt + orow_lds) = oy_out ? zero : orow_nxt;
             } else if (c_ok) nt[c_lds0] = c_xout ? T(0) : xq0[2][0];
         }
+        WAFER_F3_STAMP_AT(0);   // requests issued, next plane staged
         const T *c0 = lds0 + (z & 1) * Cfg::TILE0;
         T *w1 = lds1 + (z & 1) * Cfg::TILE1;
         const T *c1 = lds1 + ((z + 1) & 1) * Cfg::TILE1;
@@ -482,6 +505,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         };
         if (all_rows && wplane1) level1(std::true_type{});
         else level1(std::false_type{});
+        WAFER_F3_STAMP_AT(1);   // level 1, main rows (with the neighbours' LDS round trip)
         nbload(std::integral_constant<int, 2>{});
         // ---- 3x. level 1, the extra slot
         if (x_row) {
@@ -526,6 +550,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             w1[c_lds1] = rs;
             xp1[0] = rs;
         }
+        WAFER_F3_STAMP_AT(2);   // level 1, the extra slot
         // ---- 4. level 2: phi2 of the plane behind, from the phi1 queues; a, b as level 1 formed them one iteration ago
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
@@ -603,6 +628,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                 w2[c_lds2] = rs;
             }
         }
+        WAFER_F3_STAMP_AT(3);   // level 2 (main rows and the extra slot)
         // ---- 5. level 3: phi3 two planes behind from the phi2 queue, a, b as formed two iterations ago; stored
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
@@ -683,6 +709,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             else if (all_rows) level3(std::true_type{});
             else level3(std::false_type{});
         }
+        WAFER_F3_STAMP_AT(4);   // level 3 and its stores
         // whole-column peer passes: the first wt planes are out after iteration wt + 3 -- acknowledged here, counted behind the barrier
         const bool early_done = PEER && bump_early >= 0 && it == blk.wt + 3;
         if constexpr (PEER) {
@@ -699,6 +726,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
                 if (pf) __hip_atomic_fetch_add(pf, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+        WAFER_F3_STAMP_AT(5);   // the barrier
         // ---- 6. rotate the phi0 / V / a, b pipelines.  The prefetched values are pinned HERE, behind the barrier: left to itself the
         //         compiler sometimes consumes a prefetch where it was issued (the halo-column waves then wait out the whole memory
         //         latency at the top of every iteration) or ahead of the barrier (every wave waits for its loads first and for the
@@ -736,7 +764,17 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         xca = xcanew;
         xcb = xcbnew;
         orow_nxt = orow_pre;
+#ifdef WAFER_F3_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (what is left of the requests' latency, made visible)
+#endif
+        WAFER_F3_STAMP_AT(6);   // the wait for the prefetched planes, the queue rotation
     }
+#ifdef WAFER_F3_STAMP
+    if (blockIdx.x == gridDim.x / 2 + 3 && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < WAFER_F3_NSTAMP; ++k) wafer_f3_stamp_buf[wave * WAFER_F3_NSTAMP + k] = stamp_sum[k];
+    }
+#endif
     if (SYNC && blk.bump >= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -23,3 +23,12 @@ void wafer_step3_tile(int tc, int *tx, int *ty)
     if (tc == WAFER_TC_F64) { *tx = WaferF3Cfg<double>::TX; *ty = WaferF3Cfg<double>::TY; }
     else { *tx = WaferF3Cfg<float>::TX; *ty = WaferF3Cfg<float>::TY; }
 }
+
+#ifdef WAFER_F3_STAMP
+// diagnostic builds only: the per-wave cycle sums of the last launch's stamped workgroup
+extern "C" int wafer_debug_f3_stamps(unsigned long long *host_out)
+{
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wafer_f3_stamp_buf), sizeof(unsigned long long) * 8 * WAFER_F3_NSTAMP);
+}
+#endif
