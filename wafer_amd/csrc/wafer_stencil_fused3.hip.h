@@ -72,6 +72,17 @@ __device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
 #else
 #define WAFER_F3_STAMP_AT(k) do { } while (0)
 #endif
+// where in the plane iteration a wave issues its requests (see issue_group): 0 = at the top, 1 = behind level 1 of the main rows,
+// 2 = behind level 1 of the extra slot, 3 = behind level 2, 4 = behind level 3.  A: phi0 of the main rows, B: their V, C: the extra slot.
+#ifndef WAFER_F3_POS_A
+#define WAFER_F3_POS_A 0
+#endif
+#ifndef WAFER_F3_POS_B
+#define WAFER_F3_POS_B 1
+#endif
+#ifndef WAFER_F3_POS_C
+#define WAFER_F3_POS_C 2
+#endif
 template <typename T>
 struct WaferF3Cfg {
     static constexpr int VEC = WaferF3Vec<T>::N;
@@ -393,10 +404,28 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         // ---- 1. prefetch: phi0 two planes ahead, V one plane ahead
         VT pre[RY], pre_v[RY], xpre = zero, xpre_v = zero, orow_pre = zero;
 #pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            pre[r] = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + rowoff[r]) + xlu);
-            pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + SD * g.plane + rowoff[r]) + xlu);
-        }
+        for (int r = 0; r < RY; ++r) pre[r] = pre_v[r] = zero;
+        // The seven requests of a wave are NOT issued together: all eight waves leave the barrier at once, and 56 requests of 1 KiB
+        // queue at the CU's one address unit (16 cycles each) while no wave can issue arithmetic behind its own -- the in-kernel
+        // stamps (tools/f3_stamps.py) showed a sixth of the iteration going there.  Spread over the iteration (the main rows' phi0
+        // at the top, their V behind level 1, the extra slot's three behind level 2) they overlap the other waves' arithmetic:
+        // 0.249 -> 0.236 ms/step at 512^3, and the later requests hold their registers for a shorter time (244 -> 230 VGPRs).
+        auto issue_group = [&](int pos) {
+            if (pos == WAFER_F3_POS_A) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r) pre[r] = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + rowoff[r]) + xlu);
+            }
+            if (pos == WAFER_F3_POS_B) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r) pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + SD * g.plane + rowoff[r]) + xlu);
+            }
+            if (pos == WAFER_F3_POS_C) {
+                xpre = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + xslot_off);
+                xpre_v = *reinterpret_cast<const VT *>(pv + zo + SD * g.plane + xslot_off);
+                orow_pre = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + orow_slot_off);
+            }
+        };
+        issue_group(0);
         // The extra slot's requests are the SAME three instructions in every wave, the address chosen per lane (a halo row's
         // 16 bytes, or the 16 bytes that start at the lane's halo-column cell: component 0 is the cell; a wave without an outer
         // row asks for its slot's line again).  As two branches with loads of their own -- row waves / column waves -- the
@@ -404,9 +433,6 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         // one branch for life, then made the row waves wait for every request in flight before they issued theirs: the four row
         // waves of every workgroup sat out the memory latency at the top of each iteration (0.279 against 0.258 ms/step at
         // 512^3; which builds fell into it depended on the register allocator's mood).
-        xpre = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + xslot_off);
-        xpre_v = *reinterpret_cast<const VT *>(pv + zo + SD * g.plane + xslot_off);
-        orow_pre = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + orow_slot_off);
         // ---- 2. stage the next phi0 plane into the other buffer
         if (more) {
             T *nt = lds0 + ((z + 1) & 1) * Cfg::TILE0;
@@ -473,6 +499,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         };
         nbload(std::integral_constant<int, 0>{});
         nbload(std::integral_constant<int, 1>{});
+        issue_group(5);
         // ---- 3. level 1, main rows.  INTERIOR: the plane and both rows are work cells, the tile's columns too: no tests
         //         inside, the RY x VEC updates form one basic block
         auto level1 = [&](auto interior_tag) {
@@ -506,6 +533,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         if (all_rows && wplane1) level1(std::true_type{});
         else level1(std::false_type{});
         WAFER_F3_STAMP_AT(1);   // level 1, main rows (with the neighbours' LDS round trip)
+        issue_group(1);
         nbload(std::integral_constant<int, 2>{});
         // ---- 3x. level 1, the extra slot
         if (x_row) {
@@ -550,6 +578,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             w1[c_lds1] = rs;
             xp1[0] = rs;
         }
+        issue_group(2);
         WAFER_F3_STAMP_AT(2);   // level 1, the extra slot
         // ---- 4. level 2: phi2 of the plane behind, from the phi1 queues; a, b as level 1 formed them one iteration ago
 #pragma unroll
@@ -629,6 +658,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             }
         }
         WAFER_F3_STAMP_AT(3);   // level 2 (main rows and the extra slot)
+        issue_group(3);
         // ---- 5. level 3: phi3 two planes behind from the phi2 queue, a, b as formed two iterations ago; stored
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
@@ -709,6 +739,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             else if (all_rows) level3(std::true_type{});
             else level3(std::false_type{});
         }
+        issue_group(4);
         WAFER_F3_STAMP_AT(4);   // level 3 and its stores
         // whole-column peer passes: the first wt planes are out after iteration wt + 3 -- acknowledged here, counted behind the barrier
         const bool early_done = PEER && bump_early >= 0 && it == blk.wt + 3;

@@ -60,6 +60,22 @@ struct WaferX2Ptrs {
 //   0: sum Y1^2   1 .. k: sum l_j Y1   k+1 .. 2k: sum l_j Z
 static inline int wafer_x2_nsums(int k) { return 1 + 2 * k; }
 
+// where in the plane iteration a wave issues its requests (issue_group in the kernel): 0 = at the top, 1 = behind level 1 of the main
+// rows, 2 = behind level 1 of the extra slot, 3 = behind level 2.  A: the main rows' input (and V), L: their stored states, M: the images
+// M_j, X: the extra slot's.  Measured per tile (profiles/r04_ab_x2_request_placement.jsonl): on the 128 x 16 tile M and X move back
+// (0.665 -> 0.63 ms/step at k = 2); on the 128 x 8 tile only the extra slot's requests do (0.964 -> 0.87 at k = 3).
+#ifndef WAFER_X2_POS_A
+#define WAFER_X2_POS_A 0
+#endif
+#ifndef WAFER_X2_POS_L
+#define WAFER_X2_POS_L 0
+#endif
+#ifndef WAFER_X2_POS_M
+#define WAFER_X2_POS_M (RY == 2 ? 2 : 0)
+#endif
+#ifndef WAFER_X2_POS_X
+#define WAFER_X2_POS_X 3
+#endif
 template <int RY_>
 struct WaferX2Cfg {
     static constexpr int VEC = 2;
@@ -316,36 +332,58 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
         VT pre[RY], pre_l[NL][RY], pre_m[NL][RY], pre_v[RY], xpre = zero, xpre_l[NL], xpre_m[NL], xpre_v = zero;
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            pre[r] = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + rowoff[r]) + xlu);
+            pre[r] = pre_v[r] = zero;
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                pre_l[j][r] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
-                pre_m[j][r] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
-            }
-            if constexpr (VG == 0) pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + g.plane + rowoff[r]) + xlu);
-            else pre_v[r] = zero;
+            for (int j = 0; j < NL; ++j) pre_l[j][r] = pre_m[j][r] = zero;
         }
-        if (x_row) {
-            xpre = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + xoff_row) + xlu);
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                xpre_l[j] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + xoff_row) + xlu);
-                xpre_m[j] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + xoff_row) + xlu);
-            }
-            // (every row wave, also the two that only stage their row: a request inside one more branch makes the wait-count pass
-            //  wait for the requests issued before it)
-            if constexpr (VG == 0) xpre_v = *reinterpret_cast<const VT *>((pv + zo + g.plane + xoff_row) + xlu);
-        } else {
-            xpre[0] = phi[zo + 2 * g.plane + c_off];
+        for (int j = 0; j < NL; ++j) xpre_l[j] = xpre_m[j] = zero;
+        // The requests of a wave are spread over the iteration (as in the three-step kernel: all eight waves leave the barrier at
+        // once, and (2 + 4k) x 8 requests of 1 KiB queueing at the CU's one address unit kept every wave from its arithmetic):
+        // which group goes where is measured per tile shape (WAFER_X2_POS_*).
+        auto issue_group = [&](int pos) {
+            if (pos == WAFER_X2_POS_A) {
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                xpre_l[j] = zero;
-                xpre_m[j] = zero;
-                xpre_l[j][0] = st.l[j][zo + 2 * g.plane + c_off];
-                xpre_m[j][0] = st.m[j][zo + 2 * g.plane + c_off];
+                for (int r = 0; r < RY; ++r) {
+                    pre[r] = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + rowoff[r]) + xlu);
+                    if constexpr (VG == 0) pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + g.plane + rowoff[r]) + xlu);
+                }
             }
-            if constexpr (VG == 0) xpre_v[0] = pv[zo + g.plane + c_off];
-        }
+            if (pos == WAFER_X2_POS_L) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r)
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) pre_l[j][r] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
+            }
+            if (pos == WAFER_X2_POS_M) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r)
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) pre_m[j][r] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
+            }
+            if (pos == WAFER_X2_POS_X) {
+                if (x_row) {
+                    xpre = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + xoff_row) + xlu);
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) {
+                        xpre_l[j] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + xoff_row) + xlu);
+                        xpre_m[j] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + xoff_row) + xlu);
+                    }
+                    // (every row wave, also the two that only stage their row: a request inside one more branch makes the wait-count pass
+                    //  wait for the requests issued before it)
+                    if constexpr (VG == 0) xpre_v = *reinterpret_cast<const VT *>((pv + zo + g.plane + xoff_row) + xlu);
+                } else {
+                    xpre[0] = phi[zo + 2 * g.plane + c_off];
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) {
+                        xpre_l[j][0] = st.l[j][zo + 2 * g.plane + c_off];
+                        xpre_m[j][0] = st.m[j][zo + 2 * g.plane + c_off];
+                    }
+                    if constexpr (VG == 0) xpre_v[0] = pv[zo + g.plane + c_off];
+                }
+            }
+        };
+        issue_group(0);
         // ---- 2. stage the next x0 plane into the other buffer
         if (more) {
             T *nt = lds0 + ((z + 1) & 1) * Cfg::TILE0;
@@ -418,6 +456,7 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
         };
         if (all_rows && wplane1) level1(std::true_type{});
         else level1(std::false_type{});
+        issue_group(1);
         // level 2's neighbours and the stored states of the plane it is about to produce (the lane's own LDS queue), requested
         // behind level 1's arithmetic
         VT lq[NL][RY];
@@ -471,6 +510,7 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
             xp1[0] = rs;
         }
         (void)xp1;
+        issue_group(2);
         // ---- 4. level 2: Z of the plane behind from the Y1 queue, a, b as level 1 formed them one iteration ago; the sums
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
@@ -539,6 +579,7 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
             else if (all_rows && wplane2) level2(std::true_type{});
             else level2(std::false_type{});
         }
+        issue_group(3);
         // HOLD: the plane transformed last iteration (z + 1) takes the queue slot just read (same lanes: program order suffices)
         if constexpr (HOLD) {
             T *qd = qslot(z + 1);
@@ -715,9 +756,9 @@ __global__ __launch_bounds__(256) void wafer_k_x2_apply(WaferRowArgs a, double *
 static inline int wafer_x2_ry(const WaferTuning &t, int k, int vg)
 {
     (void)vg;
-    if (k > 2) return 1;
+    if (k > 2) return 1;   // (three stored states: the lane-private queue of the tall tile does not fit the LDS)
     if (t.x2_ry == 1 || t.x2_ry == 2) return t.x2_ry;
-    return k == 1 ? 2 : 1;
+    return 2;              // 128 x 16 (k = 2: since the requests are spread over the iteration the kernel fits 229 VGPRs; 0.648 against 0.677 ms/step)
 }
 static inline void wafer_x2_tile(const WaferTuning &t, int k, int vg, int *tx, int *ty)
 {

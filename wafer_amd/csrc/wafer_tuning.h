@@ -28,7 +28,7 @@ struct WaferTuning {
     int x2_max_k = 0;       // WAFER_X2_MAX_K: most stored states the two-step kernel takes (1 .. 3); 0 = by plane size: 3 up to 300 000 cells per plane, else 2 (wafer_engine.hip, x2_applies)
                             // two boxes: k = 1 0.463-0.485 / 0.609-0.634, k = 2 0.730-0.755 / 0.786-0.817, k = 3 0.984-0.990 / 0.981-1.018 ms
                             // per step: three stored states are a wash on the lower tile and keep the one-step kernel (and its memory)
-    int x2_ry = 0;          // WAFER_X2_RY: rows per lane of that kernel (1: 128 x 8 tiles, 2: 128 x 16, k = 1 only; 0: default)
+    int x2_ry = 0;          // WAFER_X2_RY: rows per lane of that kernel (1: 128 x 8 tiles, 2: 128 x 16, k = 1 and 2; 0: default = 2 where it exists)
     // observables
     int obs_lds = 1;        // WAFER_OBS_LDS: 0 = the plain scalar-load kernel
     int obs_wgs = 2;        // WAFER_OBS_WGS: workgroups per CU
