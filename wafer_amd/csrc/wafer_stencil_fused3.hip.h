@@ -74,6 +74,9 @@ __device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
 #endif
 // where in the plane iteration a wave issues its requests (see issue_group): 0 = at the top, 1 = behind level 1 of the main rows,
 // 2 = behind level 1 of the extra slot, 3 = behind level 2, 4 = behind level 3.  A: phi0 of the main rows, B: their V, C: the extra slot.
+#ifndef WAFER_F3_RING
+#define WAFER_F3_RING 1
+#endif
 #ifndef WAFER_F3_POS_A
 #define WAFER_F3_POS_A 0
 #endif
@@ -217,7 +220,7 @@ __device__ __forceinline__ const volatile WaferF3Sync *wafer_f3_sync_in_kernarg(
 // makes every wave sit out the completion of the two stores it issued a few hundred cycles earlier, once per plane (the
 // ablations of profiles/NOTES.md: the kernel without its stores 0.202 ms/step, without its loads 0.215, with both 0.253, without
 // either 0.192).  While the pipeline fills, the two stores go to the column's first plane, which the first real store overwrites.
-template <typename T, typename C, bool VIR, bool DOWN, int MODE, bool XS = false>
+template <typename T, typename C, bool VIR, bool DOWN, int MODE, bool XS = false, bool RING = false>
 __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const WaferF3Block &blk, int ntx, const WaferF3Sync &sy,
                                                   const T *__restrict__ phi, const T *__restrict__ pv, T *__restrict__ out,
                                                   T *lds0, T *lds1, T *lds2)
@@ -390,416 +393,40 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     unsigned long long stamp_sum[WAFER_F3_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
-    for (int it = 0; it < niter; ++it) {
-        const int z = z1 + SD * it;
-        const bool more = it + 1 < niter;
-#ifdef WAFER_F3_ABL_NOLOAD   // timing experiment: every prefetch asks for the column's first planes again (cache hits)
-        const long long zo = (long long)(z1 + (it & 1)) * g.plane;
-#else
-        const long long zo = (long long)z * g.plane;
-#endif
-        if constexpr (SYNC) {
-            if (blk.wait_late >= 0 && it == blk.wait_it) poisoned = wafer_f3_wait(syv, blk.wait_late, tid);
-        }
-        // ---- 1. prefetch: phi0 two planes ahead, V one plane ahead
-        VT pre[RY], pre_v[RY], xpre = zero, xpre_v = zero, orow_pre = zero;
-#pragma unroll
-        for (int r = 0; r < RY; ++r) pre[r] = pre_v[r] = zero;
-        // The seven requests of a wave are NOT issued together: all eight waves leave the barrier at once, and 56 requests of 1 KiB
-        // queue at the CU's one address unit (16 cycles each) while no wave can issue arithmetic behind its own -- the in-kernel
-        // stamps (tools/f3_stamps.py) showed a sixth of the iteration going there.  Spread over the iteration (the main rows' phi0
-        // at the top, their V behind level 1, the extra slot's three behind level 2) they overlap the other waves' arithmetic:
-        // 0.249 -> 0.236 ms/step at 512^3, and the later requests hold their registers for a shorter time (244 -> 230 VGPRs).
-        auto issue_group = [&](int pos) {
-            if (pos == WAFER_F3_POS_A) {
-#pragma unroll
-                for (int r = 0; r < RY; ++r) pre[r] = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + rowoff[r]) + xlu);
+#define WAFER_F3_Q0(m) (RING ? ((m) + WAFER_F3_PH) % 3 : (m))
+#define WAFER_F3_Q1(m) (RING ? ((m) + WAFER_F3_PH + 1) % 3 : (m))
+    if constexpr (RING) {
+        for (int it0 = 0; it0 < niter; it0 += 3) {
+            {
+                const int it = it0;
+#define WAFER_F3_PH 0
+#include "wafer_stencil_fused3_iter.inc.h"
+#undef WAFER_F3_PH
             }
-            if (pos == WAFER_F3_POS_B) {
-#pragma unroll
-                for (int r = 0; r < RY; ++r) pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + SD * g.plane + rowoff[r]) + xlu);
+            if (it0 + 1 >= niter) break;
+            {
+                const int it = it0 + 1;
+#define WAFER_F3_PH 1
+#include "wafer_stencil_fused3_iter.inc.h"
+#undef WAFER_F3_PH
             }
-            if (pos == WAFER_F3_POS_C) {
-                xpre = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + xslot_off);
-                xpre_v = *reinterpret_cast<const VT *>(pv + zo + SD * g.plane + xslot_off);
-                orow_pre = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + orow_slot_off);
-            }
-        };
-        issue_group(0);
-        // The extra slot's requests are the SAME three instructions in every wave, the address chosen per lane (a halo row's
-        // 16 bytes, or the 16 bytes that start at the lane's halo-column cell: component 0 is the cell; a wave without an outer
-        // row asks for its slot's line again).  As two branches with loads of their own -- row waves / column waves -- the
-        // compiler let the branches share destination registers, and its wait-count pass, which cannot know that a wave takes
-        // one branch for life, then made the row waves wait for every request in flight before they issued theirs: the four row
-        // waves of every workgroup sat out the memory latency at the top of each iteration (0.279 against 0.258 ms/step at
-        // 512^3; which builds fell into it depended on the register allocator's mood).
-        // ---- 2. stage the next phi0 plane into the other buffer
-        if (more) {
-            T *nt = lds0 + ((z + 1) & 1) * Cfg::TILE0;
-#pragma unroll
-            for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(nt + (yrow[r] - (y0 - 3)) * LP0 + HX0 + xl) = q0[2][r];
-            // (what was requested in place of a cell outside the work area becomes the zero it stands for HERE, where the value
-            //  is used, not where the request is waited for: a select on the prefetch registers before the barrier would put
-            //  the wait into the iteration that issued the request.  The queues of such a cell are never read otherwise:
-            //  xwk / c_wk.)
-            if (x_row) {
-                *reinterpret_cast<VT *>(nt + (xy - (y0 - 3)) * LP0 + HX0 + xl) = xy_out ? zero : xq0[2];
-                if (has_orow) *reinterpret_cast<VT *>(nt + orow_lds) = oy_out ? zero : orow_nxt;
-            } else if (c_ok) nt[c_lds0] = c_xout ? T(0) : xq0[2][0];
-        }
-        WAFER_F3_STAMP_AT(0);   // requests issued, next plane staged
-        const T *c0 = lds0 + (z & 1) * Cfg::TILE0;
-        T *w1 = lds1 + (z & 1) * Cfg::TILE1;
-        const T *c1 = lds1 + ((z + 1) & 1) * Cfg::TILE1;
-        T *w2 = lds2 + ((z + 1) & 1) * Cfg::TILE2;
-        const T *c2 = lds2 + (z & 1) * Cfg::TILE2;
-        const bool wplane1 = work_plane(z), wplane2 = work_plane(z - SD);
-        const int zp2 = z - SD;
-        const bool need2 = zp2 >= zs - 1 && zp2 <= ze;   // phi2 is read on planes zs-1 .. ze only
-        VT p1new[RY], p2new[RY], canew[RY], cbnew[RY];
-#pragma unroll
-        for (int r = 0; r < RY; ++r) p1new[r] = p2new[r] = canew[r] = cbnew[r] = zero;
-        VT xp1 = zero, xcanew = zero, xcbnew = zero;
-
-        bool all_rows = x0 + TX <= g.nx;
-#pragma unroll
-        for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];
-        // ---- 2b. the x / y neighbours of the main rows, requested one level AHEAD: level 1's and level 2's here, level 3's
-        //          behind level 1's arithmetic.  What level L reads this iteration (phi0 plane z, phi1 plane z-1, phi2 plane z-2)
-        //          was written before the last barrier, and the ring slots the levels write are the other ones: reading early
-        //          changes no value.  In program order every level's reads sat behind the previous level's ring write (which the
-        //          compiler cannot tell apart from them), so each level paid its own LDS round trip with only one other wave on
-        //          the SIMD to hide it.  Per level: the cell left of the lane's first and right of its last on each row, the
-        //          row above the first row and the row below the last.  (All three levels at the top: 255 VGPRs and scratch.)
-        T nbl[3][RY], nbr[3][RY];
-        VT nbu[3], nbd[3];
-        auto nbload = [&](auto level_tag) {
-            constexpr int L = decltype(level_tag)::value;
-            const T *cc = L == 0 ? c0 : L == 1 ? c1 : c2;
-            constexpr int lp = L == 0 ? LP0 : L == 1 ? LP1 : LP2, hx = L == 0 ? HX0 : L == 1 ? HX1 : HX2;
-            const int yb = y0 - 3 + L;
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                const int o = (yrow[r] - yb) * lp + hx + xl;
-#ifdef WAFER_F3_DPP
-                // the x neighbours of the lane's first / last cell are the last / first cell of the lane next door, which holds
-                // them in registers: a DPP wave shift instead of an LDS read; only lanes 0 and 63 take the halo column from
-                // LDS (one read per row: each of the two reads its own side)
-                const VT ctr = L == 0 ? q0[1][r] : L == 1 ? q1[2][r] : q2[2][r];   // (levels 2, 3: the queues rotate after this)
-                const T edge = cc[o + (lane == 63 ? VEC : -1)];
-                nbl[L][r] = wafer_lane_below(ctr[VEC - 1], edge);
-                nbr[L][r] = wafer_lane_above(ctr[0], edge);
-#else
-                nbl[L][r] = cc[o - 1];
-                nbr[L][r] = cc[o + VEC];
-#endif
-            }
-            nbu[L] = *reinterpret_cast<const VT *>(cc + (yrow[0] - yb - 1) * lp + hx + xl);
-            nbd[L] = *reinterpret_cast<const VT *>(cc + (yrow[RY - 1] - yb + 1) * lp + hx + xl);
-        };
-        nbload(std::integral_constant<int, 0>{});
-        nbload(std::integral_constant<int, 1>{});
-        issue_group(5);
-        // ---- 3. level 1, main rows.  INTERIOR: the plane and both rows are work cells, the tile's columns too: no tests
-        //         inside, the RY x VEC updates form one basic block
-        auto level1 = [&](auto interior_tag) {
-            constexpr bool INTERIOR = decltype(interior_tag)::value;
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                VT res = zero;
-                if (INTERIOR || (wplane1 && rowwk[r])) {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        const C w = (C)q0[1][r][v];
-                        C xs[3], ys[3], zz[3];
-                        zz[0] = (C)q0[ZLO][r][v]; zz[1] = w; zz[2] = (C)q0[ZHI][r][v];
-                        xs[1] = ys[1] = w;
-                        xs[0] = (v >= 1) ? (C)q0[1][r][(v + VEC - 1) % VEC] : (C)nbl[0][r];
-                        xs[2] = (v + 1 < VEC) ? (C)q0[1][r][(v + 1) % VEC] : (C)nbr[0][r];
-                        ys[0] = (r >= 1) ? (C)q0[1][r >= 1 ? r - 1 : 0][v] : (C)nbu[0][v];
-                        ys[2] = (r + 1 < RY) ? (C)q0[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[0][v];
-                        const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                        C ka, kb;
-                        const T rs = update_keep(w, (C)vcur[r][v], S, ka, kb);
-                        canew[r][v] = (T)ka;
-                        cbnew[r][v] = (T)kb;
-                        res[v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
-                    }
-                }
-                p1new[r] = res;
-                *reinterpret_cast<VT *>(w1 + (yrow[r] - (y0 - 2)) * LP1 + HX1 + xl) = res;
-            }
-        };
-        if (all_rows && wplane1) level1(std::true_type{});
-        else level1(std::false_type{});
-        WAFER_F3_STAMP_AT(1);   // level 1, main rows (with the neighbours' LDS round trip)
-        issue_group(1);
-        nbload(std::integral_constant<int, 2>{});
-        // ---- 3x. level 1, the extra slot
-        if (x_row) {
-            VT res = zero;
-            if (wplane1 && xwk) {
-                const int ly = xy - (y0 - 3);
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    const C w = (C)xq0[1][v];
-                    C xs[3], ys[3], zz[3];
-                    zz[0] = (C)xq0[ZLO][v]; zz[1] = w; zz[2] = (C)xq0[ZHI][v];
-                    xs[1] = ys[1] = w;
-                    xs[0] = (v >= 1) ? (C)xq0[1][(v + VEC - 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v - 1];
-                    xs[2] = (v + 1 < VEC) ? (C)xq0[1][(v + 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v + 1];
-                    ys[0] = (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
-                    ys[2] = (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
-                    const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                    C ka, kb;
-                    const T rs = update_keep(w, (C)xv[v], S, ka, kb);
-                    xcanew[v] = (T)ka;
-                    xcbnew[v] = (T)kb;
-                    res[v] = (xi + v < g.nx) ? rs : T(0);
-                }
-            }
-            xp1 = res;
-            *reinterpret_cast<VT *>(w1 + (xy - (y0 - 2)) * LP1 + HX1 + xl) = res;
-        } else if (c_l1) {
-            T rs = T(0);
-            if (wplane1 && c_wk) {
-                const C w = (C)xq0[1][0];
-                C xs[3], ys[3], zz[3];
-                zz[0] = (C)xq0[ZLO][0]; zz[1] = w; zz[2] = (C)xq0[ZHI][0];
-                xs[1] = ys[1] = w;
-                xs[0] = (C)c0[c_lds0 - 1]; xs[2] = (C)c0[c_lds0 + 1];
-                ys[0] = (C)c0[c_lds0 - LP0]; ys[2] = (C)c0[c_lds0 + LP0];
-                const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                C ka, kb;
-                rs = update_keep(w, (C)xv[0], S, ka, kb);
-                xcanew[0] = (T)ka;
-                xcbnew[0] = (T)kb;
-            }
-            w1[c_lds1] = rs;
-            xp1[0] = rs;
-        }
-        issue_group(2);
-        WAFER_F3_STAMP_AT(2);   // level 1, the extra slot
-        // ---- 4. level 2: phi2 of the plane behind, from the phi1 queues; a, b as level 1 formed them one iteration ago
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            q1[0][r] = q1[1][r];
-            q1[1][r] = q1[2][r];
-            q1[2][r] = p1new[r];
-        }
-        xq1[0] = xq1[1];
-        xq1[1] = xq1[2];
-        xq1[2] = xp1;
-        if (need2) {
-            auto level2 = [&](auto interior_tag) {
-                constexpr bool INTERIOR = decltype(interior_tag)::value;
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    VT res = zero;
-                    if (INTERIOR || (wplane2 && rowwk[r])) {
-                        const VT m1 = q1[1][r];
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            const C w = (C)m1[v];
-                            C xs[3], ys[3], zz[3];
-                            zz[0] = (C)q1[ZLO][r][v]; zz[1] = w; zz[2] = (C)q1[ZHI][r][v];
-                            xs[1] = ys[1] = w;
-                            xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)nbl[1][r];
-                            xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)nbr[1][r];
-                            ys[0] = (r >= 1) ? (C)q1[1][r >= 1 ? r - 1 : 0][v] : (C)nbu[1][v];
-                            ys[2] = (r + 1 < RY) ? (C)q1[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[1][v];
-                            const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                            const T rs = update_with(w, (C)caq[1][r][v], (C)cbq[1][r][v], S);
-                            res[v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
-                        }
-                    }
-                    p2new[r] = res;
-                    *reinterpret_cast<VT *>(w2 + (yrow[r] - (y0 - 1)) * LP2 + HX2 + xl) = res;
-                }
-            };
-            if (all_rows && wplane2) level2(std::true_type{});
-            else level2(std::false_type{});
-            if (x_row) {
-                if (x_l2) {
-                    VT res = zero;
-                    if (wplane2 && xwk) {
-                        const int ly = xy - (y0 - 2);
-                        const VT m1 = xq1[1];
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            const C w = (C)m1[v];
-                            C xs[3], ys[3], zz[3];
-                            zz[0] = (C)xq1[ZLO][v]; zz[1] = w; zz[2] = (C)xq1[ZHI][v];
-                            xs[1] = ys[1] = w;
-                            xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v - 1];
-                            xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)c1[ly * LP1 + HX1 + xl + v + 1];
-                            ys[0] = (C)c1[(ly - 1) * LP1 + HX1 + xl + v];
-                            ys[2] = (C)c1[(ly + 1) * LP1 + HX1 + xl + v];
-                            const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                            const T rs = update_with(w, (C)xca[v], (C)xcb[v], S);
-                            res[v] = (xi + v < g.nx) ? rs : T(0);
-                        }
-                    }
-                    *reinterpret_cast<VT *>(w2 + (xy - (y0 - 1)) * LP2 + HX2 + xl) = res;
-                }
-            } else if (c_l2) {
-                T rs = T(0);
-                if (wplane2 && c_wk) {
-                    const C w = (C)xq1[1][0];
-                    C xs[3], ys[3], zz[3];
-                    zz[0] = (C)xq1[ZLO][0]; zz[1] = w; zz[2] = (C)xq1[ZHI][0];
-                    xs[1] = ys[1] = w;
-                    xs[0] = (C)c1[c_lds1 - 1]; xs[2] = (C)c1[c_lds1 + 1];
-                    ys[0] = (C)c1[c_lds1 - LP1]; ys[2] = (C)c1[c_lds1 + LP1];
-                    const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                    rs = update_with(w, (C)xca[0], (C)xcb[0], S);
-                }
-                w2[c_lds2] = rs;
+            if (it0 + 2 >= niter) break;
+            {
+                const int it = it0 + 2;
+#define WAFER_F3_PH 2
+#include "wafer_stencil_fused3_iter.inc.h"
+#undef WAFER_F3_PH
             }
         }
-        WAFER_F3_STAMP_AT(3);   // level 2 (main rows and the extra slot)
-        issue_group(3);
-        // ---- 5. level 3: phi3 two planes behind from the phi2 queue, a, b as formed two iterations ago; stored
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            q2[0][r] = q2[1][r];
-            q2[1][r] = q2[2][r];
-            q2[2][r] = p2new[r];
+    } else {
+        for (int it = 0; it < niter; ++it) {
+#define WAFER_F3_PH 0
+#include "wafer_stencil_fused3_iter.inc.h"
+#undef WAFER_F3_PH
         }
-        const int zo3 = z - 2 * SD;
-        const bool last_wt = SYNC && blk.bump >= 0 && (DOWN ? zo3 < zs + blk.wt : zo3 >= ze - blk.wt);      // the last wt planes of the march
-        const bool first_wt = PEER && bump_early >= 0 && (DOWN ? zo3 >= ze - blk.wt : zo3 < zs + blk.wt);   // the first wt planes (whole-column peer passes)
-        // mode 2: the planes the exchange kernel reads while this kernel is still running go to memory at once; peer mode: nobody
-        // reads them before the kernel ends, what travels is the copy into the neighbour's ghost planes
-        const bool wthrough = last_wt && !PEER;
-        // the neighbour's buffer, shifted so that this slab's plane index addresses the ghost plane it fills (nullptr: no peer stores).
-        // Stored from the registers, inside the loop's store path: a copy from memory after the fact (the planes read back at agent
-        // scope, two more barriers per boundary) measured 0.320 against 0.280 ms/step at the bench slab.
-        T *peer_dst = nullptr;
-        if constexpr (PEER) peer_dst = first_wt ? peer_first : last_wt ? peer_last : nullptr;
-        if (XS || (zo3 >= zs && zo3 < ze)) {
-            auto level3 = [&](auto interior_tag) {
-                constexpr bool INTERIOR = decltype(interior_tag)::value;
-                VT res3[RY];
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    res3[r] = zero;
-                    if (INTERIOR || rowwk[r]) {
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            const C w = (C)q2[1][r][v];
-                            C xs[3], ys[3], zz[3];
-                            zz[0] = (C)q2[ZLO][r][v]; zz[1] = w; zz[2] = (C)q2[ZHI][r][v];
-                            xs[1] = ys[1] = w;
-                            xs[0] = (v >= 1) ? (C)q2[1][r][(v + VEC - 1) % VEC] : (C)nbl[2][r];
-                            xs[2] = (v + 1 < VEC) ? (C)q2[1][r][(v + 1) % VEC] : (C)nbr[2][r];
-                            ys[0] = (r >= 1) ? (C)q2[1][r - 1 < 0 ? 0 : r - 1][v] : (C)nbu[2][v];
-                            ys[2] = (r + 1 < RY) ? (C)q2[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[2][v];
-                            const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                            const T rs = update_with(w, (C)caq[0][r][v], (C)cbq[0][r][v], S);
-                            res3[r][v] = (SYNC && poisoned) ? (T)__builtin_nanf("") : rs;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    if (INTERIOR || rowwk[r]) {
-#ifdef WAFER_F3_ABL_NOSTORE  // timing experiment: nothing is stored (the compiler cannot know)
-                        if (a.dt > -1.0) continue;
-#endif
-                        const int zst = !XS ? zo3 : DOWN ? (zo3 < ze - 1 ? zo3 : ze - 1) : (zo3 > zs ? zo3 : zs);
-                        T *dst = (out + (long long)zst * g.plane + rowoff[r]) + xlu;
-                        if constexpr (XS) {
-                            *reinterpret_cast<VT *>(dst) = res3[r];
-                            continue;
-                        }
-                        if constexpr (PEER) {
-                            if (peer_dst) {   // into the neighbour's ghost planes (wave-uniform), system scope, written through
-                                T *pd = (peer_dst + (long long)zo3 * g.plane + rowoff[r]) + xlu;
-#pragma unroll
-                                for (int v = 0; v < VEC; ++v)
-                                    if (INTERIOR || xi + v < g.nx) __hip_atomic_store(pd + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            }
-                        }
-                        if (wthrough) {
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v)
-                                if (INTERIOR || xi + v < g.nx) __hip_atomic_store(dst + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else if (INTERIOR || xi + VEC <= g.nx) {
-                            *reinterpret_cast<VT *>(dst) = res3[r];
-                        } else {
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v)
-                                if (xi + v < g.nx) dst[v] = res3[r][v];
-                        }
-                    }
-                }
-            };
-            if constexpr (XS) level3(std::true_type{});   // (grids of whole tiles only: the launcher)
-            else if (all_rows) level3(std::true_type{});
-            else level3(std::false_type{});
-        }
-        issue_group(4);
-        WAFER_F3_STAMP_AT(4);   // level 3 and its stores
-        // whole-column peer passes: the first wt planes are out after iteration wt + 3 -- acknowledged here, counted behind the barrier
-        const bool early_done = PEER && bump_early >= 0 && it == blk.wt + 3;
-        if constexpr (PEER) {
-            if (early_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-#ifdef WAFER_F3_ABL_NOBAR      // timing experiment: no workgroup barrier in the plane loop (LDS contents race)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-        __syncthreads();
-#endif
-        if constexpr (PEER) {
-            if (early_done && tid == 0) {
-                unsigned long long *const pf = const_cast<const volatile WaferF3Peer *>(syv->peer_dev)->flag[bump_early];
-                if (pf) __hip_atomic_fetch_add(pf, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        WAFER_F3_STAMP_AT(5);   // the barrier
-        // ---- 6. rotate the phi0 / V / a, b pipelines.  The prefetched values are pinned HERE, behind the barrier: left to itself the
-        //         compiler sometimes consumes a prefetch where it was issued (the halo-column waves then wait out the whole memory
-        //         latency at the top of every iteration) or ahead of the barrier (every wave waits for its loads first and for the
-        //         slowest wave second) -- which of the two 8 % apart "states" a build landed in used to depend on unrelated edits.
-        auto pin = [](VT &x) {
-            if constexpr (VEC == 1) {
-                T t = x[0];
-                asm volatile("" : "+v"(t));
-                x[0] = t;
-            } else asm volatile("" : "+v"(x));
-        };
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            pin(pre[r]);
-            pin(pre_v[r]);
-        }
-        pin(xpre);
-        pin(xpre_v);
-        pin(orow_pre);
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            q0[0][r] = q0[1][r];
-            q0[1][r] = q0[2][r];
-            q0[2][r] = pre[r];
-            vcur[r] = pre_v[r];
-            caq[0][r] = caq[1][r];
-            cbq[0][r] = cbq[1][r];
-            caq[1][r] = canew[r];
-            cbq[1][r] = cbnew[r];
-        }
-        xq0[0] = xq0[1];
-        xq0[1] = xq0[2];
-        xq0[2] = xpre;
-        xv = xpre_v;
-        xca = xcanew;
-        xcb = xcbnew;
-        orow_nxt = orow_pre;
-#ifdef WAFER_F3_STAMP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (what is left of the requests' latency, made visible)
-#endif
-        WAFER_F3_STAMP_AT(6);   // the wait for the prefetched planes, the queue rotation
     }
+#undef WAFER_F3_Q0
+#undef WAFER_F3_Q1
 #ifdef WAFER_F3_STAMP
     if (blockIdx.x == gridDim.x / 2 + 3 && lane == 0) {
 #pragma unroll
@@ -839,8 +466,10 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) WAFER_F3_OCC void wafer_k_ste
     __shared__ __attribute__((aligned(16))) T lds1[2 * Cfg::TILE1];
     __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
     const WaferF3Block blk = table[blockIdx.x];
-    if (blk.down & 1) wafer_step3_body<T, C, VIR, true, MODE, XS>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
-    else wafer_step3_body<T, C, VIR, false, MODE, XS>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    // (ring queues where the kernel has the registers for the unrolled loop: the plain instantiation with exact store counts)
+    constexpr bool RING = XS && WAFER_F3_RING != 0;
+    if (blk.down & 1) wafer_step3_body<T, C, VIR, true, MODE, XS, RING>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    else wafer_step3_body<T, C, VIR, false, MODE, XS, RING>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
 }
 
 
