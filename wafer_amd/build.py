@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libwafer_hip.so")
 SOURCES = ["wafer_engine.hip", "wafer_tu_lds.hip", "wafer_tu_excited_r1.hip", "wafer_tu_excited_r2.hip", "wafer_tu_excited_r3.hip",
            "wafer_tu_fused2.hip", "wafer_tu_fused3.hip", "wafer_tu_x2.hip", "wafer_mailbox.hip"]
 HEADERS = ["wafer_geom.h", "wafer_tuning.h", "wafer_launch.h", "wafer_stencil.hip.h", "wafer_stencil_lds.hip.h",
-           "wafer_stencil_fused2.hip.h", "wafer_stencil_fused3.hip.h", "wafer_stencil_fused3_iter.inc.h", "wafer_stencil_x2.hip.h", "wafer_elementwise.hip.h", "wafer_rowwalk.h", "wafer_setup.hip.h",
+           "wafer_stencil_fused2.hip.h", "wafer_stencil_fused3.hip.h", "wafer_stencil_fused3_iter.inc.h", "wafer_stencil_x2.hip.h", "wafer_stencil_x2_iter.inc.h", "wafer_elementwise.hip.h", "wafer_rowwalk.h", "wafer_setup.hip.h",
            "wafer_tu_excited.inc"]
 # -ffp-contract=off: the stencil update must round exactly like the reference's
 # (rustc never fuses mul+add); see DESIGN.md "Parity contract".

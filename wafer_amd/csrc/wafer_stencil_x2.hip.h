@@ -64,6 +64,9 @@ static inline int wafer_x2_nsums(int k) { return 1 + 2 * k; }
 // rows, 2 = behind level 1 of the extra slot, 3 = behind level 2.  A: the main rows' input (and V), L: their stored states, M: the images
 // M_j, X: the extra slot's.  Measured per tile (profiles/r04_ab_x2_request_placement.jsonl): on the 128 x 16 tile M and X move back
 // (0.665 -> 0.63 ms/step at k = 2); on the 128 x 8 tile only the extra slot's requests do (0.964 -> 0.87 at k = 3).
+#ifndef WAFER_X2_RING
+#define WAFER_X2_RING 1
+#endif
 #ifndef WAFER_X2_POS_A
 #define WAFER_X2_POS_A 0
 #endif
@@ -141,6 +144,8 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     // barrier), or -- 128 x 16 tiles with two stored states, where LDS has room for two slots only -- two slots plus one plane
     // in registers (HOLD).  Only the l_j wait: the M_j are used by the transform alone (see the head of this file).
     constexpr bool HOLD = (RY == 2 && NL == 2);
+    // ring z-queues (the plane loop unrolled by three, no shifts): the kernels with exact store counts, as in the three-step kernel
+    constexpr bool RING = XS && WAFER_X2_RING != 0;
     constexpr int NSLOT = HOLD ? 2 : 3;
     __shared__ __attribute__((aligned(16))) T ldsq[NSLOT * NL * QS];   // [slot][state][row][x]
     __shared__ double red[Cfg::NW];
@@ -320,324 +325,40 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     for (int j = 0; j < NL; ++j) acc_yl[j] = acc_zl[j] = 0.0;
 
     const int niter = (ze - zs) + 2;
-    for (int it = 0; it < niter; ++it) {
-        const int z = z1 + it;
-        const bool more = it + 1 < niter;
-#ifdef WAFER_X2_ABL_NOLOAD    // timing experiment: every prefetch asks for the column's first planes again (cache hits)
-        const long long zo = (long long)(z1 + (it & 1)) * g.plane;
-#else
-        const long long zo = (long long)z * g.plane;
-#endif
-        // ---- 1. prefetch, raw: input and stored states two planes ahead, V one plane ahead
-        VT pre[RY], pre_l[NL][RY], pre_m[NL][RY], pre_v[RY], xpre = zero, xpre_l[NL], xpre_m[NL], xpre_v = zero;
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            pre[r] = pre_v[r] = zero;
-#pragma unroll
-            for (int j = 0; j < NL; ++j) pre_l[j][r] = pre_m[j][r] = zero;
-        }
-#pragma unroll
-        for (int j = 0; j < NL; ++j) xpre_l[j] = xpre_m[j] = zero;
-        // The requests of a wave are spread over the iteration (as in the three-step kernel: all eight waves leave the barrier at
-        // once, and (2 + 4k) x 8 requests of 1 KiB queueing at the CU's one address unit kept every wave from its arithmetic):
-        // which group goes where is measured per tile shape (WAFER_X2_POS_*).
-        auto issue_group = [&](int pos) {
-            if (pos == WAFER_X2_POS_A) {
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    pre[r] = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + rowoff[r]) + xlu);
-                    if constexpr (VG == 0) pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + g.plane + rowoff[r]) + xlu);
-                }
+#define WAFER_X2_Q0(m) (RING ? ((m) + WAFER_X2_PH) % 3 : (m))
+#define WAFER_X2_Q1(m) (RING ? ((m) + WAFER_X2_PH + 1) % 3 : (m))
+    if constexpr (RING) {
+        for (int it0 = 0; it0 < niter; it0 += 3) {
+            {
+                const int it = it0;
+#define WAFER_X2_PH 0
+#include "wafer_stencil_x2_iter.inc.h"
+#undef WAFER_X2_PH
             }
-            if (pos == WAFER_X2_POS_L) {
-#pragma unroll
-                for (int r = 0; r < RY; ++r)
-#pragma unroll
-                    for (int j = 0; j < NL; ++j) pre_l[j][r] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
+            if (it0 + 1 >= niter) break;
+            {
+                const int it = it0 + 1;
+#define WAFER_X2_PH 1
+#include "wafer_stencil_x2_iter.inc.h"
+#undef WAFER_X2_PH
             }
-            if (pos == WAFER_X2_POS_M) {
-#pragma unroll
-                for (int r = 0; r < RY; ++r)
-#pragma unroll
-                    for (int j = 0; j < NL; ++j) pre_m[j][r] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
-            }
-            if (pos == WAFER_X2_POS_X) {
-                if (x_row) {
-                    xpre = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + xoff_row) + xlu);
-#pragma unroll
-                    for (int j = 0; j < NL; ++j) {
-                        xpre_l[j] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + xoff_row) + xlu);
-                        xpre_m[j] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + xoff_row) + xlu);
-                    }
-                    // (every row wave, also the two that only stage their row: a request inside one more branch makes the wait-count pass
-                    //  wait for the requests issued before it)
-                    if constexpr (VG == 0) xpre_v = *reinterpret_cast<const VT *>((pv + zo + g.plane + xoff_row) + xlu);
-                } else {
-                    xpre[0] = phi[zo + 2 * g.plane + c_off];
-#pragma unroll
-                    for (int j = 0; j < NL; ++j) {
-                        xpre_l[j][0] = st.l[j][zo + 2 * g.plane + c_off];
-                        xpre_m[j][0] = st.m[j][zo + 2 * g.plane + c_off];
-                    }
-                    if constexpr (VG == 0) xpre_v[0] = pv[zo + g.plane + c_off];
-                }
-            }
-        };
-        issue_group(0);
-        // ---- 2. stage the next x0 plane into the other buffer
-        if (more) {
-            T *nt = lds0 + ((z + 1) & 1) * Cfg::TILE0;
-#pragma unroll
-            for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(nt + (yrow[r] - (y0 - 2)) * LP0 + HX0 + xl) = q0[2][r];
-            if (x_row) *reinterpret_cast<VT *>(nt + (xy - (y0 - 2)) * LP0 + HX0 + xl) = xy_out ? zero : xq0[2];
-            else if (c_ok) nt[c_lds0] = c_xout ? T(0) : xq0[2][0];
-        }
-        const T *c0 = lds0 + (z & 1) * Cfg::TILE0;
-        T *w1 = lds1 + (z & 1) * Cfg::TILE1;
-        const T *c1 = lds1 + ((z + 1) & 1) * Cfg::TILE1;
-        const bool wplane1 = work_plane(z), wplane2 = work_plane(z - 1);
-        const int zp2 = z - 1;
-        const bool act2 = zp2 >= zs && zp2 < ze;
-        VT p1new[RY], canew[RY], cbnew[RY];
-#pragma unroll
-        for (int r = 0; r < RY; ++r) p1new[r] = canew[r] = cbnew[r] = zero;
-        VT xp1 = zero;
-
-        bool all_rows = x0 + TX <= g.nx;
-#pragma unroll
-        for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];
-        // ---- 2b. x / y neighbours of the main rows at both levels, requested ahead of the arithmetic (what level L reads
-        //          this iteration was written before the last barrier; the slots written this iteration are the other ones)
-        T nbl[2][RY], nbr[2][RY];
-        VT nbu[2], nbd[2];
-        auto nbload = [&](auto level_tag) {
-            constexpr int L = decltype(level_tag)::value;
-            const T *cc = L == 0 ? c0 : c1;
-            constexpr int lp = L == 0 ? LP0 : LP1, hx = L == 0 ? HX0 : HX1;
-            const int yb = y0 - 2 + L;
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                const int o = (yrow[r] - yb) * lp + hx + xl;
-                nbl[L][r] = cc[o - 1];
-                nbr[L][r] = cc[o + VEC];
-            }
-            nbu[L] = *reinterpret_cast<const VT *>(cc + (yrow[0] - yb - 1) * lp + hx + xl);
-            nbd[L] = *reinterpret_cast<const VT *>(cc + (yrow[RY - 1] - yb + 1) * lp + hx + xl);
-        };
-        nbload(std::integral_constant<int, 0>{});
-        // ---- 3. level 1, main rows
-        auto level1 = [&](auto interior_tag) {
-            constexpr bool INTERIOR = decltype(interior_tag)::value;
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                VT res = zero;
-                if (INTERIOR || (wplane1 && rowwk[r])) {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        const C w = (C)q0[1][r][v];
-                        C xs[3], ys[3], zz[3];
-                        zz[0] = (C)q0[0][r][v]; zz[1] = w; zz[2] = (C)q0[2][r][v];
-                        xs[1] = ys[1] = w;
-                        xs[0] = (v >= 1) ? (C)q0[1][r][(v + VEC - 1) % VEC] : (C)nbl[0][r];
-                        xs[2] = (v + 1 < VEC) ? (C)q0[1][r][(v + 1) % VEC] : (C)nbr[0][r];
-                        ys[0] = (r >= 1) ? (C)q0[1][r >= 1 ? r - 1 : 0][v] : (C)nbu[0][v];
-                        ys[2] = (r + 1 < RY) ? (C)q0[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[0][v];
-                        const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                        C ka, kb;
-                        const T rs = update_keep(w, v_at((C)vcur[r][v], xi + v, yrow[r], z), S, ka, kb);
-                        canew[r][v] = (T)ka;
-                        cbnew[r][v] = (T)kb;
-                        res[v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
-                    }
-                }
-                p1new[r] = res;
-                *reinterpret_cast<VT *>(w1 + (yrow[r] - (y0 - 1)) * LP1 + HX1 + xl) = res;
-            }
-        };
-        if (all_rows && wplane1) level1(std::true_type{});
-        else level1(std::false_type{});
-        issue_group(1);
-        // level 2's neighbours and the stored states of the plane it is about to produce (the lane's own LDS queue), requested
-        // behind level 1's arithmetic
-        VT lq[NL][RY];
-        if (XS || act2) {
-            nbload(std::integral_constant<int, 1>{});
-            const T *qs = qslot(z - 1);
-#pragma unroll
-            for (int j = 0; j < NL; ++j)
-#pragma unroll
-                for (int r = 0; r < RY; ++r) lq[j][r] = *reinterpret_cast<const VT *>(qs + j * QS + qoff[r]);
-        }
-        // ---- 3x. level 1, the extra slot
-        if (x_row) {
-            if (x_l1) {
-                VT res = zero;
-                if (wplane1 && xwk) {
-                    const int ly = xy - (y0 - 2);
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        const C w = (C)xq0[1][v];
-                        C xs[3], ys[3], zz[3];
-                        zz[0] = (C)xq0[0][v]; zz[1] = w; zz[2] = (C)xq0[2][v];
-                        xs[1] = ys[1] = w;
-                        xs[0] = (v >= 1) ? (C)xq0[1][(v + VEC - 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v - 1];
-                        xs[2] = (v + 1 < VEC) ? (C)xq0[1][(v + 1) % VEC] : (C)c0[ly * LP0 + HX0 + xl + v + 1];
-                        ys[0] = (C)c0[(ly - 1) * LP0 + HX0 + xl + v];
-                        ys[2] = (C)c0[(ly + 1) * LP0 + HX0 + xl + v];
-                        const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                        C ka, kb;
-                        const T rs = update_keep(w, v_at((C)xv[v], xi + v, xy, z), S, ka, kb);
-                        res[v] = (xi + v < g.nx) ? rs : T(0);
-                    }
-                }
-                xp1 = res;
-                *reinterpret_cast<VT *>(w1 + (xy - (y0 - 1)) * LP1 + HX1 + xl) = res;
-            }
-        } else if (c_l1) {
-            T rs = T(0);
-            if (wplane1 && c_wk) {
-                const C w = (C)xq0[1][0];
-                C xs[3], ys[3], zz[3];
-                zz[0] = (C)xq0[0][0]; zz[1] = w; zz[2] = (C)xq0[2][0];
-                xs[1] = ys[1] = w;
-                xs[0] = (C)c0[c_lds0 - 1]; xs[2] = (C)c0[c_lds0 + 1];
-                ys[0] = (C)c0[c_lds0 - LP0]; ys[2] = (C)c0[c_lds0 + LP0];
-                const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                C ka, kb;
-                rs = update_keep(w, v_at((C)xv[0], cxw, cy, z), S, ka, kb);
-            }
-            w1[c_lds1] = rs;
-            xp1[0] = rs;
-        }
-        (void)xp1;
-        issue_group(2);
-        // ---- 4. level 2: Z of the plane behind from the Y1 queue, a, b as level 1 formed them one iteration ago; the sums
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            q1[0][r] = q1[1][r];
-            q1[1][r] = q1[2][r];
-            q1[2][r] = p1new[r];
-        }
-        if (XS || act2) {
-            auto level2 = [&](auto interior_tag) {
-                constexpr bool INTERIOR = decltype(interior_tag)::value;
-                VT res2[RY];
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    res2[r] = zero;
-                    if (INTERIOR || (wplane2 && rowwk[r])) {
-                        const VT m1 = q1[1][r];
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            const C w = (C)m1[v];
-                            C xs[3], ys[3], zz[3];
-                            zz[0] = (C)q1[0][r][v]; zz[1] = w; zz[2] = (C)q1[2][r][v];
-                            xs[1] = ys[1] = w;
-                            xs[0] = (v >= 1) ? (C)m1[(v + VEC - 1) % VEC] : (C)nbl[1][r];
-                            xs[2] = (v + 1 < VEC) ? (C)m1[(v + 1) % VEC] : (C)nbr[1][r];
-                            ys[0] = (r >= 1) ? (C)q1[1][r >= 1 ? r - 1 : 0][v] : (C)nbu[1][v];
-                            ys[2] = (r + 1 < RY) ? (C)q1[1][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[1][v];
-                            const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                            const T rs = update_with(w, (C)caq[r][v], (C)cbq[r][v], S);
-                            res2[r][v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
-                        }
-                    }
-                }
-                // the sums of this plane: Y1 (still in its queue) against itself and the stored states, Z against the stored
-                // states.  Cells outside the work area hold exact zeros at both levels, so nothing is masked here.
-                if (!XS || act2)
-#pragma unroll
-                for (int r = 0; r < RY; ++r)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        const double yv = q1[1][r][v], zv = res2[r][v];
-                        acc_y = __builtin_fma(yv, yv, acc_y);
-#pragma unroll
-                        for (int j = 0; j < NL; ++j) {
-                            acc_yl[j] = __builtin_fma(lq[j][r][v], yv, acc_yl[j]);
-                            acc_zl[j] = __builtin_fma(lq[j][r][v], zv, acc_zl[j]);
-                        }
-                    }
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    if (INTERIOR || rowwk[r]) {
-#ifdef WAFER_X2_ABL_NOSTORE   // timing experiment: nothing is stored (the compiler cannot know)
-                        if (a.dt > -1.0) continue;
-#endif
-                        T *dst = (out + (long long)(XS && zp2 < zs ? zs : zp2) * g.plane + rowoff[r]) + xlu;
-                        if (INTERIOR || xi + VEC <= g.nx) {
-                            *reinterpret_cast<VT *>(dst) = res2[r];
-                        } else {
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v)
-                                if (xi + v < g.nx) dst[v] = res2[r][v];
-                        }
-                    }
-                }
-            };
-            if constexpr (XS) level2(std::true_type{});   // (whole tiles, work planes only: the launcher)
-            else if (all_rows && wplane2) level2(std::true_type{});
-            else level2(std::false_type{});
-        }
-        issue_group(3);
-        // HOLD: the plane transformed last iteration (z + 1) takes the queue slot just read (same lanes: program order suffices)
-        if constexpr (HOLD) {
-            T *qd = qslot(z + 1);
-#pragma unroll
-            for (int j = 0; j < NL; ++j)
-#pragma unroll
-                for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(qd + j * QS + qoff[r]) = hold_l[j][r];
-        }
-        __syncthreads();
-        // ---- 5. rotate the pipelines; the plane requested at the top of the iteration is transformed here -- BEHIND the
-        //         barrier: the wait for those loads then overlaps the wait for the other waves.  (With the transform down to a
-        //         handful of fused multiply-adds the compiler hoisted it above the barrier, and every wave waited for its loads
-        //         first and for the slowest wave second: 0.507 against 0.485 ms/step at k = 1.  The pins keep it here.)
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            asm volatile("" : "+v"(pre[r]));
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                asm volatile("" : "+v"(pre_l[j][r]));
-                asm volatile("" : "+v"(pre_m[j][r]));
+            if (it0 + 2 >= niter) break;
+            {
+                const int it = it0 + 2;
+#define WAFER_X2_PH 2
+#include "wafer_stencil_x2_iter.inc.h"
+#undef WAFER_X2_PH
             }
         }
-        asm volatile("" : "+v"(xpre));
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            asm volatile("" : "+v"(xpre_l[j]));
-            asm volatile("" : "+v"(xpre_m[j]));
+    } else {
+        for (int it = 0; it < niter; ++it) {
+#define WAFER_X2_PH 0
+#include "wafer_stencil_x2_iter.inc.h"
+#undef WAFER_X2_PH
         }
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            q0[0][r] = q0[1][r];
-            q0[1][r] = q0[2][r];
-            VT l[NL], mm[NL];
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                l[j] = pre_l[j][r];
-                mm[j] = pre_m[j][r];
-                // plane z + 2: read at iteration z + 3, as plane (z + 3) - 1 -- its slot (z + 2) % 3 was last read at iteration z
-                if constexpr (HOLD) hold_l[j][r] = l[j];
-                else *reinterpret_cast<VT *>(qslot(z + 2) + j * QS + qoff[r]) = l[j];
-            }
-            q0[2][r] = xform_vec(pre[r], l, mm);
-            vcur[r] = pre_v[r];
-            caq[r] = canew[r];
-            cbq[r] = cbnew[r];
-        }
-        xq0[0] = xq0[1];
-        xq0[1] = xq0[2];
-        if (x_row) {
-            xq0[2] = xform_vec(xpre, xpre_l, xpre_m);
-        } else {
-            double l[NL], mm[NL];
-#pragma unroll
-            for (int j = 0; j < NL; ++j) { l[j] = xpre_l[j][0]; mm[j] = xpre_m[j][0]; }
-            xq0[2][0] = wafer_x2_xform<NL>(kf, xpre[0], l, mm);
-        }
-        xv = xpre_v;
     }
+#undef WAFER_X2_Q0
+#undef WAFER_X2_Q1
     // ---- the workgroup's partial sums
     {
         int q = 0;
