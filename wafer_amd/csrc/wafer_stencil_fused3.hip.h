@@ -77,6 +77,15 @@ __device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
 #ifndef WAFER_F3_RING
 #define WAFER_F3_RING 1
 #endif
+#ifndef WAFER_F3_RING_PEER   // the peer-store instantiation on ring queues as well
+#define WAFER_F3_RING_PEER 0
+#endif
+#ifndef WAFER_F3_XS_PEER     // the peer-store instantiation with exact store counts
+#define WAFER_F3_XS_PEER 1
+#endif
+#ifndef WAFER_F3_PEER_SPLIT  // ... and its middle iterations on the plain kernel's body (wafer_step3_body)
+#define WAFER_F3_PEER_SPLIT 1
+#endif
 #ifndef WAFER_F3_POS_A
 #define WAFER_F3_POS_A 0
 #endif
@@ -220,7 +229,7 @@ __device__ __forceinline__ const volatile WaferF3Sync *wafer_f3_sync_in_kernarg(
 // makes every wave sit out the completion of the two stores it issued a few hundred cycles earlier, once per plane (the
 // ablations of profiles/NOTES.md: the kernel without its stores 0.202 ms/step, without its loads 0.215, with both 0.253, without
 // either 0.192).  While the pipeline fills, the two stores go to the column's first plane, which the first real store overwrites.
-template <typename T, typename C, bool VIR, bool DOWN, int MODE, bool XS = false, bool RING = false>
+template <typename T, typename C, bool VIR, bool DOWN, int MODE, bool XS = false, bool RING_T = false>
 __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const WaferF3Block &blk, int ntx, const WaferF3Sync &sy,
                                                   const T *__restrict__ phi, const T *__restrict__ pv, T *__restrict__ out,
                                                   T *lds0, T *lds1, T *lds2)
@@ -238,7 +247,8 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     const int zs = blk.zs, ze = blk.ze;
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr bool PEER = MODE == 2, SYNC = MODE != 0;
-    static_assert(!XS || MODE == 0, "exact store counts: plain launches only");
+    constexpr bool RING = RING_T;   // (a local name: the peer instantiation's middle segment shadows it, with PEER and SYNC)
+    static_assert(!XS || MODE == 0 || MODE == 2, "exact store counts: plain launches and peer-store passes (mode 2's boundary planes are written through, store by store)");
     (void)sy;   // (never read through the parameter: see WaferF3KernArgs)
     [[maybe_unused]] const volatile WaferF3Sync *const syv = SYNC ? wafer_f3_sync_in_kernarg() : nullptr;
     const int wait_early = PEER ? ((blk.down >> 8) & 3) - 1 : -1, bump_early = PEER ? ((blk.down >> 16) & 3) - 1 : -1;
@@ -388,6 +398,14 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         }
         asm volatile("" : "+v"(peer_first), "+v"(peer_last));
     }
+    // The early arrival counter's address likewise: read inside the loop (two dependent volatile loads in a branch taken once per
+    // column) it made the wait-count pass end every iteration's wait for the prefetched planes in vmcnt(0) -- the stores just
+    // issued included.
+    [[maybe_unused]] unsigned long long *flag_early = nullptr;
+    if constexpr (PEER) {
+        if (bump_early >= 0) flag_early = const_cast<const volatile WaferF3Peer *>(syv->peer_dev)->flag[bump_early];
+        asm volatile("" : "+v"(flag_early));
+    }
     const int niter = (ze - zs) + 4;
 #ifdef WAFER_F3_STAMP
     unsigned long long stamp_sum[WAFER_F3_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
@@ -395,22 +413,75 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
 #endif
 #define WAFER_F3_Q0(m) (RING ? ((m) + WAFER_F3_PH) % 3 : (m))
 #define WAFER_F3_Q1(m) (RING ? ((m) + WAFER_F3_PH + 1) % 3 : (m))
-    if constexpr (RING) {
-        for (int it0 = 0; it0 < niter; it0 += 3) {
+    if constexpr (PEER && XS && WAFER_F3_PEER_SPLIT != 0) {
+        // Peer-store passes, three segments.  The peer stores, the early count and the late wait all lie within the first
+        // seven and the last five iterations of a column; everything between runs the body of the PLAIN kernel -- no peer path,
+        // no wait, ring queues (a multiple of three iterations, so that the queues enter and leave it in their natural order)
+        // -- whose waits the compiler can count exactly.  With the peer paths in every iteration the wait behind the barrier is
+        // vmcnt(0) (the rare branches' volatile loads) and the ring does not fit (24 B of scratch, 55 scalar spills).  A
+        // workgroup whose early wait gave up poisons every store: it stays on the generic body.
+        const int head_end = niter < 7 ? niter : 7;
+        int mid_len = niter - 5 - head_end;
+        mid_len = (mid_len > 0 && !poisoned) ? mid_len / 3 * 3 : 0;
+        {
+            const int IT_BEGIN = 0, IT_END = head_end;
+        for (int it = IT_BEGIN; it < IT_END; ++it) {
+#define WAFER_F3_PH 0
+#include "wafer_stencil_fused3_iter.inc.h"
+#undef WAFER_F3_PH
+        }
+        }
+        if (mid_len > 0) {
+            constexpr bool PEER = false, SYNC = false, RING = true;   // (shadow the function's: the included text reads these names)
+            const int IT_BEGIN = head_end, IT_END = head_end + mid_len;
+        for (int it0 = IT_BEGIN; it0 < IT_END; it0 += 3) {
             {
                 const int it = it0;
 #define WAFER_F3_PH 0
 #include "wafer_stencil_fused3_iter.inc.h"
 #undef WAFER_F3_PH
             }
-            if (it0 + 1 >= niter) break;
+            if (it0 + 1 >= IT_END) break;
             {
                 const int it = it0 + 1;
 #define WAFER_F3_PH 1
 #include "wafer_stencil_fused3_iter.inc.h"
 #undef WAFER_F3_PH
             }
-            if (it0 + 2 >= niter) break;
+            if (it0 + 2 >= IT_END) break;
+            {
+                const int it = it0 + 2;
+#define WAFER_F3_PH 2
+#include "wafer_stencil_fused3_iter.inc.h"
+#undef WAFER_F3_PH
+            }
+        }
+        }
+        {
+            const int IT_BEGIN = head_end + mid_len, IT_END = niter;
+        for (int it = IT_BEGIN; it < IT_END; ++it) {
+#define WAFER_F3_PH 0
+#include "wafer_stencil_fused3_iter.inc.h"
+#undef WAFER_F3_PH
+        }
+        }
+    } else if constexpr (RING) {
+        const int IT_BEGIN = 0, IT_END = niter;
+        for (int it0 = IT_BEGIN; it0 < IT_END; it0 += 3) {
+            {
+                const int it = it0;
+#define WAFER_F3_PH 0
+#include "wafer_stencil_fused3_iter.inc.h"
+#undef WAFER_F3_PH
+            }
+            if (it0 + 1 >= IT_END) break;
+            {
+                const int it = it0 + 1;
+#define WAFER_F3_PH 1
+#include "wafer_stencil_fused3_iter.inc.h"
+#undef WAFER_F3_PH
+            }
+            if (it0 + 2 >= IT_END) break;
             {
                 const int it = it0 + 2;
 #define WAFER_F3_PH 2
@@ -419,7 +490,8 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             }
         }
     } else {
-        for (int it = 0; it < niter; ++it) {
+        const int IT_BEGIN = 0, IT_END = niter;
+        for (int it = IT_BEGIN; it < IT_END; ++it) {
 #define WAFER_F3_PH 0
 #include "wafer_stencil_fused3_iter.inc.h"
 #undef WAFER_F3_PH
@@ -467,7 +539,7 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) WAFER_F3_OCC void wafer_k_ste
     __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
     const WaferF3Block blk = table[blockIdx.x];
     // (ring queues where the kernel has the registers for the unrolled loop: the plain instantiation with exact store counts)
-    constexpr bool RING = XS && WAFER_F3_RING != 0;
+    constexpr bool RING = XS && WAFER_F3_RING != 0 && (MODE == 0 || WAFER_F3_RING_PEER != 0);
     if (blk.down & 1) wafer_step3_body<T, C, VIR, true, MODE, XS, RING>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
     else wafer_step3_body<T, C, VIR, false, MODE, XS, RING>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
 }
@@ -638,16 +710,18 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     // the synchronisation a launch needs picks the instantiation (see wafer_step3_body): none, mode 2's flags and counters, peer stores
     const int mode = sy.peer ? 2 : (sy.flag != nullptr ? 1 : 0);
     // exact store counts (XS): plain launches over grids made of whole tiles (every store a full vector of work cells)
-    const bool xs = t.f3_xs != 0 && mode == 0 && a.g.nx % Cfg::TX == 0 && a.g.ny % Cfg::TY == 0;
+    const bool xs = t.f3_xs != 0 && mode != 1 && a.g.nx % Cfg::TX == 0 && a.g.ny % Cfg::TY == 0;
 #define WAFER_F3_LAUNCH(VIR_, MODE_, XS_) \
     hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out)
     if (a.v_in_range != 0) {
-        if (mode == 2) WAFER_F3_LAUNCH(true, 2, false);
+        if (mode == 2 && xs && WAFER_F3_XS_PEER) WAFER_F3_LAUNCH(true, 2, true);
+        else if (mode == 2) WAFER_F3_LAUNCH(true, 2, false);
         else if (mode == 1) WAFER_F3_LAUNCH(true, 1, false);
         else if (xs) WAFER_F3_LAUNCH(true, 0, true);
         else WAFER_F3_LAUNCH(true, 0, false);
     } else {
-        if (mode == 2) WAFER_F3_LAUNCH(false, 2, false);
+        if (mode == 2 && xs && WAFER_F3_XS_PEER) WAFER_F3_LAUNCH(false, 2, true);
+        else if (mode == 2) WAFER_F3_LAUNCH(false, 2, false);
         else if (mode == 1) WAFER_F3_LAUNCH(false, 1, false);
         else if (xs) WAFER_F3_LAUNCH(false, 0, true);
         else WAFER_F3_LAUNCH(false, 0, false);

@@ -348,17 +348,18 @@
 #endif
                         const int zst = !XS ? zo3 : DOWN ? (zo3 < ze - 1 ? zo3 : ze - 1) : (zo3 > zs ? zo3 : zs);
                         T *dst = (out + (long long)zst * g.plane + rowoff[r]) + xlu;
-                        if constexpr (XS) {
-                            *reinterpret_cast<VT *>(dst) = res3[r];
-                            continue;
-                        }
                         if constexpr (PEER) {
-                            if (peer_dst) {   // into the neighbour's ghost planes (wave-uniform), system scope, written through
+                            // (XS: level 3 also runs while the pipeline fills; what it produces then goes nowhere near a neighbour)
+                            if (peer_dst && (!XS || (zo3 >= zs && zo3 < ze))) {   // into the neighbour's ghost planes (wave-uniform), system scope, written through
                                 T *pd = (peer_dst + (long long)zo3 * g.plane + rowoff[r]) + xlu;
 #pragma unroll
                                 for (int v = 0; v < VEC; ++v)
                                     if (INTERIOR || xi + v < g.nx) __hip_atomic_store(pd + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             }
+                        }
+                        if constexpr (XS) {
+                            *reinterpret_cast<VT *>(dst) = res3[r];
+                            continue;
                         }
                         if (wthrough) {
 #pragma unroll
@@ -392,8 +393,7 @@
 #endif
         if constexpr (PEER) {
             if (early_done && tid == 0) {
-                unsigned long long *const pf = const_cast<const volatile WaferF3Peer *>(syv->peer_dev)->flag[bump_early];
-                if (pf) __hip_atomic_fetch_add(pf, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (flag_early) __hip_atomic_fetch_add(flag_early, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         WAFER_F3_STAMP_AT(5);   // the barrier
