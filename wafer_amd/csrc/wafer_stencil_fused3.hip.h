@@ -74,6 +74,25 @@ __device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
 #endif
 // where in the plane iteration a wave issues its requests (see issue_group): 0 = at the top, 1 = behind level 1 of the main rows,
 // 2 = behind level 1 of the extra slot, 3 = behind level 2, 4 = behind level 3.  A: phi0 of the main rows, B: their V, C: the extra slot.
+// A wave's issue priority falls as it advances through the plane iteration (s_setprio 3 at the top, 2 behind level 1 of the main
+// rows, 1 behind level 1 of the extra slot, 0 behind level 2): of the two waves that share a vector pipe the one that is BEHIND
+// gets it.  Left to the hardware's oldest-first arbitration the first wave of each SIMD ran ahead and then waited a quarter of
+// the iteration at the barrier while the second finished alone (tools/f3_stamps.py): -3 % (profiles/r04_ab_f3_priority.jsonl;
+// flatter schedules gain less, the reverse order loses).  -DWAFER_F3_PRIO=0: off.
+#ifndef WAFER_F3_PRIO
+#define WAFER_F3_PRIO 1
+#endif
+#ifndef WAFER_F3_PRIO_P0
+#define WAFER_F3_PRIO_P0 3
+#define WAFER_F3_PRIO_P1 2
+#define WAFER_F3_PRIO_P2 1
+#define WAFER_F3_PRIO_P3 0
+#endif
+#if WAFER_F3_PRIO
+#define WAFER_F3_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define WAFER_F3_SETPRIO(n) do { } while (0)
+#endif
 #ifndef WAFER_F3_RING
 #define WAFER_F3_RING 1
 #endif

@@ -52,6 +52,7 @@
                 }
             }
         };
+        WAFER_F3_SETPRIO(WAFER_F3_PRIO_P0);
         issue_group(0);
         // The extra slot's requests are the SAME three instructions in every wave, the address chosen per lane (a halo row's
         // 16 bytes, or the 16 bytes that start at the lane's halo-column cell: component 0 is the cell; a wave without an outer
@@ -159,6 +160,7 @@
         };
         if (all_rows && wplane1) level1(std::true_type{});
         else level1(std::false_type{});
+        WAFER_F3_SETPRIO(WAFER_F3_PRIO_P1);
         WAFER_F3_STAMP_AT(1);   // level 1, main rows (with the neighbours' LDS round trip)
         issue_group(1);
         nbload(std::integral_constant<int, 2>{});
@@ -205,6 +207,7 @@
             w1[c_lds1] = rs;
             xp1[0] = rs;
         }
+        WAFER_F3_SETPRIO(WAFER_F3_PRIO_P2);
         issue_group(2);
         WAFER_F3_STAMP_AT(2);   // level 1, the extra slot
         // ---- 4. level 2: phi2 of the plane behind, from the phi1 queues; a, b as level 1 formed them one iteration ago
@@ -292,6 +295,7 @@
                 w2[c_lds2] = rs;
             }
         }
+        WAFER_F3_SETPRIO(WAFER_F3_PRIO_P3);
         WAFER_F3_STAMP_AT(3);   // level 2 (main rows and the extra slot)
         issue_group(3);
         // ---- 5. level 3: phi3 two planes behind from the phi2 queue, a, b as formed two iterations ago; stored

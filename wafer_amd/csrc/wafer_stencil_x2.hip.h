@@ -64,6 +64,14 @@ static inline int wafer_x2_nsums(int k) { return 1 + 2 * k; }
 // rows, 2 = behind level 1 of the extra slot, 3 = behind level 2.  A: the main rows' input (and V), L: their stored states, M: the images
 // M_j, X: the extra slot's.  Measured per tile (profiles/r04_ab_x2_request_placement.jsonl): on the 128 x 16 tile M and X move back
 // (0.665 -> 0.63 ms/step at k = 2); on the 128 x 8 tile only the extra slot's requests do (0.964 -> 0.87 at k = 3).
+#ifndef WAFER_X2_PRIO   // falling issue priority through the iteration (as the three-step kernel): measured +-0.5 % here, off
+#define WAFER_X2_PRIO 0
+#endif
+#if WAFER_X2_PRIO
+#define WAFER_X2_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define WAFER_X2_SETPRIO(n) do { } while (0)
+#endif
 #ifndef WAFER_X2_RING
 #define WAFER_X2_RING 1
 #endif

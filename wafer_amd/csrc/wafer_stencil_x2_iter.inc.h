@@ -63,6 +63,7 @@
                 }
             }
         };
+        WAFER_X2_SETPRIO(3);   // (falling priority through the iteration: wafer_stencil_fused3.hip.h, WAFER_F3_PRIO)
         issue_group(0);
         // ---- 2. stage the next x0 plane into the other buffer
         if (more) {
@@ -136,6 +137,7 @@
         };
         if (all_rows && wplane1) level1(std::true_type{});
         else level1(std::false_type{});
+        WAFER_X2_SETPRIO(2);
         issue_group(1);
         // level 2's neighbours and the stored states of the plane it is about to produce (the lane's own LDS queue), requested
         // behind level 1's arithmetic
@@ -190,6 +192,7 @@
             xp1[0] = rs;
         }
         (void)xp1;
+        WAFER_X2_SETPRIO(1);
         issue_group(2);
         // ---- 4. level 2: Z of the plane behind from the Y1 queue, a, b as level 1 formed them one iteration ago; the sums
 #pragma unroll
@@ -263,6 +266,7 @@
             else if (all_rows && wplane2) level2(std::true_type{});
             else level2(std::false_type{});
         }
+        WAFER_X2_SETPRIO(0);
         issue_group(3);
         // HOLD: the plane transformed last iteration (z + 1) takes the queue slot just read (same lanes: program order suffices)
         if constexpr (HOLD) {
