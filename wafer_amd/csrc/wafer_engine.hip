@@ -187,6 +187,7 @@ struct wafer_ctx {
         int kind, lz_lo, lz_hi, aux;
         WaferF3Block *dev;
         int nblocks, nbump[2];
+        int dir;   // 1: every workgroup marches up, 2: every one down, 0: both occur
     };
     std::vector<F3Table> f3_tables;
     unsigned long long *hv_words = nullptr; // device memory, four 64-byte lines: cnt[0], cnt[1] (finished workgroups per half), flag[0], flag[1]
@@ -582,7 +583,7 @@ static int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const
     const int ntx = (c->g.nx + tx_ - 1) / tx_, nty = (c->g.ny + ty_ - 1) / ty_;
     std::vector<WaferF3Block> host;
     if (kind == F3_PLAIN) {
-        wafer_f3_schedule_plain(host, ntx, nty, lz_lo, lz_hi, aux /* planes per workgroup */, c->tune.swz != 0);
+        wafer_f3_schedule_plain(host, ntx, nty, lz_lo, lz_hi, aux /* planes per workgroup */, c->tune.swz != 0, c->tune.f3_plain_down != 0);
     } else if (kind == F3_MIXED) {
         wafer_f3_schedule_mixed(host, ntx, nty, lz_lo, lz_hi, aux /* short workgroups per tile */);
     } else if (kind == F3_WHOLE) {
@@ -606,10 +607,14 @@ static int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const
     wafer_ctx::F3Table t{};
     t.kind = kind; t.lz_lo = lz_lo; t.lz_hi = lz_hi; t.aux = aux;
     t.nblocks = (int)host.size();
+    bool any_up = false, any_down = false;
     for (const auto &k : host) {
+        if (k.down & 1) any_down = true;
+        else any_up = true;
         if (k.bump >= 0) ++t.nbump[k.bump];
         if (((k.down >> 16) & 3) != 0) ++t.nbump[((k.down >> 16) & 3) - 1];   // whole-column peer passes count on both sides
     }
+    t.dir = any_up && any_down ? 0 : (any_down ? 2 : 1);
     HIP_TRY(hipMalloc((void **)&t.dev, sizeof(WaferF3Block) * host.size()));
     hipError_t e = hipMemcpy(t.dev, host.data(), sizeof(WaferF3Block) * host.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -638,7 +643,7 @@ static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
     if (short_tail && lz_hi - lz_lo >= 8 * 4) TRY(f3_table(c, F3_MIXED, lz_lo, lz_hi, 4, &tab));
     else if (c->tune.f3_sched == 1 && !c->sharded() && lz_hi - lz_lo >= 16) TRY(f3_table(c, F3_HALVES, lz_lo, lz_hi, 2 /* no flags, no counters */, &tab));
     else TRY(f3_table(c, F3_PLAIN, lz_lo, lz_hi, wafer_f3_zchunk(c->tune, ntx, nty, lz_hi - lz_lo, c->num_cus), &tab));
-    if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, WaferF3Sync(), c->phi[src], c->v, c->phi[dst], s) != hipSuccess)
+    if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, WaferF3Sync(), c->phi[src], c->v, c->phi[dst], s, tab->dir) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
     return WAFER_OK;
 }
@@ -1589,7 +1594,7 @@ static int launch_peer_pass(wafer_ctx *c, int src, int dst, int E)
     sy.peer_buf = dst;
     for (int h = 0; h < 2; ++h) sy.need[h] = c->peer_expect[h];
     const WaferStepArgs a = step_args(c, lo, hi);
-    if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main) != hipSuccess)
+    if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main, tab->dir) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
     // what this pass's neighbours will deliver: the lower neighbour's upper half (as many boundary workgroups as I have tiles)
     if (c->has_lo()) c->peer_expect[0] += (unsigned long long)tab->nbump[1];
@@ -1627,7 +1632,7 @@ static int launch_halves_pass(wafer_ctx *c, int src, int dst, int E)
     sy.debug = c->tune.hv_debug;
     sy.max_spins = hv_spins(c, 1);
     const WaferStepArgs a = step_args(c, lo, hi);
-    if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main) != hipSuccess)
+    if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main, tab->dir) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
     c->hv_cnt_target[0] += (unsigned long long)tab->nbump[0];
     c->hv_cnt_target[1] += (unsigned long long)tab->nbump[1];

@@ -46,8 +46,10 @@ hipError_t wafer_entry_observables_lds(int tc, int R, const WaferTuning &t, cons
 hipError_t wafer_entry_step2_fused(int tc, int R, const WaferTuning &t, const WaferStepArgs &a, const void *phi, const void *pa,
                                    const void *pb, const void *pv, void *out, hipStream_t s);
 // three fused ground-state steps (ThreePoint fp64), table-driven
+// dir: 1 = every workgroup of the table marches up, 2 = every one down, 0 = both occur (picks the kernel that carries only the
+// copy of the plane loop it needs)
 hipError_t wafer_entry_step3_fused(int tc, const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
-                                   const WaferF3Sync &sy, const void *phi, const void *pv, void *out, hipStream_t s);
+                                   const WaferF3Sync &sy, const void *phi, const void *pv, void *out, hipStream_t s, int dir = 0);
 void wafer_step3_tile(int tc, int *tx, int *ty);
 
 // two excited-state steps per pass (ThreePoint fp64, 1 <= k <= 3 stored states; wafer_stencil_x2.hip.h): out = A A x with x the

@@ -96,6 +96,12 @@ __device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
 #ifndef WAFER_F3_RING
 #define WAFER_F3_RING 1
 #endif
+#ifndef WAFER_F3_RING_PEER_MID   // ring queues in the middle segment of a peer-store pass
+#define WAFER_F3_RING_PEER_MID 1
+#endif
+#ifndef WAFER_F3_RING_DOWN   // ring queues in the copy of the loop that marches down as well
+#define WAFER_F3_RING_DOWN 0
+#endif
 #ifndef WAFER_F3_RING_PEER   // the peer-store instantiation on ring queues as well
 #define WAFER_F3_RING_PEER 0
 #endif
@@ -451,30 +457,37 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         }
         }
         if (mid_len > 0) {
-            constexpr bool PEER = false, SYNC = false, RING = true;   // (shadow the function's: the included text reads these names)
+            // (shadow the function's: the included text reads these names; ring queues marching up only, see the kernel)
+            constexpr bool PEER = false, SYNC = false, RING = WAFER_F3_RING_PEER_MID != 0 && (!DOWN || WAFER_F3_RING_DOWN != 0);
             const int IT_BEGIN = head_end, IT_END = head_end + mid_len;
-        for (int it0 = IT_BEGIN; it0 < IT_END; it0 += 3) {
-            {
-                const int it = it0;
+            if constexpr (RING) {
+                for (int it0 = IT_BEGIN; it0 < IT_END; it0 += 3) {
+                    {
+                        const int it = it0;
 #define WAFER_F3_PH 0
 #include "wafer_stencil_fused3_iter.inc.h"
 #undef WAFER_F3_PH
-            }
-            if (it0 + 1 >= IT_END) break;
-            {
-                const int it = it0 + 1;
+                    }
+                    {
+                        const int it = it0 + 1;
 #define WAFER_F3_PH 1
 #include "wafer_stencil_fused3_iter.inc.h"
 #undef WAFER_F3_PH
-            }
-            if (it0 + 2 >= IT_END) break;
-            {
-                const int it = it0 + 2;
+                    }
+                    {
+                        const int it = it0 + 2;
 #define WAFER_F3_PH 2
 #include "wafer_stencil_fused3_iter.inc.h"
 #undef WAFER_F3_PH
+                    }
+                }
+            } else {
+                for (int it = IT_BEGIN; it < IT_END; ++it) {
+#define WAFER_F3_PH 0
+#include "wafer_stencil_fused3_iter.inc.h"
+#undef WAFER_F3_PH
+                }
             }
-        }
         }
         {
             const int IT_BEGIN = head_end + mid_len, IT_END = niter;
@@ -547,7 +560,9 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
 #else
 #define WAFER_F3_OCC
 #endif
-template <typename T, typename C, bool VIR, int MODE = 0, bool XS = false>
+// DIR: 0 = the table holds workgroups of both marching directions, 1 = all up, 2 = all down.  A kernel that carries one copy of the
+// plane loop instead of two gets the better register allocation (the peer instantiation: 88 B of scratch with both, none with one).
+template <typename T, typename C, bool VIR, int MODE = 0, bool XS = false, int DIR = 0>
 __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) WAFER_F3_OCC void wafer_k_step3_fused(WaferStepArgs a, int ntx, const WaferF3Block *__restrict__ table,
                                                                               WaferF3Sync sy, const T *__restrict__ phi,
                                                                               const T *__restrict__ pv, T *__restrict__ out)
@@ -559,7 +574,12 @@ __global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) WAFER_F3_OCC void wafer_k_ste
     const WaferF3Block blk = table[blockIdx.x];
     // (ring queues where the kernel has the registers for the unrolled loop: the plain instantiation with exact store counts)
     constexpr bool RING = XS && WAFER_F3_RING != 0 && (MODE == 0 || WAFER_F3_RING_PEER != 0);
-    if (blk.down & 1) wafer_step3_body<T, C, VIR, true, MODE, XS, RING>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    // (marching down keeps the shifting queues: in that copy of the loop the ring version needs 36 B of scratch, and every reload
+    //  from scratch is a vector-memory operation whose wait, vmcnt(0), also waits for every prefetch in flight -- 0.319 against
+    //  0.220 ms/step at 512^3; marching up the ring version has no scratch operation inside the loop)
+    if constexpr (DIR == 1) wafer_step3_body<T, C, VIR, false, MODE, XS, RING>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    else if constexpr (DIR == 2) wafer_step3_body<T, C, VIR, true, MODE, XS, RING && WAFER_F3_RING_DOWN != 0>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    else if (blk.down & 1) wafer_step3_body<T, C, VIR, true, MODE, XS, RING && WAFER_F3_RING_DOWN != 0>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
     else wafer_step3_body<T, C, VIR, false, MODE, XS, RING>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
 }
 
@@ -578,7 +598,7 @@ static inline int wafer_f3_xcd_slot(int b, int n)
 
 // Planes [lz_lo, lz_hi) of every tile, cut into chunks of `zchunk` planes, all marching up: the schedule of an
 // undecomposed grid (one workgroup per CU marching a long column) and of every unsplit pass.
-static inline void wafer_f3_schedule_plain(std::vector<WaferF3Block> &out, int ntx, int nty, int lz_lo, int lz_hi, int zchunk, bool swz)
+static inline void wafer_f3_schedule_plain(std::vector<WaferF3Block> &out, int ntx, int nty, int lz_lo, int lz_hi, int zchunk, bool swz, bool down = false)
 {
     const int nplanes = lz_hi - lz_lo, nch = (nplanes + zchunk - 1) / zchunk, n = ntx * nty * nch;
     out.resize((size_t)n);
@@ -588,7 +608,7 @@ static inline void wafer_f3_schedule_plain(std::vector<WaferF3Block> &out, int n
         k.tile = id % (ntx * nty);
         k.zs = lz_lo + (id / (ntx * nty)) * zchunk;
         k.ze = k.zs + zchunk < lz_hi ? k.zs + zchunk : lz_hi;
-        k.down = 0;
+        k.down = down ? 1 : 0;
         k.wait_late = k.bump = -1;
         k.wait_it = k.wt = 0;
         out[(size_t)b] = k;
@@ -721,7 +741,7 @@ static inline int wafer_f3_zchunk(const WaferTuning &t, int ntx, int nty, int np
 // Advances the planes of `table` (device copy, nblocks entries) by THREE steps: out = step(step(step(phi))).  ThreePoint only.
 template <typename T, typename C>
 static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
-                                                  const WaferF3Sync &sy, const T *phi, const T *pv, T *out, hipStream_t s)
+                                                  const WaferF3Sync &sy, const T *phi, const T *pv, T *out, hipStream_t s, int dir = 0)
 {
     using Cfg = WaferF3Cfg<T>;
     const int ntx = (a.g.nx + Cfg::TX - 1) / Cfg::TX;
@@ -730,8 +750,15 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     const int mode = sy.peer ? 2 : (sy.flag != nullptr ? 1 : 0);
     // exact store counts (XS): plain launches over grids made of whole tiles (every store a full vector of work cells)
     const bool xs = t.f3_xs != 0 && mode != 1 && a.g.nx % Cfg::TX == 0 && a.g.ny % Cfg::TY == 0;
-#define WAFER_F3_LAUNCH(VIR_, MODE_, XS_) \
-    hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out)
+#define WAFER_F3_LAUNCH3(VIR_, MODE_, XS_, DIR_) \
+    hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_, DIR_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out)
+    // (the single-direction kernels exist for the instantiations that need them: plain XS launches, peer-store passes)
+#define WAFER_F3_LAUNCH(VIR_, MODE_, XS_)                                              \
+    do {                                                                               \
+        if ((XS_) && (MODE_) != 1 && dir == 1) WAFER_F3_LAUNCH3(VIR_, MODE_, XS_, ((XS_) && (MODE_) != 1) ? 1 : 0); \
+        else if ((XS_) && (MODE_) != 1 && dir == 2) WAFER_F3_LAUNCH3(VIR_, MODE_, XS_, ((XS_) && (MODE_) != 1) ? 2 : 0); \
+        else WAFER_F3_LAUNCH3(VIR_, MODE_, XS_, 0);                                    \
+    } while (0)
     if (a.v_in_range != 0) {
         if (mode == 2 && xs && WAFER_F3_XS_PEER) WAFER_F3_LAUNCH(true, 2, true);
         else if (mode == 2) WAFER_F3_LAUNCH(true, 2, false);
@@ -746,5 +773,6 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
         else WAFER_F3_LAUNCH(false, 0, false);
     }
 #undef WAFER_F3_LAUNCH
+#undef WAFER_F3_LAUNCH3
     return hipGetLastError();
 }

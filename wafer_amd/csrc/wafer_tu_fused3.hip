@@ -3,15 +3,15 @@
 #include "wafer_stencil_fused3.hip.h"
 
 hipError_t wafer_entry_step3_fused(int tc, const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
-                                   const WaferF3Sync &sy, const void *phi, const void *pv, void *out, hipStream_t s)
+                                   const WaferF3Sync &sy, const void *phi, const void *pv, void *out, hipStream_t s, int dir)
 {
     switch (tc) {
     case WAFER_TC_F64:
         return wafer_launch_step3_fused<double, double>(t, a, table, nblocks, sy, static_cast<const double *>(phi), static_cast<const double *>(pv),
-                                                        static_cast<double *>(out), s);
+                                                        static_cast<double *>(out), s, dir);
     case WAFER_TC_F32_F32:   // a and b ride between the levels in the arithmetic type: fp32 here, as in the two-step kernel
         return wafer_launch_step3_fused<float, float>(t, a, table, nblocks, sy, static_cast<const float *>(phi), static_cast<const float *>(pv),
-                                                      static_cast<float *>(out), s);
+                                                      static_cast<float *>(out), s, dir);
     default:                 // fp32 storage with fp64 arithmetic: the carried a, b would need twice the registers
         return hipErrorInvalidValue;
     }

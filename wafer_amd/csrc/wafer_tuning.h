@@ -51,6 +51,7 @@ struct WaferTuning {
     int hv_wait_ms = 20000; // WAFER_HV_WAIT_MS: how long a workgroup of the single-launch pass waits for its ghost planes before it gives up
                             // (WAFER_ERR_COMM; the gate kernels wait four times as long)
     int f3_xs = 1;          // WAFER_F3_XS: the three-step kernel with an exact store count per plane iteration where it applies (plain launches, grids of whole tiles); 0 = never
+    int f3_plain_down = 0;  // WAFER_F3_PLAIN_DOWN: 1 = the plain schedule's workgroups march their columns downwards (the same bits; the two directions are separate copies of the loop, and the compiler's register allocation differs between them)
     int f3_sched = 0;       // WAFER_F3_SCHED: 1 = undecomposed launches use the two-halves schedule as well (timing experiments)
 };
 
@@ -91,6 +92,7 @@ static inline WaferTuning wafer_tuning_from_env()
     t.halo_cycle = wafer_env_int("WAFER_HALO_CYCLE", t.halo_cycle);
     t.hv_debug = wafer_env_int("WAFER_HV_DEBUG", t.hv_debug);
     t.f3_sched = wafer_env_int("WAFER_F3_SCHED", t.f3_sched);
+    t.f3_plain_down = wafer_env_int("WAFER_F3_PLAIN_DOWN", t.f3_plain_down);
     t.f3_xs = wafer_env_int("WAFER_F3_XS", t.f3_xs);
     t.hv_short_tiles = wafer_env_int("WAFER_HV_SHORT_TILES", t.hv_short_tiles);
     t.hv_nsub = wafer_env_int("WAFER_HV_NSUB", t.hv_nsub);
