@@ -108,6 +108,9 @@ __device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
 #ifndef WAFER_F3_XS_PEER     // the peer-store instantiation with exact store counts
 #define WAFER_F3_XS_PEER 1
 #endif
+#ifndef WAFER_F3_XS_MODE1    // overlap mode 2's single-launch pass segmented the same way (tail: the generic body)
+#define WAFER_F3_XS_MODE1 1
+#endif
 #ifndef WAFER_F3_PEER_SPLIT  // ... and its middle iterations on the plain kernel's body (wafer_step3_body)
 #define WAFER_F3_PEER_SPLIT 1
 #endif
@@ -273,7 +276,8 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr bool PEER = MODE == 2, SYNC = MODE != 0;
     constexpr bool RING = RING_T;   // (a local name: the peer instantiation's middle segment shadows it, with PEER and SYNC)
-    static_assert(!XS || MODE == 0 || MODE == 2, "exact store counts: plain launches and peer-store passes (mode 2's boundary planes are written through, store by store)");
+    // (XS with MODE 1 -- overlap mode 2's single-launch pass -- only through the segmented loop below: its boundary planes are
+    //  written through store by store in the tail segment, which runs the generic code)
     (void)sy;   // (never read through the parameter: see WaferF3KernArgs)
     [[maybe_unused]] const volatile WaferF3Sync *const syv = SYNC ? wafer_f3_sync_in_kernarg() : nullptr;
     const int wait_early = PEER ? ((blk.down >> 8) & 3) - 1 : -1, bump_early = PEER ? ((blk.down >> 16) & 3) - 1 : -1;
@@ -438,14 +442,16 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
 #endif
 #define WAFER_F3_Q0(m) (RING ? ((m) + WAFER_F3_PH) % 3 : (m))
 #define WAFER_F3_Q1(m) (RING ? ((m) + WAFER_F3_PH + 1) % 3 : (m))
-    if constexpr (PEER && XS && WAFER_F3_PEER_SPLIT != 0) {
+    if constexpr (SYNC && XS && WAFER_F3_PEER_SPLIT != 0) {
         // Peer-store passes, three segments.  The peer stores, the early count and the late wait all lie within the first
         // seven and the last five iterations of a column; everything between runs the body of the PLAIN kernel -- no peer path,
         // no wait, ring queues (a multiple of three iterations, so that the queues enter and leave it in their natural order)
         // -- whose waits the compiler can count exactly.  With the peer paths in every iteration the wait behind the barrier is
         // vmcnt(0) (the rare branches' volatile loads) and the ring does not fit (24 B of scratch, 55 scalar spills).  A
         // workgroup whose early wait gave up poisons every store: it stays on the generic body.
-        const int head_end = niter < 7 ? niter : 7;
+        // (overlap mode 2's pass has no early count and no early wait: no head segment)
+        const int head_need = PEER ? 7 : 0;
+        const int head_end = niter < head_need ? niter : head_need;
         int mid_len = niter - 5 - head_end;
         mid_len = (mid_len > 0 && !poisoned) ? mid_len / 3 * 3 : 0;
         {
@@ -749,7 +755,7 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     // the synchronisation a launch needs picks the instantiation (see wafer_step3_body): none, mode 2's flags and counters, peer stores
     const int mode = sy.peer ? 2 : (sy.flag != nullptr ? 1 : 0);
     // exact store counts (XS): plain launches over grids made of whole tiles (every store a full vector of work cells)
-    const bool xs = t.f3_xs != 0 && mode != 1 && a.g.nx % Cfg::TX == 0 && a.g.ny % Cfg::TY == 0;
+    const bool xs = t.f3_xs != 0 && (mode != 1 || WAFER_F3_XS_MODE1 != 0) && a.g.nx % Cfg::TX == 0 && a.g.ny % Cfg::TY == 0;
 #define WAFER_F3_LAUNCH3(VIR_, MODE_, XS_, DIR_) \
     hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_, DIR_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out)
     // (the single-direction kernels exist for the instantiations that need them: plain XS launches, peer-store passes)
@@ -762,12 +768,14 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     if (a.v_in_range != 0) {
         if (mode == 2 && xs && WAFER_F3_XS_PEER) WAFER_F3_LAUNCH(true, 2, true);
         else if (mode == 2) WAFER_F3_LAUNCH(true, 2, false);
+        else if (mode == 1 && xs) WAFER_F3_LAUNCH(true, 1, (WAFER_F3_XS_MODE1 != 0));
         else if (mode == 1) WAFER_F3_LAUNCH(true, 1, false);
         else if (xs) WAFER_F3_LAUNCH(true, 0, true);
         else WAFER_F3_LAUNCH(true, 0, false);
     } else {
         if (mode == 2 && xs && WAFER_F3_XS_PEER) WAFER_F3_LAUNCH(false, 2, true);
         else if (mode == 2) WAFER_F3_LAUNCH(false, 2, false);
+        else if (mode == 1 && xs) WAFER_F3_LAUNCH(false, 1, (WAFER_F3_XS_MODE1 != 0));
         else if (mode == 1) WAFER_F3_LAUNCH(false, 1, false);
         else if (xs) WAFER_F3_LAUNCH(false, 0, true);
         else WAFER_F3_LAUNCH(false, 0, false);

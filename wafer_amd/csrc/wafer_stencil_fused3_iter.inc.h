@@ -362,8 +362,11 @@
                             }
                         }
                         if constexpr (XS) {
-                            *reinterpret_cast<VT *>(dst) = res3[r];
-                            continue;
+                            // (overlap mode 2's tail: the planes the exchange reads while this kernel runs are written through)
+                            if (!(SYNC && !PEER) || !wthrough) {
+                                *reinterpret_cast<VT *>(dst) = res3[r];
+                                continue;
+                            }
                         }
                         if (wthrough) {
 #pragma unroll
