@@ -251,7 +251,7 @@ def test_fused3_zchunk_independence(wo, wa, zchunk, monkeypatch):
         assert ulp_diff(ctx.download_phi(), phi) == 0
 
 
-@pytest.mark.parametrize("sched", ["0", "1"])
+@pytest.mark.parametrize("sched", ["0", "1", "down"])
 @pytest.mark.parametrize("xs", ["0", "1"])
 @pytest.mark.parametrize("zchunk", ["1", "2", "5", "1000"])
 @pytest.mark.parametrize("shape", [(128, 16, 5), (256, 32, 11), (128, 48, 23)])
@@ -262,7 +262,10 @@ def test_fused3_exact_store_count_variant(wo, wa, shape, zchunk, xs, sched, monk
     two-halves schedule on an undecomposed grid) down"""
     monkeypatch.setenv("WAFER_ZCHUNK", zchunk)
     monkeypatch.setenv("WAFER_F3_XS", xs)
-    monkeypatch.setenv("WAFER_F3_SCHED", sched)
+    # "down": the plain schedule marching every column downwards -- the single-direction instantiation of the kernel that the
+    # whole-column peer-store passes use every other pass (ring queues only march up: the downward copy keeps the shifts)
+    monkeypatch.setenv("WAFER_F3_SCHED", "0" if sched == "down" else sched)
+    monkeypatch.setenv("WAFER_F3_PLAIN_DOWN", "1" if sched == "down" else "0")
     monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
     cfg, par = make_pair(shape, ext=1, potential="Coulomb", dn=0.2, dt=0.004, mass=1.0)
     v = wo.potential_generate(cfg)

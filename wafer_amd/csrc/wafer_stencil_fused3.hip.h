@@ -96,6 +96,9 @@ __device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
 #ifndef WAFER_F3_RING
 #define WAFER_F3_RING 1
 #endif
+#if defined(WAFER_F3_DPP) && WAFER_F3_RING
+#error "the DPP experiment reads the z-queues by their shifting indices: build it with -DWAFER_F3_RING=0"
+#endif
 #ifndef WAFER_F3_RING_PEER_MID   // ring queues in the middle segment of a peer-store pass
 #define WAFER_F3_RING_PEER_MID 1
 #endif
