@@ -17,10 +17,17 @@ for it in range(int(os.environ.get("N", "60"))):
     shape = tuple(int(x) for x in rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 64, 65, 127, 129, 130, 200, 257], size=3))
     if rng.random() < 0.5:
         shape = (shape[0], int(rng.integers(1, 40)), int(rng.integers(1, 40)))
+    whole = rng.random() < 0.3   # grids made of whole 128 x 16 tiles: the three-step kernel's exact-store / ring / single-direction code
+    if whole:
+        shape = (int(rng.choice([128, 256])), int(rng.choice([16, 32, 48])), int(rng.integers(1, 40)))
+        ext = 1
     pot = str(rng.choice(["Harmonic", "Coulomb", "SimpleCornell", "NoPotential", "Cube"]))
-    steps = int(rng.integers(1, 9))
-    variant = int(rng.choice([-1, 0, 1, 2, 3]))
+    steps = int(rng.integers(1, 13 if whole else 9))
+    variant = 3 if whole else int(rng.choice([-1, 0, 1, 2, 3]))
     os.environ["WAFER_FUSE3_MIN_NY"] = str(rng.choice([1, 16]))   # the three-step kernel also on grids thinner than its tile
+    for name, choices in (("WAFER_ZCHUNK", ["0", "1", "2", "3", "5", "7"]), ("WAFER_F3_PLAIN_DOWN", ["0", "1"]), ("WAFER_F3_XS", ["1", "1", "0"]),
+                          ("WAFER_F3_SCHED", ["0", "0", "1"])):
+        os.environ[name] = str(rng.choice(choices)) if whole else "0" if name != "WAFER_F3_XS" else "1"
     dtype = "f64"
     try:
         cfg, par = make_pair(shape, ext=ext, potential=pot, dn=0.2, dt=0.004, mass=1.3, sig=0.3, dtype=dtype)
@@ -46,8 +53,16 @@ for it in range(int(os.environ.get("N", "60")) // 2):
     shape = tuple(int(x) for x in rng.choice([2, 3, 5, 8, 15, 16, 17, 31, 33, 64, 65, 129], size=3))
     wnum = int(rng.integers(1, 6))
     steps = int(rng.integers(1, 5))
+    two = rng.random() < 0.4     # the two-steps-per-pass kernels (four steps or more, up to three stored states), whole tiles or not
+    if two:
+        shape = (int(rng.choice([128, 256, 130, 64])), int(rng.choice([8, 16, 24, 32, 17])), int(rng.integers(2, 30)))
+        ext, wnum, steps = 1, int(rng.integers(1, 4)), int(rng.integers(4, 10))
+    os.environ["WAFER_X2_MAX_K"] = "3"
+    os.environ["WAFER_X2_RY"] = str(rng.choice([0, 1, 2]))
+    os.environ["WAFER_ZCHUNK"] = str(rng.choice([0, 1, 2, 3, 5])) if two else "0"
+    os.environ["WAFER_F3_XS"] = str(rng.choice([1, 1, 0]))
     pot = str(rng.choice(["Harmonic", "Coulomb", "SimpleCornell", "NoPotential"]))
-    one_pass = int(rng.integers(0, 2))
+    one_pass = 1 if two else int(rng.integers(0, 2))
     os.environ["WAFER_ONE_PASS"] = str(one_pass)
     os.environ["WAFER_VGEN"] = str(rng.integers(0, 2))      # closed-form V in the kernel / the stored array
     os.environ["WAFER_XF_DEEP"] = str(rng.integers(0, 2))   # staging pipeline / plain prefetch
@@ -78,5 +93,7 @@ os.environ.pop("WAFER_ONE_PASS", None)
 os.environ.pop("WAFER_VGEN", None)
 os.environ.pop("WAFER_XF_DEEP", None)
 os.environ.pop("WAFER_FUSE3_MIN_NY", None)
+for name in ("WAFER_ZCHUNK", "WAFER_F3_PLAIN_DOWN", "WAFER_F3_XS", "WAFER_F3_SCHED", "WAFER_X2_MAX_K", "WAFER_X2_RY"):
+    os.environ.pop(name, None)
 print("fuzz done, bad =", bad)
 sys.exit(1 if bad else 0)
