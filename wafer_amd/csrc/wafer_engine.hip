@@ -766,7 +766,7 @@ static int excited_stencil_launch(wafer_ctx *c, int src, int dst, uint32_t wnum,
     // neighbour just loaded are gone again (512^3, 128x8 tiles: k = 2 1.24 -> 1.13 ms, k = 3
     // 1.45 -> 1.39).  The launcher doubles target_blocks.
     const int target = zchunk > 0 ? -zchunk  // planes per workgroup fixed by the caller (slab interior)
-                            : (wnum >= 2 || wafer_excited_nw(c->tune, (int)wnum) == 8) ? (c->num_cus + 1) / 2 : c->num_cus;
+                            : (wnum >= 2 || wafer_excited_nw(c->tune, (int)wnum, c->g.R, c->f32) == 8) ? (c->num_cus + 1) / 2 : c->num_cus;
     a.target_blocks = target;
     const long long nb = dispatch(c, [&](auto t, auto, auto r) {
         return (int)wafer_step_lds_excited_blocks<decltype(t), decltype(r)::value>(c->tune, g, lz_lo, lz_hi, target, (int)wnum, transform_on_load);

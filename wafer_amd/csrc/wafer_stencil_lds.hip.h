@@ -701,10 +701,18 @@ static inline hipError_t wafer_launch_step_lds_ry(const WaferTuning &t, WaferSte
 
 // Waves per workgroup of the excited-state step kernels: with one to three stored states 8 waves on a
 // 128x16 tile, one workgroup per CU (half the halo rows of phi and of every stored state per tile: at
-// 512^3 k = 1 0.87 -> 0.83 ms, k = 2 1.13 -> 1.09, k = 3 1.40 -> 1.31); WAFER_XF_NW=4 restores the 128x8 tile.
-static inline int wafer_excited_nw(const WaferTuning &t, int nlow)
+// 512^3 k = 1 0.87 -> 0.83 ms, k = 2 1.13 -> 1.09, k = 3 1.40 -> 1.31) -- WHERE THAT KERNEL FITS ITS REGISTERS: the 8-wave
+// instantiations of the wide stencils with many stored states spill, and a reload from scratch waits with vmcnt(0), every
+// prefetch in flight included.  Measured at 512^3 (tools/excited_nw_probe.sh, 8 against 4 waves, ms per step): fp64 SevenPoint
+// k = 3 3.67 / 1.89, FivePoint k = 3 1.53 / 1.51; fp32 storage FivePoint k = 2 1.55 / 0.86, k = 3 2.43 / 1.13, SevenPoint
+// k = 1 / 2 / 3 1.59 / 0.92, 2.60 / 1.22, 3.68 / 1.52 -- those take the 4-wave 128x8 kernel; everything else is faster on
+// 8 waves (fp64 SevenPoint k = 2 1.38 / 1.52 even with 44-176 B of scratch).  WAFER_XF_NW = 4 / 8 forces either.
+static inline int wafer_excited_nw(const WaferTuning &t, int nlow, int R, bool f32_storage)
 {
-    return (t.xf_nw == 8 && nlow >= 1 && nlow <= 3) ? 8 : 4;
+    if (nlow < 1 || nlow > 3) return 4;
+    if (t.xf_nw == 4 || t.xf_nw == 8) return t.xf_nw;
+    if (!f32_storage) return (R == 1 || nlow <= 2) ? 8 : 4;
+    return (R == 1 || (R == 2 && nlow == 1)) ? 8 : 4;
 }
 
 // excited-state step with `nlow` raw overlaps fused in (fixed tuning: RY 2, NT, a/b from V)
@@ -718,7 +726,7 @@ static inline hipError_t wafer_launch_step_lds_excited(const WaferTuning &t, Waf
     o.ry = 2;
     if constexpr (std::is_same<T, double>::value && std::is_same<C, double>::value) {
         // closed-form V in the kernel (fp64, transform-on-load, 8-wave tiles): one HBM stream fewer
-        if (vg != 0 && xscal && a.v_in_range != 0 && wafer_excited_nw(t, nlow) == 8) {
+        if (vg != 0 && xscal && a.v_in_range != 0 && wafer_excited_nw(t, nlow, R, !std::is_same<T, double>::value) == 8) {
             // the raw staging pipeline (DEEP) where the registers allow it (FivePoint from k = 2 and SevenPoint spill); WAFER_XF_DEEP=0: off
             const bool deep = t.xf_deep != 0;
             // (two workgroups per CU for k = 1 -- 128 VGPRs, 28 B/lane of scratch -- measured: 0.797 against 0.686 ms;
@@ -736,7 +744,7 @@ static inline hipError_t wafer_launch_step_lds_excited(const WaferTuning &t, Waf
         }
     }
     if (xscal) { // transform-on-load: phi is the raw previous step
-        if (wafer_excited_nw(t, nlow) == 8) { // 128x16 tiles, 8 waves: half the halo rows per array
+        if (wafer_excited_nw(t, nlow, R, !std::is_same<T, double>::value) == 8) { // 128x16 tiles, 8 waves: half the halo rows per array
             if constexpr (R == 1 && std::is_same<T, double>::value) { // streamed V on the raw staging pipeline (DEEP) where it fits the registers
                 if (t.xf_deep != 0) {
                     if (nlow == 1) return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, true, 8, 0, -1, true>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low, xscal, xgram);
@@ -759,7 +767,7 @@ static inline hipError_t wafer_launch_step_lds_excited(const WaferTuning &t, Waf
         default: return hipErrorInvalidValue;
         }
     }
-    if (wafer_excited_nw(t, nlow) == 8) { // the same tiles as the transform-on-load kernel: same partial sums, same bits
+    if (wafer_excited_nw(t, nlow, R, !std::is_same<T, double>::value) == 8) { // the same tiles as the transform-on-load kernel: same partial sums, same bits
         switch (nlow) {
         case 1: return wafer_launch_step_lds_ry<T, C, R, 2, 1, true, true, false, 8>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low);
         case 2: return wafer_launch_step_lds_ry<T, C, R, 2, 2, true, true, false, 8>(t, a, o, phi, pv, pv, out, partials, partials_cap, s, low);
@@ -807,7 +815,7 @@ static inline long long wafer_step_lds_excited_blocks(const WaferTuning &t, cons
 {
     using Cfg = WaferLdsCfg<T, R, 2>;
     (void)xf;
-    const int mul = (wafer_excited_nw(t, nlow) == 8) ? 2 : 1;
+    const int mul = (wafer_excited_nw(t, nlow, R, !std::is_same<T, double>::value) == 8) ? 2 : 1;
     const int TY = Cfg::TY * mul;
     const int zc = wafer_lds_zchunk<T, R>(t, g, lz_hi - lz_lo, 2 * mul, target_blocks);
     return (long long)((g.nx + Cfg::TX - 1) / Cfg::TX) * ((g.ny + TY - 1) / TY) * ((lz_hi - lz_lo + zc - 1) / zc);

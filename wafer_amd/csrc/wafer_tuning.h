@@ -20,7 +20,7 @@ struct WaferTuning {
     int abv = -1;           // WAFER_ABV: 0 = stream the stored a, b arrays instead of forming them from V
     int seven_vg = 0;       // WAFER_SEVEN_VG: closed-form V in SevenPoint's single-step kernel (measured slower)
     // excited-state step kernels
-    int xf_nw = 8;          // WAFER_XF_NW: 8 waves on 128 x 16 tiles (4: 128 x 8)
+    int xf_nw = 0;          // WAFER_XF_NW: excited-state step kernels forced onto 8 waves / 128 x 16 tiles or 4 waves / 128 x 8 (0: by stencil, storage type and number of stored states, wafer_excited_nw)
     int xf_deep = 1;        // WAFER_XF_DEEP: the raw staging pipeline
     int one_pass = 1;       // WAFER_ONE_PASS: transform-on-load (0: the two-pass scheme)
     int vgen = 1;           // WAFER_VGEN: evaluate Coulomb / SimpleCornell / Harmonic per cell instead of streaming V
