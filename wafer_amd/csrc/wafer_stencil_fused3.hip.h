@@ -456,6 +456,8 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         const int head_need = PEER ? 7 : 0;
         const int head_end = niter < head_need ? niter : head_need;
         int mid_len = niter - 5 - head_end;
+        // (the middle never reaches the iteration whose requests first touch a ghost plane: the wait belongs to the tail)
+        if (blk.wait_late >= 0 && blk.wait_it >= head_end && mid_len > blk.wait_it - head_end) mid_len = blk.wait_it - head_end;
         mid_len = (mid_len > 0 && !poisoned) ? mid_len / 3 * 3 : 0;
         {
             const int IT_BEGIN = 0, IT_END = head_end;
@@ -499,12 +501,18 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
             }
         }
         {
+            // The tail waits for its ghost side ONCE, ahead of its loop -- an iteration or so earlier than the first request that
+            // touches a ghost plane needs it, which costs nothing when the neighbour's planes arrived long ago, and keeps the
+            // wait's volatile loads out of the loop, whose waits the compiler can then count (the wait-count pathology again).
             const int IT_BEGIN = head_end + mid_len, IT_END = niter;
+            if (blk.wait_late >= 0 && blk.wait_it >= head_end) poisoned = wafer_f3_wait(syv, blk.wait_late, tid) || poisoned;
+#define WAFER_F3_LATE_WAIT_HOISTED
         for (int it = IT_BEGIN; it < IT_END; ++it) {
 #define WAFER_F3_PH 0
 #include "wafer_stencil_fused3_iter.inc.h"
 #undef WAFER_F3_PH
         }
+#undef WAFER_F3_LATE_WAIT_HOISTED
         }
     } else if constexpr (RING) {
         const int IT_BEGIN = 0, IT_END = niter;

@@ -11,9 +11,11 @@
 #else
         const long long zo = (long long)z * g.plane;
 #endif
+#ifndef WAFER_F3_LATE_WAIT_HOISTED   // (the tail segment of a segmented pass waits once, ahead of its loop: wafer_step3_body)
         if constexpr (SYNC) {
             if (blk.wait_late >= 0 && it == blk.wait_it) poisoned = wafer_f3_wait(syv, blk.wait_late, tid);
         }
+#endif
         // ---- 1. prefetch: phi0 two planes ahead, V one plane ahead
         // DIRECT (with RING): what is dead by the time its successor is requested takes the request itself -- V of the main rows
         // (last read by level 1, requested behind it), the extra slot's V, oldest phi0 plane and outer-row copy (last read by the extra
