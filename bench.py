@@ -727,8 +727,8 @@ def run_rank(args) -> int:
                 for k in (1, 2, 3):
                     ex.evolve(k, 10)
                     ms_k, st_k = None, None
-                    for _ in range(3):   # median of three 40-step evolves
-                        ex.evolve(k, 40)
+                    for _ in range(3):   # median of three 100-step evolves (a real run calls wafer_evolve with screen_update = 1000)
+                        ex.evolve(k, 100)
                         m_, s_ = ex.last_evolve_ms()
                         ms_k = sorted(([] if ms_k is None else ms_k) + [m_])
                         st_k = s_
@@ -742,7 +742,7 @@ def run_rank(args) -> int:
                 ex.close()
                 result["excited_state_step"] = {"grid": list(shape), "potential": potential, **rec,
                                                 "stored_states": "box modes (1,1,1), (2,1,1), (1,1,2)",
-                                                "note": "wafer_evolve(wnum = k) on the same grid, HIP events, median of three 40-step evolves after a 150-step warm-up (steps_per_pass 2: two one-step passes, 19 two-step passes and the pass that materialises phi); checked by excited_parity and excited_parity_two_steps_per_pass"}
+                                                "note": "wafer_evolve(wnum = k) on the same grid, HIP events, median of three 100-step evolves after a 150-step warm-up (steps_per_pass 2: two one-step passes, 49 two-step passes and the pass that materialises phi; a real run's calls are 1000 steps long); checked by excited_parity and excited_parity_two_steps_per_pass"}
             except Exception as e:  # reported, never silently dropped
                 result["excited_state_step"] = {"error": repr(e)}
 
