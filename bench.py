@@ -44,6 +44,11 @@ import time
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL's peer mappings fail with
 # "hipIpcGetMemHandle: invalid argument" otherwise); must be in the environment before the HSA runtime loads
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the CPU baseline leg (N = 1): its OpenMP threads stay where they first touched their pages.  Read by the OpenMP runtime when
+# it loads -- which may be torch's import, long before the oracle's -- so it is set here; WAFER_BENCH_OMP_BIND=0 leaves it alone.
+if os.environ.get("WAFER_BENCH_OMP_BIND", "1") != "0":
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -76,15 +81,23 @@ def parse_args(argv=None):
 
 
 def physical_cores() -> int:
-    """Wafer's own thread rule (main.rs:190-196): the rayon pool gets num_cpus::get_physical()."""
+    """Wafer's own thread rule (main.rs:190-196): the rayon pool gets num_cpus::get_physical() -- bounded by what this
+    process may really use (affinity mask, cgroup CPU quota: more threads than that only take turns)."""
+    n = max(1, len(os.sched_getaffinity(0)))
     try:
         import psutil
-        n = psutil.cpu_count(logical=False)
-        if n:
-            return int(min(n, len(os.sched_getaffinity(0))))
+        phys = psutil.cpu_count(logical=False)
+        if phys:
+            n = int(min(n, phys))
     except Exception:
         pass
-    return max(1, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
 
 
 # ---------------------------------------------------------------------------------------------
@@ -152,33 +165,68 @@ def cpu_baseline(shape, ext, potential, dn, dt, mass, sig, target_seconds):
     """The oracle (kind "port": a C restatement of Wafer's rayon path, same pass
     structure: stencil into work, copy back) timed on this host's cores on a
     bounded number of steps of the SAME grid.  Reported, not the target.
+
+    As BASELINE.md section 3 specifies it: rebuilt -O3 -march=native -ffp-contract=off on this host (oracle/Makefile
+    `native`; contraction off, so the bits stay the portable build's -- the caller checks them against the HIP engine),
+    threads bound (OMP_PROC_BIND / OMP_PLACES, set at the top of this file), every array first touched by the static
+    schedule that later streams it (the oracle's generators are the same `omp parallel for schedule(static)` loops
+    over x as its evolve).  The thread count is the fastest of {2 x usable, usable, usable / 2} on one step each, `usable`
+    = physical cores within the affinity mask and the cgroup CPU quota (the round-4 line ran 128 threads on a box whose
+    quota was 16 CPUs: 0.64 G updates/s where 16-32 threads reach 1.6-2.0, tools/cpu_baseline_probe.py).
+
     Returns (record, phi after `total_steps` steps, total_steps) so that the same
     CPU work also serves as the parity reference."""
     from oracle import wafer_oracle as wo
+    native = wo.use_native()
     cores = physical_cores()
-    wo.set_threads(cores)
     cfg = wo.Config(*shape, ext=ext, potential=potential, dn=dn, dt=dt, mass=mass, sig=sig)
+    wo.set_threads(cores)
     v = wo.potential_generate(cfg)
     a, b = wo.ab(cfg, v)
     del v
     phi = wo.initial_condition(cfg, "Boolean")
-    t0 = time.perf_counter()
-    wo.evolve(cfg, 0, a, b, phi, [], 1)
-    t1 = time.perf_counter() - t0
-    steps = int(max(2, min(200, target_seconds / max(t1, 1e-6))))
+    wo.evolve(cfg, 0, a, b, phi, [], 1)          # first touch of `work`, page faults, thread start-up
+    done = 1
+    tried = {}
+    # (under a cgroup CPU quota smaller than the affinity mask, twice the quota's worth of threads can still win: they take
+    #  turns, but each finds its pages where it left them)
+    over = min(2 * cores, len(os.sched_getaffinity(0)))
+    for t in sorted({over, cores, max(1, cores // 2)}, reverse=True):
+        wo.set_threads(t)
+        t0 = time.perf_counter()
+        wo.evolve(cfg, 0, a, b, phi, [], 1)
+        tried[t] = time.perf_counter() - t0
+        done += 1
+    threads = min(tried, key=tried.get)
+    wo.set_threads(threads)
+    t1 = tried[threads]
+    steps = int(max(2, min(400, target_seconds / max(t1, 1e-6))))
     t0 = time.perf_counter()
     wo.evolve(cfg, 0, a, b, phi, [], steps)
     dt_s = time.perf_counter() - t0
     pts = shape[0] * shape[1] * shape[2]
+    rate = pts * steps / dt_s
+    try:
+        copy_gbps = wo.host_copy_gbps(1 << 30, 3)
+        placement = wo.thread_placement()
+    except Exception:  # noqa: BLE001 -- informational
+        copy_gbps, placement = None, None
     rec = {
-        "value": pts * steps / dt_s,
+        "value": rate,
         "unit": "updates/s",
-        "cores": cores,
+        "cores": threads,
         "kind": "port",
         "sample": f"{steps} steps of the same {shape[0]}x{shape[1]}x{shape[2]} fp64 {potential} grid "
                   f"(oracle/wafer_oracle.c wo_evolve, OpenMP, {dt_s:.1f} s)",
+        "build": "-O3 -march=native -ffp-contract=off (built on this host)" if native else "-O3 -march=x86-64-v2 -ffp-contract=off (portable build: the native one failed)",
+        # the reference's pass structure moves 48 B per update: stencil pass phi, a, b in + work out, copy-back work in + phi out
+        "effective_GBps": rate * 48 / 1e9,
+        "host_copy_GBps": copy_gbps,   # an OpenMP copy between two first-touched 1 GiB buffers on the same threads (read + written)
+        "usable_cores": cores,
+        "seconds_per_step_by_threads": {str(k): round(v_, 4) for k, v_ in tried.items()},
+        "thread_placement": placement,
     }
-    return rec, phi, steps + 1
+    return rec, phi, done + steps
 
 
 def max_ulp(got, want) -> int:
@@ -209,20 +257,25 @@ def boolean_norm2(shape, ext) -> float:
     return out
 
 
-def pmc_traffic(kernel_name: str):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if any (a STATIC figure:
-    counters cannot be read inside a timed run)."""
+def pmc_traffic(kernel_instance: str):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (a STATIC figure: counters cannot be read inside a
+    timed run) -- only from the entry of EXACTLY this instantiation ("wafer_k_step3_fused<double, double, true, 0, true, 1>"
+    against the profiler's "void wafer_k_step3_fused<...>(arguments)"): another instantiation's bytes (peer stores, marching
+    down, fp32) describe another kernel.  -> (bytes or None, the matched key or None)"""
+    if "<" not in kernel_instance:
+        return None, None
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        hits = [v for k, v in d.get("kernels", {}).items() if k in kernel_name or kernel_name in k]
-        hits.sort(key=lambda v: "from" in v)   # entries tagged "from" are earlier builds / variants kept for the record
-        if hits:
-            return hits[0].get("hbm_bytes_per_launch")
+        for k, v in d.get("kernels", {}).items():
+            if "from" in v:   # entries tagged "from" are earlier builds / variants kept for the record
+                continue
+            if k.startswith("void " + kernel_instance + "(") or k == kernel_instance:
+                return v.get("hbm_bytes_per_launch"), k
     except Exception:
         pass
-    return None
+    return None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -323,6 +376,8 @@ def run_rank(args) -> int:
     # slabs are thick enough, so that the set-up trial can also time one exchange per TWO fused passes
     # (wafer_set_halo_cycle)
     per_pass = 3 * ext if (ext == 1 and args.dtype in ("f64", "f32fast")) else 2 * ext
+    if world > 1 and os.environ.get("WAFER_BENCH_PEERS", "1") == "force":
+        os.environ.setdefault("WAFER_PEER_SAME_DEVICE", "1")   # ranks folded onto one GPU on purpose (read by wafer_ctx_create)
     deep = world > 1 and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 4 * per_pass
     ctx = wafer_amd.Context(make_params(z_begin, z_count, (2 * per_pass if deep else per_pass) if world > 1 else 0))
     if args.variant >= 0:
@@ -348,9 +403,12 @@ def run_rank(args) -> int:
                 allreduce_choice = {"error": repr(e)}
         # peer stores (wafer_set_overlap mode 3): every rank maps its z-neighbours' buffers through HIP IPC; all ranks or none
         peers_ok = False
-        # (not with the host-staged test transport: ranks folded onto ONE GPU would poll for each other's stores from workgroups
-        #  that hold the CUs the other rank's kernel needs)
-        if ext == 1 and args.dtype in ("f64", "f32fast") and not host_transport and os.environ.get("WAFER_BENCH_PEERS", "1") != "0":
+        # (Not by default with the host-staged test transport: ranks folded onto ONE GPU poll for each other's stores from
+        #  workgroups that hold the CUs the other rank's kernel needs.  WAFER_BENCH_PEERS=force connects them there as well -- HIP
+        #  IPC between processes on one device -- so that a one-GPU box executes every line the first real multi-GPU run will; the
+        #  tests keep the grids at a tile per CU per rank or less, and a schedule whose bounded waits give up is dropped below.)
+        want_peers = os.environ.get("WAFER_BENCH_PEERS", "1")
+        if ext == 1 and args.dtype in ("f64", "f32fast") and want_peers != "0" and (not host_transport or want_peers == "force"):
             try:
                 peers_ok = slab.connect_peers(ctx, rank, world) and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 6
             except Exception as e:  # noqa: BLE001
@@ -408,33 +466,50 @@ def run_rank(args) -> int:
     DEFAULT_MODE = (2, 1)
     if dist is not None and os.environ.get("WAFER_OVERLAP", "") == "" and args.steps >= 8:
         trial = {}
-        for mode, cycle in ([(3, 1)] if peers_ok else []) + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []):
-            ctx.set_overlap(mode)
-            ctx.set_halo_cycle(cycle)
-            # a schedule whose bounded waits give up on this fabric (WAFER_ERR_COMM: a neighbour's planes never arrived)
-            # is dropped on every rank, not fatal: the other schedules are still timed
-            failed = 0.0
-            t_ = time.perf_counter()
+
+        def any_rank(flag: bool) -> bool:
+            t_ = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_[0]) != 0.0
+
+        def phase(n_steps: int):
+            """n_steps of evolve on this rank, then the SAME two collectives on every rank whatever happened here: a schedule
+            whose bounded waits give up on this fabric (WAFER_ERR_COMM: a neighbour's planes never arrived -- reported when
+            the rank next synchronises with its device) is dropped on every rank, never fatal, and never leaves the ranks
+            in different collectives.  -> (seconds on the slowest rank, failed on any rank)"""
+            bad = False
+            t0_ = time.perf_counter()
             try:
-                ctx.evolve(0, 9)
-                barrier()
-                t_ = time.perf_counter()
-                ctx.evolve(0, 42)
+                ctx.evolve(0, n_steps)
                 ctx.synchronize()
+                torch.cuda.synchronize()
             except wafer_amd.WaferError as e:
                 print(f"bench.py: rank {rank}: halo schedule {mode} (cycle {cycle}) failed in the set-up trial: {e}", file=sys.stderr, flush=True)
-                failed = 1.0
-            try:
-                barrier()
-            except wafer_amd.WaferError:
-                failed = 1.0
-            tt = torch.tensor([time.perf_counter() - t_, failed], dtype=torch.float64, device=coll_dev)
+                bad = True
+            dt_ = time.perf_counter() - t0_
+            dist.barrier()
+            tt = torch.tensor([dt_, 1.0 if bad else 0.0], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            if float(tt[1]) != 0.0:
+            return float(tt[0]), float(tt[1]) != 0.0
+
+        for mode, cycle in ([(3, 1)] if peers_ok else []) + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []):
+            refused = False
+            try:
+                ctx.set_overlap(mode)
+                ctx.set_halo_cycle(cycle)
+            except wafer_amd.WaferError as e:
+                print(f"bench.py: rank {rank}: halo schedule {mode} (cycle {cycle}) refused: {e}", file=sys.stderr, flush=True)
+                refused = True
+            failed = any_rank(refused)
+            if not failed:
+                _, failed = phase(9)                  # the run-in: rendezvous, first exchanges, table uploads
+            if not failed:
+                seconds, failed = phase(42)
+            if failed:
                 ctx.set_overlap(0)                    # resets the pass bookkeeping on every rank
                 ctx.set_initial_condition("Boolean")  # whatever the failed passes left behind
                 continue
-            trial[(mode, cycle)] = float(tt[0]) / 42 * 1e3
+            trial[(mode, cycle)] = seconds / 42 * 1e3
         if not trial:
             print(f"bench.py: rank {rank}: every halo schedule failed in the set-up trial", file=sys.stderr)
             return 4
@@ -486,7 +561,9 @@ def run_rank(args) -> int:
     launch_s = (kernel_ms / 1e3) / max(1, ksteps) * spl
     achieved = pts_rank * bpu * spl / launch_s / 1e9
     kname = ctx.stencil_kernel_name()
-    traffic = pmc_traffic(kname) if (n_gpus == 1 and not args.grid and args.dtype == "f64" and ext == 1) else None
+    kinst = ctx.stencil_kernel_instance()         # the instantiation the timed passes launched, as a profiler prints it
+    # (the committed counter figure belongs to one kernel on one workload: the default grid and potential only)
+    traffic, traffic_key = pmc_traffic(kinst) if (n_gpus == 1 and not args.grid and not args.potential) else (None, None)
 
     comm_info = None
     if comm is not None:
@@ -532,8 +609,8 @@ def run_rank(args) -> int:
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
             "traffic_source": ("profiles/pmc_traffic.json (static: rocprofv3 --pmc of this kernel on this workload, "
-                               "not re-measured in this run)") if traffic else None,
-            "kernel": kname,
+                               "not re-measured in this run); entry: " + traffic_key) if traffic else None,
+            "kernel": kinst,
             "avg_launch_ms": launch_s * 1e3,
             "steps_per_launch": spl,
             "algorithmic_bytes_per_launch": pts_rank * bpu * spl,

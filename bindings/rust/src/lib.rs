@@ -73,6 +73,10 @@ pub struct wafer_peer_info {
     pub phi_alloc_offset: [u64; 2],
     pub phi_ipc: [[u8; 64]; 2],
     pub flags_ipc: [u8; 64],
+    pub process_nonce: u64,
+    pub device: i32,
+    pub reserved: u32,
+    pub device_uuid: [u8; 16],
 }
 
 #[repr(C)]
@@ -146,6 +150,7 @@ extern "C" {
     ) -> c_int;
     pub fn wafer_last_evolve_ms(ctx: *mut wafer_ctx, ms: *mut f32, steps: *mut u64) -> c_int;
     pub fn wafer_stencil_kernel_name(ctx: *mut wafer_ctx) -> *const c_char;
+    pub fn wafer_stencil_kernel_instance(ctx: *mut wafer_ctx) -> *const c_char;
     pub fn wafer_stencil_steps_per_launch(ctx: *mut wafer_ctx) -> c_int;
     pub fn wafer_set_stencil_variant(ctx: *mut wafer_ctx, variant: c_int) -> c_int;
     pub fn wafer_set_halo_cycle(ctx: *mut wafer_ctx, passes: c_int) -> c_int;

@@ -231,6 +231,10 @@ int wafer_solve_state(wafer_ctx *ctx, uint32_t wnum, double tolerance, uint64_t 
 int wafer_last_evolve_ms(wafer_ctx *ctx, float *ms, uint64_t *steps);
 /* name of the stencil kernel variant the context dispatches to */
 const char *wafer_stencil_kernel_name(wafer_ctx *ctx);
+/* the template-id of the kernel the last ground-state pass launched, as a profiler prints it (e.g.
+ * "wafer_k_step3_fused<double, double, true, 0, true, 1>"); the family name where the family does not record it.  Valid until
+ * the next call on this context. */
+const char *wafer_stencil_kernel_instance(wafer_ctx *ctx);
 /* time steps one launch of that kernel advances in a ground-state evolve (2 for the fused kernel) */
 int wafer_stencil_steps_per_launch(wafer_ctx *ctx);
 /* choose a stencil kernel variant by index (tuning / A-B runs); -1 = default */
@@ -304,7 +308,12 @@ int wafer_set_overlap(wafer_ctx *ctx, int mode);
  * (device addresses valid in this process + HIP IPC handles of the allocations for other processes); the host carries the
  * records to the neighbours (any transport) and calls wafer_peer_connect with the lower / upper neighbour's record (NULL: no
  * neighbour on that side; a record exported by this same process is used by address, without IPC -- several contexts in one
- * process, or a slab whose neighbour is itself).  wafer_peer_disconnect unmaps; wafer_ctx_destroy does it too. */
+ * process, or a slab whose neighbour is itself; a context of this process on ANOTHER device is used by address after
+ * hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess, WAFER_ERR_INVALID where the devices cannot reach each other).  A neighbour
+ * that is another context on the SAME device is refused (WAFER_ERR_INVALID) unless WAFER_PEER_SAME_DEVICE=1: its kernels share
+ * this one's CUs, and a workgroup polling for a neighbour's stores can then keep that neighbour's kernel from running until the
+ * bounded wait gives up -- tests fold ranks onto one GPU on purpose; a real run has one GPU per rank.
+ * wafer_peer_disconnect unmaps; wafer_ctx_destroy does it too. */
 typedef struct wafer_peer_info {
     uint32_t struct_size;
     uint32_t z_begin, z_count, halo_depth;
@@ -314,6 +323,11 @@ typedef struct wafer_peer_info {
     uint64_t phi_alloc_offset[2]; /* byte offset of phi_addr inside its allocation (IPC maps allocations) */
     uint8_t phi_ipc[2][64];       /* hipIpcMemHandle_t */
     uint8_t flags_ipc[64];
+    uint64_t process_nonce;       /* drawn once per process: with pid it identifies the exporting process (pids alone repeat across
+                                     PID namespaces) -- the by-address shortcut is taken only when both match */
+    int32_t device;               /* HIP ordinal of the exporting context's device, as the exporting process numbers them */
+    uint32_t reserved;
+    uint8_t device_uuid[16];      /* hipDeviceGetUuid of that device: the same GPU whatever the process calls it */
 } wafer_peer_info;
 int wafer_peer_export(wafer_ctx *ctx, wafer_peer_info *out);
 int wafer_peer_connect(wafer_ctx *ctx, const wafer_peer_info *lower, const wafer_peer_info *upper);

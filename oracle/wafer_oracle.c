@@ -73,6 +73,55 @@ int wo_get_threads(void)
 #endif
 }
 
+/* What the host's memory delivers to the same threads: `iters` copies of `bytes` between two buffers that every thread
+ * first touches in the static schedule it copies with (read + written bytes per second, GB/s).  Beside the timed
+ * baseline, bench.py prints it: a stencil rate far under this figure says "threads", not "DRAM". */
+double wo_host_copy_gbps(size_t bytes, int iters)
+{
+    const size_t n = bytes / sizeof(double);
+    double *src = (double *)malloc(n * sizeof(double)), *dst = (double *)malloc(n * sizeof(double));
+    if (!src || !dst || n == 0 || iters < 1) {
+        free(src);
+        free(dst);
+        return 0.0;
+    }
+#pragma omp parallel for schedule(static)
+    for (size_t p = 0; p < n; ++p) {
+        src[p] = (double)p;
+        dst[p] = 0.0;
+    }
+    double best = 0.0;
+    for (int it = 0; it < iters; ++it) {
+#ifdef _OPENMP
+        const double t0 = omp_get_wtime();
+#endif
+#pragma omp parallel for schedule(static)
+        for (size_t p = 0; p < n; ++p) dst[p] = src[p];
+#ifdef _OPENMP
+        const double dt = omp_get_wtime() - t0;
+        if (dt > 0.0 && 2.0 * (double)bytes / dt / 1e9 > best) best = 2.0 * (double)bytes / dt / 1e9;
+#endif
+    }
+    if (dst[n / 2] != src[n / 2]) best = 0.0; /* (keeps the copy observable) */
+    free(src);
+    free(dst);
+    return best;
+}
+
+/* where the OpenMP runtime put its threads: "proc_bind=<policy> places=<count>" (OpenMP 4.5 API) */
+int wo_thread_placement(int *proc_bind, int *num_places)
+{
+#ifdef _OPENMP
+    *proc_bind = (int)omp_get_proc_bind();
+    *num_places = omp_get_num_places();
+    return 0;
+#else
+    *proc_bind = 0;
+    *num_places = 0;
+    return 1;
+#endif
+}
+
 /* ---- fixed-order extended-precision sum of per-plane partials ------------ */
 static double sum_planes(const long double *part, int64_t n)
 {

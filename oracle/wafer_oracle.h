@@ -135,6 +135,10 @@ int wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz,
 
 void wo_set_threads(int n);
 int wo_get_threads(void);
+/* diagnostics of the timed baseline leg (bench.py cpu_baseline): the host's copy bandwidth on the same threads, and
+ * the OpenMP runtime's binding policy (omp_proc_bind_t) and place count */
+double wo_host_copy_gbps(size_t bytes, int iters);
+int wo_thread_placement(int *proc_bind, int *num_places);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,28 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_NATIVE_PATH = os.path.join(_HERE, "libwafer_oracle_native.so")
+_native = False
+
+
+def use_native() -> bool:
+    """The timed baseline leg of bench.py: rebuild the same source -O3 -march=native -ffp-contract=off
+    ON THIS HOST (make native) and route every later call through it.  Contraction stays off, so the bits are the portable
+    build's.  Returns False (and changes nothing) where the build fails."""
+    global _lib, _native
+    if _native:
+        return True
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = _bind(C.CDLL(_NATIVE_PATH))
+    except Exception:  # noqa: BLE001 -- no compiler, or a host gcc does not know: the portable build serves
+        return False
+    _lib, _native = L, True
+    return True
+
+
+def is_native() -> bool:
+    return _native
 
 
 def lib():
@@ -64,7 +86,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        _lib = _bind(C.CDLL(_LIB_PATH))
+    return _lib
+
+
+def _bind(L):
+    if True:
         dp = C.POINTER(C.c_double)
         cp = C.POINTER(_Config)
         L.wo_padded_len.restype = C.c_size_t
@@ -105,8 +132,10 @@ def lib():
         L.wo_trilerp_resize_basis.argtypes = [dp] + [C.c_int64] * 3 + [dp] + [C.c_int64] * 6
         L.wo_set_threads.argtypes = [C.c_int]
         L.wo_get_threads.restype = C.c_int
-        _lib = L
-    return _lib
+        L.wo_host_copy_gbps.restype = C.c_double
+        L.wo_host_copy_gbps.argtypes = [C.c_size_t, C.c_int]
+        L.wo_thread_placement.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    return L
 
 
 def _dp(a: np.ndarray):
@@ -155,6 +184,19 @@ def set_threads(n: int) -> None:
 
 def get_threads() -> int:
     return lib().wo_get_threads()
+
+
+def host_copy_gbps(nbytes: int, iters: int = 5) -> float:
+    """read + written GB/s of an OpenMP copy between two first-touched buffers of `nbytes` on the current threads"""
+    return float(lib().wo_host_copy_gbps(int(nbytes), int(iters)))
+
+
+def thread_placement() -> dict:
+    """the OpenMP runtime's binding policy and place count (what OMP_PROC_BIND / OMP_PLACES resolved to)"""
+    pb, npl = C.c_int(0), C.c_int(0)
+    lib().wo_thread_placement(C.byref(pb), C.byref(npl))
+    names = {0: "false", 1: "true", 2: "master", 3: "close", 4: "spread"}
+    return {"proc_bind": names.get(pb.value, str(pb.value)), "places": npl.value}
 
 
 def calculate_r2(idx, size) -> float:

@@ -4,13 +4,6 @@ import sys
 
 import pytest
 
-# Several ranks of a decomposed run live in ONE process on ONE GPU in tests/test_gpu_slab.py, and in overlap mode 3 a rank's kernel
-# polls for stores of its neighbour's kernel: with the runtime's default of four hardware queues two such kernels can share a
-# queue and the poller then sits in front of the kernel it waits for until its bounded wait gives up (seen once in a full-suite
-# run).  More hardware queues (read by the runtime when it initialises, so set here before anything touches the GPU) keep the
-# streams apart; with one process per GPU -- every real run -- the situation cannot arise.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

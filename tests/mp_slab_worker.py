@@ -67,6 +67,7 @@ def main():
     # ---- peer stores (overlap mode 3): boundary workgroups write the neighbour PROCESS's ghost planes through HIP IPC ----
     from wafer_amd.slab import connect_peers
     os.environ["WAFER_FUSE3_MIN_NY"] = "1"
+    os.environ["WAFER_PEER_SAME_DEVICE"] = "1"   # the ranks share the box's one GPU on purpose (read by wafer_ctx_create)
     shape3 = (140, 40, 45)
     whole3 = wa.Params(*shape3, dn=0.2, dt=0.004, central_difference=1)
     zb, zc = partition(shape3[2], world, rank)

@@ -46,10 +46,13 @@ def test_device_side_allreduce_between_processes(world):
             f.write(f"wafer_mailbox_allreduce, {world} processes on one MI355X, 4 doubles, 200 calls back to back: {us:.2f} us per call\n")
 
 
-def _check_bench_two_rank_line(d):
+def _check_bench_two_rank_line(d, peers=False):
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["steps"] == 8 and d["scaling"] == "strong" and d["value"] > 0
     ho = d["config"]["halo_overlap"]      # the exchange schedules were tried during set-up, one was chosen for all ranks
-    assert ho["mode"] in (0, 1, 2) and len(ho["ms_per_step"]) == 5 and all(v > 0 for v in ho["ms_per_step"].values())
+    assert ho["mode"] in (0, 1, 2, 3) and len(ho["ms_per_step"]) == (6 if peers else 5) and all(v > 0 for v in ho["ms_per_step"].values())
+    # the peer-store schedule (HIP IPC between the rank processes) was connected, timed and survived its bounded waits
+    assert ("3_single_launch_peer_stores" in ho["ms_per_step"]) == peers
+    assert d["roofline"]["kernel"].startswith("wafer_k_step3_fused<double, double, ")
     assert ho["fused_passes_per_exchange"] in (1, 2)
     assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 128
     assert d["roofline"]["steps_per_launch"] == 3 and d["config"]["kernel"] == "wafer_k_step3_fused" and "cpu_baseline" not in d
@@ -62,12 +65,17 @@ def _check_bench_two_rank_line(d):
     assert d["comm"]["process_group_ranks"] == 2 and d["comm"]["halo_overlap_mode"] == ho["mode"]
 
 
-def test_bench_multi_rank_path():
+@pytest.mark.parametrize("peers", [True, False])
+def test_bench_multi_rank_path(peers):
     """bench.py's N > 1 leg end to end (slab partition, hooks, max-over-ranks timing, the undecomposed
     reference run and the slab-by-slab checksum comparison, one JSON line from rank 0) with two ranks on
-    the one GPU over the host-staged transport"""
+    the one GPU over the host-staged transport.  peers: WAFER_BENCH_PEERS=force -- every line the first real
+    multi-GPU run will execute: the ranks map each other's buffers through HIP IPC, the peer-store schedule
+    (overlap mode 3) is timed with the others in the set-up trial, and whichever wins runs the timed steps"""
     import json
-    env_extra = {"WAFER_BENCH_TRANSPORT": "host"}
+    env_extra = {"WAFER_BENCH_TRANSPORT": "host", "WAFER_HV_WAIT_MS": "5000"}
+    if peers:
+        env_extra["WAFER_BENCH_PEERS"] = "force"
     os.environ.update(env_extra)
     try:
         r = launch(2, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
@@ -78,25 +86,28 @@ def test_bench_multi_rank_path():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    _check_bench_two_rank_line(json.loads(lines[0]))
+    _check_bench_two_rank_line(json.loads(lines[0]), peers)
 
 
 def test_bench_eight_rank_path():
     """the driver's N = 8 call shape on the one GPU (host-staged transport): eight slabs of 32 planes, the set-up
-    trial over all eight exchange schedules, three-step passes with a two-step remainder, every slab's bits
-    against the undecomposed run"""
+    trial over all exchange schedules -- the peer-store one included (WAFER_BENCH_PEERS=force: eight processes mapping
+    their z-neighbours' buffers through HIP IPC; the grid is kept at 16 workgroups per rank so that all eight ranks'
+    kernels are resident together and a polling workgroup cannot keep its neighbour's kernel off the CUs) -- three-step
+    passes with a two-step remainder, every slab's bits against the undecomposed run"""
     import json
     import subprocess
     import sys
-    env = dict(os.environ, WAFER_BENCH_TRANSPORT="host")
+    env = dict(os.environ, WAFER_BENCH_TRANSPORT="host", WAFER_BENCH_PEERS="force", WAFER_HV_WAIT_MS="5000")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "11", "--warmup", "3",
-                        "--grid", "256,256,256"], env=env, capture_output=True, text=True, timeout=600)
+                        "--grid", "128,128,256"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["config"]["parallelism"] == "zslab8"
-    assert d["config"]["points_per_gpu"] == 256 * 256 * 32 and len(d["config"]["halo_overlap"]["ms_per_step"]) in (3, 5)
+    ms = d["config"]["halo_overlap"]["ms_per_step"]
+    assert d["config"]["points_per_gpu"] == 128 * 128 * 32 and len(ms) in (4, 6) and "3_single_launch_peer_stores" in ms
     assert d["parity"]["identical"] is True and d["parity"]["slabs"] == 8 and d["parity"]["differing_slabs"] == []
-    assert d["single_gpu_ref"]["grid"] == [256, 256, 256] and d["comm"]["process_group_ranks"] == 8
+    assert d["single_gpu_ref"]["grid"] == [128, 128, 256] and d["comm"]["process_group_ranks"] == 8
 
 
 def test_bench_bare_call_starts_its_own_ranks():
@@ -136,9 +147,12 @@ def test_rccl_transport_self_neighbours(ext):
     assert "RCCL-OK" in r.stdout
 
 
-def test_multi_rank_solve_driver_matches_the_native_driver(tmp_path):
+@pytest.mark.parametrize("peers", [False, True])
+def test_multi_rank_solve_driver_matches_the_native_driver(tmp_path, peers):
     """python -m wafer_amd.run on 2 ranks (z-slabs, host-staged transport on the one GPU) against
-    wafer-hip on the whole grid: same table rows, same energies, the saved planes tile the state"""
+    wafer-hip on the whole grid: same table rows, same energies, the saved planes tile the state.
+    peers: WAFER_PEER_STORES=force -- the driver connects the z-neighbours (HIP IPC between the two processes) and its
+    ground-state passes run in overlap mode 3"""
     import re
     import numpy as np
     case = os.path.join(ROOT, "tests", "golden", "cli_case.yaml")
@@ -147,11 +161,15 @@ def test_multi_rank_solve_driver_matches_the_native_driver(tmp_path):
                          capture_output=True, text=True)
     assert one.returncode == 0, one.stderr
     os.environ["WAFER_TRANSPORT"] = "host"
+    if peers:
+        os.environ["WAFER_PEER_STORES"] = "force"
     try:
         two = launch(2, "-m", "wafer_amd.run", "-c", case, "--progress", "--output-dir", str(tmp_path / "two"))
     finally:
         os.environ.pop("WAFER_TRANSPORT", None)
+        os.environ.pop("WAFER_PEER_STORES", None)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    assert ("halo schedule: overlap mode 3 (peer stores)" in two.stderr) == peers
 
     def rows(text):
         return [l for l in text.splitlines() if re.match(r"^\s+│\s*[0-9.]+ │", l)]

@@ -163,7 +163,7 @@ struct wafer_ctx {
     double potsub_scalar = 0.0;
     bool have_pot = false, have_phi = false;
     bool v_in_range = false; // 2^-400 < |1 + dt*V/2| < 2^400 everywhere (wafer_recip's short form is exact)
-    int v_in_range_all = -1; // z-slabs: ... on EVERY rank (-1: not agreed yet; x2_agree)
+    int x2_agreed[4] = {-1, -1, -1, -1}; // [k]: every rank can take the two-step excited pass with k stored states (-1: not agreed yet; x2_agree)
     int vgen_type = 0;       // V was generated from this closed form (Coulomb / SimpleCornell / Harmonic), else 0: kernels may re-evaluate it instead of streaming it
 
     double *partials = nullptr; // [1 + WAFER_MAX_LOW][partials_stride]
@@ -216,6 +216,8 @@ struct wafer_ctx {
     bool timing_valid = false;
     int variant = -1;
     std::string kernel_name;
+    bool last_instance_valid = false;   // a plain three-step launch has run: wafer_step3_last_instance names its instantiation
+    char instance_name[160] = {0};
 
     bool has_lo() const { return g.z_begin > 0; }
     bool has_hi() const { return g.z_begin + g.nzl < g.nz; }
@@ -314,7 +316,7 @@ static int check_v_range(wafer_ctx *c)
     memcpy(&lo, &got[0], 8);
     memcpy(&hi, &got[1], 8);
     c->v_in_range = (lo > 0x1p-400) && (hi < 0x1p400); // a NaN anywhere makes hi a NaN: false
-    c->v_in_range_all = -1;
+    for (int &a : c->x2_agreed) a = -1;
     return WAFER_OK;
 }
 
@@ -645,6 +647,7 @@ static int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hi
     else TRY(f3_table(c, F3_PLAIN, lz_lo, lz_hi, wafer_f3_zchunk(c->tune, ntx, nty, lz_hi - lz_lo, c->num_cus), &tab));
     if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, WaferF3Sync(), c->phi[src], c->v, c->phi[dst], s, tab->dir) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    c->last_instance_valid = true;
     return WAFER_OK;
 }
 
@@ -815,9 +818,9 @@ static int excited_step_launch_overlapped(wafer_ctx *c, int src, int dst, uint32
 
 // ---- two excited-state steps per pass (wafer_stencil_x2.hip.h) ------------------------------------------------------
 enum { X2_SUM_SLOT = 18 };   // scal[18 .. 18 + 1 + 2k): the sums of a two-step pass
-// ThreePoint fp64, one to three stored states, the potential inside the short reciprocal's range; z-slabs need two ghost
-// planes (a pass consumes two per side).  Every rank of a decomposed run takes the same decision: nothing here depends on
-// the local slab except v_in_range, on which the ranks agree in x2_agree.
+// ThreePoint fp64, one to three stored states; z-slabs need two ghost planes (a pass consumes two per side).  Nothing here
+// depends on the local slab: what does (the potential inside the short reciprocal's range, two owned planes, memory for the
+// images) is the ranks' agreement in x2_agree.
 static bool x2_applies(const wafer_ctx *c, uint32_t wnum)
 {
     // three stored states: the 128 x 8-tile kernel wins where a plane is small enough for the halo rows to stay in the XCDs' L2
@@ -825,40 +828,53 @@ static bool x2_applies(const wafer_ctx *c, uint32_t wnum)
     // profiles/r04_x2_shapes.log).  The plane extent is the same on every rank of a decomposed run.
     const int kmax = c->tune.x2_max_k > 0 ? c->tune.x2_max_k : ((long long)c->g.nx * c->g.ny <= 300000 ? 3 : 2);
     return c->tune.x2 != 0 && c->tune.one_pass != 0 && !c->f32 && c->g.R == 1 && wnum >= 1 && wnum <= 3 && (int)wnum <= kmax &&
-           active_variant(c) >= 1 && c->v_in_range && (!c->sharded() || c->g.G >= 2);
+           active_variant(c) >= 1 && (!c->sharded() || c->g.G >= 2);
 }
 
-// z-slabs: the two-step pass changes what the ranks exchange (two planes per pass, 2 + 3k sums), so every rank must take it
-// or none.  x2_applies depends on nothing local except v_in_range, which is a property of the local slab's V: the ranks
-// agree on it once per potential (a collective: every rank reaches its first excited-state wafer_evolve together).
-static int x2_agree(wafer_ctx *c, uint32_t wnum, bool *out)
+// Storage for M_j = A l_j of the first wnum stored states.  Running out of memory here is not an error of the call that asked:
+// the one-step path needs none of it (x2_agree).
+static int alloc_mstates(wafer_ctx *c, uint32_t wnum)
 {
-    *out = false;
-    if (!c->sharded()) { *out = x2_applies(c, wnum); return WAFER_OK; }
-    if (!c->allreduce_hook) return WAFER_OK;
-    if (c->v_in_range_all < 0) {
-        c->scal_host[13] = c->v_in_range ? 0.0 : 1.0;
-        HIP_TRY(hipMemcpyAsync(c->scal + 13, c->scal_host + 13, sizeof(double), hipMemcpyHostToDevice, c->s_main));
-        if (c->allreduce_hook(c->hook_user, c->scal + 13, 1, (void *)c->s_main) != 0) return fail(WAFER_ERR_COMM, "allreduce hook failed");
-        double bad = 1.0;
-        TRY(read_scal(c, 13, 1, &bad, c->s_main));
-        c->v_in_range_all = bad == 0.0 ? 1 : 0;
-    }
-    *out = c->v_in_range_all == 1 && x2_applies(c, wnum);
-    return WAFER_OK;
-}
-
-// M_j = A l_j for the first wnum stored states (one ground-state step of each, grid.rs:568-592) and the matrix <l_j, M_i> of
-// the coefficient kernel.  Rebuilt when w_store or the potential changed.
-static int ensure_x2(wafer_ctx *c, uint32_t wnum)
-{
-    if (c->x2_ready >= (int)wnum) return WAFER_OK;
-    const WaferGeom &g = c->g;
     while (c->mstates.size() < wnum) {
         void *slot = nullptr;
         TRY(alloc_grid_array(c, &slot, c->s_main));
         c->mstates.push_back(slot);
     }
+    return WAFER_OK;
+}
+
+// The two-step pass changes what the ranks of a decomposed run exchange (two planes per pass, 2 + 3k sums), so every rank must
+// take it or none.  x2_applies depends on nothing local; what does -- V inside the short reciprocal's range on this slab, two
+// owned planes to send, memory for the images M_j -- is agreed on once per potential and number of stored states (a collective:
+// every rank reaches its first excited-state wafer_evolve at that level together).  A rank that cannot take the pass makes
+// every rank keep the one-step kernels: no error, and nobody is left in a collective.
+static int x2_agree(wafer_ctx *c, uint32_t wnum, bool *out)
+{
+    *out = false;
+    if (!x2_applies(c, wnum)) return WAFER_OK;
+    bool local_ok = c->v_in_range && (!c->sharded() || c->g.nzl >= 2);
+    if (local_ok && alloc_mstates(c, wnum) != WAFER_OK) local_ok = false;
+    if (!c->sharded()) { *out = local_ok; return WAFER_OK; }
+    if (!c->allreduce_hook) return WAFER_OK;
+    if (c->x2_agreed[wnum] < 0) {
+        c->scal_host[13] = local_ok ? 0.0 : 1.0;
+        HIP_TRY(hipMemcpyAsync(c->scal + 13, c->scal_host + 13, sizeof(double), hipMemcpyHostToDevice, c->s_main));
+        if (c->allreduce_hook(c->hook_user, c->scal + 13, 1, (void *)c->s_main) != 0) return fail(WAFER_ERR_COMM, "allreduce hook failed");
+        double bad = 1.0;
+        TRY(read_scal(c, 13, 1, &bad, c->s_main));
+        c->x2_agreed[wnum] = bad == 0.0 ? 1 : 0;
+    }
+    *out = c->x2_agreed[wnum] == 1;
+    return WAFER_OK;
+}
+
+// M_j = A l_j for the first wnum stored states (one ground-state step of each, grid.rs:568-592) and the matrix <l_j, M_i> of
+// the coefficient kernel.  Rebuilt when w_store or the potential changed.  (Storage: alloc_mstates, through x2_agree.)
+static int ensure_x2(wafer_ctx *c, uint32_t wnum)
+{
+    if (c->x2_ready >= (int)wnum) return WAFER_OK;
+    const WaferGeom &g = c->g;
+    TRY(alloc_mstates(c, wnum));
     if (kernels_stream_ab(c, 1)) TRY(ensure_ab(c));
     for (uint32_t j = 0; j < wnum; ++j) {
         // z-slabs: the pass transforms two ghost planes per side, so l_j and M_j must be current there (a stored state
@@ -1596,6 +1612,7 @@ static int launch_peer_pass(wafer_ctx *c, int src, int dst, int E)
     const WaferStepArgs a = step_args(c, lo, hi);
     if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main, tab->dir) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    c->last_instance_valid = true;
     // what this pass's neighbours will deliver: the lower neighbour's upper half (as many boundary workgroups as I have tiles)
     if (c->has_lo()) c->peer_expect[0] += (unsigned long long)tab->nbump[1];
     if (c->has_hi()) c->peer_expect[1] += (unsigned long long)tab->nbump[0];
@@ -1634,6 +1651,7 @@ static int launch_halves_pass(wafer_ctx *c, int src, int dst, int E)
     const WaferStepArgs a = step_args(c, lo, hi);
     if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main, tab->dir) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    c->last_instance_valid = true;
     c->hv_cnt_target[0] += (unsigned long long)tab->nbump[0];
     c->hv_cnt_target[1] += (unsigned long long)tab->nbump[1];
     for (int i = 0; i < 2; ++i) {
@@ -1865,6 +1883,19 @@ const char *wafer_stencil_kernel_name(wafer_ctx *c)
     const int spl = wafer_stencil_steps_per_launch(c);
     if (v >= 2) v = spl == 3 ? 3 : spl == 2 ? 2 : 1; // what the fused variants fall back to where they do not apply
     return kVariants[(v >= 0 && v < kNumVariants) ? v : 0].name;
+}
+
+// The template-id of the kernel the last ground-state pass launched, as a profiler prints it (e.g.
+// "wafer_k_step3_fused<double, double, true, 0, true, 1>"): what bench.py writes into roofline.kernel and matches the committed
+// counter figures by.  Falls back to the family name (no template arguments) for the families that do not record theirs.
+const char *wafer_stencil_kernel_instance(wafer_ctx *c)
+{
+    if (!c) return "";
+    if (c->last_instance_valid && wafer_stencil_steps_per_launch(c) == 3) {
+        wafer_step3_last_instance(c->instance_name, sizeof c->instance_name);
+        if (c->instance_name[0]) return c->instance_name;
+    }
+    return wafer_stencil_kernel_name(c);
 }
 
 int wafer_stencil_steps_per_launch(wafer_ctx *c)
@@ -2217,6 +2248,22 @@ int wafer_set_overlap(wafer_ctx *c, int mode)
     return WAFER_OK;
 }
 
+// drawn once per process (the by-address shortcut of wafer_peer_connect must not misfire on a pid that another PID namespace
+// handed out as well)
+static uint64_t process_nonce()
+{
+    static const uint64_t nonce = [] {
+        uint64_t v = 0;
+        if (FILE *f = fopen("/dev/urandom", "rb")) {
+            if (fread(&v, sizeof v, 1, f) != 1) v = 0;
+            fclose(f);
+        }
+        if (v == 0) v = ((uint64_t)getpid() << 32) ^ (uint64_t)(uintptr_t)&v ^ 0x9e3779b97f4a7c15ull;
+        return v;
+    }();
+    return nonce;
+}
+
 int wafer_peer_export(wafer_ctx *c, wafer_peer_info *out)
 {
     if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
@@ -2229,6 +2276,14 @@ int wafer_peer_export(wafer_ctx *c, wafer_peer_info *out)
     out->z_count = (uint32_t)c->g.nzl;
     out->halo_depth = (uint32_t)c->g.G;
     out->pid = (uint64_t)getpid();
+    out->process_nonce = process_nonce();
+    out->device = c->P.device;
+    {
+        hipUUID u;
+        static_assert(sizeof u.bytes == sizeof out->device_uuid, "uuid size");
+        HIP_TRY(hipDeviceGetUuid(&u, c->P.device));
+        memcpy(out->device_uuid, u.bytes, sizeof out->device_uuid);
+    }
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
     for (int b = 0; b < 2; ++b) {
         out->phi_addr[b] = (uint64_t)(uintptr_t)c->phi[b];
@@ -2279,7 +2334,29 @@ int wafer_peer_connect(wafer_ctx *c, const wafer_peer_info *lower, const wafer_p
         if (!adjacent) return fail(WAFER_ERR_INVALID, "wafer_peer_connect: the %s record is not the z-neighbour's", h == 0 ? "lower" : "upper");
         wafer_ctx::PeerSide &ps = c->peer[h];
         ps.nzl = (int)r->z_count;
-        if (r->pid == (uint64_t)getpid()) {
+        const bool same_process = r->pid == (uint64_t)getpid() && r->process_nonce == process_nonce();
+        const bool self_loop = same_process && (int)r->z_begin == c->g.z_begin && r->phi_addr[0] == (uint64_t)(uintptr_t)c->phi[0];
+        hipUUID mine;
+        HIP_TRY(hipDeviceGetUuid(&mine, c->P.device));
+        const bool same_device = memcmp(mine.bytes, r->device_uuid, sizeof mine.bytes) == 0;
+        // another context on THIS device shares its CUs: a workgroup that polls for that neighbour's stores can keep the neighbour's
+        // kernel from running (tests fold ranks onto one GPU and say so)
+        if (same_device && !self_loop && c->tune.peer_same_device == 0)
+            return fail(WAFER_ERR_INVALID, "wafer_peer_connect: the %s neighbour is another context on this device (a polling workgroup "
+                                           "can starve the kernel it waits for); set WAFER_PEER_SAME_DEVICE=1 to allow it",
+                        h == 0 ? "lower" : "upper");
+        if (same_process) {
+            if (!same_device) {
+                // one process, several GPUs: the neighbour's memory must be mapped on this device before a kernel stores into it
+                int can = 0;
+                HIP_TRY(hipDeviceCanAccessPeer(&can, c->P.device, r->device));
+                if (!can) return fail(WAFER_ERR_INVALID, "wafer_peer_connect: device %d cannot access its %s neighbour's device %d",
+                                      c->P.device, h == 0 ? "lower" : "upper", r->device);
+                const hipError_t pe = hipDeviceEnablePeerAccess(r->device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(WAFER_ERR_HIP, "hipDeviceEnablePeerAccess(%d) failed: %s", r->device, hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
             ps.phi[0] = (void *)(uintptr_t)r->phi_addr[0];
             ps.phi[1] = (void *)(uintptr_t)r->phi_addr[1];
             ps.flags = (unsigned long long *)(uintptr_t)r->flags_addr;

@@ -51,6 +51,9 @@ hipError_t wafer_entry_step2_fused(int tc, int R, const WaferTuning &t, const Wa
 hipError_t wafer_entry_step3_fused(int tc, const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
                                    const WaferF3Sync &sy, const void *phi, const void *pv, void *out, hipStream_t s, int dir = 0);
 void wafer_step3_tile(int tc, int *tx, int *ty);
+// the template-id of the instantiation this thread's last wafer_entry_step3_fused launched, as rocprofv3 prints it
+// ("wafer_k_step3_fused<double, double, true, 0, true, 1>"); empty before the first launch
+void wafer_step3_last_instance(char *buf, size_t n);
 
 // two excited-state steps per pass (ThreePoint fp64, 1 <= k <= 3 stored states; wafer_stencil_x2.hip.h): out = A A x with x the
 // load transform of phi by `coef`; l / m: the stored states and their images M_j = A l_j; the 1 + 2k sums of the pass go to

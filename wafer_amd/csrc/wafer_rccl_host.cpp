@@ -13,6 +13,7 @@
 //       same rank, so halo planes really travel through ncclSend / ncclRecv (and scalars through
 //       ncclAllReduce); the run is repeated with plain device copies as hooks and must agree bit for
 //       bit.  Prints SELF-OK.  (tests/test_gpu_multiprocess.py)
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -193,9 +194,9 @@ int main(int argc, char **argv)
     wafer_rccl_default_env();
     {
         // ncclCommInitRank blocks for ever when a peer never arrives (or arrived with another id): a watchdog ends the
-        // process instead.  WAFER_COMM_INIT_TIMEOUT_S (default 300) bounds the call.
+        // process instead.  WAFER_COMM_INIT_TIMEOUT_S (default 300, at least 1: a limit of 0 would end the process at once) bounds the call.
         std::atomic<bool> init_done{false};
-        const int limit_s = env_int("WAFER_COMM_INIT_TIMEOUT_S", 300);
+        const int limit_s = std::max(1, env_int("WAFER_COMM_INIT_TIMEOUT_S", 300));
         std::thread watchdog([&init_done, limit_s, rank]() {
             for (int i = 0; i < limit_s * 10 && !init_done.load(); ++i) std::this_thread::sleep_for(std::chrono::milliseconds(100));
             if (!init_done.load()) {

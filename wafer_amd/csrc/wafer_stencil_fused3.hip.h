@@ -755,6 +755,18 @@ static inline int wafer_f3_zchunk(const WaferTuning &t, int ntx, int nty, int np
     return wafer_pick_zchunk(per_layer, nplanes, target, 6);   // four iterations of pipeline fill + the prologue
 }
 
+// which instantiation the last launch of this thread took (bench.py prints it and matches the committed counter figures by it)
+struct WaferF3Instance {
+    int tsize = 0, csize = 0;   // sizeof storage / arithmetic type (0: nothing launched yet)
+    bool vir = false, xs = false;
+    int mode = 0, dir = 0;
+};
+inline WaferF3Instance &wafer_f3_last_instance()
+{
+    static thread_local WaferF3Instance inst;
+    return inst;
+}
+
 // Advances the planes of `table` (device copy, nblocks entries) by THREE steps: out = step(step(step(phi))).  ThreePoint only.
 template <typename T, typename C>
 static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
@@ -767,8 +779,12 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     const int mode = sy.peer ? 2 : (sy.flag != nullptr ? 1 : 0);
     // exact store counts (XS): plain launches over grids made of whole tiles (every store a full vector of work cells)
     const bool xs = t.f3_xs != 0 && (mode != 1 || WAFER_F3_XS_MODE1 != 0) && a.g.nx % Cfg::TX == 0 && a.g.ny % Cfg::TY == 0;
-#define WAFER_F3_LAUNCH3(VIR_, MODE_, XS_, DIR_) \
-    hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_, DIR_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out)
+#define WAFER_F3_LAUNCH3(VIR_, MODE_, XS_, DIR_)                                                                                                  \
+    do {                                                                                                                                          \
+        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_, DIR_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out); \
+        WaferF3Instance &li_ = wafer_f3_last_instance();                                                                                          \
+        li_.tsize = (int)sizeof(T); li_.csize = (int)sizeof(C); li_.vir = (VIR_); li_.mode = (MODE_); li_.xs = (XS_); li_.dir = (DIR_);           \
+    } while (0)
     // (the single-direction kernels exist for the instantiations that need them: plain XS launches, peer-store passes)
 #define WAFER_F3_LAUNCH(VIR_, MODE_, XS_)                                              \
     do {                                                                               \

@@ -1,4 +1,5 @@
 // translation unit: three fused ground-state steps (ThreePoint; fp64, and fp32 storage with fp32 step arithmetic)
+#include <cstdio>
 #include "wafer_launch.h"
 #include "wafer_stencil_fused3.hip.h"
 
@@ -22,6 +23,16 @@ void wafer_step3_tile(int tc, int *tx, int *ty)
 {
     if (tc == WAFER_TC_F64) { *tx = WaferF3Cfg<double>::TX; *ty = WaferF3Cfg<double>::TY; }
     else { *tx = WaferF3Cfg<float>::TX; *ty = WaferF3Cfg<float>::TY; }
+}
+
+void wafer_step3_last_instance(char *buf, size_t n)
+{
+    const WaferF3Instance &li = wafer_f3_last_instance();
+    if (n == 0) return;
+    buf[0] = 0;
+    if (li.tsize == 0) return;
+    snprintf(buf, n, "wafer_k_step3_fused<%s, %s, %s, %d, %s, %d>", li.tsize == 8 ? "double" : "float", li.csize == 8 ? "double" : "float",
+             li.vir ? "true" : "false", li.mode, li.xs ? "true" : "false", li.dir);
 }
 
 #ifdef WAFER_F3_STAMP

@@ -26,8 +26,7 @@ struct WaferTuning {
     int vgen = 1;           // WAFER_VGEN: evaluate Coulomb / SimpleCornell / Harmonic per cell instead of streaming V
     int x2 = 1;             // WAFER_X2: two excited-state steps per pass (ThreePoint fp64, 1..3 stored states); 0: one step per pass
     int x2_max_k = 0;       // WAFER_X2_MAX_K: most stored states the two-step kernel takes (1 .. 3); 0 = by plane size: 3 up to 300 000 cells per plane, else 2 (wafer_engine.hip, x2_applies)
-                            // two boxes: k = 1 0.463-0.485 / 0.609-0.634, k = 2 0.730-0.755 / 0.786-0.817, k = 3 0.984-0.990 / 0.981-1.018 ms
-                            // per step: three stored states are a wash on the lower tile and keep the one-step kernel (and its memory)
+                            // (k = 3 runs on 128 x 8 tiles: -4 % per step at 512 x 512 planes, +3 ... +5 % at 1024 x 1024, profiles/r04_x2_shapes.log)
     int x2_ry = 0;          // WAFER_X2_RY: rows per lane of that kernel (1: 128 x 8 tiles, 2: 128 x 16, k = 1 and 2; 0: default = 2 where it exists)
     // observables
     int obs_lds = 1;        // WAFER_OBS_LDS: 0 = the plain scalar-load kernel
@@ -50,6 +49,7 @@ struct WaferTuning {
                             // the two halves, 4 = always whole columns (default: whole columns where there is a tile per CU)
     int hv_wait_ms = 20000; // WAFER_HV_WAIT_MS: how long a workgroup of the single-launch pass waits for its ghost planes before it gives up
                             // (WAFER_ERR_COMM; the gate kernels wait four times as long)
+    int peer_same_device = 0; // WAFER_PEER_SAME_DEVICE: 1 = wafer_peer_connect accepts a neighbour that is another context on this device (tests: ranks folded onto one GPU)
     int f3_xs = 1;          // WAFER_F3_XS: the three-step kernel with an exact store count per plane iteration where it applies (plain launches, grids of whole tiles); 0 = never
     int f3_plain_down = 0;  // WAFER_F3_PLAIN_DOWN: 1 = the plain schedule's workgroups march their columns downwards (the same bits; the two directions are separate copies of the loop, and the compiler's register allocation differs between them)
     int f3_sched = 0;       // WAFER_F3_SCHED: 1 = undecomposed launches use the two-halves schedule as well (timing experiments)
@@ -99,6 +99,7 @@ static inline WaferTuning wafer_tuning_from_env()
     t.hv_layout = wafer_env_int("WAFER_HV_LAYOUT", t.hv_layout);
     t.hv_wait_ms = wafer_env_int("WAFER_HV_WAIT_MS", t.hv_wait_ms);
     if (t.hv_wait_ms < 1) t.hv_wait_ms = 1;
+    t.peer_same_device = wafer_env_int("WAFER_PEER_SAME_DEVICE", t.peer_same_device);
     return t;
 }
 

@@ -38,7 +38,7 @@ EXPORTS = [
     "wafer_download_phi", "wafer_upload_phi_resampled", "wafer_set_potential_resampled", "wafer_evolve", "wafer_observables", "wafer_norm2", "wafer_normalise",
     "wafer_orthogonalise", "wafer_push_state", "wafer_load_state", "wafer_download_state",
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
-    "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
+    "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_kernel_instance", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
     "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check",
     "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_set_halo_cycle", "wafer_diag_x2_passes",
@@ -58,6 +58,7 @@ class _PeerInfo(C.Structure):
         ("struct_size", C.c_uint32), ("z_begin", C.c_uint32), ("z_count", C.c_uint32), ("halo_depth", C.c_uint32),
         ("pid", C.c_uint64), ("phi_addr", C.c_uint64 * 2), ("flags_addr", C.c_uint64), ("phi_alloc_offset", C.c_uint64 * 2),
         ("phi_ipc", (C.c_uint8 * 64) * 2), ("flags_ipc", C.c_uint8 * 64),
+        ("process_nonce", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_uint32), ("device_uuid", C.c_uint8 * 16),
     ]
 
 
@@ -173,6 +174,8 @@ def load_library():
     L.wafer_last_evolve_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     L.wafer_stencil_kernel_name.argtypes = [vp]
     L.wafer_stencil_kernel_name.restype = C.c_char_p
+    L.wafer_stencil_kernel_instance.argtypes = [vp]
+    L.wafer_stencil_kernel_instance.restype = C.c_char_p
     L.wafer_stencil_steps_per_launch.argtypes = [vp]
     L.wafer_set_stencil_variant.argtypes = [vp, C.c_int]
     L.wafer_set_comm_hooks.argtypes = [vp, HALO_FN, ALLREDUCE_FN, vp]
@@ -428,6 +431,10 @@ class Context:
 
     def stencil_kernel_name(self) -> str:
         return self._L.wafer_stencil_kernel_name(self._h).decode()
+
+    def stencil_kernel_instance(self) -> str:
+        """template-id of the kernel the last ground-state pass launched, as a profiler prints it"""
+        return self._L.wafer_stencil_kernel_instance(self._h).decode()
 
     def steps_per_launch(self) -> int:
         return int(self._L.wafer_stencil_steps_per_launch(self._h))

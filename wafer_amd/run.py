@@ -224,6 +224,8 @@ def main(argv=None) -> int:
         dist.broadcast_object_list(box, src=0)
         out_dir, seed = box
 
+    if world > 1 and os.environ.get("WAFER_PEER_STORES", "0") == "force":
+        os.environ.setdefault("WAFER_PEER_SAME_DEVICE", "1")   # read by wafer_ctx_create
     symmetry = cfg["init_symmetry"]
     t0 = time.perf_counter()
     exit_code = 0
@@ -239,10 +241,14 @@ def main(argv=None) -> int:
                 choice = comm.pick_allreduce()
                 if rank == 0:
                     print(f"scalar all-reduce: {choice}", file=sys.stderr, flush=True)
-            # peer stores for the ground-state passes where every rank can map its neighbours (HIP IPC) and WAFER_PEER_STORES=1 asks for it
-            if not host_transport and os.environ.get("WAFER_PEER_STORES", "0") not in ("", "0"):
+            # peer stores for the ground-state passes where every rank can map its neighbours (HIP IPC) and WAFER_PEER_STORES=1 asks
+            # for it (=force: also with the host-staged test transport, ranks folded onto one GPU -- tests)
+            want_peers = os.environ.get("WAFER_PEER_STORES", "0")
+            if want_peers not in ("", "0") and (not host_transport or want_peers == "force"):
                 if slab.connect_peers(ctx, rank, world) and min(slab.partition(par.nz, world, r)[1] for r in range(world)) >= 6:
                     ctx.set_overlap(3)
+                    if rank == 0:
+                        print("halo schedule: overlap mode 3 (peer stores)", file=sys.stderr, flush=True)
         def from_input(stem, pad, shape, what):
             a = staged_array(args.input_dir, stem, cfg["file_type"], pad, rank)
             if a is not None and (a.dtype != np.float64 or tuple(a.shape) != tuple(shape)):

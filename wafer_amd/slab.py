@@ -428,28 +428,34 @@ class NativeRcclSlabComm:
             return float(t[0])
 
         def timed():
+            """-> (us per call, every call returned 0 and the sum is right)"""
             t = torch.ones(4, dtype=torch.float64, device=self.device)
+            rcs = []
             with torch.cuda.stream(stream):
                 for _ in range(10):
-                    L.wafer_rccl_allreduce_now(self._handle, t.data_ptr(), 4, stream.cuda_stream)
+                    rcs.append(L.wafer_rccl_allreduce_now(self._handle, t.data_ptr(), 4, stream.cuda_stream))
                 stream.synchronize()
                 t.fill_(1.0)
-                L.wafer_rccl_allreduce_now(self._handle, t.data_ptr(), 4, stream.cuda_stream)
+                rcs.append(L.wafer_rccl_allreduce_now(self._handle, t.data_ptr(), 4, stream.cuda_stream))
                 stream.synchronize()
                 good = bool(torch.all(t == float(world)).item())
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 for _ in range(calls):
-                    L.wafer_rccl_allreduce_now(self._handle, t.data_ptr(), 4, stream.cuda_stream)
+                    rcs.append(L.wafer_rccl_allreduce_now(self._handle, t.data_ptr(), 4, stream.cuda_stream))
                 e1.record(stream)
                 stream.synchronize()
-            return e0.elapsed_time(e1) * 1e3 / calls, good
+            # (a mailbox whose wait gave up stays dead and says so through the return code of every later call)
+            return e0.elapsed_time(e1) * 1e3 / calls, good and not any(rcs)
 
         out = {}
         had = self.mailbox
-        L.wafer_rccl_use_mailbox(self._handle, None)
-        us_nccl, good = timed()
+        if L.wafer_rccl_use_mailbox(self._handle, None) != 0:
+            raise RuntimeError("wafer_rccl_use_mailbox: " + L.wafer_rccl_last_error().decode())
+        us_nccl, good_nccl = timed()
         out["ncclAllReduce_us"] = slowest(us_nccl)
+        if slowest(0.0 if good_nccl else 1.0) != 0.0:
+            out["ncclAllReduce_error"] = "a call failed or summed wrongly on some rank"
         mb = had
         if mb is None:
             try:
@@ -458,8 +464,8 @@ class NativeRcclSlabComm:
                 out["mailbox_error"] = repr(e)
                 mb = None
         if mb is not None:
-            L.wafer_rccl_use_mailbox(self._handle, mb.handle)
-            us_mb, good = timed()
+            attached = L.wafer_rccl_use_mailbox(self._handle, mb.handle) == 0
+            us_mb, good = timed() if attached else (float("inf"), False)
             bad = slowest(0.0 if good else 1.0)
             out["mailbox_us"] = slowest(us_mb)
             if bad == 0.0 and out["mailbox_us"] < out["ncclAllReduce_us"]:
@@ -467,8 +473,7 @@ class NativeRcclSlabComm:
                 out["chosen"] = "mailbox"
                 return out
             L.wafer_rccl_use_mailbox(self._handle, None)
-            if had is None:
-                mb.close()
+            mb.close()          # whoever made it: a mailbox that lost (or died) serves nobody, and close() could no longer reach it
             self.mailbox = None
         out["chosen"] = "ncclAllReduce"
         return out
