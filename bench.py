@@ -372,10 +372,10 @@ def run_rank(args) -> int:
                                 central_difference=ext, dtype=args.dtype, max_states=1, device=local_rank,
                                 z_begin=zb, z_count=zc, halo_depth=halo)
 
-    # ghost planes: 3*ext (ThreePoint: three fused steps per exchange; otherwise 2*ext: two); twice that where the
+    # ghost planes: 3*ext (ThreePoint, every dtype: three fused steps per exchange; otherwise 2*ext: two); twice that where the
     # slabs are thick enough, so that the set-up trial can also time one exchange per TWO fused passes
     # (wafer_set_halo_cycle)
-    per_pass = 3 * ext if (ext == 1 and args.dtype in ("f64", "f32fast")) else 2 * ext
+    per_pass = 3 * ext if ext == 1 else 2 * ext
     if world > 1 and os.environ.get("WAFER_BENCH_PEERS", "1") == "force":
         os.environ.setdefault("WAFER_PEER_SAME_DEVICE", "1")   # ranks folded onto one GPU on purpose (read by wafer_ctx_create)
     deep = world > 1 and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 4 * per_pass
@@ -408,7 +408,7 @@ def run_rank(args) -> int:
         #  IPC between processes on one device -- so that a one-GPU box executes every line the first real multi-GPU run will; the
         #  tests keep the grids at a tile per CU per rank or less, and a schedule whose bounded waits give up is dropped below.)
         want_peers = os.environ.get("WAFER_BENCH_PEERS", "1")
-        if ext == 1 and args.dtype in ("f64", "f32fast") and want_peers != "0" and (not host_transport or want_peers == "force"):
+        if ext == 1 and want_peers != "0" and (not host_transport or want_peers == "force"):
             try:
                 peers_ok = slab.connect_peers(ctx, rank, world) and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 6
             except Exception as e:  # noqa: BLE001

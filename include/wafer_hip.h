@@ -334,8 +334,8 @@ int wafer_peer_connect(wafer_ctx *ctx, const wafer_peer_info *lower, const wafer
 int wafer_peer_disconnect(wafer_ctx *ctx);
 
 /* z-slabs, ground state: fused passes per halo exchange.  One fused pass advances K time steps and consumes
- * K * ext ghost planes per side (K = 3 where the three-step kernel applies: ThreePoint, dtype WAFER_F64 or
- * WAFER_F32_FAST, with halo_depth >= 3 * ext; else K = 2 -- every rank of a run must be created alike).  With `passes` > 1 the exchange moves K * ext * passes planes at once and
+ * K * ext ghost planes per side (K = 3 where the three-step kernel applies: ThreePoint, any dtype,
+ * with halo_depth >= 3 * ext; else K = 2 -- every rank of a run must be created alike).  With `passes` > 1 the exchange moves K * ext * passes planes at once and
  * the passes in between run unsplit over the owned planes plus the ghost planes that are still valid -- fewer
  * boundary launches, exchanges and stream hops for a few redundant planes.  Needs wafer_params.halo_depth >=
  * K * ext * passes (WAFER_ERR_INVALID otherwise); the default is 1.  All settings give identical results. */

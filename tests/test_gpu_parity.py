@@ -1045,6 +1045,38 @@ def test_f32_storage_every_kernel_gives_the_same_bits(wa, dtype, ext):
     assert np.array_equal(out[2], out[1])
 
 
+@pytest.mark.parametrize("sched", ["up", "halves", "down"])
+@pytest.mark.parametrize("shape,steps", [((200, 37, 29), 9), ((300, 20, 18), 7), ((257, 33, 40), 12), ((64, 16, 9), 6),
+                                         ((128, 16, 5), 9), ((256, 32, 11), 10), ((128, 48, 23), 11)])   # the last three: whole 128 x 16 tiles (exact store counts, ring queues)
+def test_fp32_storage_three_step_kernel_gives_the_single_step_kernels_bits(wa, shape, steps, sched, monkeypatch):
+    """dtype f32 -- fp32 STORAGE, fp64 arithmetic: config #5's -- on the three-step kernel (round 5: float in HBM, the fp64
+    kernel's registers and LDS, every level's result rounded to float before it is used) against the single-step kernel and
+    the two-step kernel on the same storage: every cell's bits; ragged tiles and grids of whole tiles (exact store counts and
+    ring queues), z-chunks, marching up / down / as two halves, step counts with a two-step and a one-step remainder"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    monkeypatch.setenv("WAFER_F3_SCHED", "1" if sched == "halves" else "0")
+    monkeypatch.setenv("WAFER_F3_PLAIN_DOWN", "1" if sched == "down" else "0")
+    out = {}
+    for variant, zchunk in ((3, ""), (3, "5"), (3, "2"), (2, ""), (1, "")):
+        if zchunk:
+            monkeypatch.setenv("WAFER_ZCHUNK", zchunk)
+        else:
+            monkeypatch.delenv("WAFER_ZCHUNK", raising=False)
+        par = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.3, central_difference=1, dtype="f32")
+        with wa.Context(par) as ctx:
+            ctx.set_stencil_variant(variant)
+            ctx.set_potential("Coulomb")
+            ctx.set_initial_condition("Gaussian", seed=5)
+            if variant == 3:
+                assert ctx.stencil_kernel_name() == "wafer_k_step3_fused" and ctx.steps_per_launch() == 3
+            ctx.evolve(0, steps)
+            if variant == 3:
+                assert ctx.stencil_kernel_instance().startswith("wafer_k_step3_fused<wafer_f32_wide, double, ")
+            out[(variant, zchunk)] = ctx.download_phi()
+    for key in ((3, ""), (3, "5"), (3, "2"), (2, "")):
+        assert np.array_equal(out[key], out[(1, "")]), key
+
+
 @pytest.mark.parametrize("shape,steps", [((200, 37, 29), 9), ((300, 20, 18), 7), ((257, 33, 40), 12), ((64, 16, 9), 6)])
 def test_all_fp32_three_step_kernel_gives_the_single_step_kernels_bits(wa, shape, steps, monkeypatch):
     """f32fast (fp32 storage AND fp32 step arithmetic) on the three-step kernel -- 256 x 16 tiles, a and b carried between the

@@ -530,6 +530,36 @@ def test_all_fp32_three_step_kernel_on_slabs_bit_exact(wa, overlap, monkeypatch)
     assert np.array_equal(assemble(base, world, [r[0] for r in res]), want)
 
 
+@pytest.mark.parametrize("overlap", [3, 2, 1, 0])
+@pytest.mark.parametrize("world,shape", [(3, (264, 40, 72)), (2, (256, 32, 41))])   # ragged tiles / whole tiles (exact store counts), uneven slabs
+@peer_store_process
+def test_fp32_storage_three_step_kernel_on_slabs_bit_exact(wa, world, shape, overlap, monkeypatch):
+    """dtype f32 (fp32 storage, fp64 arithmetic) with three ghost planes: the three-step kernel on z-slabs, every schedule -- peer
+    stores (float stores into the neighbour's ghost planes) included -- against one context"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    steps = 11
+    base = wa.Params(*shape, dn=0.2, dt=0.004, central_difference=1, dtype="f32", halo_depth=3)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, central_difference=1, dtype="f32")) as ctx:
+        assert ctx.stencil_kernel_name() == "wafer_k_step3_fused"
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)
+        want = ctx.download_phi()
+
+    def body(ctx, rank):
+        ctx.set_overlap(overlap)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)
+        return ctx.download_phi(), ctx.steps_per_launch()
+
+    res, _ = run_slabs(wa, base, world, body)
+    assert all(r[1] == 3 for r in res)
+    assert np.array_equal(assemble(base, world, [r[0] for r in res]), want)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f32fast"])
 def test_fp32_storage_on_slabs_bit_exact(wa, dtype):
     """fp32 storage (and fp32 step arithmetic) on z-slabs: the same bits as one context"""

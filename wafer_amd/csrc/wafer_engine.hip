@@ -424,8 +424,8 @@ static int default_variant(const wafer_ctx *c)
     // SevenPoint: the two-step kernel exists (variant 2, bit-exact, 128 x 8 tiles) but recomputes phi1 on 14 rows
     // per 8 and is issue-bound: 0.93 ms/step at 512^3 against 0.63 for the single-step kernel on 128 x 16 tiles
     if (c->g.R == 3) return 1;
-    // ThreePoint, fp64 or all-fp32: three steps per pass (wafer_stencil_fused3.hip.h); everything else two
-    if ((!c->f32 || c->f32_arith) && c->g.R == 1 && c->tune.fuse3 != 0) return 3;
+    // ThreePoint, every type combination: three steps per pass (wafer_stencil_fused3.hip.h); everything else two
+    if (c->g.R == 1 && c->tune.fuse3 != 0) return 3;
     return 2;
 }
 
@@ -542,7 +542,7 @@ static long long step_partials_count(wafer_ctx *c, int lz_lo, int lz_hi)
     return (long long)c->bx * c->by * nchunks_of(lz_hi - lz_lo, zc);
 }
 
-// the three-step kernel serves ThreePoint fp64 grids whose rows fill its 128 x 16 tiles -- undecomposed, or
+// the three-step kernel serves ThreePoint grids (fp64; fp32 storage with either arithmetic) whose rows fill its tiles -- undecomposed, or
 // z-slabs created with at least 3 * ext ghost planes; everything else takes the two-step kernel.
 // Every rank of a decomposed run must take the same decision (the ranks exchange K * ext planes per K-step pass):
 // for a slab it therefore depends only on what all ranks share -- the global nx, ny, the ghost depth the host created
@@ -556,7 +556,7 @@ static bool fuse3_applies(const wafer_ctx *c)
     const int ny_env = c->tune.fuse3_min_ny;
     const int min_ny = ny_env >= 0 ? ny_env : 16;
     const long long min_cells = ny_env >= 0 ? 0 : c->tune.fuse3_min_cells;
-    if (!(active_variant(c) == 3 && c->g.R == 1 && (!c->f32 || c->f32_arith) && c->g.ny >= min_ny)) return false;
+    if (!(active_variant(c) == 3 && c->g.R == 1 && c->g.ny >= min_ny)) return false;
     if (c->sharded()) return c->g.G >= 3 * c->g.R;
     return (long long)c->g.nx * c->g.ny * c->g.nz >= min_cells;
 }

@@ -45,11 +45,13 @@ hipError_t wafer_entry_observables_lds(int tc, int R, const WaferTuning &t, cons
 // two fused ground-state steps
 hipError_t wafer_entry_step2_fused(int tc, int R, const WaferTuning &t, const WaferStepArgs &a, const void *phi, const void *pa,
                                    const void *pb, const void *pv, void *out, hipStream_t s);
-// three fused ground-state steps (ThreePoint fp64), table-driven
+// three fused ground-state steps (ThreePoint; every type combination), table-driven
 // dir: 1 = every workgroup of the table marches up, 2 = every one down, 0 = both occur (picks the kernel that carries only the
 // copy of the plane loop it needs)
 hipError_t wafer_entry_step3_fused(int tc, const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
                                    const WaferF3Sync &sy, const void *phi, const void *pv, void *out, hipStream_t s, int dir = 0);
+hipError_t wafer_entry_step3_fused_wide(const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
+                                        const WaferF3Sync &sy, const void *phi, const void *pv, void *out, hipStream_t s, int dir);
 void wafer_step3_tile(int tc, int *tx, int *ty);
 // the template-id of the instantiation this thread's last wafer_entry_step3_fused launched, as rocprofv3 prints it
 // ("wafer_k_step3_fused<double, double, true, 0, true, 1>"); empty before the first launch

@@ -126,6 +126,27 @@ __device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
 #ifndef WAFER_F3_POS_C
 #define WAFER_F3_POS_C 2
 #endif
+// What the kernel's first template argument stands for.  A plain type: stored, queued and staged as that type.
+// wafer_f32_wide: fp32 STORAGE with fp64 arithmetic (dtype WAFER_F32: config #5's) -- the arrays in HBM are float, 8 bytes per lane
+// and request; everything inside the CU (z-queues, LDS rings, the carried a and b * dt) is double, exactly the fp64 kernel's, and
+// every level's result is rounded to float before it is used or stored: the bits of three single fp32-storage steps.  (Queues and
+// LDS in float would halve the LDS traffic but put a conversion in front of every operand: 4 more vector instructions per update
+// where this form has 2.7, and the fp64 kernel is bound by the in-CU pipeline, not by bytes.)
+struct wafer_f32_wide {};
+template <typename T> struct WaferF3Store { using S = T; using Q = T; };
+template <> struct WaferF3Store<wafer_f32_wide> { using S = float; using Q = double; };
+template <typename SV, typename QV, int N>
+__device__ __forceinline__ QV wafer_f3_widen(const SV &x)
+{
+    if constexpr (std::is_same<SV, QV>::value) return x;
+    else {
+        QV r;
+#pragma unroll
+        for (int v = 0; v < N; ++v) r[v] = x[v];
+        return r;
+    }
+}
+
 template <typename T>
 struct WaferF3Cfg {
     static constexpr int VEC = WaferF3Vec<T>::N;
@@ -260,13 +281,24 @@ __device__ __forceinline__ const volatile WaferF3Sync *wafer_f3_sync_in_kernarg(
 // makes every wave sit out the completion of the two stores it issued a few hundred cycles earlier, once per plane (the
 // ablations of profiles/NOTES.md: the kernel without its stores 0.202 ms/step, without its loads 0.215, with both 0.253, without
 // either 0.192).  While the pipeline fills, the two stores go to the column's first plane, which the first real store overwrites.
-template <typename T, typename C, bool VIR, bool DOWN, int MODE, bool XS = false, bool RING_T = false>
+template <typename TS, typename C, bool VIR, bool DOWN, int MODE, bool XS = false, bool RING_T = false>
 __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const WaferF3Block &blk, int ntx, const WaferF3Sync &sy,
-                                                  const T *__restrict__ phi, const T *__restrict__ pv, T *__restrict__ out,
-                                                  T *lds0, T *lds1, T *lds2)
+                                                  const typename WaferF3Store<TS>::S *__restrict__ phi, const typename WaferF3Store<TS>::S *__restrict__ pv,
+                                                  typename WaferF3Store<TS>::S *__restrict__ out,
+                                                  typename WaferF3Store<TS>::Q *lds0, typename WaferF3Store<TS>::Q *lds1, typename WaferF3Store<TS>::Q *lds2)
 {
+    using T = typename WaferF3Store<TS>::Q;   // queues, LDS rings, carried a / b * dt
+    using ST = typename WaferF3Store<TS>::S;  // the arrays in HBM
+    constexpr bool WIDE = !std::is_same<ST, T>::value;
     using Cfg = WaferF3Cfg<T>;
     using VT = typename WaferF3Vec<T>::type;
+    typedef ST __attribute__((ext_vector_type(WaferF3Vec<T>::N))) SVT;   // a lane's request: the same cells, in the storage type
+    // global loads of a lane's vector / of one cell, widened to the register type
+    auto gload = [](const ST *p) -> VT { return wafer_f3_widen<SVT, VT, WaferF3Vec<T>::N>(*reinterpret_cast<const SVT *>(p)); };
+    auto gload_raw = [](const ST *p) -> SVT { return *reinterpret_cast<const SVT *>(p); };
+    auto widen = [](const SVT &x) -> VT { return wafer_f3_widen<SVT, VT, WaferF3Vec<T>::N>(x); };
+    // a level's result as the storage type holds it (fp32 storage: rounded once per step, like a store and a load would)
+    auto as_stored = [](C x) -> T { return (T)(ST)x; };
     constexpr int R = 1;
     constexpr int VEC = Cfg::VEC, RY = Cfg::RY, TX = Cfg::TX, TY = Cfg::TY;
     constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, HX2 = Cfg::HX2, LP0 = Cfg::LP0, LP1 = Cfg::LP1, LP2 = Cfg::LP2;
@@ -363,9 +395,9 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         C cb;
         wafer_ab_from_v<C>(vv, dt, vir, ca, cb);
         cbdt = cb * dt;
-        return (T)(w * ca + wafer_div_invariant<C>(cbdt * S, den));
+        return as_stored(w * ca + wafer_div_invariant<C>(cbdt * S, den));
     };
-    auto update_with = [&](C w, C ca, C cbdt, C S) -> T { return (T)(w * ca + wafer_div_invariant<C>(cbdt * S, den)); };
+    auto update_with = [&](C w, C ca, C cbdt, C S) -> T { return as_stored(w * ca + wafer_div_invariant<C>(cbdt * S, den)); };
 
     // ---- state.  Main rows: three z-queues, V of the level-1 plane, a / b of the planes of levels 2 and 3.
     //      Extra slot (component 0 only for a halo-column cell): phi0 and phi1 queues, V, a / b of the level-2 plane.
@@ -385,16 +417,16 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     for (int m = 0; m < 3; ++m) {
         const long long po = (long long)(z1 + SD * (m - 1)) * g.plane;
 #pragma unroll
-        for (int r = 0; r < RY; ++r) q0[m][r] = *reinterpret_cast<const VT *>((phi + po + rowoff[r]) + xlu);
-        if (x_row) xq0[m] = *reinterpret_cast<const VT *>((phi + po + xoff_row) + xlu);
-        else xq0[m][0] = phi[po + c_off];
+        for (int r = 0; r < RY; ++r) q0[m][r] = gload((phi + po + rowoff[r]) + xlu);
+        if (x_row) xq0[m] = gload((phi + po + xoff_row) + xlu);
+        else xq0[m][0] = (T)phi[po + c_off];
     }
     {
         const long long po = (long long)z1 * g.plane;
 #pragma unroll
-        for (int r = 0; r < RY; ++r) vcur[r] = *reinterpret_cast<const VT *>((pv + po + rowoff[r]) + xlu);
-        if (x_row) xv = *reinterpret_cast<const VT *>((pv + po + xoff_row) + xlu);
-        else xv[0] = pv[po + c_off];
+        for (int r = 0; r < RY; ++r) vcur[r] = gload((pv + po + rowoff[r]) + xlu);
+        if (x_row) xv = gload((pv + po + xoff_row) + xlu);
+        else xv[0] = (T)pv[po + c_off];
     }
     for (int i = tid; i < 2 * Cfg::TILE0; i += Cfg::NT_) lds0[i] = T(0);
     for (int i = tid; i < 2 * Cfg::TILE1; i += Cfg::NT_) lds1[i] = T(0);
@@ -406,26 +438,26 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(t0 + (yrow[r] - (y0 - 3)) * LP0 + HX0 + xl) = q0[1][r];
         if (x_row) *reinterpret_cast<VT *>(t0 + (xy - (y0 - 3)) * LP0 + HX0 + xl) = xy_out ? zero : xq0[1];
         else if (c_ok) t0[c_lds0] = c_xout ? T(0) : xq0[1][0];
-        if (has_orow) *reinterpret_cast<VT *>(t0 + orow_lds) = oy_out ? zero : *reinterpret_cast<const VT *>((phi + (long long)z1 * g.plane + orow_off) + xlu);
+        if (has_orow) *reinterpret_cast<VT *>(t0 + orow_lds) = oy_out ? zero : gload((phi + (long long)z1 * g.plane + orow_off) + xlu);
     }
     VT orow_nxt = zero;
-    if (has_orow) orow_nxt = *reinterpret_cast<const VT *>((phi + (long long)(z1 + SD) * g.plane + orow_off) + xlu);
+    if (has_orow) orow_nxt = gload((phi + (long long)(z1 + SD) * g.plane + orow_off) + xlu);
     __syncthreads();
 
     // Peer stores: where the first / last wt planes of the march go in the neighbours' buffers, read ONCE from the device copy
     // of the connection and held in VECTOR registers (the pin): as scalars they stay live across a plane loop that has none to
     // spare (6-8 % in round 4's first version), and read inside the loop the loads of a rarely taken branch make the wait-count
     // pass pessimistic about every prefetch in flight (0.325 against 0.273 ms/step at the bench slab).
-    [[maybe_unused]] T *peer_first = nullptr, *peer_last = nullptr;
+    [[maybe_unused]] ST *peer_first = nullptr, *peer_last = nullptr;
     if constexpr (PEER) {
         const volatile WaferF3Peer *pi = syv->peer_dev;
         const int buf = syv->peer_buf;
         if (bump_early >= 0) {
-            T *const base = static_cast<T *>(pi->out[bump_early][buf]);
+            ST *const base = static_cast<ST *>(pi->out[bump_early][buf]);
             if (base) peer_first = base + pi->zshift[bump_early] * g.plane;
         }
         if (blk.bump >= 0) {
-            T *const base = static_cast<T *>(pi->out[blk.bump & 1][buf]);
+            ST *const base = static_cast<ST *>(pi->out[blk.bump & 1][buf]);
             if (base) peer_last = base + pi->zshift[blk.bump & 1] * g.plane;
         }
         asm volatile("" : "+v"(peer_first), "+v"(peer_last));
@@ -580,14 +612,15 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
 // DIR: 0 = the table holds workgroups of both marching directions, 1 = all up, 2 = all down.  A kernel that carries one copy of the
 // plane loop instead of two gets the better register allocation (the peer instantiation: 88 B of scratch with both, none with one).
 template <typename T, typename C, bool VIR, int MODE = 0, bool XS = false, int DIR = 0>
-__global__ __launch_bounds__((WaferF3Cfg<T>::NT_)) WAFER_F3_OCC void wafer_k_step3_fused(WaferStepArgs a, int ntx, const WaferF3Block *__restrict__ table,
-                                                                              WaferF3Sync sy, const T *__restrict__ phi,
-                                                                              const T *__restrict__ pv, T *__restrict__ out)
+__global__ __launch_bounds__((WaferF3Cfg<typename WaferF3Store<T>::Q>::NT_)) WAFER_F3_OCC void wafer_k_step3_fused(WaferStepArgs a, int ntx, const WaferF3Block *__restrict__ table,
+                                                                              WaferF3Sync sy, const typename WaferF3Store<T>::S *__restrict__ phi,
+                                                                              const typename WaferF3Store<T>::S *__restrict__ pv, typename WaferF3Store<T>::S *__restrict__ out)
 {
-    using Cfg = WaferF3Cfg<T>;
-    __shared__ __attribute__((aligned(16))) T lds0[2 * Cfg::TILE0];
-    __shared__ __attribute__((aligned(16))) T lds1[2 * Cfg::TILE1];
-    __shared__ __attribute__((aligned(16))) T lds2[2 * Cfg::TILE2];
+    using Q = typename WaferF3Store<T>::Q;
+    using Cfg = WaferF3Cfg<Q>;
+    __shared__ __attribute__((aligned(16))) Q lds0[2 * Cfg::TILE0];
+    __shared__ __attribute__((aligned(16))) Q lds1[2 * Cfg::TILE1];
+    __shared__ __attribute__((aligned(16))) Q lds2[2 * Cfg::TILE2];
     const WaferF3Block blk = table[blockIdx.x];
     // (ring queues where the kernel has the registers for the unrolled loop: the plain instantiation with exact store counts)
     constexpr bool RING = XS && WAFER_F3_RING != 0 && (MODE == 0 || WAFER_F3_RING_PEER != 0);
@@ -770,9 +803,10 @@ inline WaferF3Instance &wafer_f3_last_instance()
 // Advances the planes of `table` (device copy, nblocks entries) by THREE steps: out = step(step(step(phi))).  ThreePoint only.
 template <typename T, typename C>
 static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const WaferStepArgs &a, const WaferF3Block *table, int nblocks,
-                                                  const WaferF3Sync &sy, const T *phi, const T *pv, T *out, hipStream_t s, int dir = 0)
+                                                  const WaferF3Sync &sy, const typename WaferF3Store<T>::S *phi, const typename WaferF3Store<T>::S *pv,
+                                                  typename WaferF3Store<T>::S *out, hipStream_t s, int dir = 0)
 {
-    using Cfg = WaferF3Cfg<T>;
+    using Cfg = WaferF3Cfg<typename WaferF3Store<T>::Q>;
     const int ntx = (a.g.nx + Cfg::TX - 1) / Cfg::TX;
     const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
     // the synchronisation a launch needs picks the instantiation (see wafer_step3_body): none, mode 2's flags and counters, peer stores
@@ -783,7 +817,7 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     do {                                                                                                                                          \
         hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_, DIR_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out); \
         WaferF3Instance &li_ = wafer_f3_last_instance();                                                                                          \
-        li_.tsize = (int)sizeof(T); li_.csize = (int)sizeof(C); li_.vir = (VIR_); li_.mode = (MODE_); li_.xs = (XS_); li_.dir = (DIR_);           \
+        li_.tsize = std::is_same<T, wafer_f32_wide>::value ? -4 : (int)sizeof(T); li_.csize = (int)sizeof(C); li_.vir = (VIR_); li_.mode = (MODE_); li_.xs = (XS_); li_.dir = (DIR_);           \
     } while (0)
     // (the single-direction kernels exist for the instantiations that need them: plain XS launches, peer-store passes)
 #define WAFER_F3_LAUNCH(VIR_, MODE_, XS_)                                              \

@@ -20,11 +20,16 @@
         // DIRECT (with RING): what is dead by the time its successor is requested takes the request itself -- V of the main rows
         // (last read by level 1, requested behind it), the extra slot's V, oldest phi0 plane and outer-row copy (last read by the extra
         // slot's level 1 / the staging at the top, requested behind them): no staging registers and no copies for these four.
-        constexpr bool DIRECT = RING;
+        // (fp32 storage: what arrives is float and is widened where the queues rotate, behind the barrier -- a request cannot
+        //  write the slot itself)
+        constexpr bool DIRECT = RING && !WIDE;
         static_assert(!DIRECT || (WAFER_F3_POS_B >= 1 && WAFER_F3_POS_B != 5 && WAFER_F3_POS_C >= 2 && WAFER_F3_POS_C != 5), "requests behind the last reads");
-        VT pre[RY], pre_v[RY], xpre = zero, xpre_v = zero, orow_pre = zero;
+        SVT szero;
 #pragma unroll
-        for (int r = 0; r < RY; ++r) pre[r] = pre_v[r] = zero;
+        for (int v = 0; v < VEC; ++v) szero[v] = ST(0);
+        SVT pre[RY], pre_v[RY], xpre = szero, xpre_v = szero, orow_pre = szero;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) pre[r] = pre_v[r] = szero;
         // The seven requests of a wave are NOT issued together: all eight waves leave the barrier at once, and 56 requests of 1 KiB
         // queue at the CU's one address unit (16 cycles each) while no wave can issue arithmetic behind its own -- the in-kernel
         // stamps (tools/f3_stamps.py) showed a sixth of the iteration going there.  Spread over the iteration (the main rows' phi0
@@ -33,24 +38,24 @@
         auto issue_group = [&](int pos) {
             if (pos == WAFER_F3_POS_A) {
 #pragma unroll
-                for (int r = 0; r < RY; ++r) pre[r] = *reinterpret_cast<const VT *>((phi + zo + SD * 2 * g.plane + rowoff[r]) + xlu);
+                for (int r = 0; r < RY; ++r) pre[r] = gload_raw((phi + zo + SD * 2 * g.plane + rowoff[r]) + xlu);
             }
             if (pos == WAFER_F3_POS_B) {
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
-                    if constexpr (DIRECT) vcur[r] = *reinterpret_cast<const VT *>((pv + zo + SD * g.plane + rowoff[r]) + xlu);
-                    else pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + SD * g.plane + rowoff[r]) + xlu);
+                    if constexpr (DIRECT) vcur[r] = gload((pv + zo + SD * g.plane + rowoff[r]) + xlu);
+                    else pre_v[r] = gload_raw((pv + zo + SD * g.plane + rowoff[r]) + xlu);
                 }
             }
             if (pos == WAFER_F3_POS_C) {
                 if constexpr (DIRECT) {
-                    xq0[WAFER_F3_Q0(0)] = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + xslot_off);
-                    xv = *reinterpret_cast<const VT *>(pv + zo + SD * g.plane + xslot_off);
-                    orow_nxt = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + orow_slot_off);
+                    xq0[WAFER_F3_Q0(0)] = gload(phi + zo + SD * 2 * g.plane + xslot_off);
+                    xv = gload(pv + zo + SD * g.plane + xslot_off);
+                    orow_nxt = gload(phi + zo + SD * 2 * g.plane + orow_slot_off);
                 } else {
-                    xpre = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + xslot_off);
-                    xpre_v = *reinterpret_cast<const VT *>(pv + zo + SD * g.plane + xslot_off);
-                    orow_pre = *reinterpret_cast<const VT *>(phi + zo + SD * 2 * g.plane + orow_slot_off);
+                    xpre = gload_raw(phi + zo + SD * 2 * g.plane + xslot_off);
+                    xpre_v = gload_raw(pv + zo + SD * g.plane + xslot_off);
+                    orow_pre = gload_raw(phi + zo + SD * 2 * g.plane + orow_slot_off);
                 }
             }
         };
@@ -320,7 +325,7 @@
         // the neighbour's buffer, shifted so that this slab's plane index addresses the ghost plane it fills (nullptr: no peer stores).
         // Stored from the registers, inside the loop's store path: a copy from memory after the fact (the planes read back at agent
         // scope, two more barriers per boundary) measured 0.320 against 0.280 ms/step at the bench slab.
-        T *peer_dst = nullptr;
+        ST *peer_dst = nullptr;
         if constexpr (PEER) peer_dst = first_wt ? peer_first : last_wt ? peer_last : nullptr;
         if (XS || (zo3 >= zs && zo3 < ze)) {
             auto level3 = [&](auto interior_tag) {
@@ -353,33 +358,36 @@
                         if (a.dt > -1.0) continue;
 #endif
                         const int zst = !XS ? zo3 : DOWN ? (zo3 < ze - 1 ? zo3 : ze - 1) : (zo3 > zs ? zo3 : zs);
-                        T *dst = (out + (long long)zst * g.plane + rowoff[r]) + xlu;
+                        ST *dst = (out + (long long)zst * g.plane + rowoff[r]) + xlu;
+                        SVT st3;   // (the value is a storage-type number already: as_stored)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) st3[v] = (ST)res3[r][v];
                         if constexpr (PEER) {
                             // (XS: level 3 also runs while the pipeline fills; what it produces then goes nowhere near a neighbour)
                             if (peer_dst && (!XS || (zo3 >= zs && zo3 < ze))) {   // into the neighbour's ghost planes (wave-uniform), system scope, written through
-                                T *pd = (peer_dst + (long long)zo3 * g.plane + rowoff[r]) + xlu;
+                                ST *pd = (peer_dst + (long long)zo3 * g.plane + rowoff[r]) + xlu;
 #pragma unroll
                                 for (int v = 0; v < VEC; ++v)
-                                    if (INTERIOR || xi + v < g.nx) __hip_atomic_store(pd + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    if (INTERIOR || xi + v < g.nx) __hip_atomic_store(pd + v, st3[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             }
                         }
                         if constexpr (XS) {
                             // (overlap mode 2's tail: the planes the exchange reads while this kernel runs are written through)
                             if (!(SYNC && !PEER) || !wthrough) {
-                                *reinterpret_cast<VT *>(dst) = res3[r];
+                                *reinterpret_cast<SVT *>(dst) = st3;
                                 continue;
                             }
                         }
                         if (wthrough) {
 #pragma unroll
                             for (int v = 0; v < VEC; ++v)
-                                if (INTERIOR || xi + v < g.nx) __hip_atomic_store(dst + v, res3[r][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (INTERIOR || xi + v < g.nx) __hip_atomic_store(dst + v, st3[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         } else if (INTERIOR || xi + VEC <= g.nx) {
-                            *reinterpret_cast<VT *>(dst) = res3[r];
+                            *reinterpret_cast<SVT *>(dst) = st3;
                         } else {
 #pragma unroll
                             for (int v = 0; v < VEC; ++v)
-                                if (xi + v < g.nx) dst[v] = res3[r][v];
+                                if (xi + v < g.nx) dst[v] = st3[v];
                         }
                     }
                 }
@@ -410,9 +418,9 @@
         //         compiler sometimes consumes a prefetch where it was issued (the halo-column waves then wait out the whole memory
         //         latency at the top of every iteration) or ahead of the barrier (every wave waits for its loads first and for the
         //         slowest wave second) -- which of the two 8 % apart "states" a build landed in used to depend on unrelated edits.
-        auto pin = [](VT &x) {
+        auto pin = [](auto &x) {
             if constexpr (VEC == 1) {
-                T t = x[0];
+                auto t = x[0];
                 asm volatile("" : "+v"(t));
                 x[0] = t;
             } else asm volatile("" : "+v"(x));
@@ -435,13 +443,13 @@
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             if constexpr (RING) {
-                q0[WAFER_F3_Q0(0)][r] = pre[r];
+                q0[WAFER_F3_Q0(0)][r] = widen(pre[r]);
             } else {
                 q0[0][r] = q0[1][r];
                 q0[1][r] = q0[2][r];
-                q0[2][r] = pre[r];
+                q0[2][r] = widen(pre[r]);
             }
-            if constexpr (!DIRECT) vcur[r] = pre_v[r];
+            if constexpr (!DIRECT) vcur[r] = widen(pre_v[r]);
             caq[0][r] = caq[1][r];
             cbq[0][r] = cbq[1][r];
             caq[1][r] = canew[r];
@@ -450,16 +458,16 @@
         if constexpr (DIRECT) {
             // (requested into the slot itself)
         } else if constexpr (RING) {
-            xq0[WAFER_F3_Q0(0)] = xpre;
+            xq0[WAFER_F3_Q0(0)] = widen(xpre);
         } else {
             xq0[0] = xq0[1];
             xq0[1] = xq0[2];
-            xq0[2] = xpre;
+            xq0[2] = widen(xpre);
         }
-        if constexpr (!DIRECT) xv = xpre_v;
+        if constexpr (!DIRECT) xv = widen(xpre_v);
         xca = xcanew;
         xcb = xcbnew;
-        if constexpr (!DIRECT) orow_nxt = orow_pre;
+        if constexpr (!DIRECT) orow_nxt = widen(orow_pre);
 #ifdef WAFER_F3_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (what is left of the requests' latency, made visible)
 #endif

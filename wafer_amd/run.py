@@ -208,7 +208,7 @@ def main(argv=None) -> int:
     z_begin, z_count = (0, 0) if world == 1 else slab.partition(cfg["nz"], world, rank)
     par = wafer_amd.Params(cfg["nx"], cfg["ny"], cfg["nz"], dn=cfg["dn"], dt=cfg["dt"], mass=cfg["mass"], sig=cfg["sig"],
                            central_difference=ext, dtype=cfg["dtype"], max_states=cfg["wavemax"] + 1, device=local_rank,
-                           z_begin=z_begin, z_count=z_count, halo_depth=(3 if ext == 1 and cfg["dtype"] in ("f64", "f32fast") else 2 * ext if ext <= 2 else 0) if world > 1 else 0)
+                           z_begin=z_begin, z_count=z_count, halo_depth=(3 if ext == 1 else 2 * ext if ext <= 2 else 0) if world > 1 else 0)
     say = (lambda *a, **k: print(*a, **k, flush=True)) if rank == 0 else (lambda *a, **k: None)
     out_dir = None
     if rank == 0:
