@@ -211,6 +211,56 @@ def test_fused_two_step_kernel_bit_exact(wo, wa, shape, ext, steps):
         assert ulp_diff(ctx.download_phi(), phi) == 0
 
 
+@pytest.mark.parametrize("wide", ["1", "0"])
+@pytest.mark.parametrize("zchunk", ["", "1", "3", "7"])
+@pytest.mark.parametrize("shape,steps", [((150, 37, 29), 6), ((257, 20, 11), 5), ((128, 16, 9), 4), ((129, 33, 40), 7), ((300, 50, 7), 2),
+                                         ((5, 4, 3), 4), ((1, 1, 1), 3), ((64, 70, 2), 8), ((256, 32, 21), 6)])
+def test_five_point_two_step_kernels_bit_exact(wo, wa, shape, steps, zchunk, wide, monkeypatch):
+    """FivePoint, two steps per pass: the 128 x 16-tile kernel in the three-step kernel's structure (wafer_stencil_fused2w.hip.h:
+    eight even waves, round 5) and the kernel with dedicated helper waves it replaces (WAFER_F2_WIDE=0) against the oracle, every
+    cell's bits (grid.rs:593-624): ragged tiles, grids smaller than a tile and of whole tiles, one-plane / odd z-chunks, even and
+    odd step counts, every frame cell still exactly zero"""
+    monkeypatch.setenv("WAFER_F2_WIDE", wide)
+    if zchunk:
+        monkeypatch.setenv("WAFER_ZCHUNK", zchunk)
+    cfg, par = make_pair(shape, ext=2, potential="Coulomb", dn=0.2, dt=0.004, mass=1.0)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=12)
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(2)
+        assert ctx.stencil_kernel_name() == "wafer_k_step2_fused" and ctx.steps_per_launch() == 2
+        ctx.set_potential("Coulomb")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, steps)
+        wo.evolve(cfg, 0, a, b, phi, [], steps)
+        got = ctx.download_phi()
+        assert ulp_diff(got, phi) == 0
+        assert not got[:2].any() and not got[-2:].any() and not got[:, :2].any() and not got[:, :, -2:].any()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f32fast"])
+@pytest.mark.parametrize("shape,steps", [((200, 37, 29), 8), ((300, 20, 18), 7), ((256, 32, 21), 6), ((512, 16, 9), 4)])
+def test_five_point_two_step_kernel_fp32_storage_gives_the_single_step_kernels_bits(wa, dtype, shape, steps, monkeypatch):
+    """the same kernel on fp32 storage -- with fp64 arithmetic (float in HBM, double in the CU, every level rounded to float) and
+    with fp32 arithmetic (256 x 16 tiles) -- against the single-step kernel on the same storage: every cell's bits"""
+    out = {}
+    for variant, zchunk in ((2, ""), (2, "5"), (1, "")):
+        if zchunk:
+            monkeypatch.setenv("WAFER_ZCHUNK", zchunk)
+        else:
+            monkeypatch.delenv("WAFER_ZCHUNK", raising=False)
+        par = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.3, central_difference=2, dtype=dtype)
+        with wa.Context(par) as ctx:
+            ctx.set_stencil_variant(variant)
+            ctx.set_potential("Coulomb")
+            ctx.set_initial_condition("Gaussian", seed=5)
+            ctx.evolve(0, steps)
+            out[(variant, zchunk)] = ctx.download_phi()
+    assert np.array_equal(out[(2, "")], out[(1, "")])
+    assert np.array_equal(out[(2, "5")], out[(1, "")])
+
+
 @pytest.mark.parametrize("steps", [3, 7, 11, 12])
 @pytest.mark.parametrize("shape", SHAPES + [(150, 37, 29), (257, 20, 11), (128, 16, 9), (129, 33, 40), (300, 50, 7)])
 def test_fused_three_step_kernel_bit_exact(wo, wa, shape, steps, monkeypatch):

@@ -418,9 +418,10 @@ static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 static int default_variant(const wafer_ctx *c)
 {
     if (c->tune.stencil_variant >= 0) return c->tune.stencil_variant;
-    // FivePoint on fp32 storage: the fused kernel needs 256 VGPRs (and spills) there; the single-step
-    // kernel is faster (512^3: 0.337 against 0.383 ms/step, f32fast 0.287 against 0.302)
-    if (c->f32 && c->g.R == 2) return 1;
+    // FivePoint on fp32 storage with fp64 arithmetic: the single-step kernel and the two-step kernel on 128 x 16 tiles
+    // (wafer_stencil_fused2w.hip.h) take the same time (512^3: 0.337 against 0.335 ms/step) and the single step needs half the
+    // ghost planes on slabs; with fp32 arithmetic as well the two-step kernel wins (0.250 against 0.288)
+    if (c->f32 && !c->f32_arith && c->g.R == 2) return 1;
     // SevenPoint: the two-step kernel exists (variant 2, bit-exact, 128 x 8 tiles) but recomputes phi1 on 14 rows
     // per 8 and is issue-bound: 0.93 ms/step at 512^3 against 0.63 for the single-step kernel on 128 x 16 tiles
     if (c->g.R == 3) return 1;

@@ -45,6 +45,8 @@ hipError_t wafer_entry_observables_lds(int tc, int R, const WaferTuning &t, cons
 // two fused ground-state steps
 hipError_t wafer_entry_step2_fused(int tc, int R, const WaferTuning &t, const WaferStepArgs &a, const void *phi, const void *pa,
                                    const void *pb, const void *pv, void *out, hipStream_t s);
+// ... FivePoint on 128 x 16 tiles, eight even waves (wafer_stencil_fused2w.hip.h)
+hipError_t wafer_entry_step2_wide(int tc, const WaferTuning &t, const WaferStepArgs &a, const void *phi, const void *pv, void *out, hipStream_t s);
 // three fused ground-state steps (ThreePoint; every type combination), table-driven
 // dir: 1 = every workgroup of the table marches up, 2 = every one down, 0 = both occur (picks the kernel that carries only the
 // copy of the plane loop it needs)

@@ -19,6 +19,8 @@ static hipError_t f2_r(int R, const WaferTuning &t, const WaferStepArgs &a, cons
 hipError_t wafer_entry_step2_fused(int tc, int R, const WaferTuning &t, const WaferStepArgs &a, const void *phi, const void *pa,
                                    const void *pb, const void *pv, void *out, hipStream_t s)
 {
+    // FivePoint: the 128 x 16-tile kernel in the three-step kernel's structure (wafer_stencil_fused2w.hip.h); WAFER_F2_WIDE=0: this unit's
+    if (R == 2 && t.f2_wide != 0) return wafer_entry_step2_wide(tc, t, a, phi, pv, out, s);
     switch (tc) {
     case WAFER_TC_F64: return f2_r<double, double>(R, t, a, phi, pa, pb, pv, out, s);
     case WAFER_TC_F32_F64: return f2_r<float, double>(R, t, a, phi, pa, pb, pv, out, s);

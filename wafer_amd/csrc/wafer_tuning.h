@@ -33,6 +33,7 @@ struct WaferTuning {
     int obs_wgs = 2;        // WAFER_OBS_WGS: workgroups per CU
     // fused kernels
     int f2_nw2 = 0;         // WAFER_F2_NW2: main waves of the two-step kernel (0: default)
+    int f2_wide = 1;        // WAFER_F2_WIDE: 0 keeps FivePoint on the two-step kernel with dedicated helper waves (128 x 8 tiles)
     int fuse3 = 1;          // WAFER_FUSE3: 0 keeps ThreePoint fp64 on the two-step kernel
     int fuse3_min_ny = -1;  // WAFER_FUSE3_MIN_NY (tests; lifts the cell threshold too)
     long long fuse3_min_cells = 6000000; // WAFER_FUSE3_MIN_CELLS
@@ -84,6 +85,7 @@ static inline WaferTuning wafer_tuning_from_env()
     t.obs_lds = wafer_env_int("WAFER_OBS_LDS", t.obs_lds);
     t.obs_wgs = wafer_env_int("WAFER_OBS_WGS", t.obs_wgs);
     t.f2_nw2 = wafer_env_int("WAFER_F2_NW2", t.f2_nw2);
+    t.f2_wide = wafer_env_int("WAFER_F2_WIDE", t.f2_wide);
     t.fuse3 = wafer_env_int("WAFER_FUSE3", t.fuse3);
     t.fuse3_min_ny = wafer_env_int("WAFER_FUSE3_MIN_NY", t.fuse3_min_ny);
     t.fuse3_min_cells = wafer_env_int("WAFER_FUSE3_MIN_CELLS", (int)t.fuse3_min_cells);
