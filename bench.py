@@ -82,12 +82,13 @@ def parse_args(argv=None):
 
 def physical_cores() -> int:
     """Wafer's own thread rule (main.rs:190-196): the rayon pool gets num_cpus::get_physical() -- bounded by what this
-    process may really use (affinity mask, cgroup CPU quota: more threads than that only take turns)."""
+    process may really use (affinity mask, cgroup CPU quota: more threads than that only take turns).  A physical-core
+    count that cannot be right (virtual machines report sockets, or 1) is ignored."""
     n = max(1, len(os.sched_getaffinity(0)))
     try:
         import psutil
         phys = psutil.cpu_count(logical=False)
-        if phys:
+        if phys and phys * 4 >= n:       # (SMT up to four ways; anything smaller is not a core count of this machine)
             n = int(min(n, phys))
     except Exception:
         pass

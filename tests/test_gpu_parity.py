@@ -335,7 +335,7 @@ def test_fused3_exact_store_count_variant(wo, wa, shape, zchunk, xs, sched, monk
 def test_fused3_thousand_steps_64cubed_and_default_dispatch(wo, wa, monkeypatch):
     """1000 steps (333 three-step passes + one single step) at 64^3 (forced onto the kernel) against the
     oracle; the three-step kernel is what a ThreePoint fp64 context of 6 M cells or more runs by default,
-    the two-step kernel what small grids, FivePoint, fp32 storage and slabs with two ghost planes run"""
+    the two-step kernel what small grids, FivePoint and slabs with two ghost planes run"""
     with wa.Context(wa.Params(64, 64, 64, dn=0.2, dt=8e-3)) as ctx:      # small: launch-bound, the two-step kernel is faster
         assert ctx.stencil_kernel_name() == "wafer_k_step2_fused"
     with wa.Context(wa.Params(256, 256, 192, dn=0.2, dt=8e-3, max_states=1)) as ctx:
@@ -352,9 +352,11 @@ def test_fused3_thousand_steps_64cubed_and_default_dispatch(wo, wa, monkeypatch)
         ctx.set_initial_condition("Boolean")
         ctx.evolve(0, 1000)
         assert ulp_diff(ctx.download_phi(), phi) == 0
-    for kw in (dict(central_difference=2), dict(dtype="f32"), dict(z_begin=16, z_count=16, halo_depth=2)):
+    for kw in (dict(central_difference=2), dict(z_begin=16, z_count=16, halo_depth=2)):
         with wa.Context(wa.Params(64, 64, 64, dn=0.2, dt=8e-3, **kw)) as ctx:
             assert ctx.stencil_kernel_name() == "wafer_k_step2_fused" and ctx.steps_per_launch() == 2
+    with wa.Context(wa.Params(64, 64, 64, dn=0.2, dt=8e-3, dtype="f32")) as ctx:   # fp32 storage, fp64 arithmetic: the three-step kernel too (round 5)
+        assert ctx.stencil_kernel_name() == "wafer_k_step3_fused" and ctx.steps_per_launch() == 3
 
 
 @pytest.mark.parametrize("zchunk", ["1", "2", "5", "1000"])

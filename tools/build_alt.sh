@@ -1,7 +1,7 @@
 #!/bin/bash
 # An alternative build of libwafer_hip.so for same-box A/B runs (tools/gpu_batch.sh ab_alt*): the same sources with extra
 # compile-time definitions, into wafer_amd/build/alt_<name>/ (travels to the GPU box; WAFER_HIP_LIB selects it).
-#   bash tools/build_alt.sh <name> "-DWAFER_X2_DIV_XFORM"
+#   bash tools/build_alt.sh <name> "-DWAFER_DIAG=8"
 set -e
 cd "$(dirname "$0")/../wafer_amd/csrc"
 NAME=$1; DEFS=$2

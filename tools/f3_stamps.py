@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Where a plane iteration of the three-step kernel spends its cycles, per wave (a -DWAFER_F3_STAMP build:
-bash tools/build_alt.sh stamp "-DWAFER_F3_STAMP"; WAFER_HIP_LIB=.../alt_stamp/libwafer_hip.so python3 tools/f3_stamps.py).
+"""Where a plane iteration of the three-step kernel spends its cycles, per wave (a -DWAFER_DIAG=1 build:
+bash tools/build_alt.sh stamp "-DWAFER_DIAG=1"; WAFER_HIP_LIB=.../alt_stamp/libwafer_hip.so python3 tools/f3_stamps.py).
 Shares, not times: the stamps' own waits forbid overlaps the real kernel has."""
 import ctypes as C
 import json

@@ -13,10 +13,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwafer_hip.so")
 # One translation unit per kernel family (wafer_launch.h): they compile in parallel and an edit to one kernel
-# rebuilds one unit.  The engine unit holds the host logic and the small elementwise / set-up kernels.
-SOURCES = ["wafer_engine.hip", "wafer_tu_lds.hip", "wafer_tu_excited_r1.hip", "wafer_tu_excited_r2.hip", "wafer_tu_excited_r3.hip",
+# rebuilds one unit.  The engine units (wafer_engine*.hip, shared declarations in wafer_engine.h) hold the host logic and the
+# small elementwise / set-up kernels.
+SOURCES = ["wafer_engine.hip", "wafer_engine_schedules.hip", "wafer_engine_comm.hip", "wafer_engine_solve.hip", "wafer_tu_lds.hip", "wafer_tu_excited_r1.hip", "wafer_tu_excited_r2.hip", "wafer_tu_excited_r3.hip",
            "wafer_tu_fused2.hip", "wafer_tu_fused2w.hip", "wafer_tu_fused3.hip", "wafer_tu_fused3_wide.hip", "wafer_tu_x2.hip", "wafer_mailbox.hip"]
-HEADERS = ["wafer_geom.h", "wafer_tuning.h", "wafer_launch.h", "wafer_stencil.hip.h", "wafer_stencil_lds.hip.h",
+HEADERS = ["wafer_engine.h", "wafer_storage.h", "wafer_geom.h", "wafer_tuning.h", "wafer_launch.h", "wafer_stencil_fused2w.hip.h", "wafer_stencil.hip.h", "wafer_stencil_lds.hip.h",
            "wafer_stencil_fused2.hip.h", "wafer_stencil_fused3.hip.h", "wafer_stencil_fused3_iter.inc.h", "wafer_stencil_x2.hip.h", "wafer_stencil_x2_iter.inc.h", "wafer_elementwise.hip.h", "wafer_rowwalk.h", "wafer_setup.hip.h",
            "wafer_tu_excited.inc"]
 # -ffp-contract=off: the stencil update must round exactly like the reference's

@@ -13,7 +13,7 @@
 
 // Fixed-order second stage: out[q] = sum of partials[q*stride .. q*stride+n).
 // One 256-thread block per quantity; strided serial sums, then an LDS tree.
-__global__ __launch_bounds__(256) void wafer_k_reduce(const double *__restrict__ partials,
+static __global__ __launch_bounds__(256) void wafer_k_reduce(const double *__restrict__ partials,
                                                       long long n, long long stride,
                                                       double *__restrict__ out)
 {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void wafer_k_gs_apply(WaferRowArgs a, T *__res
 
 // scal[0] = 1, scal[1..n) = 0: the scalars for which the load transform / wafer_k_gs_apply is the
 // identity (x/1 - l*0), i.e. "phi is already normalised and projected"
-__global__ void wafer_k_identity_scalars(double *__restrict__ scal, int n)
+static __global__ void wafer_k_identity_scalars(double *__restrict__ scal, int n)
 {
     const int i = threadIdx.x;
     if (i < n) scal[i] = (i == 0) ? 1.0 : 0.0;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void wafer_k_checksum(WaferRowArgs a, const T 
 // Every thread draws `per_thread` operands x from a counter-based generator (splitmix64 of the global
 // operand index and the seed): uniform significand and sign, biased exponent uniform in [lo_exp, hi_exp].
 // Counts the operands for which wafer_div_invariant(x, den) and x / den differ in any bit.
-__global__ __launch_bounds__(256) void wafer_k_div_check(double den, unsigned long long seed, int per_thread, int lo_exp,
+static __global__ __launch_bounds__(256) void wafer_k_div_check(double den, unsigned long long seed, int per_thread, int lo_exp,
                                                          int hi_exp, unsigned long long *__restrict__ mismatches)
 {
     const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -211,78 +211,3 @@ __global__ __launch_bounds__(256) void wafer_k_step_direct(WaferStepArgs a, cons
             partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
     }
 }
-
-// ---------------------------------------------------------------------------
-// compute_observables (grid.rs:303-445): the four work-area sums in ONE pass
-// over phi and V.  Always evaluated in fp64 (fp32 storage is widened first).
-// partials layout: [4][nblocks].
-// ---------------------------------------------------------------------------
-struct WaferObsArgs {
-    WaferGeom g;
-    int zchunk;
-    double den;
-    int potsub_kind;      // wafer_potsub_kind
-    double potsub_scalar;
-    long long nblocks;
-};
-
-template <typename T, int R>
-__global__ __launch_bounds__(256) void wafer_k_observables(WaferObsArgs a, const T *__restrict__ phi,
-                                                           const T *__restrict__ v,
-                                                           const T *__restrict__ potsub,
-                                                           double *__restrict__ partials)
-{
-    __shared__ double red[4];
-    const WaferGeom &g = a.g;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    const int j = blockIdx.y * 4 + threadIdx.y;
-    const int zs = g.G + blockIdx.z * a.zchunk;
-    const int ze = min(zs + a.zchunk, g.G + g.nzl);
-    const bool active = (i < g.nx) && (j < g.ny);
-    double se = 0.0, sn = 0.0, sv = 0.0, sr = 0.0;
-    if (active) {
-        const long long col = (long long)(j + R) * g.pitch + g.xoff + (i + R);
-        const T *p = phi + col;
-        // potential::calculate_r2 on the WORK-AREA index (grid.rs:429-435, potential.rs:366-371)
-        const double dx = (double)i - ((double)g.nx + 1.) / 2.;
-        const double dy = (double)j - ((double)g.ny + 1.) / 2.;
-        double zq[2 * R + 1];
-#pragma unroll
-        for (int m = 1; m <= 2 * R; ++m) zq[m] = (double)p[(long long)(zs + m - 1 - R) * g.plane];
-        for (int z = zs; z < ze; ++z) {
-#pragma unroll
-            for (int m = 0; m < 2 * R; ++m) zq[m] = zq[m + 1];
-            const long long o = (long long)z * g.plane;
-            zq[2 * R] = (double)p[o + (long long)R * g.plane];
-            double xs[2 * R + 1], ys[2 * R + 1];
-#pragma unroll
-            for (int d = -R; d <= R; ++d) {
-                xs[d + R] = (d == 0) ? zq[R] : (double)p[o + d];
-                ys[d + R] = (d == 0) ? zq[R] : (double)p[o + (long long)d * g.pitch];
-            }
-            const double w = zq[R];
-            const double S = wafer_stencil_sum<double, R>(xs, ys, zq, w);
-            const double vv = (double)v[col + o];
-            se += vv * w * w - w * S / a.den; // grid.rs:325-332
-            sn += w * w;                      // grid.rs:407
-            if (a.potsub_kind == 2)
-                sv += w * w * (double)potsub[col + o]; // grid.rs:410-418
-            else if (a.potsub_kind == 1)
-                sv += w * w * a.potsub_scalar; // grid.rs:419-424
-            const int kg = g.z_begin + (z - g.G);
-            const double dz = (double)kg - ((double)g.nz + 1.) / 2.;
-            sr += w * w * (dx * dx + dy * dy + dz * dz); // grid.rs:428-437
-        }
-    }
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    double s;
-    s = wafer_block_sum<4>(se, red, tid);
-    if (tid == 0) partials[0 * a.nblocks + b] = s;
-    s = wafer_block_sum<4>(sn, red, tid);
-    if (tid == 0) partials[1 * a.nblocks + b] = s;
-    s = wafer_block_sum<4>(sv, red, tid);
-    if (tid == 0) partials[2 * a.nblocks + b] = s;
-    s = wafer_block_sum<4>(sr, red, tid);
-    if (tid == 0) partials[3 * a.nblocks + b] = s;
-}

@@ -16,9 +16,11 @@
 // buffers (the plane of level 1 and the one being staged), phi1 in a ring of three planes (level 2 reads the plane written two
 // iterations earlier).  One s_barrier per plane.
 //
-// a and b of a cell (potential.rs:104-110) are formed once, at level 1, and ride to level 2 as a and b * dt (grid.rs:606-621
-// uses b only through that product): two planes deep.  Requests are spread over the iteration and a wave's issue priority
-// falls as it advances (the three-step kernel's round-4 findings).  The first template argument is the storage tag of
+// a and b of a cell (potential.rs:104-110) are formed from V at both levels (V of planes z-2, z-1 waits in a two-plane queue):
+// carrying them as a and b * dt needs 32 more registers than the kernel has -- measured with the phi1 z-queue moved into a deeper
+// LDS ring to make room: 0.377 against 0.378 ms/step, the kernel is not bound by its instruction count
+// (profiles/r05_ab_fivepoint_carry.jsonl).  Requests are spread over the iteration and a wave's issue priority falls as it
+// advances (the three-step kernel's round-4 findings).  The first template argument is the storage tag of
 // wafer_storage.h: fp64, fp32 storage with fp64 arithmetic (float in HBM, everything in the CU double, each level rounded to
 // float), or all-fp32 (256 x 16 tiles).  Per-update arithmetic is the single-step kernel's: bit-identical to two single steps.
 #pragma once
@@ -30,17 +32,7 @@
 #include "wafer_stencil_fused2.hip.h"
 #include "wafer_storage.h"
 
-#ifndef WAFER_W2_PRIO
-#define WAFER_W2_PRIO 1
-#endif
-#ifndef WAFER_W2_CARRY   // 1: a and b * dt ride from level 1 to level 2 (32 more VGPRs); 0: level 2 forms them again from a two-plane V queue
-#define WAFER_W2_CARRY 0
-#endif
-#if WAFER_W2_PRIO
 #define WAFER_W2_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define WAFER_W2_SETPRIO(n) do { } while (0)
-#endif
 
 template <typename T>
 struct WaferW2Cfg {
@@ -64,7 +56,7 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
     WaferStepArgs a, int ntx, int nty, int swz, const typename WaferF3Store<TS>::S *__restrict__ phi,
     const typename WaferF3Store<TS>::S *__restrict__ pv, typename WaferF3Store<TS>::S *__restrict__ out)
 {
-    using T = typename WaferF3Store<TS>::Q;    // z-queues, LDS, carried a / b * dt
+    using T = typename WaferF3Store<TS>::Q;    // z-queues and LDS
     using ST = typename WaferF3Store<TS>::S;   // the arrays in HBM
     using Cfg = WaferW2Cfg<T>;
     using VT = typename WaferVec<T>::type;
@@ -156,13 +148,11 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
         cbdt = cb * dt;
         return as_stored(w * ca + wafer_div_invariant<C>(cbdt * S, den));
     };
-    auto update_with = [&](C w, C ca, C cbdt, C S) -> T { return as_stored(w * ca + wafer_div_invariant<C>(cbdt * S, den)); };
 
-    // ---- state.  Main rows: phi0 planes z-2 .. z+2, phi1 planes z-4 .. z-1, V of plane z, a / b * dt of planes z-2, z-1.
+    // ---- state.  Main rows: phi0 planes z-2 .. z+2, phi1 planes z-4 .. z-1, V of planes z-2 .. z.
     //      Extra slot (component 0 only for a halo-column cell): phi0 planes z-2 .. z+2, V of plane z, the outer row of plane z+1.
     const int z1 = zs - R;   // the first phi1 plane
-    constexpr bool CARRY = WAFER_W2_CARRY != 0;
-    VT q0[2 * R + 1][RY], q1[2 * R][RY], vcur[RY], caq[R][RY], cbq[R][RY];   // (!CARRY: caq is the V queue of planes z-2, z-1; cbq unused)
+    VT q0[2 * R + 1][RY], q1[2 * R][RY], vcur[RY], vq[R][RY];
     VT xq0[2 * R + 1], xv, orow_nxt = zero;
 #pragma unroll
     for (int m = 0; m <= 2 * R; ++m) {
@@ -182,7 +172,7 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
 #pragma unroll
     for (int m = 0; m < R; ++m)
 #pragma unroll
-        for (int r = 0; r < RY; ++r) caq[m][r] = cbq[m][r] = zero;
+        for (int r = 0; r < RY; ++r) vq[m][r] = zero;
     {
         const long long po = (long long)z1 * g.plane;
 #pragma unroll
@@ -273,9 +263,9 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
         };
         // ---- 3. level 1, main rows.  INTERIOR: the plane, both rows and the tile's columns are work cells: no tests inside, the
         //         RY x VEC updates form one basic block
-        VT p1new[RY], canew[RY], cbnew[RY];
+        VT p1new[RY];
 #pragma unroll
-        for (int r = 0; r < RY; ++r) p1new[r] = canew[r] = cbnew[r] = zero;
+        for (int r = 0; r < RY; ++r) p1new[r] = zero;
         bool all_rows = x0 + TX <= g.nx;
 #pragma unroll
         for (int r = 0; r < RY; ++r) all_rows = all_rows && rowwk[r];
@@ -296,10 +286,6 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
                         const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
                         C ka, kb;
                         const T rs = update_keep(w, (C)vcur[r][v], S, ka, kb);
-                        if constexpr (CARRY) {
-                            canew[r][v] = (T)ka;
-                            cbnew[r][v] = (T)kb;
-                        }
                         res[v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
                     }
                 }
@@ -366,8 +352,8 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
         xpre = gload_raw(phi + zo + (long long)(R + 1) * g.plane + xslot_off);
         xpre_v = gload_raw(pv + zo + g.plane + xslot_off);
         orow_pre = gload_raw(phi + zo + 2 * g.plane + oslot_off);
-        // ---- 4. level 2: phi2 of plane z-2 from the phi1 queue (planes z-4 .. z-1 and the plane just made), a and b * dt as
-        //         level 1 formed them two iterations ago; stored
+        // ---- 4. level 2: phi2 of plane z-2 from the phi1 queue (planes z-4 .. z-1 and the plane just made), a and b from V of
+        //         that plane; stored
         if (do2) {
             auto level2 = [&](auto interior_tag) {
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
@@ -386,11 +372,8 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
                             xs[R] = ys[R] = w;
                             gather(std::integral_constant<int, 1>{}, q1[R], r, v, xs, ys);
                             const C S = wafer_stencil_sum<C, R>(xs, ys, zz, w);
-                            if constexpr (CARRY) res2[r][v] = update_with(w, (C)caq[0][r][v], (C)cbq[0][r][v], S);
-                            else {
-                                C ka, kb;
-                                res2[r][v] = update_keep(w, (C)caq[0][r][v], S, ka, kb);
-                            }
+                            C ka, kb;
+                            res2[r][v] = update_keep(w, (C)vq[0][r][v], S, ka, kb);
                         }
                     }
                 }
@@ -435,12 +418,8 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
             for (int m = 0; m + 1 < 2 * R; ++m) q1[m][r] = q1[m + 1][r];
             q1[2 * R - 1][r] = p1new[r];
 #pragma unroll
-            for (int m = 0; m + 1 < R; ++m) {
-                caq[m][r] = caq[m + 1][r];
-                cbq[m][r] = cbq[m + 1][r];
-            }
-            caq[R - 1][r] = CARRY ? canew[r] : vcur[r];   // (before vcur takes the next plane's V)
-            cbq[R - 1][r] = cbnew[r];
+            for (int m = 0; m + 1 < R; ++m) vq[m][r] = vq[m + 1][r];
+            vq[R - 1][r] = vcur[r];
             vcur[r] = widen(pre_v[r]);
         }
 #pragma unroll

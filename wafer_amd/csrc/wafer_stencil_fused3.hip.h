@@ -47,18 +47,19 @@
 #include "wafer_stencil_fused2.hip.h"
 #include "wafer_storage.h"
 
-// Cells per lane.  -DWAFER_F3_VEC1: one fp64 cell per lane (a 64 x 16 tile, half the registers and half the LDS per workgroup:
-// two workgroups per CU) -- an experiment, see profiles/NOTES.md.
-#ifdef WAFER_F3_VEC1
-template <typename T> struct WaferF3Vec : WaferVec<T> {};
-template <> struct WaferF3Vec<double> { static constexpr int N = 1; typedef double __attribute__((ext_vector_type(1))) type; };
-#else
-template <typename T> struct WaferF3Vec : WaferVec<T> {};
+template <typename T> struct WaferF3Vec : WaferVec<T> {};   // cells per lane: 16 bytes of x
+// Diagnostic builds (never timed as the product, never shipped): -DWAFER_DIAG=<bits>
+//   1  in-kernel stamps (cdna_hip_programming.md, "In-kernel stamps"): one workgroup adds up, per wave, the shader-clock cycles
+//      between fixed points of the plane iteration and leaves the sums in a buffer of their own (wafer_debug_f3_stamps reads it;
+//      tools/f3_stamps.py prints the shares)
+//   2  every prefetch asks for the column's first planes again (cache hits)      4  nothing is stored      8  no barrier in the plane loop
+// What was built with further switches, measured and rejected in rounds 3 and 4 (x neighbours by DPP wave shifts, one cell per lane with
+// two workgroups per CU, ring queues marching down / in the peer instantiation, other request placements, no issue priorities) is in
+// git history and profiles/NOTES.md, not here.
+#ifndef WAFER_DIAG
+#define WAFER_DIAG 0
 #endif
-// -DWAFER_F3_STAMP: a diagnostic build (cdna_hip_programming.md, "In-kernel stamps") -- one workgroup adds up, per wave, the
-// shader-clock cycles between fixed points of the plane iteration and leaves the sums in a buffer of their own
-// (wafer_debug_f3_stamps reads it; tools/f3_stamps.py prints the shares).  Never timed, never shipped.
-#ifdef WAFER_F3_STAMP
+#if WAFER_DIAG & 1
 enum { WAFER_F3_NSTAMP = 8 };
 __device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
 #define WAFER_F3_STAMP_AT(k)                                                                        \
@@ -73,60 +74,12 @@ __device__ unsigned long long wafer_f3_stamp_buf[8 * WAFER_F3_NSTAMP];
 #else
 #define WAFER_F3_STAMP_AT(k) do { } while (0)
 #endif
-// where in the plane iteration a wave issues its requests (see issue_group): 0 = at the top, 1 = behind level 1 of the main rows,
-// 2 = behind level 1 of the extra slot, 3 = behind level 2, 4 = behind level 3.  A: phi0 of the main rows, B: their V, C: the extra slot.
 // A wave's issue priority falls as it advances through the plane iteration (s_setprio 3 at the top, 2 behind level 1 of the main
 // rows, 1 behind level 1 of the extra slot, 0 behind level 2): of the two waves that share a vector pipe the one that is BEHIND
 // gets it.  Left to the hardware's oldest-first arbitration the first wave of each SIMD ran ahead and then waited a quarter of
 // the iteration at the barrier while the second finished alone (tools/f3_stamps.py): -3 % (profiles/r04_ab_f3_priority.jsonl;
-// flatter schedules gain less, the reverse order loses).  -DWAFER_F3_PRIO=0: off.
-#ifndef WAFER_F3_PRIO
-#define WAFER_F3_PRIO 1
-#endif
-#ifndef WAFER_F3_PRIO_P0
-#define WAFER_F3_PRIO_P0 3
-#define WAFER_F3_PRIO_P1 2
-#define WAFER_F3_PRIO_P2 1
-#define WAFER_F3_PRIO_P3 0
-#endif
-#if WAFER_F3_PRIO
+// flatter schedules gain less, the reverse order loses).
 #define WAFER_F3_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define WAFER_F3_SETPRIO(n) do { } while (0)
-#endif
-#ifndef WAFER_F3_RING
-#define WAFER_F3_RING 1
-#endif
-#if defined(WAFER_F3_DPP) && WAFER_F3_RING
-#error "the DPP experiment reads the z-queues by their shifting indices: build it with -DWAFER_F3_RING=0"
-#endif
-#ifndef WAFER_F3_RING_PEER_MID   // ring queues in the middle segment of a peer-store pass
-#define WAFER_F3_RING_PEER_MID 1
-#endif
-#ifndef WAFER_F3_RING_DOWN   // ring queues in the copy of the loop that marches down as well
-#define WAFER_F3_RING_DOWN 0
-#endif
-#ifndef WAFER_F3_RING_PEER   // the peer-store instantiation on ring queues as well
-#define WAFER_F3_RING_PEER 0
-#endif
-#ifndef WAFER_F3_XS_PEER     // the peer-store instantiation with exact store counts
-#define WAFER_F3_XS_PEER 1
-#endif
-#ifndef WAFER_F3_XS_MODE1    // overlap mode 2's single-launch pass segmented the same way (tail: the generic body)
-#define WAFER_F3_XS_MODE1 1
-#endif
-#ifndef WAFER_F3_PEER_SPLIT  // ... and its middle iterations on the plain kernel's body (wafer_step3_body)
-#define WAFER_F3_PEER_SPLIT 1
-#endif
-#ifndef WAFER_F3_POS_A
-#define WAFER_F3_POS_A 0
-#endif
-#ifndef WAFER_F3_POS_B
-#define WAFER_F3_POS_B 1
-#endif
-#ifndef WAFER_F3_POS_C
-#define WAFER_F3_POS_C 2
-#endif
 template <typename T>
 struct WaferF3Cfg {
     static constexpr int VEC = WaferF3Vec<T>::N;
@@ -451,13 +404,13 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         asm volatile("" : "+v"(flag_early));
     }
     const int niter = (ze - zs) + 4;
-#ifdef WAFER_F3_STAMP
+#if WAFER_DIAG & 1
     unsigned long long stamp_sum[WAFER_F3_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
 #define WAFER_F3_Q0(m) (RING ? ((m) + WAFER_F3_PH) % 3 : (m))
 #define WAFER_F3_Q1(m) (RING ? ((m) + WAFER_F3_PH + 1) % 3 : (m))
-    if constexpr (SYNC && XS && WAFER_F3_PEER_SPLIT != 0) {
+    if constexpr (SYNC && XS) {
         // Peer-store passes, three segments.  The peer stores, the early count and the late wait all lie within the first
         // seven and the last five iterations of a column; everything between runs the body of the PLAIN kernel -- no peer path,
         // no wait, ring queues (a multiple of three iterations, so that the queues enter and leave it in their natural order)
@@ -481,7 +434,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
         }
         if (mid_len > 0) {
             // (shadow the function's: the included text reads these names; ring queues marching up only, see the kernel)
-            constexpr bool PEER = false, SYNC = false, RING = WAFER_F3_RING_PEER_MID != 0 && (!DOWN || WAFER_F3_RING_DOWN != 0);
+            constexpr bool PEER = false, SYNC = false, RING = !DOWN;
             const int IT_BEGIN = head_end, IT_END = head_end + mid_len;
             if constexpr (RING) {
                 for (int it0 = IT_BEGIN; it0 < IT_END; it0 += 3) {
@@ -560,7 +513,7 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     }
 #undef WAFER_F3_Q0
 #undef WAFER_F3_Q1
-#ifdef WAFER_F3_STAMP
+#if WAFER_DIAG & 1
     if (blockIdx.x == gridDim.x / 2 + 3 && lane == 0) {
 #pragma unroll
         for (int k = 0; k < WAFER_F3_NSTAMP; ++k) wafer_f3_stamp_buf[wave * WAFER_F3_NSTAMP + k] = stamp_sum[k];
@@ -584,15 +537,10 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     }
 }
 
-#if defined(WAFER_F3_VEC1) && defined(WAFER_F3_VEC1_OCC2)
-#define WAFER_F3_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
-#else
-#define WAFER_F3_OCC
-#endif
 // DIR: 0 = the table holds workgroups of both marching directions, 1 = all up, 2 = all down.  A kernel that carries one copy of the
 // plane loop instead of two gets the better register allocation (the peer instantiation: 88 B of scratch with both, none with one).
 template <typename T, typename C, bool VIR, int MODE = 0, bool XS = false, int DIR = 0>
-__global__ __launch_bounds__((WaferF3Cfg<typename WaferF3Store<T>::Q>::NT_)) WAFER_F3_OCC void wafer_k_step3_fused(WaferStepArgs a, int ntx, const WaferF3Block *__restrict__ table,
+__global__ __launch_bounds__((WaferF3Cfg<typename WaferF3Store<T>::Q>::NT_)) void wafer_k_step3_fused(WaferStepArgs a, int ntx, const WaferF3Block *__restrict__ table,
                                                                               WaferF3Sync sy, const typename WaferF3Store<T>::S *__restrict__ phi,
                                                                               const typename WaferF3Store<T>::S *__restrict__ pv, typename WaferF3Store<T>::S *__restrict__ out)
 {
@@ -603,13 +551,14 @@ __global__ __launch_bounds__((WaferF3Cfg<typename WaferF3Store<T>::Q>::NT_)) WAF
     __shared__ __attribute__((aligned(16))) Q lds2[2 * Cfg::TILE2];
     const WaferF3Block blk = table[blockIdx.x];
     // (ring queues where the kernel has the registers for the unrolled loop: the plain instantiation with exact store counts)
-    constexpr bool RING = XS && WAFER_F3_RING != 0 && (MODE == 0 || WAFER_F3_RING_PEER != 0);
+    constexpr bool RING = XS && MODE == 0;
     // (marching down keeps the shifting queues: in that copy of the loop the ring version needs 36 B of scratch, and every reload
     //  from scratch is a vector-memory operation whose wait, vmcnt(0), also waits for every prefetch in flight -- 0.319 against
-    //  0.220 ms/step at 512^3; marching up the ring version has no scratch operation inside the loop)
+    //  0.220 ms/step at 512^3; marching up the ring version has no scratch operation inside the loop.  The synchronising
+    //  instantiations take ring queues in the middle segment of their passes only: wafer_step3_body)
     if constexpr (DIR == 1) wafer_step3_body<T, C, VIR, false, MODE, XS, RING>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
-    else if constexpr (DIR == 2) wafer_step3_body<T, C, VIR, true, MODE, XS, RING && WAFER_F3_RING_DOWN != 0>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
-    else if (blk.down & 1) wafer_step3_body<T, C, VIR, true, MODE, XS, RING && WAFER_F3_RING_DOWN != 0>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    else if constexpr (DIR == 2) wafer_step3_body<T, C, VIR, true, MODE, XS, false>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
+    else if (blk.down & 1) wafer_step3_body<T, C, VIR, true, MODE, XS, false>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
     else wafer_step3_body<T, C, VIR, false, MODE, XS, RING>(a, blk, ntx, sy, phi, pv, out, lds0, lds1, lds2);
 }
 
@@ -792,7 +741,7 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     // the synchronisation a launch needs picks the instantiation (see wafer_step3_body): none, mode 2's flags and counters, peer stores
     const int mode = sy.peer ? 2 : (sy.flag != nullptr ? 1 : 0);
     // exact store counts (XS): plain launches over grids made of whole tiles (every store a full vector of work cells)
-    const bool xs = t.f3_xs != 0 && (mode != 1 || WAFER_F3_XS_MODE1 != 0) && a.g.nx % Cfg::TX == 0 && a.g.ny % Cfg::TY == 0;
+    const bool xs = t.f3_xs != 0 && a.g.nx % Cfg::TX == 0 && a.g.ny % Cfg::TY == 0;
 #define WAFER_F3_LAUNCH3(VIR_, MODE_, XS_, DIR_)                                                                                                  \
     do {                                                                                                                                          \
         hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_, DIR_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out); \
@@ -807,16 +756,16 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
         else WAFER_F3_LAUNCH3(VIR_, MODE_, XS_, 0);                                    \
     } while (0)
     if (a.v_in_range != 0) {
-        if (mode == 2 && xs && WAFER_F3_XS_PEER) WAFER_F3_LAUNCH(true, 2, true);
+        if (mode == 2 && xs) WAFER_F3_LAUNCH(true, 2, true);
         else if (mode == 2) WAFER_F3_LAUNCH(true, 2, false);
-        else if (mode == 1 && xs) WAFER_F3_LAUNCH(true, 1, (WAFER_F3_XS_MODE1 != 0));
+        else if (mode == 1 && xs) WAFER_F3_LAUNCH(true, 1, true);
         else if (mode == 1) WAFER_F3_LAUNCH(true, 1, false);
         else if (xs) WAFER_F3_LAUNCH(true, 0, true);
         else WAFER_F3_LAUNCH(true, 0, false);
     } else {
-        if (mode == 2 && xs && WAFER_F3_XS_PEER) WAFER_F3_LAUNCH(false, 2, true);
+        if (mode == 2 && xs) WAFER_F3_LAUNCH(false, 2, true);
         else if (mode == 2) WAFER_F3_LAUNCH(false, 2, false);
-        else if (mode == 1 && xs) WAFER_F3_LAUNCH(false, 1, (WAFER_F3_XS_MODE1 != 0));
+        else if (mode == 1 && xs) WAFER_F3_LAUNCH(false, 1, true);
         else if (mode == 1) WAFER_F3_LAUNCH(false, 1, false);
         else if (xs) WAFER_F3_LAUNCH(false, 0, true);
         else WAFER_F3_LAUNCH(false, 0, false);

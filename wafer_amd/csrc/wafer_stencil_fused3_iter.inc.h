@@ -6,7 +6,7 @@
 // instructions) disappear.  phi1 / phi2 queues advance in mid-iteration (before the level that reads them): WAFER_F3_Q1.
         const int z = z1 + SD * it;
         const bool more = it + 1 < niter;
-#ifdef WAFER_F3_ABL_NOLOAD   // timing experiment: every prefetch asks for the column's first planes again (cache hits)
+#if WAFER_DIAG & 2   // timing experiment: every prefetch asks for the column's first planes again (cache hits)
         const long long zo = (long long)(z1 + (it & 1)) * g.plane;
 #else
         const long long zo = (long long)z * g.plane;
@@ -23,7 +23,6 @@
         // (fp32 storage: what arrives is float and is widened where the queues rotate, behind the barrier -- a request cannot
         //  write the slot itself)
         constexpr bool DIRECT = RING && !WIDE;
-        static_assert(!DIRECT || (WAFER_F3_POS_B >= 1 && WAFER_F3_POS_B != 5 && WAFER_F3_POS_C >= 2 && WAFER_F3_POS_C != 5), "requests behind the last reads");
         SVT szero;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) szero[v] = ST(0);
@@ -35,32 +34,32 @@
         // stamps (tools/f3_stamps.py) showed a sixth of the iteration going there.  Spread over the iteration (the main rows' phi0
         // at the top, their V behind level 1, the extra slot's three behind level 2) they overlap the other waves' arithmetic:
         // 0.249 -> 0.236 ms/step at 512^3, and the later requests hold their registers for a shorter time (244 -> 230 VGPRs).
-        auto issue_group = [&](int pos) {
-            if (pos == WAFER_F3_POS_A) {
+        // A: phi0 of the main rows, at the top; B: their V, behind level 1 of the main rows; C: the extra slot's three, behind level 1
+        // of the extra slot (where the placements were measured: profiles/r04_ab_f3_request_placement.jsonl)
+        auto issue_A = [&]() {
 #pragma unroll
-                for (int r = 0; r < RY; ++r) pre[r] = gload_raw((phi + zo + SD * 2 * g.plane + rowoff[r]) + xlu);
-            }
-            if (pos == WAFER_F3_POS_B) {
+            for (int r = 0; r < RY; ++r) pre[r] = gload_raw((phi + zo + SD * 2 * g.plane + rowoff[r]) + xlu);
+        };
+        auto issue_B = [&]() {
 #pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    if constexpr (DIRECT) vcur[r] = gload((pv + zo + SD * g.plane + rowoff[r]) + xlu);
-                    else pre_v[r] = gload_raw((pv + zo + SD * g.plane + rowoff[r]) + xlu);
-                }
-            }
-            if (pos == WAFER_F3_POS_C) {
-                if constexpr (DIRECT) {
-                    xq0[WAFER_F3_Q0(0)] = gload(phi + zo + SD * 2 * g.plane + xslot_off);
-                    xv = gload(pv + zo + SD * g.plane + xslot_off);
-                    orow_nxt = gload(phi + zo + SD * 2 * g.plane + orow_slot_off);
-                } else {
-                    xpre = gload_raw(phi + zo + SD * 2 * g.plane + xslot_off);
-                    xpre_v = gload_raw(pv + zo + SD * g.plane + xslot_off);
-                    orow_pre = gload_raw(phi + zo + SD * 2 * g.plane + orow_slot_off);
-                }
+            for (int r = 0; r < RY; ++r) {
+                if constexpr (DIRECT) vcur[r] = gload((pv + zo + SD * g.plane + rowoff[r]) + xlu);
+                else pre_v[r] = gload_raw((pv + zo + SD * g.plane + rowoff[r]) + xlu);
             }
         };
-        WAFER_F3_SETPRIO(WAFER_F3_PRIO_P0);
-        issue_group(0);
+        auto issue_C = [&]() {
+            if constexpr (DIRECT) {
+                xq0[WAFER_F3_Q0(0)] = gload(phi + zo + SD * 2 * g.plane + xslot_off);
+                xv = gload(pv + zo + SD * g.plane + xslot_off);
+                orow_nxt = gload(phi + zo + SD * 2 * g.plane + orow_slot_off);
+            } else {
+                xpre = gload_raw(phi + zo + SD * 2 * g.plane + xslot_off);
+                xpre_v = gload_raw(pv + zo + SD * g.plane + xslot_off);
+                orow_pre = gload_raw(phi + zo + SD * 2 * g.plane + orow_slot_off);
+            }
+        };
+        WAFER_F3_SETPRIO(3);
+        issue_A();
         // The extra slot's requests are the SAME three instructions in every wave, the address chosen per lane (a halo row's
         // 16 bytes, or the 16 bytes that start at the lane's halo-column cell: component 0 is the cell; a wave without an outer
         // row asks for its slot's line again).  As two branches with loads of their own -- row waves / column waves -- the
@@ -116,25 +115,14 @@
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
                 const int o = (yrow[r] - yb) * lp + hx + xl;
-#ifdef WAFER_F3_DPP
-                // the x neighbours of the lane's first / last cell are the last / first cell of the lane next door, which holds
-                // them in registers: a DPP wave shift instead of an LDS read; only lanes 0 and 63 take the halo column from
-                // LDS (one read per row: each of the two reads its own side)
-                const VT ctr = L == 0 ? q0[1][r] : L == 1 ? q1[2][r] : q2[2][r];   // (levels 2, 3: the queues rotate after this)
-                const T edge = cc[o + (lane == 63 ? VEC : -1)];
-                nbl[L][r] = wafer_lane_below(ctr[VEC - 1], edge);
-                nbr[L][r] = wafer_lane_above(ctr[0], edge);
-#else
                 nbl[L][r] = cc[o - 1];
                 nbr[L][r] = cc[o + VEC];
-#endif
             }
             nbu[L] = *reinterpret_cast<const VT *>(cc + (yrow[0] - yb - 1) * lp + hx + xl);
             nbd[L] = *reinterpret_cast<const VT *>(cc + (yrow[RY - 1] - yb + 1) * lp + hx + xl);
         };
         nbload(std::integral_constant<int, 0>{});
         nbload(std::integral_constant<int, 1>{});
-        issue_group(5);
         // ---- 3. level 1, main rows.  INTERIOR: the plane and both rows are work cells, the tile's columns too: no tests
         //         inside, the RY x VEC updates form one basic block
         auto level1 = [&](auto interior_tag) {
@@ -167,9 +155,9 @@
         };
         if (all_rows && wplane1) level1(std::true_type{});
         else level1(std::false_type{});
-        WAFER_F3_SETPRIO(WAFER_F3_PRIO_P1);
+        WAFER_F3_SETPRIO(2);
         WAFER_F3_STAMP_AT(1);   // level 1, main rows (with the neighbours' LDS round trip)
-        issue_group(1);
+        issue_B();
         nbload(std::integral_constant<int, 2>{});
         // ---- 3x. level 1, the extra slot
         if (x_row) {
@@ -214,8 +202,8 @@
             w1[c_lds1] = rs;
             xp1[0] = rs;
         }
-        WAFER_F3_SETPRIO(WAFER_F3_PRIO_P2);
-        issue_group(2);
+        WAFER_F3_SETPRIO(1);
+        issue_C();
         WAFER_F3_STAMP_AT(2);   // level 1, the extra slot
         // ---- 4. level 2: phi2 of the plane behind, from the phi1 queues; a, b as level 1 formed them one iteration ago
 #pragma unroll
@@ -302,9 +290,8 @@
                 w2[c_lds2] = rs;
             }
         }
-        WAFER_F3_SETPRIO(WAFER_F3_PRIO_P3);
+        WAFER_F3_SETPRIO(0);
         WAFER_F3_STAMP_AT(3);   // level 2 (main rows and the extra slot)
-        issue_group(3);
         // ---- 5. level 3: phi3 two planes behind from the phi2 queue, a, b as formed two iterations ago; stored
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
@@ -354,7 +341,7 @@
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     if (INTERIOR || rowwk[r]) {
-#ifdef WAFER_F3_ABL_NOSTORE  // timing experiment: nothing is stored (the compiler cannot know)
+#if WAFER_DIAG & 4   // timing experiment: nothing is stored (the compiler cannot know)
                         if (a.dt > -1.0) continue;
 #endif
                         const int zst = !XS ? zo3 : DOWN ? (zo3 < ze - 1 ? zo3 : ze - 1) : (zo3 > zs ? zo3 : zs);
@@ -396,14 +383,13 @@
             else if (all_rows) level3(std::true_type{});
             else level3(std::false_type{});
         }
-        issue_group(4);
         WAFER_F3_STAMP_AT(4);   // level 3 and its stores
         // whole-column peer passes: the first wt planes are out after iteration wt + 3 -- acknowledged here, counted behind the barrier
         const bool early_done = PEER && bump_early >= 0 && it == blk.wt + 3;
         if constexpr (PEER) {
             if (early_done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#ifdef WAFER_F3_ABL_NOBAR      // timing experiment: no workgroup barrier in the plane loop (LDS contents race)
+#if WAFER_DIAG & 8   // timing experiment: no workgroup barrier in the plane loop (LDS contents race)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
         __syncthreads();
@@ -468,7 +454,7 @@
         xca = xcanew;
         xcb = xcbnew;
         if constexpr (!DIRECT) orow_nxt = widen(orow_pre);
-#ifdef WAFER_F3_STAMP
+#if WAFER_DIAG & 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (what is left of the requests' latency, made visible)
 #endif
         WAFER_F3_STAMP_AT(6);   // the wait for the prefetched planes, the queue rotation

@@ -160,8 +160,7 @@ __device__ __forceinline__ double wafer_vgen_at(const WaferPotArgs &a, int ix, i
 // NLOW = -2: compute_observables (grid.rs:303-445) on the same pipeline -- `pa` is V, nothing is
 // written, and the four work-area sums (energy integrand V w^2 - w S / den, w^2, w^2 pot_sub,
 // w^2 r^2 with the WORK-area index, grid.rs:429-435) go to partials[q * pstride + workgroup];
-// an array pot_sub rides in low.p[0].  16 B per lane from HBM instead of the scalar loads of
-// wafer_k_observables (kept as the plain reference kernel: WAFER_OBS_LDS=0).
+// an array pot_sub rides in low.p[0].  16 B per lane from HBM (round 1's scalar-load kernel is gone).
 // VG != 0 (fp64, with ABV): V is not streamed at all.  The potential is one of the closed forms of
 // potential.rs:188-274 (VG = its wafer_potential number: Coulomb, SimpleCornell, Harmonic) and every
 // lane evaluates wafer_potential_at -- the function that filled the stored array, so the same bits --
@@ -798,9 +797,7 @@ static inline hipError_t wafer_launch_observables_lds(const WaferTuning &t, Wafe
     using Cfg = WaferLdsCfg<T, R, 2, NW>;
     WaferLowPtrs low;
     low.p[0] = potsub;
-    { // two workgroups per CU (110 VGPRs at 512 threads): 0.51 -> 0.37 ms at 512^3 incl. the host sync; WAFER_OBS_WGS=1: one
-        if (NW == 8 && t.obs_wgs == 1) a.target_blocks = (a.target_blocks + 1) / 2;
-    }
+    // (two workgroups per CU -- 110 VGPRs at 512 threads: 0.51 -> 0.37 ms at 512^3 incl. the host sync)
     const int zc = wafer_lds_zchunk<T, R>(t, a.g, a.lz_hi - a.lz_lo, 2 * (NW / 4), a.target_blocks);
     *nblocks_out = (long long)((a.g.nx + Cfg::TX - 1) / Cfg::TX) * ((a.g.ny + Cfg::TY - 1) / Cfg::TY) * ((a.lz_hi - a.lz_lo + zc - 1) / zc);
     // (the closed-form V of the step kernels, template parameter VG, was measured here too: with two workgroups

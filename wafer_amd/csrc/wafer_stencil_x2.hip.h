@@ -64,28 +64,11 @@ static inline int wafer_x2_nsums(int k) { return 1 + 2 * k; }
 // rows, 2 = behind level 1 of the extra slot, 3 = behind level 2.  A: the main rows' input (and V), L: their stored states, M: the images
 // M_j, X: the extra slot's.  Measured per tile (profiles/r04_ab_x2_request_placement.jsonl): on the 128 x 16 tile M and X move back
 // (0.665 -> 0.63 ms/step at k = 2); on the 128 x 8 tile only the extra slot's requests do (0.964 -> 0.87 at k = 3).
-#ifndef WAFER_X2_PRIO   // falling issue priority through the iteration (as the three-step kernel): measured +-0.5 % here, off
-#define WAFER_X2_PRIO 0
-#endif
-#if WAFER_X2_PRIO
-#define WAFER_X2_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define WAFER_X2_SETPRIO(n) do { } while (0)
-#endif
-#ifndef WAFER_X2_RING
-#define WAFER_X2_RING 1
-#endif
-#ifndef WAFER_X2_POS_A
-#define WAFER_X2_POS_A 0
-#endif
-#ifndef WAFER_X2_POS_L
-#define WAFER_X2_POS_L 0
-#endif
-#ifndef WAFER_X2_POS_M
-#define WAFER_X2_POS_M (RY == 2 ? 2 : 0)
-#endif
-#ifndef WAFER_X2_POS_X
-#define WAFER_X2_POS_X 3
+// (positions as constants of the kernel: wafer_stencil_x2_iter.inc.h.  Falling issue priorities through the iteration, the three-step
+//  kernel's -3 %, measured +-0.5 % here and are not used; ring z-queues are: -2 %.  Diagnostic builds: -DWAFER_DIAG=<bits>, 2 = every
+//  prefetch asks for the column's first planes again, 4 = nothing is stored -- see wafer_stencil_fused3.hip.h.)
+#ifndef WAFER_DIAG
+#define WAFER_DIAG 0
 #endif
 template <int RY_>
 struct WaferX2Cfg {
@@ -153,7 +136,7 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     // in registers (HOLD).  Only the l_j wait: the M_j are used by the transform alone (see the head of this file).
     constexpr bool HOLD = (RY == 2 && NL == 2);
     // ring z-queues (the plane loop unrolled by three, no shifts): the kernels with exact store counts, as in the three-step kernel
-    constexpr bool RING = XS && WAFER_X2_RING != 0;
+    constexpr bool RING = XS;
     constexpr int NSLOT = HOLD ? 2 : 3;
     __shared__ __attribute__((aligned(16))) T ldsq[NSLOT * NL * QS];   // [slot][state][row][x]
     __shared__ double red[Cfg::NW];

@@ -3,7 +3,7 @@
 // `it` is the iteration; everything else is the enclosing kernel's.  The Y1 queue advances in mid-iteration: WAFER_X2_Q1.
         const int z = z1 + it;
         const bool more = it + 1 < niter;
-#ifdef WAFER_X2_ABL_NOLOAD    // timing experiment: every prefetch asks for the column's first planes again (cache hits)
+#if WAFER_DIAG & 2    // timing experiment: every prefetch asks for the column's first planes again (cache hits)
         const long long zo = (long long)(z1 + (it & 1)) * g.plane;
 #else
         const long long zo = (long long)z * g.plane;
@@ -20,28 +20,30 @@
         for (int j = 0; j < NL; ++j) xpre_l[j] = xpre_m[j] = zero;
         // The requests of a wave are spread over the iteration (as in the three-step kernel: all eight waves leave the barrier at
         // once, and (2 + 4k) x 8 requests of 1 KiB queueing at the CU's one address unit kept every wave from its arithmetic):
-        // which group goes where is measured per tile shape (WAFER_X2_POS_*).
+        // which group goes where was measured per tile shape (profiles/r04_ab_x2_request_placement.jsonl): A (the main rows' input and V)
+        // and L (their stored states) at the top, M (the images M_j) behind level 1 of the extra slot on the tall tile and at the top on the
+        // low one, X (the extra slot's) behind level 2.
         auto issue_group = [&](int pos) {
-            if (pos == WAFER_X2_POS_A) {
+            if (pos == 0) {   // A
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     pre[r] = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + rowoff[r]) + xlu);
                     if constexpr (VG == 0) pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + g.plane + rowoff[r]) + xlu);
                 }
             }
-            if (pos == WAFER_X2_POS_L) {
+            if (pos == 0) {   // L
 #pragma unroll
                 for (int r = 0; r < RY; ++r)
 #pragma unroll
                     for (int j = 0; j < NL; ++j) pre_l[j][r] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
             }
-            if (pos == WAFER_X2_POS_M) {
+            if (pos == (RY == 2 ? 2 : 0)) {   // M
 #pragma unroll
                 for (int r = 0; r < RY; ++r)
 #pragma unroll
                     for (int j = 0; j < NL; ++j) pre_m[j][r] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
             }
-            if (pos == WAFER_X2_POS_X) {
+            if (pos == 3) {   // X
                 if (x_row) {
                     xpre = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + xoff_row) + xlu);
 #pragma unroll
@@ -63,7 +65,6 @@
                 }
             }
         };
-        WAFER_X2_SETPRIO(3);   // (falling priority through the iteration: wafer_stencil_fused3.hip.h, WAFER_F3_PRIO)
         issue_group(0);
         // ---- 2. stage the next x0 plane into the other buffer
         if (more) {
@@ -137,7 +138,6 @@
         };
         if (all_rows && wplane1) level1(std::true_type{});
         else level1(std::false_type{});
-        WAFER_X2_SETPRIO(2);
         issue_group(1);
         // level 2's neighbours and the stored states of the plane it is about to produce (the lane's own LDS queue), requested
         // behind level 1's arithmetic
@@ -192,7 +192,6 @@
             xp1[0] = rs;
         }
         (void)xp1;
-        WAFER_X2_SETPRIO(1);
         issue_group(2);
         // ---- 4. level 2: Z of the plane behind from the Y1 queue, a, b as level 1 formed them one iteration ago; the sums
 #pragma unroll
@@ -248,7 +247,7 @@
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     if (INTERIOR || rowwk[r]) {
-#ifdef WAFER_X2_ABL_NOSTORE   // timing experiment: nothing is stored (the compiler cannot know)
+#if WAFER_DIAG & 4   // timing experiment: nothing is stored (the compiler cannot know)
                         if (a.dt > -1.0) continue;
 #endif
                         T *dst = (out + (long long)(XS && zp2 < zs ? zs : zp2) * g.plane + rowoff[r]) + xlu;
@@ -266,7 +265,6 @@
             else if (all_rows && wplane2) level2(std::true_type{});
             else level2(std::false_type{});
         }
-        WAFER_X2_SETPRIO(0);
         issue_group(3);
         // HOLD: the plane transformed last iteration (z + 1) takes the queue slot just read (same lanes: program order suffices)
         if constexpr (HOLD) {

@@ -38,7 +38,7 @@ void wafer_step3_last_instance(char *buf, size_t n)
              li.vir ? "true" : "false", li.mode, li.xs ? "true" : "false", li.dir);
 }
 
-#ifdef WAFER_F3_STAMP
+#if WAFER_DIAG & 1
 // diagnostic builds only: the per-wave cycle sums of the last launch's stamped workgroup
 extern "C" int wafer_debug_f3_stamps(unsigned long long *host_out)
 {

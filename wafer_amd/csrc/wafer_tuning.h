@@ -28,24 +28,18 @@ struct WaferTuning {
     int x2_max_k = 0;       // WAFER_X2_MAX_K: most stored states the two-step kernel takes (1 .. 3); 0 = by plane size: 3 up to 300 000 cells per plane, else 2 (wafer_engine.hip, x2_applies)
                             // (k = 3 runs on 128 x 8 tiles: -4 % per step at 512 x 512 planes, +3 ... +5 % at 1024 x 1024, profiles/r04_x2_shapes.log)
     int x2_ry = 0;          // WAFER_X2_RY: rows per lane of that kernel (1: 128 x 8 tiles, 2: 128 x 16, k = 1 and 2; 0: default = 2 where it exists)
-    // observables
-    int obs_lds = 1;        // WAFER_OBS_LDS: 0 = the plain scalar-load kernel
-    int obs_wgs = 2;        // WAFER_OBS_WGS: workgroups per CU
     // fused kernels
     int f2_nw2 = 0;         // WAFER_F2_NW2: main waves of the two-step kernel (0: default)
     int f2_wide = 1;        // WAFER_F2_WIDE: 0 keeps FivePoint on the two-step kernel with dedicated helper waves (128 x 8 tiles)
     int fuse3 = 1;          // WAFER_FUSE3: 0 keeps ThreePoint fp64 on the two-step kernel
     int fuse3_min_ny = -1;  // WAFER_FUSE3_MIN_NY (tests; lifts the cell threshold too)
     long long fuse3_min_cells = 6000000; // WAFER_FUSE3_MIN_CELLS
-    int stencil_variant = -1; // WAFER_STENCIL_VARIANT
     // z-slabs
     int overlap = -1;       // WAFER_OVERLAP: initial wafer_set_overlap mode (-1: default)
-    int halo_cycle = 1;     // WAFER_HALO_CYCLE
     int hv_debug = 0;       // WAFER_HV_DEBUG: experiments on the single-launch pass (bits: 4 no acquire fence
                             // (timing only), 8 no short pieces, 16 XCD-contiguous tile order inside each half, 32 no counters / gates (timing only),
                             // 64 exchange stream at normal priority)
     int hv_short_tiles = -1; // WAFER_HV_SHORT_TILES: tiles per half cut into short pieces (-1: 1/16 of the tiles)
-    int hv_nsub = 4;        // WAFER_HV_NSUB: pieces per short column
     int hv_layout = 0;      // WAFER_HV_LAYOUT: where the short columns go (wafer_f3_schedule_halves); peer-store passes (mode 3): 3 = always
                             // the two halves, 4 = always whole columns (default: whole columns where there is a tile per CU)
     int hv_wait_ms = 20000; // WAFER_HV_WAIT_MS: how long a workgroup of the single-launch pass waits for its ghost planes before it gives up
@@ -82,22 +76,17 @@ static inline WaferTuning wafer_tuning_from_env()
     t.x2 = wafer_env_int("WAFER_X2", t.x2);
     t.x2_ry = wafer_env_int("WAFER_X2_RY", t.x2_ry);
     t.x2_max_k = wafer_env_int("WAFER_X2_MAX_K", t.x2_max_k);
-    t.obs_lds = wafer_env_int("WAFER_OBS_LDS", t.obs_lds);
-    t.obs_wgs = wafer_env_int("WAFER_OBS_WGS", t.obs_wgs);
     t.f2_nw2 = wafer_env_int("WAFER_F2_NW2", t.f2_nw2);
     t.f2_wide = wafer_env_int("WAFER_F2_WIDE", t.f2_wide);
     t.fuse3 = wafer_env_int("WAFER_FUSE3", t.fuse3);
     t.fuse3_min_ny = wafer_env_int("WAFER_FUSE3_MIN_NY", t.fuse3_min_ny);
     t.fuse3_min_cells = wafer_env_int("WAFER_FUSE3_MIN_CELLS", (int)t.fuse3_min_cells);
-    t.stencil_variant = wafer_env_int("WAFER_STENCIL_VARIANT", t.stencil_variant);
     t.overlap = wafer_env_int("WAFER_OVERLAP", t.overlap);
-    t.halo_cycle = wafer_env_int("WAFER_HALO_CYCLE", t.halo_cycle);
     t.hv_debug = wafer_env_int("WAFER_HV_DEBUG", t.hv_debug);
     t.f3_sched = wafer_env_int("WAFER_F3_SCHED", t.f3_sched);
     t.f3_plain_down = wafer_env_int("WAFER_F3_PLAIN_DOWN", t.f3_plain_down);
     t.f3_xs = wafer_env_int("WAFER_F3_XS", t.f3_xs);
     t.hv_short_tiles = wafer_env_int("WAFER_HV_SHORT_TILES", t.hv_short_tiles);
-    t.hv_nsub = wafer_env_int("WAFER_HV_NSUB", t.hv_nsub);
     t.hv_layout = wafer_env_int("WAFER_HV_LAYOUT", t.hv_layout);
     t.hv_wait_ms = wafer_env_int("WAFER_HV_WAIT_MS", t.hv_wait_ms);
     if (t.hv_wait_ms < 1) t.hv_wait_ms = 1;
