@@ -29,6 +29,9 @@ for it in range(int(os.environ.get("N", "60"))):
                           ("WAFER_F3_SCHED", ["0", "0", "1"])):
         os.environ[name] = str(rng.choice(choices)) if whole else "0" if name != "WAFER_F3_XS" else "1"
     dtype = "f64"
+    os.environ["WAFER_F2_WIDE"] = str(rng.choice([1, 1, 0]))   # FivePoint two steps per pass: the 128 x 16-tile kernel / the one with helper waves
+    if ext == 2 and not whole:
+        os.environ["WAFER_ZCHUNK"] = str(rng.choice([0, 1, 2, 3, 5]))
     try:
         cfg, par = make_pair(shape, ext=ext, potential=pot, dn=0.2, dt=0.004, mass=1.3, sig=0.3, dtype=dtype)
         v = wo.potential_generate(cfg); a, b = wo.ab(cfg, v)
@@ -47,6 +50,32 @@ for it in range(int(os.environ.get("N", "60"))):
     except Exception as e:
         bad += 1
         print("ERROR", shape, ext, pot, steps, variant, repr(e)[:200], flush=True)
+# fp32 storage (fp64 or fp32 step arithmetic): no oracle to the bit, but every kernel family must give the single-step kernel's bits --
+# the three-step kernel (float in HBM, double in the CU), the FivePoint two-step kernel on 128 x 16 tiles, the two-step kernel
+for it in range(int(os.environ.get("N", "60")) // 3):
+    ext = int(rng.integers(1, 3))
+    shape = (int(rng.choice([64, 128, 130, 200, 256, 257, 300, 512])), int(rng.choice([1, 8, 16, 17, 32, 37, 48])), int(rng.integers(1, 30)))
+    dtype = str(rng.choice(["f32", "f32fast"]))
+    steps = int(rng.integers(1, 12))
+    pot = str(rng.choice(["Harmonic", "Coulomb", "SimpleCornell", "Cube"]))
+    os.environ["WAFER_FUSE3_MIN_NY"] = "1"
+    os.environ["WAFER_F2_WIDE"] = "1"
+    got = {}
+    try:
+        for variant in (3 if ext == 1 else 2, 1):
+            os.environ["WAFER_ZCHUNK"] = str(rng.choice([0, 1, 2, 3, 5])) if variant != 1 else "0"
+            os.environ["WAFER_F3_PLAIN_DOWN"] = str(rng.choice([0, 1])) if variant == 3 else "0"
+            with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.3, sig=0.3, central_difference=ext, dtype=dtype)) as ctx:
+                ctx.set_stencil_variant(variant)
+                ctx.set_potential(pot); ctx.set_initial_condition("Gaussian", seed=it + 1); ctx.evolve(0, steps)
+                got[variant] = ctx.download_phi()
+        a_, b_ = got.values()
+        if not np.array_equal(a_, b_, equal_nan=True):
+            bad += 1
+            print("MISMATCH fp32 storage", shape, ext, dtype, pot, steps, float(np.max(np.abs(a_ - b_))), flush=True)
+    except Exception as e:
+        bad += 1
+        print("ERROR fp32 storage", shape, ext, dtype, pot, steps, repr(e)[:200], flush=True)
 # excited states: normalise + modified Gram-Schmidt after every step (grid.rs:674-681)
 for it in range(int(os.environ.get("N", "60")) // 2):
     ext = int(rng.integers(1, 4))
@@ -57,6 +86,7 @@ for it in range(int(os.environ.get("N", "60")) // 2):
     if two:
         shape = (int(rng.choice([128, 256, 130, 64])), int(rng.choice([8, 16, 24, 32, 17])), int(rng.integers(2, 30)))
         ext, wnum, steps = 1, int(rng.integers(1, 4)), int(rng.integers(4, 10))
+    os.environ["WAFER_F3_PLAIN_DOWN"] = "0"
     os.environ["WAFER_X2_MAX_K"] = "3"
     os.environ["WAFER_X2_RY"] = str(rng.choice([0, 1, 2]))
     os.environ["WAFER_ZCHUNK"] = str(rng.choice([0, 1, 2, 3, 5])) if two else "0"
@@ -93,7 +123,7 @@ os.environ.pop("WAFER_ONE_PASS", None)
 os.environ.pop("WAFER_VGEN", None)
 os.environ.pop("WAFER_XF_DEEP", None)
 os.environ.pop("WAFER_FUSE3_MIN_NY", None)
-for name in ("WAFER_ZCHUNK", "WAFER_F3_PLAIN_DOWN", "WAFER_F3_XS", "WAFER_F3_SCHED", "WAFER_X2_MAX_K", "WAFER_X2_RY"):
+for name in ("WAFER_ZCHUNK", "WAFER_F3_PLAIN_DOWN", "WAFER_F3_XS", "WAFER_F3_SCHED", "WAFER_X2_MAX_K", "WAFER_X2_RY", "WAFER_F2_WIDE"):
     os.environ.pop(name, None)
 print("fuzz done, bad =", bad)
 sys.exit(1 if bad else 0)
