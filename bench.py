@@ -493,6 +493,15 @@ def run_rank(args) -> int:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt[0]), float(tt[1]) != 0.0
 
+        # Peer stores have never crossed a link (tools/first_contact_8gpu.md): before the schedule is timed, let alone trusted with the
+        # timed steps, it has to reproduce the bits of an exchange through the halo hook on every rank -- else it is dropped here
+        # instead of surfacing as a parity failure of the whole run
+        peer_check = None
+        if peers_ok:
+            peers_ok = slab.overlap_modes_agree(ctx, rank, world, 3, 0, steps=15, device=coll_dev)
+            peer_check = {"against": "overlap mode 0 (exchange through the halo hook), 15 steps, every rank's checksum", "identical": peers_ok}
+            if not peers_ok and rank == 0:
+                print("bench.py: peer stores (overlap mode 3) do not reproduce the exchange's bits on this fabric: dropped", file=sys.stderr, flush=True)
         for mode, cycle in ([(3, 1)] if peers_ok else []) + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []):
             refused = False
             try:
@@ -519,7 +528,8 @@ def run_rank(args) -> int:
         ctx.set_halo_cycle(best[1])
         names = {3: "3_single_launch_peer_stores", 2: "2_single_launch_two_halves", 1: "1_boundary_first_three_launches", 0: "0_no_overlap"}
         overlap_choice = {"mode": best[0], "fused_passes_per_exchange": best[1],
-                          "ms_per_step": {names[m] + ("" if cy == 1 else f"_exchange_every_{cy}_passes"): v for (m, cy), v in trial.items()}}
+                          "ms_per_step": {names[m] + ("" if cy == 1 else f"_exchange_every_{cy}_passes"): v for (m, cy), v in trial.items()},
+                          **({"peer_store_check": peer_check} if peer_check else {})}
         ctx.set_initial_condition("Boolean")
     elif dist is not None:
         mode = int(os.environ.get("WAFER_OVERLAP", "") or DEFAULT_MODE[0])

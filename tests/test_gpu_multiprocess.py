@@ -52,6 +52,8 @@ def _check_bench_two_rank_line(d, peers=False):
     assert ho["mode"] in (0, 1, 2, 3) and len(ho["ms_per_step"]) == (6 if peers else 5) and all(v > 0 for v in ho["ms_per_step"].values())
     # the peer-store schedule (HIP IPC between the rank processes) was connected, timed and survived its bounded waits
     assert ("3_single_launch_peer_stores" in ho["ms_per_step"]) == peers
+    if peers:   # ... after it had reproduced an exchange's bits on every rank (slab.overlap_modes_agree)
+        assert ho["peer_store_check"]["identical"] is True
     assert d["roofline"]["kernel"].startswith("wafer_k_step3_fused<double, double, ")
     assert ho["fused_passes_per_exchange"] in (1, 2)
     assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 128
@@ -106,6 +108,7 @@ def test_bench_eight_rank_path():
     assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["config"]["parallelism"] == "zslab8"
     ms = d["config"]["halo_overlap"]["ms_per_step"]
     assert d["config"]["points_per_gpu"] == 128 * 128 * 32 and len(ms) in (4, 6) and "3_single_launch_peer_stores" in ms
+    assert d["config"]["halo_overlap"]["peer_store_check"]["identical"] is True
     assert d["parity"]["identical"] is True and d["parity"]["slabs"] == 8 and d["parity"]["differing_slabs"] == []
     assert d["single_gpu_ref"]["grid"] == [128, 128, 256] and d["comm"]["process_group_ranks"] == 8
 

@@ -231,6 +231,7 @@ def main(argv=None) -> int:
     exit_code = 0
     with wafer_amd.Context(par) as ctx:
         comm = None
+        use_peer_stores = False
         if world > 1:
             comm, _name = slab.make_slab_comm(ctx, rank, world, torch.device("cuda", local_rank),
                                               "host" if host_transport else None)
@@ -246,9 +247,7 @@ def main(argv=None) -> int:
             want_peers = os.environ.get("WAFER_PEER_STORES", "0")
             if want_peers not in ("", "0") and (not host_transport or want_peers == "force"):
                 if slab.connect_peers(ctx, rank, world) and min(slab.partition(par.nz, world, r)[1] for r in range(world)) >= 6:
-                    ctx.set_overlap(3)
-                    if rank == 0:
-                        print("halo schedule: overlap mode 3 (peer stores)", file=sys.stderr, flush=True)
+                    use_peer_stores = True   # (switched on below, once the potential is set and the schedule has proved itself)
         def from_input(stem, pad, shape, what):
             a = staged_array(args.input_dir, stem, cfg["file_type"], pad, rank)
             if a is not None and (a.dtype != np.float64 or tuple(a.shape) != tuple(shape)):
@@ -265,6 +264,15 @@ def main(argv=None) -> int:
             del v
         else:
             ctx.set_potential(cfg["potential"])
+        if use_peer_stores:
+            # peer stores have never crossed a link: they have to reproduce the bits of an exchange through the halo hook on every
+            # rank (15 ground-state steps from the Boolean start, every cell) before the solve is handed to them
+            ok = slab.overlap_modes_agree(ctx, rank, world, 3, 2, steps=15, device="cpu" if host_transport else f"cuda:{local_rank}")
+            if ok:
+                ctx.set_overlap(3)
+            if rank == 0:
+                print("halo schedule: overlap mode 3 (peer stores)" if ok else
+                      "halo schedule: peer stores do not reproduce the exchange's bits on this fabric; overlap mode 2", file=sys.stderr, flush=True)
         sub = staged_array(args.input_dir, "potential_sub", cfg["file_type"], 0, rank)   # potential.rs:113-131
         if sub is not None:
             variable = cfg["potential"] == "FullCornell"

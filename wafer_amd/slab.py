@@ -193,6 +193,41 @@ def connect_peers(ctx, rank: int, world: int, group=None) -> bool:
     return ok
 
 
+def overlap_modes_agree(ctx, rank: int, world: int, mode: int, ref_mode: int, steps: int = 15, group=None, device="cpu") -> bool:
+    """Collective self-check before a schedule is trusted on a fabric it has never run on (peer stores between GPUs: nothing
+    in this repository has crossed a link): the same `steps` ground-state steps from the Boolean initial condition under overlap
+    `mode` and under `ref_mode` (an exchange through the halo hook), the checksum of this rank's own planes after each -- every
+    cell's bits -- and True only if they are equal on EVERY rank.  A WAFER_ERR_COMM in either run counts as disagreement.  The
+    potential must be set; phi is left at the Boolean initial condition and the overlap mode at `ref_mode`."""
+    import torch
+    import torch.distributed as dist
+    from .engine import WaferError
+    sums, bad = [], False
+    for m in (mode, ref_mode):
+        try:
+            ctx.set_overlap(m)
+            ctx.set_initial_condition("Boolean")
+            ctx.evolve(0, steps)
+            ctx.synchronize()
+            sums.append(ctx.checksum(ctx.params.z_begin, ctx.params.z_count))
+        except WaferError:
+            bad = True
+            sums.append(None)
+        if world > 1:   # the same collectives on every rank whatever happened here
+            dist.barrier(group=group)
+    bad = bad or sums[0] != sums[1]
+    if world > 1:
+        t = torch.tensor([1.0 if bad else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        bad = float(t[0]) != 0.0
+    try:
+        ctx.set_overlap(ref_mode)
+        ctx.set_initial_condition("Boolean")
+    except WaferError:
+        pass
+    return not bad
+
+
 class MailboxAllReduce:
     """include/wafer_mailbox.h through ctypes: the device-side all-reduce of libwafer_hip.so -- every rank's mailbox
     mapped into every other rank through HIP IPC, one one-wave kernel per call, sums in rank order (the same bits on
