@@ -466,33 +466,6 @@ def run_rank(args) -> int:
     overlap_choice = None
     DEFAULT_MODE = (2, 1)
     if dist is not None and os.environ.get("WAFER_OVERLAP", "") == "" and args.steps >= 8:
-        trial = {}
-
-        def any_rank(flag: bool) -> bool:
-            t_ = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            return float(t_[0]) != 0.0
-
-        def phase(n_steps: int):
-            """n_steps of evolve on this rank, then the SAME two collectives on every rank whatever happened here: a schedule
-            whose bounded waits give up on this fabric (WAFER_ERR_COMM: a neighbour's planes never arrived -- reported when
-            the rank next synchronises with its device) is dropped on every rank, never fatal, and never leaves the ranks
-            in different collectives.  -> (seconds on the slowest rank, failed on any rank)"""
-            bad = False
-            t0_ = time.perf_counter()
-            try:
-                ctx.evolve(0, n_steps)
-                ctx.synchronize()
-                torch.cuda.synchronize()
-            except wafer_amd.WaferError as e:
-                print(f"bench.py: rank {rank}: halo schedule {mode} (cycle {cycle}) failed in the set-up trial: {e}", file=sys.stderr, flush=True)
-                bad = True
-            dt_ = time.perf_counter() - t0_
-            dist.barrier()
-            tt = torch.tensor([dt_, 1.0 if bad else 0.0], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt[0]), float(tt[1]) != 0.0
-
         # Peer stores have never crossed a link (tools/first_contact_8gpu.md): before the schedule is timed, let alone trusted with the
         # timed steps, it has to reproduce the bits of an exchange through the halo hook on every rank -- else it is dropped here
         # instead of surfacing as a parity failure of the whole run
@@ -502,24 +475,11 @@ def run_rank(args) -> int:
             peer_check = {"against": "overlap mode 0 (exchange through the halo hook), 15 steps, every rank's checksum", "identical": peers_ok}
             if not peers_ok and rank == 0:
                 print("bench.py: peer stores (overlap mode 3) do not reproduce the exchange's bits on this fabric: dropped", file=sys.stderr, flush=True)
-        for mode, cycle in ([(3, 1)] if peers_ok else []) + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []):
-            refused = False
-            try:
-                ctx.set_overlap(mode)
-                ctx.set_halo_cycle(cycle)
-            except wafer_amd.WaferError as e:
-                print(f"bench.py: rank {rank}: halo schedule {mode} (cycle {cycle}) refused: {e}", file=sys.stderr, flush=True)
-                refused = True
-            failed = any_rank(refused)
-            if not failed:
-                _, failed = phase(9)                  # the run-in: rendezvous, first exchanges, table uploads
-            if not failed:
-                seconds, failed = phase(42)
-            if failed:
-                ctx.set_overlap(0)                    # resets the pass bookkeeping on every rank
-                ctx.set_initial_condition("Boolean")  # whatever the failed passes left behind
-                continue
-            trial[(mode, cycle)] = seconds / 42 * 1e3
+        # (slab.time_overlap_schedules: the same collective calls on every rank whatever happens on it; a schedule that fails
+        #  anywhere is dropped everywhere)
+        trial = slab.time_overlap_schedules(
+            ctx, ([(3, 1)] if peers_ok else []) + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []), rank, device=coll_dev,
+            log=lambda msg: print("bench.py: " + msg, file=sys.stderr, flush=True), device_sync=torch.cuda.synchronize)
         if not trial:
             print(f"bench.py: rank {rank}: every halo schedule failed in the set-up trial", file=sys.stderr)
             return 4

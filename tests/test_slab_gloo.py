@@ -197,3 +197,107 @@ def test_native_hook_fallback_is_agreed_by_all_ranks(tmp_path, phase, failing_ra
     world = 2
     mp.spawn(_fallback_worker, args=(world, _free_port(), failing_rank, phase, str(tmp_path)), nprocs=world, join=True)
     assert [open(tmp_path / f"ok{r}").read() for r in range(world)] == ["1"] * world
+
+
+# ---- the set-up trial of the halo schedules (bench.py --gpus N): a schedule that fails on ONE rank must be dropped on ALL,
+# ---- with every rank making the same collective calls (the old loop paired one rank's barrier with the others' all-reduce)
+class _TrialCtx:
+    """what slab.time_overlap_schedules needs of a context; `fail` = (mode, where) makes this rank's context fail there"""
+
+    def __init__(self, fail=None):
+        self.fail, self.mode, self.log = fail, 0, []
+
+    def _maybe(self, where):
+        from wafer_amd.engine import WaferError
+        if self.fail and self.fail[0] == self.mode and self.fail[1] == where:
+            raise WaferError(-6, f"simulated failure in {where}")
+
+    def set_overlap(self, mode):
+        self.mode = mode
+        self.log.append(("overlap", mode))
+        self._maybe("set_overlap")
+
+    def set_halo_cycle(self, cycle):
+        pass
+
+    def evolve(self, wnum, steps):
+        self.log.append(("evolve", self.mode, steps))
+        self._maybe(f"evolve{steps}")
+
+    def synchronize(self):
+        self._maybe("synchronize")
+
+    def set_initial_condition(self, name):
+        self.log.append(("ic", name))
+
+
+def _trial_worker(rank, world, port, failing_rank, fail, out_dir):
+    from wafer_amd import slab
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        ctx = _TrialCtx(fail if rank == failing_rank else None)
+        trial = slab.time_overlap_schedules(ctx, [(3, 1), (2, 1), (1, 1), (0, 1)], rank, device="cpu", run_in=9, steps=42)
+        dist.barrier()                           # every rank is still in step: a desynchronised collective would hang or throw before here
+        gathered = [None] * world
+        dist.all_gather_object(gathered, sorted(trial))
+        ok = all(g == gathered[0] for g in gathered) and (fail[0], 1) not in trial and len(trial) == 3
+        # the rank that did NOT fail must not have run the failed schedule's remaining phases
+        evolves = [e for e in ctx.log if e[0] == "evolve" and e[1] == fail[0]]
+        ok = ok and len(evolves) == {"set_overlap": 0, "evolve9": 1, "synchronize": 1, "evolve42": 2}[fail[1]]
+        ok = ok and ("overlap", 0) in ctx.log and ("ic", "Boolean") in ctx.log    # bookkeeping reset on every rank
+        with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+            f.write("1" if ok else "0")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [(3, "set_overlap"), (3, "evolve9"), (2, "synchronize"), (1, "evolve42")])
+@pytest.mark.parametrize("failing_rank", [0, 2])
+def test_schedule_trial_drops_a_failed_schedule_on_every_rank(tmp_path, fail, failing_rank):
+    """slab.time_overlap_schedules over three gloo ranks with a context that fails on ONE rank -- refused by set_overlap, in
+    the run-in, at the synchronisation (where a bounded wait that gave up is reported), in the timed phase: every rank returns
+    the same three surviving schedules, none hangs, none runs phases the others skipped"""
+    world = 3
+    mp.spawn(_trial_worker, args=(world, _free_port(), failing_rank, fail, str(tmp_path)), nprocs=world, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(world)] == ["1"] * world
+
+
+class _AgreeCtx(_TrialCtx):
+    """... and of slab.overlap_modes_agree: a checksum that depends on the overlap mode on the rank told to disagree"""
+
+    def __init__(self, disagree, fail=None):
+        super().__init__(fail)
+        self.disagree = disagree
+
+        class P:
+            z_begin, z_count = 0, 8
+        self.params = P()
+
+    def checksum(self, z_begin, z_count):
+        return 1234 + (self.mode if self.disagree else 0)
+
+
+def _agree_worker(rank, world, port, bad_rank, kind, out_dir):
+    from wafer_amd import slab
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        mine = rank == bad_rank
+        ctx = _AgreeCtx(disagree=mine and kind == "bits", fail=(3, "synchronize") if mine and kind == "error" else None)
+        got = slab.overlap_modes_agree(ctx, rank, world, 3, 2, steps=15, device="cpu")
+        dist.barrier()
+        want = kind == "fine"
+        with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+            f.write("1" if (got == want and ctx.mode == 2) else "0")    # every rank hears the same answer and ends on the reference mode
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["fine", "bits", "error"])
+def test_peer_store_self_check_is_agreed_by_all_ranks(tmp_path, kind):
+    """slab.overlap_modes_agree (what bench.py and wafer_amd.run ask before overlap mode 3 is used): equal checksums on every
+    rank -> True everywhere; other bits on ONE rank, or a WAFER_ERR_COMM there -> False everywhere, nobody left in a collective"""
+    world = 3
+    mp.spawn(_agree_worker, args=(world, _free_port(), 1, kind, str(tmp_path)), nprocs=world, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(world)] == ["1"] * world

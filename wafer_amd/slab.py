@@ -228,6 +228,69 @@ def overlap_modes_agree(ctx, rank: int, world: int, mode: int, ref_mode: int, st
     return not bad
 
 
+def time_overlap_schedules(ctx, candidates, rank: int, device="cpu", group=None, run_in: int = 9, steps: int = 42, log=None,
+                           device_sync=None) -> dict:
+    """Collective.  Times every halo schedule of `candidates` -- (overlap mode, fused passes per exchange) pairs -- over a run-in
+    of `run_in` and `steps` further ground-state steps and returns {(mode, cycle): ms per step on the slowest rank} for those that
+    worked on EVERY rank.  Every rank makes the same sequence of collective calls whatever happens on it: a schedule that this
+    rank's context refuses, or whose bounded waits give up on this fabric (WAFER_ERR_COMM -- a neighbour's planes never arrived;
+    reported when the rank next synchronises with its device), is agreed on right after the phase in which it happened and
+    dropped on all ranks; nobody walks on into a barrier that pairs with somebody else's all-reduce.  phi is left undefined
+    (the caller re-initialises); after a failure the pass bookkeeping is reset on every rank (set_overlap(0))."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from .engine import WaferError
+    say = log or (lambda msg: None)
+
+    def any_rank(flag: bool) -> bool:
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return float(t[0]) != 0.0
+
+    def phase(n_steps: int, what: str):
+        bad = False
+        t0 = time.perf_counter()
+        try:
+            ctx.evolve(0, n_steps)
+            ctx.synchronize()
+            if device_sync is not None:
+                device_sync()
+        except WaferError as e:
+            say(f"rank {rank}: halo schedule {what} failed in the set-up trial: {e}")
+            bad = True
+        dt = time.perf_counter() - t0
+        dist.barrier(group=group)
+        tt = torch.tensor([dt, 1.0 if bad else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+        return float(tt[0]), float(tt[1]) != 0.0
+
+    trial = {}
+    for mode, cycle in candidates:
+        what = f"{mode} (cycle {cycle})"
+        refused = False
+        try:
+            ctx.set_overlap(mode)
+            ctx.set_halo_cycle(cycle)
+        except WaferError as e:
+            say(f"rank {rank}: halo schedule {what} refused: {e}")
+            refused = True
+        failed = any_rank(refused)
+        if not failed:
+            _, failed = phase(run_in, what)      # the run-in: rendezvous, first exchanges, table uploads
+        if not failed:
+            seconds, failed = phase(steps, what)
+        if failed:
+            try:
+                ctx.set_overlap(0)                    # resets the pass bookkeeping on every rank
+                ctx.set_initial_condition("Boolean")  # whatever the failed passes left behind
+            except WaferError:
+                pass
+            continue
+        trial[(mode, cycle)] = seconds / steps * 1e3
+    return trial
+
+
 class MailboxAllReduce:
     """include/wafer_mailbox.h through ctypes: the device-side all-reduce of libwafer_hip.so -- every rank's mailbox
     mapped into every other rank through HIP IPC, one one-wave kernel per call, sums in rank order (the same bits on
