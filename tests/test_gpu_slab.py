@@ -477,6 +477,16 @@ def test_peer_store_four_slabs_in_a_subprocess():
         assert r.returncode == 0 and "PEER-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("seed", [41, 42])
+def test_randomised_slab_sweep_against_the_oracle(seed):
+    """tests/fuzz_slabs.py: random grids, stencil orders, storage types, 2 - 4 uneven slabs, every overlap mode (peer stores in both
+    pass layouts), deep halos, several evolve calls, potentials incl. the z-special ones -- the assembled slabs against the ORACLE
+    bit for bit (fp32 storage: against one context), all-reduced observables to 1e-11; in a process of its own (hardware queues)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_slabs.py")], capture_output=True, text=True,
+                       env=dict(os.environ, N="40", SEED=str(seed), GPU_MAX_HW_QUEUES="16", WAFER_PEER_SAME_DEVICE="1"), timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "bad = 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_peer_store_mode_needs_a_connection(wa):
     par = wa.Params(64, 32, 40, dn=0.2, dt=0.004, central_difference=1, z_begin=0, z_count=20, halo_depth=3)
     with wa.Context(par) as ctx:
