@@ -3,7 +3,7 @@
 tests/test_gpu_slab.py, and run by it in a process of its own): random grids, stencil orders, storage types, 2 - 4 uneven
 z-slabs as contexts of this process (device copies stand in for the fabric), every overlap mode the shape allows incl. peer
 stores (both pass layouts), deep halos, several evolve calls with step counts that leave every kind of remainder, potentials
-incl. the ones whose formula singles out z.  fp64: the assembled slabs equal the ORACLE bit for bit (FullCornell: device libm,
+incl. the ones whose formula singles out z; then excited-state steps (one and two per pass, k = 1 .. 3, thin and uneven slabs).  fp64: the assembled slabs equal the ORACLE bit for bit (FullCornell: device libm,
 1e-12) and the all-reduced observables agree to 1e-11; fp32 storage: the slabs equal one context.
     N=40 SEED=3 python tests/fuzz_slabs.py"""
 import os, sys, numpy as np
@@ -75,6 +75,63 @@ for it in range(int(os.environ.get("N", "30"))):
     except Exception as e:
         bad += 1
         print("ERROR", tag, repr(e)[:300], flush=True)
+# excited states on slabs: renormalise + Gram-Schmidt every step (grid.rs:674-681), one and two steps per pass, the 1 + k / 2 + 3k sums
+# all-reduced -- against one context (1e-12 per cell: the sums associate per slab) and against the oracle (1e-10)
+import sys as _sys
+_sys.setswitchinterval(1e-4)
+for it in range(int(os.environ.get("N", "30")) // 3):
+    ext = int(rng.choice([1, 1, 1, 2, 3]))
+    world = int(rng.integers(2, 5))
+    wnum = int(rng.integers(1, 4))
+    nx = int(rng.choice([24, 40, 64, 128, 130, 140]))
+    ny = int(rng.choice([8, 16, 17, 24, 40]))
+    depth = int(rng.choice([2, 3])) if ext == 1 else ext
+    nz = int(rng.integers(max(world * depth, world * 2 * ext) + 1, 44))
+    pot = str(rng.choice(["Harmonic", "Coulomb", "SimpleCornell", "Cube"]))
+    calls = [int(rng.integers(1, 10)) for _ in range(int(rng.integers(1, 3)))]
+    mode = int(rng.choice([0, 1, 2]))
+    os.environ["WAFER_X2_MAX_K"] = "3"
+    os.environ["WAFER_X2"] = str(rng.choice([1, 1, 0]))
+    os.environ["WAFER_VGEN"] = str(rng.choice([1, 0]))
+    tag = ("excited", nx, ny, nz, ext, world, wnum, pot, calls, mode, depth, os.environ["WAFER_X2"], os.environ["WAFER_VGEN"])
+    try:
+        params = dict(dn=0.25, dt=0.006, mass=1.3, sig=0.3)
+        base = wa.Params(nx, ny, nz, central_difference=ext, max_states=wnum, halo_depth=depth, **params)
+        single = wa.Params(nx, ny, nz, central_difference=ext, max_states=wnum, **params)
+
+        def body(ctx, rank=0):
+            ctx.set_overlap(mode)
+            ctx.set_potential(pot)
+            for j in range(wnum):      # orthonormalised random stored states, identical on every slab (the start is keyed by the global cell index)
+                ctx.set_initial_condition("Gaussian", seed=40 + 7 * it + j)
+                ctx.normalise(ctx.norm2()); ctx.orthogonalise(j); ctx.normalise(ctx.norm2())
+                ctx.push_state()
+            ctx.set_initial_condition("Gaussian", seed=7 + it)
+            start = ctx.download_phi()
+            for n in calls:
+                ctx.evolve(wnum, n)
+            return ctx.download_phi(), ctx.norm2(), start, [ctx.download_state(j) for j in range(wnum)]
+
+        with wa.Context(single) as ctx:
+            want, want_n2, start, lowers = body(ctx)
+        res, _ = run_slabs(wa, base, world, body)
+        got = assemble(base, world, [r[0] for r in res])
+        scale = max(1.0, float(np.max(np.abs(want))))
+        ok = float(np.max(np.abs(got - want))) / scale <= 1e-12 and all(abs(r[1] - want_n2) <= 1e-12 * max(1.0, abs(want_n2)) for r in res)
+        cfg = wo.Config(nx, ny, nz, ext=ext, potential=pot, **params)
+        v = wo.potential_generate(cfg); a, b = wo.ab(cfg, v)
+        ref = start.copy()
+        for n in calls:
+            wo.evolve(cfg, wnum, a, b, ref, lowers, n)
+        ok2 = float(np.max(np.abs(got - ref))) / max(1.0, float(np.max(np.abs(ref)))) <= 1e-10
+        if not (ok and ok2):
+            bad += 1
+            print("MISMATCH", tag, ok, ok2, float(np.max(np.abs(got - want))), float(np.max(np.abs(got - ref))), flush=True)
+    except Exception as e:
+        bad += 1
+        print("ERROR", tag, repr(e)[:300], flush=True)
+for name in ("WAFER_X2_MAX_K", "WAFER_X2", "WAFER_VGEN"):
+    os.environ.pop(name, None)
 for name in ("WAFER_FUSE3_MIN_NY", "WAFER_HV_LAYOUT", "WAFER_ZCHUNK"):
     os.environ.pop(name, None)
 print("slab fuzz done,", int(os.environ.get("N", "30")), "cases, bad =", bad)

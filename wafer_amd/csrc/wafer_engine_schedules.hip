@@ -773,9 +773,19 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 //  from an interior launch that packs the CUs exactly: the interior ends later by about the exchange's own
                 //  duration, and the two thin boundary launches come on top -- bench slab, native RCCL to the same rank,
                 //  k = 1: 0.772 ms/step split against 0.718 unsplit (undecomposed 0.643); k = 3: 1.210 against 1.121 (1.033).)
+                // The split depends on the LOCAL slab thickness (slab.partition hands out uneven slabs: 3, 2, 2, 2 planes of 9), so
+                // both branches call the hooks in the SAME ORDER -- the halo exchange first, the all-reduce of the sums second --
+                // or ranks that took different branches would queue a send / receive and a collective on one communicator in
+                // different orders and wait for each other for ever (found by tests/fuzz_slabs.py, round 5, with the in-process
+                // fabric; RCCL would have hung).
                 const bool split = one_pass && !last && c->sharded() && c->overlap_mode == 1 && g.nzl > 2 * R;
                 if (split) {
                     TRY(excited_step_launch_overlapped(c, src, dst, wnum, one_pass));
+                } else if (one_pass && !last) {
+                    long long nb = 0;
+                    TRY(excited_stencil_launch(c, src, dst, wnum, one_pass, g.G, g.G + g.nzl, 0, c->s_main, &nb));
+                    TRY(exchange_halo(c, dst, c->s_main, R));                       // the raw result's planes (stream order: behind the launch)
+                    TRY(reduce_to_scal(c, 1 + (int)wnum, nb, 0, c->s_main));
                 } else {
                     TRY(excited_step_launch(c, src, dst, wnum, one_pass, c->s_main));
                     if (!one_pass || last) TRY(excited_apply(c, dst, wnum, c->s_main));
