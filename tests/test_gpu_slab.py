@@ -97,7 +97,7 @@ class FakeFabric:
             self.send[rank] = dict(lo=slo, hi=shi)
             self.call[rank] = ("halo", nbytes)
             self.bar.wait()
-            assert all(c == self.call[rank] for c in self.call), f"ranks are in different hook calls: {self.call}
+            assert all(c == self.call[rank] for c in self.call), f"ranks are in different hook calls: {self.call}"
             if rlo:  # my lower ghost planes <- lower neighbour's top owned planes
                 assert hip.hipMemcpy(rlo, self.send[rank - 1]["hi"], nbytes, 3) == 0
             if rhi:
@@ -118,7 +118,7 @@ class FakeFabric:
             self.scal[rank] = np.array(buf[:])
             self.call[rank] = ("allreduce", count)
             self.bar.wait()
-            assert all(c == self.call[rank] for c in self.call), f"ranks are in different hook calls: {self.call}
+            assert all(c == self.call[rank] for c in self.call), f"ranks are in different hook calls: {self.call}"
             total = np.sum(np.stack(self.scal), axis=0)   # same order on every rank
             self.bar.wait()
             out = (C.c_double * count)(*total)
