@@ -294,12 +294,14 @@ def test_native_rccl_host_self_neighbours():
     r = subprocess.run([exe, "--self", "136", "40", "96", "9"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "SELF-OK" in r.stdout and "halo_calls=" in r.stdout
+    # the third run of --self: peer stores (overlap mode 3), connected and checked against an exchange's bits as a multi-rank run does it
+    assert "ms_per_step_peer_stores=" in r.stdout
     # the same binary as an ordinary single-rank run prints one JSON record
     import json
     r = subprocess.run([exe, "64", "48", "40", "10"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert rec["n_gpus"] == 1 and rec["steps"] == 10 and rec["norm2"] > 0
+    assert rec["n_gpus"] == 1 and rec["steps"] == 10 and rec["norm2"] > 0 and rec["halo_overlap_mode"] == 2 and rec["peer_store_check"] == -1
 
 
 def test_native_rccl_hooks_from_python_self_neighbours():

@@ -34,12 +34,16 @@ static inline int wafer_rccl_halo(void *user, void *send_lo, void *send_hi, void
     WaferRcclFabric *f = static_cast<WaferRcclFabric *>(user);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (ncclGroupStart() != ncclSuccess) return 1;
-    // receives first, then sends: between one pair of ranks they match in posting order
+    // receives first, then sends: between one pair of ranks they match in posting order.  When ONE rank is both neighbours
+    // (a ring of one or two slabs: the self-neighbour test) the sends go upper first, so that the lower ghost planes receive
+    // the neighbour's upper boundary planes -- the same ring a one-direction call (send_lo + recv_hi) and the peer stores close
+    const bool ring = f->lower >= 0 && f->lower == f->upper;
     bool ok = true;
     if (recv_lo) ok = ok && ncclRecv(recv_lo, bytes, ncclChar, f->lower, f->comm, s) == ncclSuccess;
     if (recv_hi) ok = ok && ncclRecv(recv_hi, bytes, ncclChar, f->upper, f->comm, s) == ncclSuccess;
+    if (ring && send_hi) ok = ok && ncclSend(send_hi, bytes, ncclChar, f->upper, f->comm, s) == ncclSuccess;
     if (send_lo) ok = ok && ncclSend(send_lo, bytes, ncclChar, f->lower, f->comm, s) == ncclSuccess;
-    if (send_hi) ok = ok && ncclSend(send_hi, bytes, ncclChar, f->upper, f->comm, s) == ncclSuccess;
+    if (!ring && send_hi) ok = ok && ncclSend(send_hi, bytes, ncclChar, f->upper, f->comm, s) == ncclSuccess;
     if (ncclGroupEnd() != ncclSuccess || !ok) return 1;
     ++f->halo_calls;
     return 0;

@@ -11,8 +11,11 @@
 //   wafer-hip-slabs --self NX NY NZ STEPS
 //       ONE process, one GPU: the slab is a middle slab of an 8-rank world whose neighbours are this
 //       same rank, so halo planes really travel through ncclSend / ncclRecv (and scalars through
-//       ncclAllReduce); the run is repeated with plain device copies as hooks and must agree bit for
-//       bit.  Prints SELF-OK.  (tests/test_gpu_multiprocess.py)
+//       ncclAllReduce); the run is repeated with plain device copies as hooks, and once more with peer stores (overlap
+//       mode 3: connected and self-checked exactly as a multi-rank run does), and all three must agree bit for bit.
+//       Prints SELF-OK.  (tests/test_gpu_multiprocess.py)
+//   Multi-rank runs use peer stores (the z-neighbours' buffers mapped through HIP IPC, records exchanged with ncclAllGather) once
+//   15 steps under them have left every rank's planes with the bits of an exchange through the halo hook; WAFER_PEER_STORES=0: never.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -60,21 +63,16 @@ using Fabric = WaferRcclFabric;
 static auto &rccl_halo = wafer_rccl_halo;
 static auto &rccl_allreduce = wafer_rccl_allreduce;
 
-// the same exchange with itself as both neighbours, by device copies: what the self test expects RCCL to deliver.  With one
-// rank as both neighbours RCCL pairs receives and sends in posting order (wafer_rccl_halo posts recv_lo, recv_hi, then
-// send_lo, send_hi).  The single-launch pass (wafer_set_overlap mode 2) calls the hook with ONE direction -- send_lo and
-// recv_hi, or send_hi and recv_lo, the other two NULL: the pairing by posting order covers that as well.
+// the same exchange with itself as both neighbours, by device copies: what the self test expects RCCL to deliver -- a ring
+// of one slab, the lower ghost planes taking the slab's own upper boundary planes and the other way round (wafer_rccl_halo
+// posts its sends in that order when one rank is both neighbours).  The single-launch pass (wafer_set_overlap mode 2) calls
+// the hook with ONE direction -- send_lo and recv_hi, or send_hi and recv_lo, the other two NULL: the same ring.
 static int copy_halo(void *, void *send_lo, void *send_hi, void *recv_lo, void *recv_hi, size_t bytes, void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    void *recvs[2] = {recv_lo, recv_hi}, *sends[2] = {send_lo, send_hi};
-    int is = 0;
-    for (int ir = 0; ir < 2; ++ir) {
-        if (!recvs[ir]) continue;
-        while (is < 2 && !sends[is]) ++is;
-        if (is == 2) return 1; // a receive without a send: not a self-neighbour exchange
-        if (hipMemcpyAsync(recvs[ir], sends[is++], bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
-    }
+    if ((recv_lo && !send_hi) || (recv_hi && !send_lo)) return 1; // a receive without its send: not a self-neighbour exchange
+    if (recv_lo && hipMemcpyAsync(recv_lo, send_hi, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
+    if (recv_hi && hipMemcpyAsync(recv_hi, send_lo, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return 1;
     return 0;
 }
 static int copy_allreduce(void *, void *, size_t, void *) { return 0; }
@@ -90,16 +88,89 @@ struct RunResult {
     wafer_observables_t obs;
     float ms = 0.f;
     uint64_t steps = 0;
+    int overlap_mode = 2;        // what the timed steps ran under
+    int peer_check = -1;         // -1: peer stores not tried, 0: tried and dropped (connection or bits), 1: checked and in use
 };
 
+// all ranks: is `mine` true everywhere?  (world 1: yes if mine)
+static int all_agree(Fabric *fab, int world, bool mine, bool *out)
+{
+    *out = mine;
+    if (world <= 1 || !fab) return 0;
+    int *d = nullptr, h = mine ? 1 : 0;
+    HIPCHECK(hipMalloc((void **)&d, sizeof(int)));
+    HIPCHECK(hipMemcpy(d, &h, sizeof h, hipMemcpyHostToDevice));
+    NCCLCHECK(ncclAllReduce(d, d, 1, ncclInt, ncclMin, fab->comm, nullptr));
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    *out = h == 1;
+    return 0;
+}
+
+// Peer stores (wafer_set_overlap mode 3) for this host: every rank's wafer_peer_info travels through ncclAllGather, each rank maps
+// its z-neighbours', and -- nothing in this repository has crossed a link -- the mode has to reproduce the bits of an exchange
+// through the halo hook on EVERY rank (15 steps from the Boolean start, the checksum of the rank's own planes) before it is used;
+// any failure anywhere leaves every rank on mode 2.  Collective.  self_loop: the one rank is its own neighbour on both sides.
+static int try_peer_stores(wafer_ctx *ctx, const wafer_params &p, Fabric *fab, int rank, int world, bool self_loop, int *result)
+{
+    *result = 0;
+    wafer_peer_info mine;
+    bool ok = wafer_peer_export(ctx, &mine) == WAFER_OK, all_ok = false;
+    std::vector<wafer_peer_info> all((size_t)world, mine);
+    if (world > 1) {
+        char *d = nullptr;
+        HIPCHECK(hipMalloc((void **)&d, sizeof mine * (size_t)(world + 1)));
+        HIPCHECK(hipMemcpy(d, &mine, sizeof mine, hipMemcpyHostToDevice));
+        NCCLCHECK(ncclAllGather(d, d + sizeof mine, sizeof mine, ncclChar, fab->comm, nullptr));
+        HIPCHECK(hipDeviceSynchronize());
+        HIPCHECK(hipMemcpy(all.data(), d + sizeof mine, sizeof mine * (size_t)world, hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+    }
+    if (all_agree(fab, world, ok, &all_ok)) return 1;
+    if (!all_ok) return 0;
+    const wafer_peer_info *lower = self_loop ? &mine : (rank > 0 ? &all[(size_t)rank - 1] : nullptr);
+    const wafer_peer_info *upper = self_loop ? &mine : (rank + 1 < world ? &all[(size_t)rank + 1] : nullptr);
+    ok = wafer_peer_connect(ctx, lower, upper) == WAFER_OK;
+    if (!ok) fprintf(stderr, "rank %d: wafer_peer_connect: %s\n", rank, wafer_last_error());
+    if (all_agree(fab, world, ok, &all_ok)) return 1;
+    if (!all_ok) { (void)wafer_peer_disconnect(ctx); return 0; }
+    uint64_t sum[2] = {0, 0};
+    ok = true;
+    for (int i = 0; i < 2 && ok; ++i) {
+        // (self_loop: the generated start carries the GLOBAL grid's values in its ghost planes, the wrap-around exchange delivers this
+        //  slab's own; dividing by sqrt(1) changes no bit and marks the ghost planes stale, so both schedules start from an exchange)
+        ok = wafer_set_overlap(ctx, i == 0 ? 3 : 2) == WAFER_OK && wafer_set_initial_condition(ctx, WAFER_IC_BOOLEAN, 0) == WAFER_OK &&
+             (!self_loop || wafer_normalise(ctx, 1.0) == WAFER_OK) &&
+             wafer_evolve(ctx, 0, 15) == WAFER_OK && wafer_synchronize(ctx) == WAFER_OK &&
+             wafer_diag_checksum(ctx, p.z_begin, p.z_count, &sum[i]) == WAFER_OK;
+        bool everyone = false;   // the same collectives on every rank whatever happened here
+        if (all_agree(fab, world, ok, &everyone)) return 1;
+        ok = everyone;
+    }
+    ok = ok && sum[0] == sum[1];
+    if (all_agree(fab, world, ok, &all_ok)) return 1;
+    if (!all_ok && rank == 0) fprintf(stderr, "peer stores (overlap mode 3) do not reproduce the exchange's bits on this fabric: overlap mode 2\n");
+    WCHECK(wafer_set_overlap(ctx, all_ok ? 3 : 2));
+    *result = all_ok ? 1 : 0;
+    return 0;
+}
+
+// peers: try overlap mode 3 (fab: the communicator the records travel through; rank / world / self_loop as in try_peer_stores)
 static int run_slab(const wafer_params &p, int potential, uint64_t steps, wafer_halo_fn halo, wafer_allreduce_fn allreduce,
-                    void *user, bool download, RunResult &out)
+                    void *user, bool download, RunResult &out, bool peers = false, Fabric *fab = nullptr, int rank = 0, int world = 1,
+                    bool self_loop = false, bool wrap = false)
 {
     wafer_ctx *ctx = nullptr;
     WCHECK(wafer_ctx_create(&p, &ctx));
     WCHECK(wafer_set_comm_hooks(ctx, halo, allreduce, user));
     WCHECK(wafer_set_potential_builtin(ctx, potential));
+    if (peers && p.z_count >= 6) {
+        if (try_peer_stores(ctx, p, fab, rank, world, self_loop, &out.peer_check)) return 1;
+        out.overlap_mode = out.peer_check == 1 ? 3 : 2;
+    }
     WCHECK(wafer_set_initial_condition(ctx, WAFER_IC_BOOLEAN, 0));
+    if (wrap) WCHECK(wafer_normalise(ctx, 1.0));   // --self: every schedule takes its first ghost planes from the (wrap-around) exchange
     WCHECK(wafer_evolve(ctx, 0, steps < 20 ? steps : 20)); // warm-up (and channel set-up) outside the timing
     WCHECK(wafer_evolve(ctx, 0, steps));
     WCHECK(wafer_last_evolve_ms(ctx, &out.ms, &out.steps));
@@ -229,20 +300,39 @@ int main(int argc, char **argv)
         if (per < 4) { fprintf(stderr, "--self needs NZ >= 32\n"); return 2; }
         p.z_begin = 4 * per; p.z_count = per; // a middle slab: neighbours on both sides
         fab.lower = fab.upper = 0;
-        RunResult via_rccl, via_copies;
-        if ((rc = run_slab(p, potential, steps, rccl_halo, rccl_allreduce, &fab, true, via_rccl))) return rc;
-        if ((rc = run_slab(p, potential, steps, copy_halo, copy_allreduce, nullptr, true, via_copies))) return rc;
-        const bool same = via_rccl.phi.size() == via_copies.phi.size() &&
-                          memcmp(via_rccl.phi.data(), via_copies.phi.data(), via_rccl.phi.size() * sizeof(double)) == 0 &&
-                          memcmp(&via_rccl.obs, &via_copies.obs, sizeof(wafer_observables_t)) == 0;
+        RunResult via_rccl, via_copies, via_peers;
+        if ((rc = run_slab(p, potential, steps, rccl_halo, rccl_allreduce, &fab, true, via_rccl, false, nullptr, 0, 1, false, true))) return rc;
+        if ((rc = run_slab(p, potential, steps, copy_halo, copy_allreduce, nullptr, true, via_copies, false, nullptr, 0, 1, false, true))) return rc;
+        // ... and with the boundary workgroups storing into the neighbour's (= this slab's own) ghost planes themselves, after the
+        // self-check every rank of a real run makes (try_peer_stores)
+        if ((rc = run_slab(p, potential, steps, rccl_halo, rccl_allreduce, &fab, true, via_peers, true, &fab, 0, 1, true, true))) return rc;
+        const bool same_copies = via_rccl.phi.size() == via_copies.phi.size() &&
+                                 memcmp(via_rccl.phi.data(), via_copies.phi.data(), via_rccl.phi.size() * sizeof(double)) == 0 &&
+                                 memcmp(&via_rccl.obs, &via_copies.obs, sizeof(wafer_observables_t)) == 0;
+        const bool same_peers = via_peers.peer_check == 1 && via_peers.overlap_mode == 3 && via_peers.phi.size() == via_rccl.phi.size() &&
+                                memcmp(via_peers.phi.data(), via_rccl.phi.data(), via_rccl.phi.size() * sizeof(double)) == 0 &&
+                                memcmp(&via_peers.obs, &via_rccl.obs, sizeof(wafer_observables_t)) == 0;
+        const bool same = same_copies && same_peers;
+        if (!same) {
+            fprintf(stderr, "rccl vs copies: %d; peer stores vs rccl: %d (peer check %d, mode %d)\n", (int)same_copies, (int)same_peers,
+                    via_peers.peer_check, via_peers.overlap_mode);
+            // which z planes (padded index) differ: ghost planes of the slab, or owned ones?
+            const size_t pz = nz + 2;
+            std::vector<long> per_plane(pz, 0);
+            for (size_t i = 0; i < via_rccl.phi.size() && i < via_peers.phi.size(); ++i)
+                if (memcmp(&via_rccl.phi[i], &via_peers.phi[i], sizeof(double)) != 0) ++per_plane[i % pz];
+            for (size_t k = 0; k < pz; ++k)
+                if (per_plane[k]) fprintf(stderr, "  padded z %zu: %ld cells differ (slab owns padded z %u .. %u)\n", k, per_plane[k], p.z_begin + 1, p.z_begin + p.z_count);
+        }
         double sum = 0.0;
         for (double v : via_rccl.phi) sum += v * v;
         if (!same || !(sum > 0.0) || fab.halo_calls == 0 || fab.reduce_calls == 0) {
             fprintf(stderr, "SELF-FAIL same=%d sum=%g halo_calls=%ld reduce_calls=%ld\n", (int)same, sum, fab.halo_calls, fab.reduce_calls);
             return 1;
         }
-        printf("SELF-OK halo_calls=%ld reduce_calls=%ld ms_per_step_rccl=%.4f ms_per_step_copies=%.4f\n", fab.halo_calls,
-               fab.reduce_calls, via_rccl.ms / (double)via_rccl.steps, via_copies.ms / (double)via_copies.steps);
+        printf("SELF-OK halo_calls=%ld reduce_calls=%ld ms_per_step_rccl=%.4f ms_per_step_copies=%.4f ms_per_step_peer_stores=%.4f\n", fab.halo_calls,
+               fab.reduce_calls, via_rccl.ms / (double)via_rccl.steps, via_copies.ms / (double)via_copies.steps,
+               via_peers.ms / (double)via_peers.steps);
     } else {
         // contiguous balanced z-ranges, the rule of wafer_amd.slab.partition
         const uint32_t base = nz / (uint32_t)world, extra = nz % (uint32_t)world;
@@ -252,7 +342,9 @@ int main(int argc, char **argv)
         fab.lower = rank > 0 ? rank - 1 : -1;
         fab.upper = rank + 1 < world ? rank + 1 : -1;
         RunResult r;
-        if ((rc = run_slab(p, potential, steps, rccl_halo, rccl_allreduce, &fab, false, r))) return rc;
+        // peer stores unless WAFER_PEER_STORES=0: connected, checked against an exchange's bits on every rank, else mode 2
+        const bool peers = world > 1 && env_int("WAFER_PEER_STORES", 1) != 0;
+        if ((rc = run_slab(p, potential, steps, rccl_halo, rccl_allreduce, &fab, false, r, peers, &fab, rank, world, false))) return rc;
         // slowest rank's kernel time decides
         float *dms = nullptr;
         HIPCHECK(hipMalloc((void **)&dms, sizeof(float)));
@@ -263,9 +355,10 @@ int main(int argc, char **argv)
         (void)hipFree(dms);
         if (rank == 0)
             printf("{\"n_gpus\": %d, \"grid\": [%u, %u, %u], \"steps\": %llu, \"ms_per_step\": %.5f, \"updates_per_s\": %.6e, "
-                   "\"energy_per_norm2\": %.12e, \"norm2\": %.12e, \"halo_calls\": %ld}\n",
+                   "\"energy_per_norm2\": %.12e, \"norm2\": %.12e, \"halo_calls\": %ld, \"halo_overlap_mode\": %d, \"peer_store_check\": %d}\n",
                    world, nx, ny, nz, (unsigned long long)r.steps, r.ms / (double)r.steps,
-                   (double)nx * ny * nz * (double)r.steps / (r.ms * 1e-3), r.obs.energy / r.obs.norm2, r.obs.norm2, fab.halo_calls);
+                   (double)nx * ny * nz * (double)r.steps / (r.ms * 1e-3), r.obs.energy / r.obs.norm2, r.obs.norm2, fab.halo_calls,
+                   r.overlap_mode, r.peer_check);
     }
     ncclCommDestroy(fab.comm);
     return 0;
