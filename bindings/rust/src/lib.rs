@@ -59,6 +59,23 @@ pub struct wafer_observables_output {
     pub l_r: f64,
 }
 
+/// wafer_div_plan_t: how the step kernels divide by the run's stencil denominator (wafer_div_plan, wafer_get_div_plan)
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct wafer_div_plan_t {
+    pub den: f64,
+    pub zh: f64,
+    pub zl: f64,
+    pub checked: i32,
+    pub n_candidates: i32,
+    pub zl_shift: i32,
+    pub reserved: i32,
+}
+
+/// wafer_params.flags
+pub const WAFER_FLAG_SKIP_DT_CHECK: u32 = 1;
+pub const WAFER_FLAG_UNPLANNED_DIV: u32 = 2;
+
 /// wafer_peer_info (peer stores, wafer_set_overlap mode 3): what a rank publishes to its z-neighbours
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -161,6 +178,10 @@ extern "C" {
     pub fn wafer_peer_connect(ctx: *mut wafer_ctx, lower: *const wafer_peer_info, upper: *const wafer_peer_info) -> c_int;
     pub fn wafer_peer_disconnect(ctx: *mut wafer_ctx) -> c_int;
     pub fn wafer_diag_div_check(ctx: *mut wafer_ctx, den: f64, seed: u64, n_operands: u64, lo_exp: c_int, hi_exp: c_int, mismatches: *mut u64) -> c_int;
+    pub fn wafer_div_plan(den: f64, out: *mut wafer_div_plan_t, candidates: *mut f64, cap: usize, n_written: *mut usize) -> c_int;
+    pub fn wafer_get_div_plan(ctx: *mut wafer_ctx, out: *mut wafer_div_plan_t) -> c_int;
+    pub fn wafer_diag_div_planned(ctx: *mut wafer_ctx, plan: *const wafer_div_plan_t, seed: u64, n_random: u64, lo_exp: c_int, hi_exp: c_int,
+                                  operands: *const f64, n_operands: usize, mismatches_random: *mut u64, mismatches_operands: *mut u64) -> c_int;
 }
 
 /// `Err(message)` for any non-zero status; a Wafer integration maps it to an `ErrorKind`.

@@ -112,6 +112,8 @@ typedef struct wafer_params {
 } wafer_params;
 
 #define WAFER_FLAG_SKIP_DT_CHECK 1u /* do not enforce dt <= dn^2/3 (config.rs:362-365) */
+#define WAFER_FLAG_UNPLANNED_DIV 2u /* ignore the verdict of the division plan (wafer_div_plan): every x / (c dn^2 m) of the step
+                                     * kernels takes the extra Markstein round, as for a denominator the plan could not clear */
 
 /* grid.rs:17-28, un-normalised, in this order */
 typedef struct wafer_observables_t {
@@ -255,13 +257,35 @@ int wafer_diag_checksum(wafer_ctx *ctx, uint32_t z_begin, uint32_t z_count, uint
  * stored states) this context has launched so far -- tests assert that the kernel they mean to test is the one that ran. */
 int wafer_diag_x2_passes(wafer_ctx *ctx, uint64_t *out);
 
-/* Diagnostic: the divisions by loop-invariant denominators (c*dn^2*m in the stencil update, the norm in
- * the excited-state transform) use a hoisted reciprocal with two exact remainders instead of the IEEE
- * sequence (wafer_div_invariant, wafer_stencil.hip.h).  Draws n_operands (rounded up to 2^18) doubles
+/* Diagnostic: the divisions by loop-invariant denominators the host has not planned (the norm in the excited-state
+ * transform, projection coefficients) use a hoisted reciprocal with two exact remainders instead of the IEEE
+ * sequence (wafer_div_invariant(x, den), wafer_stencil.hip.h).  Draws n_operands (rounded up to 2^18) doubles
  * with uniform sign / significand and biased exponent uniform in [lo_exp, hi_exp] and counts those
  * whose quotient by `den` differs in any bit from the device's IEEE x / den. */
 int wafer_diag_div_check(wafer_ctx *ctx, double den, uint64_t seed, uint64_t n_operands, int lo_exp, int hi_exp,
                          uint64_t *mismatches);
+
+/* The division by the run's ONE stencil denominator c dn^2 m (grid.rs:569 / 594 / 626) is planned when the context is created
+ * (wafer_amd/csrc/wafer_divplan.h): q = RN(x zh + RN(x zl)) with zh = RN(1/den), zl = RN(1/den - zh) (moved by zl_shift ulps if
+ * that gets more operands through) is RN(x/den) except for the few dozen significands x whose quotient lies within 2^-50 ulp of
+ * the midpoint of two doubles; the plan enumerates those (n_candidates) and tries each with the device's instruction sequence.
+ * checked = 1: all came out as the IEEE quotient, so the three-instruction form is the division for every x (|x/den| >= 2^-960);
+ * checked = 0: the kernels add one Markstein round (always correct, two instructions more). */
+typedef struct wafer_div_plan_t {
+    double den, zh, zl;
+    int32_t checked, n_candidates, zl_shift, reserved;
+} wafer_div_plan_t;
+/* Host only (no GPU needed): the plan for `den`; candidates (may be NULL): up to `cap` of the enumerated significands, as doubles
+ * in [2^52, 2^53), *n_written of them. */
+int wafer_div_plan(double den, wafer_div_plan_t *out, double *candidates, size_t cap, size_t *n_written);
+/* the plan this context's kernels run with */
+int wafer_get_div_plan(wafer_ctx *ctx, wafer_div_plan_t *out);
+/* Diagnostic: the planned division as the kernels perform it (wafer_div_invariant(x, WaferDen)) with the given plan -- any
+ * plan, also one whose `checked` the caller has forced -- on n_random drawn operands (as wafer_diag_div_check) and on the
+ * n_operands doubles at `operands` (host memory; may be NULL): the number of quotients that differ from the device's IEEE
+ * x / den in any bit, separately. */
+int wafer_diag_div_planned(wafer_ctx *ctx, const wafer_div_plan_t *plan, uint64_t seed, uint64_t n_random, int lo_exp, int hi_exp,
+                           const double *operands, size_t n_operands, uint64_t *mismatches_random, uint64_t *mismatches_operands);
 
 /* ---- multi-GPU: communication hooks --------------------------------------- */
 /* The engine never links a communication library.  A host that z-slabs the

@@ -452,6 +452,98 @@ def test_hoisted_division_equals_the_ieee_division_on_2e10_operands(wa):
         assert ctx.div_check(dens[0], 1 << 24, lo_exp=1, hi_exp=40, seed=7) > 0
 
 
+DENS_NEEDING_A_MOVED_ZL = [0.007395769697490762, 0.1078657875904072, 0.20222586000144446]   # tests/test_div_plan.py
+
+
+def candidate_operands(cand):
+    """the plan's significands over the exponent range, both signs"""
+    ops = [np.ldexp(cand, e) for e in (-52, -900, -400, 0, 300, 900)]
+    ops = np.concatenate(ops)
+    return np.concatenate([ops, -ops])
+
+
+def test_planned_division_equals_the_ieee_division(wa):
+    """the three-instruction x / (c dn^2 m) of the step kernels (wafer_div_invariant(x, WaferDen), planned by wafer_div_plan)
+    against the device's IEEE division, bit for bit: 2^31 random operands per denominator, and the operands that matter --
+    every significand whose quotient comes within 2^-50 ulp of a rounding boundary (the plan's candidates), over the exponent
+    range and with both signs"""
+    from wafer_amd import engine
+    dens = [2 * 0.05 ** 2 * 1.0, 2 * 0.02 ** 2 * 2.35, 24 * 0.2 ** 2 * 1.3, 360 * 0.01 ** 2 * 0.7, 2 * 0.2 ** 2, 3.0,
+            float(np.nextafter(2.0, 0.0)), float(np.nextafter(1.0, 2.0)), 1.7320508075688772e-3] + DENS_NEEDING_A_MOVED_ZL
+    with wa.Context(wa.Params(8, 8, 8, dn=0.2, dt=0.004)) as ctx:
+        mine = ctx.div_plan()
+        assert mine.den == 2 * 0.2 * 0.2 * 1.0 and mine.checked == 1
+        for i, den in enumerate(dens):
+            plan, cand = engine.div_plan(den)
+            assert plan.checked == 1, den
+            ops = candidate_operands(cand) if cand.size else None
+            assert ctx.div_planned_check(plan, 1 << 31, ops, seed=300 + i) == (0, 0), den
+            # without the plan's verdict: the extra round, the same bits
+            plan.checked = 0
+            assert ctx.div_planned_check(plan, 1 << 28, ops, seed=400 + i) == (0, 0), den
+        # below the range the plan speaks for (x zl subnormal) some quotients differ by an ulp: the counter is live
+        plan, _ = engine.div_plan(dens[0])
+        assert ctx.div_planned_check(plan, 1 << 24, None, lo_exp=1, hi_exp=40, seed=7)[0] > 0
+
+
+def test_the_plan_catches_what_the_device_gets_wrong(wa):
+    """divisors whose RN(1/den - zh) is NOT good enough: forced onto the three-instruction form with that zl the device does
+    return a wrong last bit for some of the plan's candidates -- the operands the plan exists to try -- while 2^31 random
+    operands show nothing; with the zl the plan settled on, or with the extra round, every one of them is right"""
+    from wafer_amd import engine
+    with wa.Context(wa.Params(8, 8, 8, dn=0.2, dt=0.004)) as ctx:
+        for i, den in enumerate(DENS_NEEDING_A_MOVED_ZL):
+            plan, cand = engine.div_plan(den)
+            ops = candidate_operands(cand)
+            assert plan.zl_shift != 0 and ctx.div_planned_check(plan, 0, ops) == (0, 0)
+            unmoved = engine._DivPlan(den, plan.zh, float(np.nextafter(plan.zl, -np.inf if plan.zl_shift > 0 else np.inf)), 1, 0, 0, 0)
+            assert abs(plan.zl_shift) == 1
+            bad_random, bad_ops = ctx.div_planned_check(unmoved, 1 << 31, ops, seed=500 + i)
+            assert bad_ops > 0 and bad_random == 0, (den, bad_random, bad_ops)
+            unmoved.checked = 0
+            assert ctx.div_planned_check(unmoved, 1 << 28, ops, seed=600 + i) == (0, 0)
+
+
+def grid_spacing_whose_divisor_needs_a_moved_zl(lead, mass):
+    from wafer_amd import engine
+    rng = np.random.default_rng(3)
+    for _ in range(4000):
+        dn = float(rng.uniform(0.05, 0.4))
+        if engine.div_plan(lead * dn * dn * mass)[0].zl_shift != 0:
+            return dn
+    raise AssertionError("no such grid spacing found")
+
+
+@pytest.mark.parametrize("mode", ["moved_zl", "unplanned"])
+@pytest.mark.parametrize("ext,variant,steps", [(1, 3, 7), (1, 2, 5), (1, 1, 3), (2, 2, 5), (3, 1, 2)])
+def test_step_kernels_with_an_awkward_divisor_and_without_the_plan(wo, wa, ext, variant, steps, mode, monkeypatch):
+    """the step kernels against the oracle (which divides) where the plan has work to do: a grid spacing whose c dn^2 m needs its
+    zl moved, and WAFER_FLAG_UNPLANNED_DIV (every division with the extra round -- the instantiations a divisor the plan cannot
+    clear would run: VIR = false, b by the full division as well)"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    lead = {1: 2.0, 2: 24.0, 3: 360.0}[ext]
+    dn = grid_spacing_whose_divisor_needs_a_moved_zl(lead, 1.3) if mode == "moved_zl" else 0.2
+    cfg, par = make_pair((150, 37, 29), ext=ext, potential="Coulomb", dn=dn, dt=dn * dn / 10, mass=1.3, unplanned_div=(mode == "unplanned"))
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=21)
+    with wa.Context(par) as ctx:
+        plan = ctx.div_plan()
+        assert plan.checked == (0 if mode == "unplanned" else 1) and (plan.zl_shift != 0) == (mode == "moved_zl")
+        ctx.set_stencil_variant(variant)
+        ctx.set_potential("Coulomb")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, steps)
+        if variant == 3 and ext == 1:
+            assert ctx.stencil_kernel_instance().startswith("wafer_k_step3_fused<double, double, %s," % ("false" if mode == "unplanned" else "true"))
+        obs = ctx.observables()
+        wo.evolve(cfg, 0, a, b, phi, [], steps)
+        assert ulp_diff(ctx.download_phi(), phi) == 0
+        want = wo.observables(cfg, v, phi)
+        for k in want:   # (the energy integrand divides by the same denominator)
+            assert obs[k] == pytest.approx(want[k], rel=REL_SUM, abs=1e-300)
+
+
 def test_evolve_zero_steps_takes_one(wo, wa):
     """grid.rs:682-685"""
     cfg, par = make_pair((8, 8, 8))

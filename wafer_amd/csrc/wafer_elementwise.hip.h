@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void wafer_k_checksum(WaferRowArgs a, const T 
 // Every thread draws `per_thread` operands x from a counter-based generator (splitmix64 of the global
 // operand index and the seed): uniform significand and sign, biased exponent uniform in [lo_exp, hi_exp].
 // Counts the operands for which wafer_div_invariant(x, den) and x / den differ in any bit.
-static __global__ __launch_bounds__(256) void wafer_k_div_check(double den, unsigned long long seed, int per_thread, int lo_exp,
+template <bool PLANNED>
+static __global__ __launch_bounds__(256) void wafer_k_div_check(WaferDen<double> dv, unsigned long long seed, int per_thread, int lo_exp,
                                                          int hi_exp, unsigned long long *__restrict__ mismatches)
 {
     const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,9 +247,19 @@ static __global__ __launch_bounds__(256) void wafer_k_div_check(double den, unsi
         const unsigned long long e = (unsigned long long)lo_exp + (z >> 53) % (unsigned long long)(hi_exp - lo_exp + 1);
         const unsigned long long bits = (z & 0x800fffffffffffffull) | (e << 52);
         const double x = __longlong_as_double((long long)bits);
-        const double q_fast = wafer_div_invariant<double>(x, den);
-        const double q_ieee = x / den;
+        const double q_fast = PLANNED ? wafer_div_invariant<double>(x, dv) : wafer_div_invariant<double>(x, dv.den);
+        const double q_ieee = x / dv.den;
         bad += (unsigned long long)(__double_as_longlong(q_fast) != __double_as_longlong(q_ieee));
     }
     if (bad) atomicAdd(mismatches, bad);
+}
+// ... the planned division on a list of operands (the plan's candidates, scaled over the exponent range by the caller)
+static __global__ __launch_bounds__(256) void wafer_k_div_operands(WaferDen<double> dv, const double *__restrict__ x, unsigned long long n,
+                                                            unsigned long long *__restrict__ mismatches)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double q_fast = wafer_div_invariant<double>(x[i], dv);
+    const double q_ieee = x[i] / dv.den;
+    if (__double_as_longlong(q_fast) != __double_as_longlong(q_ieee)) atomicAdd(mismatches, 1ull);
 }

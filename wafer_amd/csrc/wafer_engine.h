@@ -22,6 +22,7 @@
 
 #include "../../include/wafer_hip.h"
 #include "wafer_geom.h"
+#include "wafer_divplan.h"
 #include "wafer_stencil.hip.h"
 #include "wafer_stencil_fused3.hip.h"
 #include "wafer_launch.h"
@@ -120,6 +121,7 @@ struct wafer_ctx {
     int potsub_kind = WAFER_POTSUB_NONE;
     double potsub_scalar = 0.0;
     bool have_pot = false, have_phi = false;
+    WaferDivPlan div_plan;   // x / (c dn^2 m) in the step kernels (wafer_divplan.h), made once, at wafer_ctx_create
     bool v_in_range = false; // 2^-400 < |1 + dt*V/2| < 2^400 everywhere (wafer_recip's short form is exact)
     int x2_agreed[4] = {-1, -1, -1, -1}; // [k]: every rank can take the two-step excited pass with k stored states (-1: not agreed yet; x2_agree)
     int vgen_type = 0;       // V was generated from this closed form (Coulomb / SimpleCornell / Harmonic), else 0: kernels may re-evaluate it instead of streaming it
@@ -183,6 +185,20 @@ struct wafer_ctx {
 };
 
 
+// denominators of grid.rs:569 / 594 / 626 (and :314 / 337 / 367)
+static inline double wafer_stencil_den(int R, double dn, double mass)
+{
+    const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
+    return lead * dn * dn * mass;
+}
+// WaferStepArgs::v_in_range: the kernels may take the short arithmetic forms (wafer_recip for b, three instructions for x / den)
+static inline bool short_forms(const wafer_ctx *c) { return c->v_in_range && c->div_plan.checked != 0; }
+static inline void set_den_args(const wafer_ctx *c, WaferStepArgs &a)
+{
+    a.den = c->div_plan.den;
+    a.den_zh = c->div_plan.zh;
+    a.den_zl = c->div_plan.zl;
+}
 static inline int nchunks_of(int nplanes, int zchunk) { return (nplanes + zchunk - 1) / zchunk; }
 template <typename T>
 static inline T *as(void *p) { return static_cast<T *>(p); }

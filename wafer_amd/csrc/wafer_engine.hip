@@ -142,6 +142,9 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
         return fail(WAFER_ERR_INVALID, "central_difference must be 1 (Three), 2 (Five) or 3 (SevenPoint)");
     if (p->dtype != WAFER_F64 && p->dtype != WAFER_F32 && p->dtype != WAFER_F32_FAST) return fail(WAFER_ERR_INVALID, "bad dtype");
     if (!(p->dn > 0) || !(p->dt > 0) || !(p->mass > 0)) return fail(WAFER_ERR_INVALID, "dn, dt, mass must be > 0");
+    const double stencil_den = wafer_stencil_den(p->central_difference, p->dn, p->mass);
+    if (!std::isnormal(stencil_den) || !std::isnormal(1.0 / stencil_den))
+        return fail(WAFER_ERR_INVALID, "dn^2 * mass = %g is outside the range of normal doubles (or its reciprocal is)", p->dn * p->dn * p->mass);
     // config.rs:362-365 (ErrorKind::LargeDt)
     if (!(p->flags & WAFER_FLAG_SKIP_DT_CHECK) && p->dt > p->dn * p->dn / 3.)
         return fail(WAFER_ERR_INVALID, "LargeDt: dt must be <= dn^2/3 (config.rs:363)");
@@ -172,6 +175,8 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->g = wafer_make_geom((int)p->nx, (int)p->ny, (int)p->nz, R, G, (int)zb, (int)zc, (int)c->esz);
     c->bx = (c->g.px + 63) / 64; // covers both the work area and the padded extent
     c->by = (c->g.py + 3) / 4;
+    c->div_plan = wafer_divplan_make(stencil_den);
+    if (p->flags & WAFER_FLAG_UNPLANNED_DIV) c->div_plan.checked = 0;
     c->tune = wafer_tuning_from_env(); // the only place the WAFER_* tuning variables are read
     c->overlap_mode = (c->tune.overlap >= 0 && c->tune.overlap <= 2) ? c->tune.overlap : 2; // the modes of wafer_set_overlap
     // fused passes per halo exchange: 1 unless the host asks for deep halos (wafer_set_halo_cycle) -- a
@@ -791,30 +796,89 @@ int wafer_diag_checksum(wafer_ctx *c, uint32_t z_begin, uint32_t z_count, uint64
     return WAFER_OK;
 }
 
+static int div_check_launch(wafer_ctx *c, const WaferDen<double> &dv, bool planned, uint64_t seed, uint64_t n_random, int lo_exp, int hi_exp,
+                            const double *operands, size_t n_operands, uint64_t *bad_random, uint64_t *bad_operands)
+{
+    if (lo_exp < 0 || hi_exp > 2046 || lo_exp > hi_exp) return fail(WAFER_ERR_INVALID, "biased exponents in 0..2046");
+    HIP_TRY(hipSetDevice(c->P.device));
+    unsigned long long *d = nullptr;
+    double *dx = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 2 * sizeof *d));
+    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof *d, c->s_main);
+    const int per_thread = 1024, threads = 256;
+    const uint64_t blocks = (n_random + (uint64_t)per_thread * threads - 1) / ((uint64_t)per_thread * threads);
+    if (e == hipSuccess && blocks > 0) {
+        const dim3 grid((unsigned)std::min<uint64_t>(blocks, 1u << 30));
+        if (planned) hipLaunchKernelGGL(wafer_k_div_check<true>, grid, dim3(threads), 0, c->s_main, dv, (unsigned long long)seed, per_thread, lo_exp, hi_exp, d);
+        else hipLaunchKernelGGL(wafer_k_div_check<false>, grid, dim3(threads), 0, c->s_main, dv, (unsigned long long)seed, per_thread, lo_exp, hi_exp, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && operands && n_operands) {
+        e = hipMalloc((void **)&dx, n_operands * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpyAsync(dx, operands, n_operands * sizeof(double), hipMemcpyHostToDevice, c->s_main);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(wafer_k_div_operands, dim3((unsigned)((n_operands + 255) / 256)), dim3(256), 0, c->s_main, dv, dx,
+                               (unsigned long long)n_operands, d + 1);
+            e = hipGetLastError();
+        }
+    }
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->s_main);
+    hipError_t e2 = hipStreamSynchronize(c->s_main);
+    (void)hipFree(d);
+    if (dx) (void)hipFree(dx);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(WAFER_ERR_HIP, "division check failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    if (bad_random) *bad_random = h[0];
+    if (bad_operands) *bad_operands = h[1];
+    return WAFER_OK;
+}
+
 int wafer_diag_div_check(wafer_ctx *c, double den, uint64_t seed, uint64_t n_operands, int lo_exp, int hi_exp,
                          uint64_t *mismatches)
 {
     if (!c || !mismatches) return fail(WAFER_ERR_INVALID, "null argument");
-    if (lo_exp < 0 || hi_exp > 2046 || lo_exp > hi_exp) return fail(WAFER_ERR_INVALID, "biased exponents in 0..2046");
-    HIP_TRY(hipSetDevice(c->P.device));
-    unsigned long long *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, sizeof *d));
-    hipError_t e = hipMemsetAsync(d, 0, sizeof *d, c->s_main);
-    const int per_thread = 1024, threads = 256;
-    const uint64_t blocks = (n_operands + (uint64_t)per_thread * threads - 1) / ((uint64_t)per_thread * threads);
-    if (e == hipSuccess && blocks > 0) {
-        hipLaunchKernelGGL(wafer_k_div_check, dim3((unsigned)std::min<uint64_t>(blocks, 1u << 30)), dim3(threads), 0, c->s_main, den,
-                           (unsigned long long)seed, per_thread, lo_exp, hi_exp, d);
-        e = hipGetLastError();
+    return div_check_launch(c, WaferDen<double>{den, 0.0, 0.0, false}, false, seed, n_operands, lo_exp, hi_exp, nullptr, 0, mismatches, nullptr);
+}
+
+static void plan_out(const WaferDivPlan &p, wafer_div_plan_t *out)
+{
+    out->den = p.den;
+    out->zh = p.zh;
+    out->zl = p.zl;
+    out->checked = p.checked;
+    out->n_candidates = p.n_candidates;
+    out->zl_shift = p.zl_shift;
+    out->reserved = 0;
+}
+
+int wafer_div_plan(double den, wafer_div_plan_t *out, double *candidates, size_t cap, size_t *n_written)
+{
+    if (!out) return fail(WAFER_ERR_INVALID, "null argument");
+    plan_out(wafer_divplan_make(den), out);
+    if (n_written) *n_written = 0;
+    if (candidates && cap) {
+        const std::vector<double> cand = wafer_divplan_candidates(den);
+        const size_t n = std::min(cap, cand.size());
+        std::copy(cand.begin(), cand.begin() + (ptrdiff_t)n, candidates);
+        if (n_written) *n_written = n;
     }
-    unsigned long long h = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, c->s_main);
-    hipError_t e2 = hipStreamSynchronize(c->s_main);
-    (void)hipFree(d);
-    if (e != hipSuccess || e2 != hipSuccess)
-        return fail(WAFER_ERR_HIP, "division check failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
-    *mismatches = h;
     return WAFER_OK;
+}
+
+int wafer_get_div_plan(wafer_ctx *c, wafer_div_plan_t *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    plan_out(c->div_plan, out);
+    return WAFER_OK;
+}
+
+int wafer_diag_div_planned(wafer_ctx *c, const wafer_div_plan_t *plan, uint64_t seed, uint64_t n_random, int lo_exp, int hi_exp,
+                           const double *operands, size_t n_operands, uint64_t *mismatches_random, uint64_t *mismatches_operands)
+{
+    if (!c || !plan) return fail(WAFER_ERR_INVALID, "null argument");
+    return div_check_launch(c, WaferDen<double>{plan->den, plan->zh, plan->zl, plan->checked != 0}, true, seed, n_random, lo_exp, hi_exp, operands,
+                            n_operands, mismatches_random, mismatches_operands);
 }
 
 int wafer_set_stream(wafer_ctx *c, void *hip_stream)

@@ -107,10 +107,8 @@ WaferStepArgs step_args(const wafer_ctx *c, int lz_lo, int lz_hi)
     a.lz_hi = lz_hi;
     a.dt = c->P.dt;
     a.target_blocks = c->num_cus;
-    a.v_in_range = c->v_in_range ? 1 : 0;
-    const int R = c->g.R;
-    const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
-    a.den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:569 / 594 / 626
+    a.v_in_range = short_forms(c) ? 1 : 0;
+    set_den_args(c, a);
     set_vg_args(c, a);
     return a;
 }
@@ -495,7 +493,7 @@ int x2_agree(wafer_ctx *c, uint32_t wnum, bool *out)
 {
     *out = false;
     if (!x2_applies(c, wnum)) return WAFER_OK;
-    bool local_ok = c->v_in_range && (!c->sharded() || c->g.nzl >= 2);
+    bool local_ok = short_forms(c) && (!c->sharded() || c->g.nzl >= 2);
     if (local_ok && alloc_mstates(c, wnum) != WAFER_OK) local_ok = false;
     if (!c->sharded()) { *out = local_ok; return WAFER_OK; }
     if (!c->allreduce_hook) return WAFER_OK;
@@ -872,8 +870,6 @@ int wafer_observables(wafer_ctx *c, wafer_observables_t *out)
     RoctxRange range_("wafer_observables");
     TRY(ensure_halo(c, c->g.R));
     const int R = c->g.R;
-    const double lead = (R == 1) ? 2. : (R == 2) ? 24. : 360.;
-    const double den = lead * c->P.dn * c->P.dn * c->P.mass; // grid.rs:314 / 337 / 367
     long long nb = 0;
     {
         // the LDS pipeline of the step kernel in its observables mode: 16 B per lane from HBM
@@ -882,8 +878,9 @@ int wafer_observables(wafer_ctx *c, wafer_observables_t *out)
         sa.lz_lo = c->g.G;
         sa.lz_hi = c->g.G + c->g.nzl;
         sa.dt = c->P.dt;
-        sa.den = den;
+        set_den_args(c, sa);   // grid.rs:314 / 337 / 367: the step's denominator
         sa.target_blocks = c->num_cus;
+        sa.v_in_range = short_forms(c) ? 1 : 0;
         sa.potsub_kind = c->potsub_kind;
         sa.potsub_scalar = c->potsub_scalar;
         set_vg_args(c, sa);

@@ -6,6 +6,7 @@
 // bit-for-bit what rustc emits for the same inputs (IEEE add/mul/div, no FMA).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "wafer_geom.h"
 #include "wafer_tuning.h"
 
@@ -98,15 +99,13 @@ __device__ __forceinline__ double wafer_recip(double x, bool in_range)
 }
 __device__ __forceinline__ float wafer_recip(float x, bool) { return 1.0f / x; }
 
-// x / den for the loop-invariant denominator c*dn^2*m.  The fp64 form hoists y = RN(1/den) (the
-// compiler moves the one IEEE division out of the plane loop) and refines q = x*y with two exact
-// remainders: after the first, q is a faithful quotient; Markstein's theorem (correctly rounded
-// reciprocal + faithful quotient + exact remainder by FMA) makes the second RN(x/den) -- the bits of
-// the IEEE division, in 5 full-rate instructions instead of the 11 of the division sequence with its
-// quarter-rate v_rcp_f64.  v_div_fixup restores the IEEE results for zero / infinite / NaN operands.
-// Outside the theorem: |x| < 2^-960 (the remainder is no longer exact in the subnormal range; the
-// quotient is then within one ulp) -- wavefunction values below 1e-289.  -DWAFER_IEEE_DIV keeps the
-// division.
+// x / den for a loop-invariant divisor the host has NOT planned (norms, projection coefficients).  The fp64 form hoists
+// y = RN(1/den) (the compiler moves the one IEEE division out of the loop) and refines q = x*y with two exact remainders: after
+// the first, q is a faithful quotient; Markstein's theorem (correctly rounded reciprocal + faithful quotient + exact remainder by
+// FMA) makes the second RN(x/den) -- the bits of the IEEE division, in 5 full-rate instructions instead of the 11 of the division
+// sequence with its quarter-rate v_rcp_f64.  v_div_fixup restores the IEEE results for zero / infinite / NaN operands.
+// Outside the theorem: |x| < 2^-960 (the remainder is no longer exact in the subnormal range; the quotient is then within one
+// ulp) -- wavefunction values below 1e-289.  -DWAFER_IEEE_DIV keeps the division.
 template <typename T>
 __device__ __forceinline__ T wafer_div_invariant(T x, T den)
 {
@@ -126,9 +125,49 @@ __device__ __forceinline__ double wafer_div_invariant<double>(double x, double d
 }
 #endif
 
+// x / den for the run's ONE stencil denominator c*dn^2*m (grid.rs:569 / 594 / 626), which the host plans when the context is
+// created (wafer_divplan.h, wafer_div_plan): zh = RN(1/den) and zl ~ RN(1/den - zh) arrive as kernel arguments (scalar
+// registers), and q = RN(x*zh + RN(x*zl)) -- a multiplication and a fused multiply-add (Brisebarre, Muller, Raina 2004) -- is x/den
+// with an error below 2^-52 ulp BEFORE its one rounding: it is RN(x/den) unless x/den lies that close to the midpoint of two
+// neighbouring doubles.  For a given den only a few dozen significands x come that close (solutions of X*2^s - M*den_mant = k,
+// |k| small: the plan enumerates them all), and the plan tries every one of them, with the very instructions below, against the
+// IEEE division: `checked` says that they all came out right -- then the three instructions give the bits of the division for
+// EVERY x (|x/den| >= 2^-960; v_div_fixup again for zero / infinite / NaN operands).  Nine divisors in ten pass with the first
+// zl tried, the plan may move zl by an ulp or two to get the rest through, and a divisor that still fails (none seen) runs with
+// one Markstein round more (q is faithful whatever the plan found, so that round yields RN(x/den) by the theorem above).
+// 3 or 5 instructions against 6: the step kernels are bound by their vector issue slots as much as by HBM (profiles/NOTES.md,
+// round 5), 16 divisions per wave and plane in the three-step kernel.
+template <typename T>
+struct WaferDen {
+    T den;
+};
+template <>
+struct WaferDen<double> {
+    double den, zh, zl;
+    bool checked;
+};
+template <typename T>
+__device__ __forceinline__ T wafer_div_invariant(T x, const WaferDen<T> &d)
+{
+#ifdef WAFER_DIV_UNPLANNED   // (A/B builds: the hoisted reciprocal with two remainders, what every division was before the plan)
+    return wafer_div_invariant<T>(x, d.den);
+#endif
+#ifndef WAFER_IEEE_DIV
+    if constexpr (std::is_same_v<T, double>) {
+        double q = __builtin_fma(x, d.zh, x * d.zl);
+        if (!d.checked) {   // (a template argument in the multi-step kernels)
+            const double r = __builtin_fma(-q, d.den, x);
+            q = __builtin_fma(r, d.zh, q);
+        }
+        return __builtin_amdgcn_div_fixup(q, d.den, x);
+    } else
+#endif
+        return x / d.den;
+}
+
 // grid.rs:580-589: *work = w*pa + pb*dt*S/denominator
 template <typename T>
-__device__ __forceinline__ T wafer_update(T w, T pa, T pb, T dt, T S, T den)
+__device__ __forceinline__ T wafer_update(T w, T pa, T pb, T dt, T S, const WaferDen<T> &den)
 {
     return w * pa + wafer_div_invariant<T>(pb * dt * S, den);
 }
@@ -143,12 +182,14 @@ struct WaferStepArgs {
     int lz_lo, lz_hi;   // local planes [lz_lo, lz_hi) to update
     int zchunk;         // planes marched by one workgroup
     int target_blocks;  // workgroups a launch should aim for (the device's CU count)
-    int v_in_range;     // 2^-400 < |1 + dt*V/2| < 2^400 everywhere: wafer_recip may take its short form
+    int v_in_range;     // the short arithmetic forms are exact for this run: 2^-400 < |1 + dt*V/2| < 2^400 everywhere (wafer_recip)
+                        // AND the plan of x / den is checked (WaferDen)
     // fused kernel, mixed launch (slab interiors): the first n_long workgroups march all of
     // [lz_lo, lz_hi) for one tile each, the remaining tiles are cut into nsub workgroups of zchunk
     // planes; nsub <= 1: every tile is cut into workgroups of zchunk planes
     int n_long, nsub;
     double dt, den;
+    double den_zh = 0.0, den_zl = 0.0;   // the plan of x / den (WaferDen, wafer_divplan.h); "checked" travels in v_in_range
     // observables mode of the LDS kernel (NLOW = -2): wafer_potsub_kind and the scalar pot_sub
     int potsub_kind = 0;
     double potsub_scalar = 0.0;
@@ -156,6 +197,15 @@ struct WaferStepArgs {
     // wafer_k_step_lds): the parameters potential.rs:188-274 reads
     double vg_dn = 0.0, vg_mass = 0.0, vg_sig = 0.0;
 };
+
+// short_forms: WaferStepArgs::v_in_range, as the kernel knows it -- a template argument (VIR) in the multi-step kernels, where the
+// extra round is then compiled in or out; tested at run time in the single-step ones (the compiler turns that into a select)
+template <typename T>
+__device__ __forceinline__ WaferDen<T> wafer_den(const WaferStepArgs &a, bool short_forms)
+{
+    if constexpr (std::is_same_v<T, double>) return WaferDen<double>{a.den, a.den_zh, a.den_zl, short_forms};
+    else return WaferDen<T>{(T)a.den};
+}
 
 // ---------------------------------------------------------------------------
 // Variant 0: z-marching, register queue along z, x/y neighbours straight from
@@ -177,7 +227,8 @@ __global__ __launch_bounds__(256) void wafer_k_step_direct(WaferStepArgs a, cons
     const int zs = a.lz_lo + blockIdx.z * a.zchunk;
     const int ze = min(zs + a.zchunk, a.lz_hi);
     const bool active = (i < g.nx) && (j < g.ny);
-    const C dt = (C)a.dt, den = (C)a.den;
+    const C dt = (C)a.dt;
+    const WaferDen<C> den = wafer_den<C>(a, a.v_in_range != 0);
     double acc = 0.0;
     if (active) {
         const long long col = (long long)(j + R) * g.pitch + g.xoff + (i + R);

@@ -60,11 +60,11 @@ struct WaferF2Cfg {
 
 // a, b from V, then the update: potential.rs:104-110 + grid.rs:580-589
 template <typename C>
-__device__ __forceinline__ C wafer_update_v(C w, C vv, C dt, C S, C den, bool v_in_range)
+__device__ __forceinline__ C wafer_update_v(C w, C vv, C dt, C S, const WaferDen<C> &den, bool v_in_range)
 {
     const C cb = wafer_recip(C(1) + dt * vv / C(2), v_in_range);
     const C ca = (C(1) - dt * vv / C(2)) * cb;
-    return w * ca + cb * dt * S / den;
+    return w * ca + wafer_div_invariant<C>(cb * dt * S, den);
 }
 
 // a, b of one cell from V (potential.rs:104-110)
@@ -123,8 +123,9 @@ __global__ __launch_bounds__((WaferF2Cfg<T, R, NW2>::NT_)) void wafer_k_step2_fu
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: role tests become scalar branches
     const int x0 = tx_i * TX, y0 = ty_i * TY;
-    const C dt = (C)a.dt, den = (C)a.den;
+    const C dt = (C)a.dt;
     constexpr bool vir = VIR;
+    const WaferDen<C> den = wafer_den<C>(a, vir);
     const bool is_main = wave < Cfg::NW2;
     const bool is_hrow = wave >= Cfg::NW2 && wave < Cfg::NW2 + Cfg::NWH;
     const bool is_hcol = wave == Cfg::NW - 1;

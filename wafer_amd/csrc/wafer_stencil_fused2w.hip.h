@@ -84,8 +84,9 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = tx_i * TX, y0 = ty_i * TY;
-    const C dt = (C)a.dt, den = (C)a.den;
+    const C dt = (C)a.dt;
     constexpr bool vir = VIR;
+    const WaferDen<C> den = wafer_den<C>(a, vir);
     const bool x_row = wave < 2 || wave >= 6;   // the extra slot is a halo row (else: halo-column cells)
 
     VT zero;

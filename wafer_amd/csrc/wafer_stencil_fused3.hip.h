@@ -256,8 +256,9 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = tx_i * TX, y0 = ty_i * TY;
-    const C dt = (C)a.dt, den = (C)a.den;
+    const C dt = (C)a.dt;
     constexpr bool vir = VIR;
+    const WaferDen<C> den = wafer_den<C>(a, vir);
     // the extra slot: a halo row (waves 0, 1, 6, 7) or halo-column cells (waves 2..5)
     const bool x_row = wave < 2 || wave >= 6;
     const bool x_l2 = wave == 0 || wave == 7;            // the halo row next to the tile: phi2 as well

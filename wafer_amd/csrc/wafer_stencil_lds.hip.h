@@ -276,7 +276,8 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
         hcol_lds[q] = (row + R) * LP + ((k < R) ? (HX - 1 - k) : (HX + TX + (k - R)));
     }
 
-    const C dt = (C)a.dt, den = (C)a.den;
+    const C dt = (C)a.dt;
+    const WaferDen<C> den = wafer_den<C>(a, VIRT < 0 ? a.v_in_range != 0 : VIRT != 0);
     [[maybe_unused]] WaferPotArgs vgen;   // only the fields wafer_potential_at reads for these types
     if constexpr (VG != 0) {
         vgen.g = g;
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(NW * 64) void wafer_k_step_lds(WaferStepArgs a, int
                         double vv;
                         if constexpr (VG != 0) vv = wafer_vgen_at<VG>(vgen, xi + v + R, y0 + yl + r + R, g.zp_of(z));
                         else vv = (double)ab_a[r][v];
-                        ob_e += vv * w * w - wafer_div_invariant<double>(w * S, den); // grid.rs:325-332 (the bits of the IEEE quotient)
+                        ob_e += vv * w * w - wafer_div_invariant<double>(w * S, wafer_den<double>(a, a.v_in_range != 0)); // grid.rs:325-332 (the bits of the IEEE quotient)
                         ob_n += w * w;                      // grid.rs:407
                         if (a.potsub_kind == 2) ob_v += w * w * (double)psub[v];      // grid.rs:410-418
                         else if (a.potsub_kind == 1) ob_v += w * w * a.potsub_scalar; // grid.rs:419-424

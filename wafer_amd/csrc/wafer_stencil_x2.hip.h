@@ -153,8 +153,9 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = tx_i * TX, y0 = ty_i * TY;
-    const C dt = (C)a.dt, den = (C)a.den;
+    const C dt = (C)a.dt;
     constexpr bool vir = VIR;
+    const WaferDen<C> den = wafer_den<C>(a, vir);
     const bool x_row = wave < 2 || wave >= 6;
     const bool x_l1 = wave == 0 || wave == 7;            // the halo row next to the tile: Y1 as well
 

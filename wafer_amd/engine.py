@@ -30,6 +30,7 @@ CENTRAL_DIFFERENCE = {"ThreePoint": 1, "FivePoint": 2, "SevenPoint": 3}  # confi
 WAFER_OK = 0
 WAFER_ERR_MAX_STEP = -5
 FLAG_SKIP_DT_CHECK = 1
+FLAG_UNPLANNED_DIV = 2
 
 EXPORTS = [
     "wafer_abi_version", "wafer_last_error", "wafer_ctx_create", "wafer_ctx_destroy",
@@ -40,10 +41,19 @@ EXPORTS = [
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_kernel_instance", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
-    "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check",
+    "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check", "wafer_div_plan", "wafer_get_div_plan", "wafer_diag_div_planned",
     "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_set_halo_cycle", "wafer_diag_x2_passes",
     "wafer_peer_export", "wafer_peer_connect", "wafer_peer_disconnect",
 ]
+
+
+class _DivPlan(C.Structure):
+    """wafer_div_plan_t (include/wafer_hip.h)"""
+    _fields_ = [("den", C.c_double), ("zh", C.c_double), ("zl", C.c_double), ("checked", C.c_int32), ("n_candidates", C.c_int32),
+                ("zl_shift", C.c_int32), ("reserved", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
 class WaferError(RuntimeError):
@@ -145,6 +155,10 @@ def load_library():
     L.wafer_symmetrise.argtypes = [vp, C.c_int]
     L.wafer_download_phi_owned.argtypes = [vp, dp]
     L.wafer_diag_div_check.argtypes = [vp, C.c_double, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    L.wafer_div_plan.argtypes = [C.c_double, C.POINTER(_DivPlan), dp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.wafer_get_div_plan.argtypes = [vp, C.POINTER(_DivPlan)]
+    L.wafer_diag_div_planned.argtypes = [vp, C.POINTER(_DivPlan), C.c_uint64, C.c_uint64, C.c_int, C.c_int, dp, C.c_size_t,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.wafer_diag_copy_bw.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     L.wafer_diag_checksum.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.wafer_diag_x2_passes.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -208,6 +222,7 @@ class Params:
     z_count: int = 0                 # 0 = whole grid
     halo_depth: int = 0              # 0 = ext
     skip_dt_check: bool = False
+    unplanned_div: bool = False      # WAFER_FLAG_UNPLANNED_DIV: x / (c dn^2 m) always with the extra Markstein round
 
     @property
     def ext(self) -> int:
@@ -227,7 +242,20 @@ class Params:
         return _Params(C.sizeof(_Params), self.nx, self.ny, self.nz, self.ext,
                        {"f64": 0, "f32": 1, "f32fast": 2}[self.dtype], self.dn, self.dt, self.mass, self.sig,
                        self.max_states, self.device, self.z_begin, self.z_count, self.halo_depth,
-                       FLAG_SKIP_DT_CHECK if self.skip_dt_check else 0)
+                       (FLAG_SKIP_DT_CHECK if self.skip_dt_check else 0) | (FLAG_UNPLANNED_DIV if self.unplanned_div else 0))
+
+
+def div_plan(den: float, max_candidates: int = 4096):
+    """(plan, candidates): wafer_div_plan -- host only, no GPU: how the step kernels will divide by `den`, and the significands
+    (doubles in [2^52, 2^53)) the plan had to try"""
+    L = load_library()
+    p = _DivPlan()
+    cand = np.zeros(max_candidates)
+    n = C.c_size_t(0)
+    rc = L.wafer_div_plan(den, C.byref(p), _dp(cand), cand.size, C.byref(n))
+    if rc != 0:
+        raise WaferError(rc, L.wafer_last_error().decode())
+    return p, cand[:n.value].copy()
 
 
 def _dp(a: np.ndarray):
@@ -323,6 +351,21 @@ class Context:
         bad = C.c_uint64(0)
         self._check(self._L.wafer_diag_div_check(self._h, den, seed, n_operands, lo_exp, hi_exp, C.byref(bad)))
         return int(bad.value)
+
+    def div_plan(self) -> _DivPlan:
+        """the plan of x / (c dn^2 m) this context's kernels run with (wafer_get_div_plan)"""
+        p = _DivPlan()
+        self._check(self._L.wafer_get_div_plan(self._h, C.byref(p)))
+        return p
+
+    def div_planned_check(self, plan: _DivPlan, n_random: int = 0, operands=None, lo_exp: int = 64, hi_exp: int = 1983, seed: int = 1):
+        """(mismatches among n_random drawn operands, mismatches among `operands`): the planned division as the kernels perform
+        it against the device's IEEE x / den, bit for bit (wafer_diag_div_planned)"""
+        ops = np.ascontiguousarray(operands, dtype=np.float64) if operands is not None else np.zeros(0)
+        bad_r, bad_o = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._L.wafer_diag_div_planned(self._h, C.byref(plan), seed, n_random, lo_exp, hi_exp,
+                                                   _dp(ops) if ops.size else None, ops.size, C.byref(bad_r), C.byref(bad_o)))
+        return int(bad_r.value), int(bad_o.value)
 
     def download_phi_owned(self) -> np.ndarray:
         """the work cells of the planes this context owns, (nx, ny, z_count)"""
