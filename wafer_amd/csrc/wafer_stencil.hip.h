@@ -37,6 +37,18 @@ __device__ __forceinline__ double wafer_block_sum(double v, double *red, int tid
     return s;
 }
 
+// The multi-step kernels' result stores: streamed (non-temporal) -- nobody reads the new wavefunction before the next launch.
+// -DWAFER_PLAIN_STORES: A/B builds.
+template <typename VT>
+__device__ __forceinline__ void wafer_store_result(VT *p, VT v)
+{
+#ifdef WAFER_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
 // ---- a value of the neighbouring lane by DPP (gfx9 wave shifts), for x neighbours that the lane next door holds in registers.
 // wafer_lane_below(own, edge): lane i gets lane i-1's `own`, lane 0 keeps `edge`; wafer_lane_above: lane i gets lane i+1's,
 // lane 63 keeps `edge`.  Two v_mov_b32 with a DPP control per double (the shifts exist for 32-bit operands only).

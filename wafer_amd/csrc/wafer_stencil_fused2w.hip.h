@@ -385,7 +385,7 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
                         SVT st;   // (the value is a storage-type number already: as_stored)
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) st[v] = (ST)res2[r][v];
-                        if (INTERIOR || xi + VEC <= g.nx) *reinterpret_cast<SVT *>(dst) = st;
+                        if (INTERIOR || xi + VEC <= g.nx) wafer_store_result(reinterpret_cast<SVT *>(dst), st);   // (streamed: wafer_stencil_fused3.hip.h, gstore)
                         else {
 #pragma unroll
                             for (int v = 0; v < VEC; ++v)

@@ -229,6 +229,10 @@ __device__ __forceinline__ void wafer_step3_body(const WaferStepArgs &a, const W
     // global loads of a lane's vector / of one cell, widened to the register type
     auto gload = [](const ST *p) -> VT { return wafer_f3_widen<SVT, VT, WaferF3Vec<T>::N>(*reinterpret_cast<const SVT *>(p)); };
     auto gload_raw = [](const ST *p) -> SVT { return *reinterpret_cast<const SVT *>(p); };
+    // the result is streamed: nobody reads it before the next launch (the same box, 512^3 / 1024^3: 0.2150 -> 0.2067 / 1.98 -> 1.87
+    // ms per step against plain stores; non-temporal LOADS of V or phi0 lose 4-12 %: the halo requests of the tiles next door want
+    // those lines in the L2 -- profiles/r05_ab_f3_nontemporal.jsonl)
+    auto gstore = [](ST *p, SVT v) { wafer_store_result(reinterpret_cast<SVT *>(p), v); };
     auto widen = [](const SVT &x) -> VT { return wafer_f3_widen<SVT, VT, WaferF3Vec<T>::N>(x); };
     // a level's result as the storage type holds it (fp32 storage: rounded once per step, like a store and a load would)
     auto as_stored = [](C x) -> T { return (T)(ST)x; };

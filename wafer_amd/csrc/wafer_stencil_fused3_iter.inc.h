@@ -341,8 +341,12 @@
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     if (INTERIOR || rowwk[r]) {
-#if WAFER_DIAG & 4   // timing experiment: nothing is stored (the compiler cannot know)
-                        if (a.dt > -1.0) continue;
+#if WAFER_DIAG & 4   // timing experiment: nothing is stored; level 3's results stay live (a test on a kernel argument let the
+                     // compiler sink level 3's arithmetic behind the test -- the round-5 "no stores" figure had lost a fifth of the
+                     // vector work with the stores)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) asm volatile("" ::"v"(res3[r][v]));
+                        continue;
 #endif
                         const int zst = !XS ? zo3 : DOWN ? (zo3 < ze - 1 ? zo3 : ze - 1) : (zo3 > zs ? zo3 : zs);
                         ST *dst = (out + (long long)zst * g.plane + rowoff[r]) + xlu;
@@ -361,7 +365,7 @@
                         if constexpr (XS) {
                             // (overlap mode 2's tail: the planes the exchange reads while this kernel runs are written through)
                             if (!(SYNC && !PEER) || !wthrough) {
-                                *reinterpret_cast<SVT *>(dst) = st3;
+                                gstore(dst, st3);
                                 continue;
                             }
                         }
@@ -370,7 +374,7 @@
                             for (int v = 0; v < VEC; ++v)
                                 if (INTERIOR || xi + v < g.nx) __hip_atomic_store(dst + v, st3[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         } else if (INTERIOR || xi + VEC <= g.nx) {
-                            *reinterpret_cast<SVT *>(dst) = st3;
+                            gstore(dst, st3);
                         } else {
 #pragma unroll
                             for (int v = 0; v < VEC; ++v)

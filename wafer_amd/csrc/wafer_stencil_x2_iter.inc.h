@@ -252,7 +252,7 @@
 #endif
                         T *dst = (out + (long long)(XS && zp2 < zs ? zs : zp2) * g.plane + rowoff[r]) + xlu;
                         if (INTERIOR || xi + VEC <= g.nx) {
-                            *reinterpret_cast<VT *>(dst) = res2[r];
+                            wafer_store_result(reinterpret_cast<VT *>(dst), res2[r]);   // (streamed: wafer_stencil_fused3.hip.h, gstore)
                         } else {
 #pragma unroll
                             for (int v = 0; v < VEC; ++v)
