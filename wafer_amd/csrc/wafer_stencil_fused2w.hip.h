@@ -33,6 +33,9 @@
 #include "wafer_storage.h"
 
 #define WAFER_W2_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#ifndef WAFER_DIAG
+#define WAFER_DIAG 0
+#endif
 
 template <typename T>
 struct WaferW2Cfg {
@@ -202,7 +205,11 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
     const int zend = ze + R;   // phi1 planes z1 .. zend - 1
     for (int z = z1; z < zend; ++z) {
         const bool more = z + 1 < zend;
+#if WAFER_DIAG & 2   // timing experiment (wafer_stencil_fused3.hip.h): every prefetch asks for the column's first planes again (cache hits)
+        const long long zo = (long long)(z1 + (z & 1)) * g.plane;
+#else
         const long long zo = (long long)z * g.plane;
+#endif
         // ---- 1. prefetch: phi0 three planes ahead, V one plane ahead, the outer row two planes ahead -- not issued together:
         //         the main rows' phi0 at the top, their V behind level 1, the extra slot's three behind its level 1
         SVT pre[RY], pre_v[RY], xpre = szero, xpre_v = szero, orow_pre = szero;
@@ -381,6 +388,11 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
                     if (INTERIOR || rowwk[r]) {
+#if WAFER_DIAG & 4   // timing experiment: nothing is stored, the results stay live
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) asm volatile("" ::"v"(res2[r][v]));
+                        continue;
+#endif
                         ST *dst = out + (long long)zo2 * g.plane + rowoff[r];
                         SVT st;   // (the value is a storage-type number already: as_stored)
 #pragma unroll
