@@ -843,6 +843,13 @@ const char *wafer_stencil_kernel_instance(wafer_ctx *c)
         wafer_step3_last_instance(c->instance_name, sizeof c->instance_name);
         if (c->instance_name[0]) return c->instance_name;
     }
+    if (wafer_stencil_steps_per_launch(c) == 2 && c->g.R == 2 && c->tune.f2_wide != 0) {   // wafer_entry_step2_fused hands FivePoint on
+        const int tc = type_combo(c, true);
+        snprintf(c->instance_name, sizeof c->instance_name, "wafer_k_step2_wide<%s, %s, %s>",
+                 tc == WAFER_TC_F64 ? "double" : tc == WAFER_TC_F32_F64 ? "wafer_f32_wide" : "float", tc == WAFER_TC_F32_F32 ? "float" : "double",
+                 short_forms(c) ? "true" : "false");
+        return c->instance_name;
+    }
     return wafer_stencil_kernel_name(c);
 }
 
