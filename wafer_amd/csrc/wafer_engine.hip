@@ -172,12 +172,12 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->f32 = (p->dtype == WAFER_F32 || p->dtype == WAFER_F32_FAST);
     c->f32_arith = (p->dtype == WAFER_F32_FAST);
     c->esz = c->f32 ? 4 : 8;
-    c->g = wafer_make_geom((int)p->nx, (int)p->ny, (int)p->nz, R, G, (int)zb, (int)zc, (int)c->esz);
+    c->tune = wafer_tuning_from_env(); // the only place the WAFER_* tuning variables are read
+    c->g = wafer_make_geom((int)p->nx, (int)p->ny, (int)p->nz, R, G, (int)zb, (int)zc, (int)c->esz, c->tune.plane_pad_rows);
     c->bx = (c->g.px + 63) / 64; // covers both the work area and the padded extent
     c->by = (c->g.py + 3) / 4;
     c->div_plan = wafer_divplan_make(stencil_den);
     if (p->flags & WAFER_FLAG_UNPLANNED_DIV) c->div_plan.checked = 0;
-    c->tune = wafer_tuning_from_env(); // the only place the WAFER_* tuning variables are read
     c->overlap_mode = (c->tune.overlap >= 0 && c->tune.overlap <= 2) ? c->tune.overlap : 2; // the modes of wafer_set_overlap
     // fused passes per halo exchange: 1 unless the host asks for deep halos (wafer_set_halo_cycle) -- a
     // concentrated exchange outlasts the interior launch it hides behind on anything but a very fast link

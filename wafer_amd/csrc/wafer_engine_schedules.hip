@@ -287,8 +287,15 @@ int launch_step3(wafer_ctx *c, int src, int dst, int lz_lo, int lz_hi, hipStream
     if (short_tail && lz_hi - lz_lo >= 8 * 4) TRY(f3_table(c, F3_MIXED, lz_lo, lz_hi, 4, &tab));
     else if (c->tune.f3_sched == 1 && !c->sharded() && lz_hi - lz_lo >= 16) TRY(f3_table(c, F3_HALVES, lz_lo, lz_hi, 2 /* no flags, no counters */, &tab));
     else TRY(f3_table(c, F3_PLAIN, lz_lo, lz_hi, wafer_f3_zchunk(c->tune, ntx, nty, lz_hi - lz_lo, c->num_cus), &tab));
-    if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, WaferF3Sync(), c->phi[src], c->v, c->phi[dst], s, tab->dir) != hipSuccess)
-        return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    // More workgroups than CUs and whole rounds of them per layer of tiles: one launch per round of CUs (wafer_f3_zchunk says why).  The
+    // table hands XCD k a contiguous band in blocks of 8, so a sub-range that starts at a multiple of 8 keeps every workgroup on the XCD the table meant it for.
+    const int slots = c->tune.target_blocks > 0 ? c->tune.target_blocks : c->num_cus;
+    const int per_launch = (tab->kind == F3_PLAIN && slots % 8 == 0 && wafer_f3_by_rounds(c->tune, (long long)ntx * nty, lz_hi - lz_lo, slots)) ? slots : tab->nblocks;
+    for (int first = 0; first < tab->nblocks; first += per_launch) {
+        const int nb = std::min(per_launch, tab->nblocks - first);
+        if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev + first, nb, WaferF3Sync(), c->phi[src], c->v, c->phi[dst], s, tab->dir) != hipSuccess)
+            return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     c->last_instance_valid = true;
     return WAFER_OK;
 }

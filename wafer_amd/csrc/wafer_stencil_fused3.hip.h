@@ -712,6 +712,12 @@ static inline void wafer_f3_schedule_whole(std::vector<WaferF3Block> &out, int n
     }
 }
 
+// a plain launch goes as one launch per round of CUs, its columns cut to at most 384 planes (wafer_f3_zchunk says when and why)
+static inline bool wafer_f3_by_rounds(const WaferTuning &t, long long tiles_per_layer, int nplanes, long long slots)
+{
+    return t.f3_rounds != 0 && t.zchunk <= 0 && tiles_per_layer > slots && tiles_per_layer % slots == 0 && nplanes > 384;
+}
+
 // planes per workgroup of the plain schedule: one workgroup per CU marching a long column (as the two-step kernel)
 static inline int wafer_f3_zchunk(const WaferTuning &t, int ntx, int nty, int nplanes, int target_blocks)
 {
@@ -719,7 +725,17 @@ static inline int wafer_f3_zchunk(const WaferTuning &t, int ntx, int nty, int np
     if (target_blocks < 0) return -target_blocks < nplanes ? -target_blocks : nplanes;
     const long long per_layer = (long long)ntx * nty;
     const long long target = t.target_blocks > 0 ? t.target_blocks : (target_blocks > 0 ? target_blocks : 256);
-    return wafer_pick_zchunk(per_layer, nplanes, target, 6);   // four iterations of pipeline fill + the prologue
+    const int zc = wafer_pick_zchunk(per_layer, nplanes, target, 6);   // four iterations of pipeline fill + the prologue
+    // More workgroups than CUs (1024^3 on one GPU: 512 tiles): over columns of a thousand planes the workgroups of a round drift
+    // apart, the second round starts staggered, and the halo rows of the tile next door are no longer in the XCD's L2 when a
+    // workgroup asks for them (1.25 x the arrays in traffic against 1.08 at 512^3); how far apart depends on the box: 1.78 - 2.05
+    // ms per step over the pool.  Columns of at most 384 planes, every round of CUs a launch of its own (launch_step3): 1.69 - 1.83
+    // on the same boxes (profiles/r05_sweep_rounds_1024.jsonl).
+    // Only where a layer of tiles is whole rounds of CUs (a launch per round ends on its slowest workgroup; rounds that do not fill
+    // the chip are better served by one launch that hands a free CU the next column) and the columns are long (1024 x 1024 x 256:
+    // 2.6 % slower by rounds).
+    if (wafer_f3_by_rounds(t, per_layer, nplanes, target)) return wafer_pick_zchunk(per_layer, nplanes, target, 6, 384);
+    return zc;
 }
 
 // which instantiation the last launch of this thread took (bench.py prints it and matches the committed counter figures by it)

@@ -47,6 +47,9 @@ struct WaferTuning {
     int peer_same_device = 0; // WAFER_PEER_SAME_DEVICE: 1 = wafer_peer_connect accepts a neighbour that is another context on this device (tests: ranks folded onto one GPU)
     int f3_xs = 1;          // WAFER_F3_XS: the three-step kernel with an exact store count per plane iteration where it applies (plain launches, grids of whole tiles); 0 = never
     int f3_plain_down = 0;  // WAFER_F3_PLAIN_DOWN: 1 = the plain schedule's workgroups march their columns downwards (the same bits; the two directions are separate copies of the loop, and the compiler's register allocation differs between them)
+    int plane_pad_rows = 0; // WAFER_PLANE_PAD_ROWS: extra zero rows behind every plane (experiment: the plane stride's power-of-two factor)
+    int f3_rounds = -1;     // WAFER_F3_ROUNDS: a plain launch of the three-step kernel with more workgroups than CUs goes as one launch per round of CUs, its
+                            // columns cut to at most 384 planes (-1: yes; 0: one launch, columns as long as the makespan rule says -- rounds 1-4)
     int f3_sched = 0;       // WAFER_F3_SCHED: 1 = undecomposed launches use the two-halves schedule as well (timing experiments)
 };
 
@@ -85,6 +88,8 @@ static inline WaferTuning wafer_tuning_from_env()
     t.hv_debug = wafer_env_int("WAFER_HV_DEBUG", t.hv_debug);
     t.f3_sched = wafer_env_int("WAFER_F3_SCHED", t.f3_sched);
     t.f3_plain_down = wafer_env_int("WAFER_F3_PLAIN_DOWN", t.f3_plain_down);
+    t.f3_rounds = wafer_env_int("WAFER_F3_ROUNDS", t.f3_rounds);
+    t.plane_pad_rows = wafer_env_int("WAFER_PLANE_PAD_ROWS", t.plane_pad_rows);
     t.f3_xs = wafer_env_int("WAFER_F3_XS", t.f3_xs);
     t.hv_short_tiles = wafer_env_int("WAFER_HV_SHORT_TILES", t.hv_short_tiles);
     t.hv_layout = wafer_env_int("WAFER_HV_LAYOUT", t.hv_layout);
@@ -101,7 +106,7 @@ static inline WaferTuning wafer_tuning_from_env()
 // nearest integer instead, which is the same at 256^3, 512^3 and 1024^3 but not in between: 384^3 has 72 tiles per layer
 // of the three-step kernel, 3.55 rounded to 4 chunks = 288 workgroups = a full round and a second round of 32 -- two rounds
 // of 100 iterations where 7 chunks give two full rounds of 59 (325 against 449 G updates/s, profiles/NOTES.md).
-static inline int wafer_pick_zchunk(long long per_layer, int nplanes, long long slots, int fill)
+static inline int wafer_pick_zchunk(long long per_layer, int nplanes, long long slots, int fill, int max_planes = 0)
 {
     if (per_layer < 1) per_layer = 1;
     if (slots < 1) slots = 1;
@@ -113,6 +118,7 @@ static inline int wafer_pick_zchunk(long long per_layer, int nplanes, long long 
         const int real = (nplanes + zc - 1) / zc;
         const long long rounds = (per_layer * real + slots - 1) / slots;
         const long long cost = rounds * (zc + fill);
+        if (max_planes > 0 && zc > max_planes && nch < nch_max) continue;   // (columns no longer than that: see wafer_f3_zchunk)
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_zc = zc; }
     }
     return best_zc;
