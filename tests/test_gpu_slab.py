@@ -357,7 +357,8 @@ def test_single_launch_pass_thin_and_uneven_slabs_bit_exact(wa, world, shape, st
     assert len(set(fabric.halo_calls)) == 1   # every rank made the same number of exchange calls
 
 
-@pytest.mark.parametrize("layout", ["3", "4"])   # the two halves marched outwards / whole columns, direction alternating per pass
+@pytest.mark.parametrize("layout", ["3", "4", "5"])   # the two halves marched outwards / whole columns, direction alternating per pass / by the
+                                                        # slab's thickness: the thinner ranks of an uneven partition whole, the thicker in halves
 @pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 12), 12), (3, (140, 40, 19), 9), (2, (300, 70, 96), 15), (3, (130, 33, 20), 6),
                                                (3, (260, 50, 40), 30)])
 @peer_store_process
@@ -368,6 +369,8 @@ def test_peer_store_pass_uneven_slabs_bit_exact(wa, world, shape, steps, layout,
     an operation in between that invalidates the ghost planes; norm through the all-reduce hook"""
     monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
     monkeypatch.setenv("WAFER_HV_LAYOUT", layout)
+    if layout == "5":   # (an even partition: every rank whole -- the uneven ones are the point)
+        monkeypatch.setenv("WAFER_HV_WHOLE_MAX", str(shape[2] // world))
     base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1, halo_depth=3)
     with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1)) as ctx:
         ctx.set_potential("Coulomb")

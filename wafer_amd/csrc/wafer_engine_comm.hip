@@ -165,12 +165,17 @@ int launch_peer_pass(wafer_ctx *c, int src, int dst, int E)
     (void)E;
     const int first = c->hv_first;
     const wafer_ctx::F3Table *tab = nullptr;
-    // Whole columns (no cut) where every CU gets a tile of its own; else the two halves (twice the workgroups).  Rank-invariant:
-    // the tile count follows nx, ny only.  WAFER_HV_LAYOUT=3 forces the halves.
+    // Whole columns (no cut) where every CU gets a tile of its own and the slab is no thicker than 384 planes; else the two halves
+    // (twice the workgroups, columns half as long: over long columns the workgroups drift apart and lose each other's halo rows in
+    // the L2 -- a 1024 x 1024 x 512 slab: 0.896 ms per step in halves against 0.927 whole, 0.852 undecomposed; at 128 planes whole
+    // wins, 0.235 against 0.241).  The tile count follows nx, ny only; the thickness may differ between ranks (uneven partitions),
+    // and ranks may then take different layouts: either one delivers one arrival per tile and side and pass, and waits for as many
+    // (test_peer_store_pass_uneven_slabs_bit_exact, layout 5).  WAFER_HV_LAYOUT=3 forces the halves, 4 whole columns, 5 = by the
+    // thickness alone (tests).
     int tx_, ty_;
     wafer_step3_tile(type_combo(c, true), &tx_, &ty_);
     const long long ntiles = (long long)((g.nx + tx_ - 1) / tx_) * ((g.ny + ty_ - 1) / ty_);
-    const bool whole = (ntiles >= c->num_cus && c->tune.hv_layout != 3) || c->tune.hv_layout == 4;   // (4: always, tests)
+    const bool whole = c->tune.hv_layout == 4 || (c->tune.hv_layout != 3 && (ntiles >= c->num_cus || c->tune.hv_layout == 5) && g.nzl <= c->tune.hv_whole_max);
     // aux bits: 1 the half dispatched first / the marching direction, 4 peer mode (no short columns), 8 / 16: a neighbour below / above (who waits)
     TRY(f3_table(c, whole ? F3_WHOLE : F3_HALVES, lo, hi, first | 4 | (c->has_lo() ? 8 : 0) | (c->has_hi() ? 16 : 0), &tab));
     WaferF3Sync sy;

@@ -40,6 +40,7 @@ struct WaferTuning {
                             // (timing only), 8 no short pieces, 16 XCD-contiguous tile order inside each half, 32 no counters / gates (timing only),
                             // 64 exchange stream at normal priority)
     int hv_short_tiles = -1; // WAFER_HV_SHORT_TILES: tiles per half cut into short pieces (-1: 1/16 of the tiles)
+    int hv_whole_max = 384; // WAFER_HV_WHOLE_MAX: peer-store passes march whole columns on slabs of up to this many planes, the two halves on thicker ones
     int hv_layout = 0;      // WAFER_HV_LAYOUT: where the short columns go (wafer_f3_schedule_halves); peer-store passes (mode 3): 3 = always
                             // the two halves, 4 = always whole columns (default: whole columns where there is a tile per CU)
     int hv_wait_ms = 20000; // WAFER_HV_WAIT_MS: how long a workgroup of the single-launch pass waits for its ghost planes before it gives up
@@ -93,6 +94,7 @@ static inline WaferTuning wafer_tuning_from_env()
     t.f3_xs = wafer_env_int("WAFER_F3_XS", t.f3_xs);
     t.hv_short_tiles = wafer_env_int("WAFER_HV_SHORT_TILES", t.hv_short_tiles);
     t.hv_layout = wafer_env_int("WAFER_HV_LAYOUT", t.hv_layout);
+    t.hv_whole_max = wafer_env_int("WAFER_HV_WHOLE_MAX", t.hv_whole_max);
     t.hv_wait_ms = wafer_env_int("WAFER_HV_WAIT_MS", t.hv_wait_ms);
     if (t.hv_wait_ms < 1) t.hv_wait_ms = 1;
     t.peer_same_device = wafer_env_int("WAFER_PEER_SAME_DEVICE", t.peer_same_device);
