@@ -10,7 +10,8 @@ namespace wafer_eng __attribute__((visibility("hidden"))) {
 // planes per workgroup so that a launch over `nplanes` has >= target blocks
 int pick_zchunk(const wafer_ctx *c, int nplanes, int target_blocks)
 {
-    if (c->tune.zchunk > 0) return c->tune.zchunk;
+    // (WAFER_ZCHUNK, but never more than the 64 chunks per column the partial-sum rows are sized for)
+    if (c->tune.zchunk > 0) return std::max(c->tune.zchunk, (nplanes + 63) / 64);
     const long long per_layer = (long long)c->bx * c->by;
     long long nch = (target_blocks + per_layer - 1) / per_layer;
     if (nch < 1) nch = 1;
