@@ -211,13 +211,31 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
         const long long zo = (long long)z * g.plane;
 #endif
         // ---- 1. prefetch: phi0 three planes ahead, V one plane ahead, the outer row two planes ahead -- not issued together:
-        //         the main rows' phi0 at the top, their V behind level 1, the extra slot's three behind its level 1
+        //         the main rows' phi0 and V at the top, the extra slot's three behind level 1 of the main rows.  Everything
+        //         requested in an iteration is consumed at its END (the rotation behind the barrier), so a request placed late in
+        //         the iteration has a fraction of an iteration to come back: with V behind level 1 and the extra slot's behind ITS
+        //         level 1 -- the three-step kernel's placement, where those values are consumed an iteration later -- this kernel
+        //         waited for memory behind every barrier and reached 0.88 of the copy rate: 0.364 -> 0.3455 ms/step (all seven
+        //         at the top: 256 VGPRs and scratch, 0.361; profiles/r05_ab_fivepoint_request_placement.jsonl)
         SVT pre[RY], pre_v[RY], xpre = szero, xpre_v = szero, orow_pre = szero;
 #pragma unroll
         for (int r = 0; r < RY; ++r) pre[r] = pre_v[r] = szero;
         WAFER_W2_SETPRIO(3);
 #pragma unroll
         for (int r = 0; r < RY; ++r) pre[r] = gload_raw(phi + zo + (long long)(R + 1) * g.plane + rowoff[r]);
+        // (all-fp32, 256 x 16 tiles, 16 B of floats per lane: the early placement costs that instantiation 32 B of scratch; it keeps
+        //  V behind level 1 and the extra slot's three behind its level 1)
+        constexpr bool EARLY = sizeof(C) == 8;
+        auto issue_v = [&]() {
+#pragma unroll
+            for (int r = 0; r < RY; ++r) pre_v[r] = gload_raw(pv + zo + g.plane + rowoff[r]);
+        };
+        auto issue_x = [&]() {
+            xpre = gload_raw(phi + zo + (long long)(R + 1) * g.plane + xslot_off);
+            xpre_v = gload_raw(pv + zo + g.plane + xslot_off);
+            orow_pre = gload_raw(phi + zo + 2 * g.plane + oslot_off);
+        };
+        if constexpr (EARLY) issue_v();
         // ---- 2. stage phi0 plane z+1 into the other buffer (what was requested in place of a cell outside the work area becomes
         //         the zero it stands for here)
         if (more) {
@@ -304,8 +322,8 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
         if (all_rows && wplane1) level1(std::true_type{});
         else level1(std::false_type{});
         WAFER_W2_SETPRIO(2);
-#pragma unroll
-        for (int r = 0; r < RY; ++r) pre_v[r] = gload_raw(pv + zo + g.plane + rowoff[r]);
+        if constexpr (EARLY) issue_x();
+        else issue_v();
         if (do2) nbload(std::integral_constant<int, 1>{});   // (behind level 1: both levels' neighbours at once do not fit the registers)
         // ---- 3x. level 1, the extra slot: every neighbour from LDS, the z-column from its own queue
         if (x_row) {
@@ -357,9 +375,7 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
             w1[c_lds1] = rs;
         }
         WAFER_W2_SETPRIO(1);
-        xpre = gload_raw(phi + zo + (long long)(R + 1) * g.plane + xslot_off);
-        xpre_v = gload_raw(pv + zo + g.plane + xslot_off);
-        orow_pre = gload_raw(phi + zo + 2 * g.plane + oslot_off);
+        if constexpr (!EARLY) issue_x();
         // ---- 4. level 2: phi2 of plane z-2 from the phi1 queue (planes z-4 .. z-1 and the plane just made), a and b from V of
         //         that plane; stored
         if (do2) {
