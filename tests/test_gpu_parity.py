@@ -807,6 +807,37 @@ def test_excited_state_evolve(wo, wa, wnum, variant):
             assert abs(np.sum(l * got)) < 1e-13
 
 
+@pytest.mark.parametrize("wnum", [1, 3])
+def test_excited_state_evolve_without_the_division_plan(wo, wa, wnum):
+    """WAFER_FLAG_UNPLANNED_DIV (what a denominator the plan cannot clear would run): the excited-state steps keep to the one-step
+    kernels -- the two-steps-per-pass kernel exists for the short arithmetic forms only -- and agree with the oracle as ever"""
+    cfg, par = make_pair((130, 36, 40), ext=1, potential="Coulomb", dn=0.3, dt=0.01, unplanned_div=True)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    lowers = _orthonormal_store(wo, cfg, wnum)
+    phi = random_phi(cfg, seed=41)
+    with wa.Context(par) as ctx:
+        assert ctx.div_plan().checked == 0
+        ctx.set_potential("Coulomb")
+        for i, l in enumerate(lowers):
+            ctx.load_state(i, l)
+        ctx.upload_phi(phi)
+        ctx.evolve(wnum, 12)
+        assert ctx.x2_passes() == 0
+        wo.evolve(cfg, wnum, a, b, phi, lowers, 12)
+        assert np.allclose(ctx.download_phi(), phi, rtol=0, atol=1e-13)
+        assert ctx.norm2() == pytest.approx(wo.norm2(cfg, phi), rel=1e-12)
+    par.unplanned_div = False
+    with wa.Context(par) as ctx:   # ... and with the plan the same grid does take two steps per pass
+        ctx.set_potential("Coulomb")
+        for i, l in enumerate(lowers):
+            ctx.load_state(i, l)
+        ctx.upload_phi(random_phi(cfg, seed=41))
+        ctx.evolve(wnum, 12)
+        assert ctx.x2_passes() > 0
+        assert np.allclose(ctx.download_phi(), phi, rtol=0, atol=1e-13)
+
+
 @pytest.mark.parametrize("wnum", [2, 4, 5])
 def test_excited_state_evolve_nonorthogonal_store(wo, wa, wnum):
     """stored states that are NOT orthonormal: the one-pass Gram-Schmidt (raw
