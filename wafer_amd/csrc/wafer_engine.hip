@@ -173,7 +173,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->f32_arith = (p->dtype == WAFER_F32_FAST);
     c->esz = c->f32 ? 4 : 8;
     c->tune = wafer_tuning_from_env(); // the only place the WAFER_* tuning variables are read
-    c->g = wafer_make_geom((int)p->nx, (int)p->ny, (int)p->nz, R, G, (int)zb, (int)zc, (int)c->esz, c->tune.plane_pad_rows);
+    c->g = wafer_make_geom((int)p->nx, (int)p->ny, (int)p->nz, R, G, (int)zb, (int)zc, (int)c->esz);
     c->bx = (c->g.px + 63) / 64; // covers both the work area and the padded extent
     c->by = (c->g.py + 3) / 4;
     c->div_plan = wafer_divplan_make(stencil_den);

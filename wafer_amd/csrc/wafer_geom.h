@@ -49,7 +49,7 @@ struct WaferGeom {
 };
 
 static inline WaferGeom wafer_make_geom(int nx, int ny, int nz, int R, int G, int z_begin, int nzl,
-                                        int elem_bytes, int plane_pad_rows = 0)
+                                        int elem_bytes)
 {
     WaferGeom g;
     g.nx = nx; g.ny = ny; g.nz = nz; g.R = R; g.G = G;
@@ -63,7 +63,7 @@ static inline WaferGeom wafer_make_geom(int nx, int ny, int nz, int R, int G, in
     g.gy = 16 + 2 * R + R;                        // tallest tile (16 rows) overhang + 2R halo rows
     g.gz = 3 * R;                                 // the three-step kernel (ext 1) loads up to 3 planes past the slab's ghost planes
                                                   // in either marching direction; the two-step kernel 2R
-    g.plane = (long long)(g.py + 2 * g.gy + plane_pad_rows) * g.pitch;
+    g.plane = (long long)(g.py + 2 * g.gy) * g.pitch;
     g.total = (long long)(g.lz + 2 * g.gz) * g.plane;
     g.base_off = (long long)g.gz * g.plane + (long long)g.gy * g.pitch;
     return g;

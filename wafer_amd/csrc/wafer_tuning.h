@@ -48,7 +48,6 @@ struct WaferTuning {
     int peer_same_device = 0; // WAFER_PEER_SAME_DEVICE: 1 = wafer_peer_connect accepts a neighbour that is another context on this device (tests: ranks folded onto one GPU)
     int f3_xs = 1;          // WAFER_F3_XS: the three-step kernel with an exact store count per plane iteration where it applies (plain launches, grids of whole tiles); 0 = never
     int f3_plain_down = 0;  // WAFER_F3_PLAIN_DOWN: 1 = the plain schedule's workgroups march their columns downwards (the same bits; the two directions are separate copies of the loop, and the compiler's register allocation differs between them)
-    int plane_pad_rows = 0; // WAFER_PLANE_PAD_ROWS: extra zero rows behind every plane (experiment: the plane stride's power-of-two factor)
     int f3_rounds = -1;     // WAFER_F3_ROUNDS: a plain launch of the three-step kernel with more workgroups than CUs goes as one launch per round of CUs, its
                             // columns cut to at most 384 planes (-1: yes; 0: one launch, columns as long as the makespan rule says -- rounds 1-4)
     int f3_sched = 0;       // WAFER_F3_SCHED: 1 = undecomposed launches use the two-halves schedule as well (timing experiments)
@@ -90,7 +89,6 @@ static inline WaferTuning wafer_tuning_from_env()
     t.f3_sched = wafer_env_int("WAFER_F3_SCHED", t.f3_sched);
     t.f3_plain_down = wafer_env_int("WAFER_F3_PLAIN_DOWN", t.f3_plain_down);
     t.f3_rounds = wafer_env_int("WAFER_F3_ROUNDS", t.f3_rounds);
-    t.plane_pad_rows = wafer_env_int("WAFER_PLANE_PAD_ROWS", t.plane_pad_rows);
     t.f3_xs = wafer_env_int("WAFER_F3_XS", t.f3_xs);
     t.hv_short_tiles = wafer_env_int("WAFER_HV_SHORT_TILES", t.hv_short_tiles);
     t.hv_layout = wafer_env_int("WAFER_HV_LAYOUT", t.hv_layout);
