@@ -25,6 +25,20 @@ def test_oracle_under_asan_ubsan():
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 
 
+def test_division_plan_under_asan_ubsan(tmp_path):
+    """wafer_divplan.h: the enumeration's 128-bit integer arithmetic and shifts, awkward divisors (zero, infinite, NaN, subnormal, the
+    ends of the range, negative, powers of two) and 2000 random ones; every checked plan holds on its own candidates and the extra
+    Markstein round is right on every candidate whatever the plan found"""
+    out = str(tmp_path / "divplan-asan")
+    cmd = ["g++", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off",
+           "-std=c++17", os.path.join(ROOT, "tests", "divplan_sanitize_driver.cpp"), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    r = subprocess.run([out], capture_output=True, text=True, env=dict(os.environ, **SAN_ENV), timeout=600)
+    assert r.returncode == 0 and "DIVPLAN-OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
 @pytest.fixture(scope="module")
 def asan_cli(tmp_path_factory):
     from wafer_amd import build
