@@ -452,12 +452,13 @@ def test_hoisted_division_equals_the_ieee_division_on_2e10_operands(wa):
         assert ctx.div_check(dens[0], 1 << 24, lo_exp=1, hi_exp=40, seed=7) > 0
 
 
-def test_three_step_kernel_one_launch_per_round_of_cus(wo, wa, monkeypatch):
+@pytest.mark.parametrize("shape,steps", [((256, 128, 400), 7), ((256, 192, 500), 9), ((128, 256, 1153), 6)])
+def test_three_step_kernel_one_launch_per_round_of_cus(wo, wa, shape, steps, monkeypatch):
     """a layer of tiles that is whole rounds of CUs and columns longer than 384 planes (1024^3 on one GPU): the columns are cut and
     every round of CUs is a launch of its own (wafer_f3_by_rounds) -- here with 8 'CUs' (WAFER_TARGET_BLOCKS) and 16 tiles per layer;
     the same bits as the oracle, and as one launch over the uncut columns"""
     monkeypatch.setenv("WAFER_TARGET_BLOCKS", "8")
-    cfg, par = make_pair((256, 128, 400), ext=1, potential="Coulomb", dn=0.2, dt=0.004)
+    cfg, par = make_pair(shape, ext=1, potential="Coulomb", dn=0.2, dt=0.004)
     v = wo.potential_generate(cfg)
     a, b = wo.ab(cfg, v)
     phi0 = random_phi(cfg, seed=5)
@@ -468,11 +469,11 @@ def test_three_step_kernel_one_launch_per_round_of_cus(wo, wa, monkeypatch):
             ctx.set_stencil_variant(3)
             ctx.set_potential("Coulomb")
             ctx.upload_phi(phi0)
-            ctx.evolve(0, 7)
+            ctx.evolve(0, steps)
             assert ctx.stencil_kernel_name() == "wafer_k_step3_fused"
             got[rounds] = ctx.download_phi()
     phi = phi0.copy()
-    wo.evolve(cfg, 0, a, b, phi, [], 7)
+    wo.evolve(cfg, 0, a, b, phi, [], steps)
     assert ulp_diff(got["-1"], phi) == 0 and ulp_diff(got["0"], phi) == 0
 
 
