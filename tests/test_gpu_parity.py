@@ -477,6 +477,29 @@ def test_three_step_kernel_one_launch_per_round_of_cus(wo, wa, shape, steps, mon
     assert ulp_diff(got["-1"], phi) == 0 and ulp_diff(got["0"], phi) == 0
 
 
+@pytest.mark.parametrize("shape,steps", [((256, 128, 400), 6), ((128, 256, 777), 5)])
+def test_five_point_kernel_one_launch_per_round_of_cus(wo, wa, shape, steps, monkeypatch):
+    """the FivePoint two-step kernel under the same launch rule (it derives its tile from blockIdx: a round carries its offset into the
+    whole schedule): 8 'CUs', 16 tiles per layer, columns cut to at most 384 planes; the oracle's bits, with the rule and without"""
+    monkeypatch.setenv("WAFER_TARGET_BLOCKS", "8")
+    cfg, par = make_pair(shape, ext=2, potential="Coulomb", dn=0.2, dt=0.002)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi0 = random_phi(cfg, seed=6)
+    got = {}
+    for rounds in ("-1", "0"):
+        monkeypatch.setenv("WAFER_F3_ROUNDS", rounds)
+        with wa.Context(par) as ctx:
+            ctx.set_potential("Coulomb")
+            ctx.upload_phi(phi0)
+            ctx.evolve(0, steps)
+            assert ctx.stencil_kernel_instance().startswith("wafer_k_step2_wide<double")
+            got[rounds] = ctx.download_phi()
+    phi = phi0.copy()
+    wo.evolve(cfg, 0, a, b, phi, [], steps)
+    assert ulp_diff(got["-1"], phi) == 0 and ulp_diff(got["0"], phi) == 0
+
+
 DENS_NEEDING_A_MOVED_ZL = [0.007395769697490762, 0.1078657875904072, 0.20222586000144446]   # tests/test_div_plan.py
 
 

@@ -202,6 +202,9 @@ struct WaferStepArgs {
     int n_long, nsub;
     double dt, den;
     double den_zh = 0.0, den_zl = 0.0;   // the plan of x / den (WaferDen, wafer_divplan.h); "checked" travels in v_in_range
+    // a launch that is one round of a longer schedule (wafer_f3_by_rounds): its first workgroup's index in the schedule and the
+    // schedule's length (0: the launch is the schedule) -- kernels that derive their tile from blockIdx (wafer_k_step2_wide)
+    int block0 = 0, nblocks_all = 0;
     // observables mode of the LDS kernel (NLOW = -2): wafer_potsub_kind and the scalar pot_sub
     int potsub_kind = 0;
     double potsub_scalar = 0.0;

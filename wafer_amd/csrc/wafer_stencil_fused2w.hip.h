@@ -76,9 +76,9 @@ __global__ __launch_bounds__((WaferW2Cfg<typename WaferF3Store<TS>::Q>::NT_)) vo
     auto as_stored = [](C x) -> T { return (T)(ST)x; };
 
     const WaferGeom &g = a.g;
-    int bid = blockIdx.x;
-    if (swz) {   // XCD-contiguous tile ranges (workgroup b runs on XCD b % 8)
-        const int n = gridDim.x, q = n >> 3, r = n & 7, k = bid & 7;
+    int bid = blockIdx.x + a.block0;
+    if (swz) {   // XCD-contiguous tile ranges (workgroup b runs on XCD b % 8; a round of a longer schedule starts at a multiple of 8)
+        const int n = a.nblocks_all > 0 ? a.nblocks_all : (int)gridDim.x, q = n >> 3, r = n & 7, k = bid & 7;
         bid = k * q + min(k, r) + (bid >> 3);
     }
     const int tz_i = bid / (ntx * nty);
@@ -482,11 +482,22 @@ static inline hipError_t wafer_launch_step2_wide(const WaferTuning &t, WaferStep
     const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX, nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     // (the mixed launch of slab interiors -- long columns and a few short ones -- is the two-step kernel's; here every column
     //  is cut alike: nsub > 1 asks for that many pieces)
-    if (a.nsub > 1 && a.lz_hi - a.lz_lo >= 8 * a.nsub) a.zchunk = (a.lz_hi - a.lz_lo + a.nsub - 1) / a.nsub;
-    else a.zchunk = wafer_w2_zchunk<T>(t, g, a.lz_hi - a.lz_lo, a.target_blocks);
-    const long long nblocks = (long long)ntx * nty * ((a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk);
-    const dim3 grid((unsigned)nblocks), block(Cfg::NT_);
-    if (a.v_in_range != 0) hipLaunchKernelGGL((wafer_k_step2_wide<TS, C, true>), grid, block, (size_t)t.lds_pad, s, a, ntx, nty, t.swz, phi, pv, out);
-    else hipLaunchKernelGGL((wafer_k_step2_wide<TS, C, false>), grid, block, (size_t)t.lds_pad, s, a, ntx, nty, t.swz, phi, pv, out);
+    const int nplanes = a.lz_hi - a.lz_lo;
+    const long long slots = t.target_blocks > 0 ? t.target_blocks : (a.target_blocks > 0 ? a.target_blocks : 256);
+    // (long columns on several whole rounds of CUs: cut to 384 planes at most and launched round by round -- wafer_f3_by_rounds)
+    const bool rounds = !(a.nsub > 1) && a.target_blocks >= 0 && slots % 8 == 0 && wafer_f3_by_rounds(t, (long long)ntx * nty, nplanes, slots);
+    if (a.nsub > 1 && nplanes >= 8 * a.nsub) a.zchunk = (nplanes + a.nsub - 1) / a.nsub;
+    else if (rounds) a.zchunk = wafer_pick_zchunk((long long)ntx * nty, nplanes, slots, 2 * 2 + 3, 384);
+    else a.zchunk = wafer_w2_zchunk<T>(t, g, nplanes, a.target_blocks);
+    const long long nblocks = (long long)ntx * nty * ((nplanes + a.zchunk - 1) / a.zchunk);
+    const long long per_launch = rounds ? slots : nblocks;
+    const dim3 block(Cfg::NT_);
+    a.nblocks_all = (int)nblocks;
+    for (long long first = 0; first < nblocks; first += per_launch) {
+        const dim3 grid((unsigned)std::min(per_launch, nblocks - first));
+        a.block0 = (int)first;
+        if (a.v_in_range != 0) hipLaunchKernelGGL((wafer_k_step2_wide<TS, C, true>), grid, block, (size_t)t.lds_pad, s, a, ntx, nty, t.swz, phi, pv, out);
+        else hipLaunchKernelGGL((wafer_k_step2_wide<TS, C, false>), grid, block, (size_t)t.lds_pad, s, a, ntx, nty, t.swz, phi, pv, out);
+    }
     return hipGetLastError();
 }

@@ -712,12 +712,6 @@ static inline void wafer_f3_schedule_whole(std::vector<WaferF3Block> &out, int n
     }
 }
 
-// a plain launch goes as one launch per round of CUs, its columns cut to at most 384 planes (wafer_f3_zchunk says when and why)
-static inline bool wafer_f3_by_rounds(const WaferTuning &t, long long tiles_per_layer, int nplanes, long long slots)
-{
-    return t.f3_rounds != 0 && t.zchunk <= 0 && tiles_per_layer > slots && tiles_per_layer % slots == 0 && nplanes > 384;
-}
-
 // planes per workgroup of the plain schedule: one workgroup per CU marching a long column (as the two-step kernel)
 static inline int wafer_f3_zchunk(const WaferTuning &t, int ntx, int nty, int nplanes, int target_blocks)
 {

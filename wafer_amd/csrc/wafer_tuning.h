@@ -123,3 +123,10 @@ static inline int wafer_pick_zchunk(long long per_layer, int nplanes, long long 
     }
     return best_zc;
 }
+
+// A plain launch of a multi-step kernel goes as one launch per round of CUs, its columns cut to at most 384 planes
+// (wafer_f3_zchunk in wafer_stencil_fused3.hip.h says when and why; the FivePoint two-step kernel follows the same rule)
+static inline bool wafer_f3_by_rounds(const WaferTuning &t, long long tiles_per_layer, int nplanes, long long slots)
+{
+    return t.f3_rounds != 0 && t.zchunk <= 0 && tiles_per_layer > slots && tiles_per_layer % slots == 0 && nplanes > 384;
+}
