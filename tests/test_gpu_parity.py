@@ -334,12 +334,13 @@ def test_fused3_exact_store_count_variant(wo, wa, shape, zchunk, xs, sched, monk
 
 def test_fused3_thousand_steps_64cubed_and_default_dispatch(wo, wa, monkeypatch):
     """1000 steps (333 three-step passes + one single step) at 64^3 (forced onto the kernel) against the
-    oracle; the three-step kernel is what a ThreePoint fp64 context of 6 M cells or more runs by default,
+    oracle; the three-step kernel is what a ThreePoint fp64 context of 1.5 M cells or more runs by default,
     the two-step kernel what small grids, FivePoint and slabs with two ghost planes run"""
     with wa.Context(wa.Params(64, 64, 64, dn=0.2, dt=8e-3)) as ctx:      # small: launch-bound, the two-step kernel is faster
         assert ctx.stencil_kernel_name() == "wafer_k_step2_fused"
-    with wa.Context(wa.Params(256, 256, 192, dn=0.2, dt=8e-3, max_states=1)) as ctx:
-        assert ctx.stencil_kernel_name() == "wafer_k_step3_fused" and ctx.steps_per_launch() == 3
+    for shape in ((256, 256, 192), (128, 128, 128)):
+        with wa.Context(wa.Params(*shape, dn=0.2, dt=8e-3, max_states=1)) as ctx:
+            assert ctx.stencil_kernel_name() == "wafer_k_step3_fused" and ctx.steps_per_launch() == 3
     monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
     cfg, par = make_pair((64, 64, 64), ext=1, potential="Harmonic", dn=0.2, dt=8e-3, mass=1.0)
     v = wo.potential_generate(cfg)

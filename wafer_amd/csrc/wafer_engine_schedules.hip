@@ -194,9 +194,9 @@ long long step_partials_count(wafer_ctx *c, int lz_lo, int lz_hi)
 // when nz % world != 0; wafer_ctx_create has already refused a slab thinner than its ghost depth).
 bool fuse3_applies(const wafer_ctx *c)
 {
-    // Small undecomposed grids are launch- and fill-bound and the deeper pipeline costs there: 50^3 5.8 against 4.5
-    // us/step for the two-step kernel, 64^3 6.0 / 4.7, 128^3 9.1 / 8.7; from 256^3 up it wins (40.5 / 41.9 us, 384^3
-    // 0.177 / 0.196 ms).  WAFER_FUSE3_MIN_NY (tests) lifts both thresholds.
+    // Small undecomposed grids are launch- and fill-bound and the deeper pipeline costs there: 64^3 4.8 against 4.6 us/step for the
+    // two-step kernel, 96^3 6.4 / 6.4; from 128^3 up it wins (7.6 / 8.1, 160^3 14.8 / 16.0, 192^3 19.4 / 20.8, 224^3 24.7 / 28.6 us;
+    // round-5 kernels -- with round 3's the crossover was at 256^3).  WAFER_FUSE3_MIN_NY (tests) lifts both thresholds.
     const int ny_env = c->tune.fuse3_min_ny;
     const int min_ny = ny_env >= 0 ? ny_env : 16;
     const long long min_cells = ny_env >= 0 ? 0 : c->tune.fuse3_min_cells;

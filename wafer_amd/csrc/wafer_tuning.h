@@ -33,7 +33,7 @@ struct WaferTuning {
     int f2_wide = 1;        // WAFER_F2_WIDE: 0 keeps FivePoint on the two-step kernel with dedicated helper waves (128 x 8 tiles)
     int fuse3 = 1;          // WAFER_FUSE3: 0 keeps ThreePoint fp64 on the two-step kernel
     int fuse3_min_ny = -1;  // WAFER_FUSE3_MIN_NY (tests; lifts the cell threshold too)
-    long long fuse3_min_cells = 6000000; // WAFER_FUSE3_MIN_CELLS
+    long long fuse3_min_cells = 1500000; // WAFER_FUSE3_MIN_CELLS (round 5: 6 000 000 until the planned division and the streamed stores moved the crossover)
     // z-slabs
     int overlap = -1;       // WAFER_OVERLAP: initial wafer_set_overlap mode (-1: default)
     int hv_debug = 0;       // WAFER_HV_DEBUG: experiments on the single-launch pass (bits: 4 no acquire fence
