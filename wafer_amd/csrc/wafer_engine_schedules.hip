@@ -63,10 +63,9 @@ const char *variant_name(int v) { return kVariants[(v >= 0 && v < kNumVariants) 
 
 int default_variant(const wafer_ctx *c)
 {
-    // FivePoint on fp32 storage with fp64 arithmetic: the single-step kernel and the two-step kernel on 128 x 16 tiles
-    // (wafer_stencil_fused2w.hip.h) take the same time (512^3: 0.337 against 0.335 ms/step) and the single step needs half the
-    // ghost planes on slabs; with fp32 arithmetic as well the two-step kernel wins (0.250 against 0.288)
-    if (c->f32 && !c->f32_arith && c->g.R == 2) return 1;
+    // (FivePoint on fp32 storage with fp64 arithmetic stayed on the single-step kernel while the two-step kernel on 128 x 16 tiles
+    //  was a tie with it, 0.337 against 0.335 ms/step at 512^3; with the planned division, streamed stores and its requests placed
+    //  early the two-step kernel takes 0.301 against 0.334)
     // SevenPoint: the two-step kernel exists (variant 2, bit-exact, 128 x 8 tiles) but recomputes phi1 on 14 rows
     // per 8 and is issue-bound: 0.93 ms/step at 512^3 against 0.63 for the single-step kernel on 128 x 16 tiles
     if (c->g.R == 3) return 1;
