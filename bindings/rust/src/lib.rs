@@ -72,6 +72,17 @@ pub struct wafer_div_plan_t {
     pub reserved: i32,
 }
 
+/// wafer_div_plan_f32_t: the same plan in fp32 (WAFER_F32_FAST contexts)
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct wafer_div_plan_f32_t {
+    pub den: f32,
+    pub zh: f32,
+    pub zl: f32,
+    pub checked: i32,
+    pub zl_shift: i32,
+}
+
 /// wafer_params.flags
 pub const WAFER_FLAG_SKIP_DT_CHECK: u32 = 1;
 pub const WAFER_FLAG_UNPLANNED_DIV: u32 = 2;
@@ -180,6 +191,8 @@ extern "C" {
     pub fn wafer_diag_div_check(ctx: *mut wafer_ctx, den: f64, seed: u64, n_operands: u64, lo_exp: c_int, hi_exp: c_int, mismatches: *mut u64) -> c_int;
     pub fn wafer_div_plan(den: f64, out: *mut wafer_div_plan_t, candidates: *mut f64, cap: usize, n_written: *mut usize) -> c_int;
     pub fn wafer_get_div_plan(ctx: *mut wafer_ctx, out: *mut wafer_div_plan_t) -> c_int;
+    pub fn wafer_div_plan_f32(den: f32, out: *mut wafer_div_plan_f32_t) -> c_int;
+    pub fn wafer_diag_div_planned_f32(ctx: *mut wafer_ctx, plan: *const wafer_div_plan_f32_t, lo_exp: c_int, hi_exp: c_int, mismatches: *mut u64) -> c_int;
     pub fn wafer_diag_div_planned(ctx: *mut wafer_ctx, plan: *const wafer_div_plan_t, seed: u64, n_random: u64, lo_exp: c_int, hi_exp: c_int,
                                   operands: *const f64, n_operands: usize, mismatches_random: *mut u64, mismatches_operands: *mut u64) -> c_int;
 }

@@ -287,6 +287,17 @@ int wafer_get_div_plan(wafer_ctx *ctx, wafer_div_plan_t *out);
 int wafer_diag_div_planned(wafer_ctx *ctx, const wafer_div_plan_t *plan, uint64_t seed, uint64_t n_random, int lo_exp, int hi_exp,
                            const double *operands, size_t n_operands, uint64_t *mismatches_random, uint64_t *mismatches_operands);
 
+/* The same plan in fp32, for WAFER_F32_FAST contexts (whose step kernels compute in fp32): q = RN(x zh + RN(x zl)) in float, checked by
+ * trying all 2^23 significands on the host (tens of milliseconds; |x/den| >= 2^-100, |den| in [2^-60, 2^60]).  Unchecked: the kernels divide. */
+typedef struct wafer_div_plan_f32_t {
+    float den, zh, zl;
+    int32_t checked, zl_shift;
+} wafer_div_plan_f32_t;
+int wafer_div_plan_f32(float den, wafer_div_plan_f32_t *out);   /* host only */
+/* Diagnostic: the planned fp32 division on EVERY float with a biased exponent in [lo_exp, hi_exp] (all significands, both signs)
+ * against the device's IEEE x / den: the number of quotients that differ in any bit. */
+int wafer_diag_div_planned_f32(wafer_ctx *ctx, const wafer_div_plan_f32_t *plan, int lo_exp, int hi_exp, uint64_t *mismatches);
+
 /* ---- multi-GPU: communication hooks --------------------------------------- */
 /* The engine never links a communication library.  A host that z-slabs the
  * grid over several contexts installs two hooks (RCCL via torch.distributed in

@@ -175,3 +175,32 @@ def test_divisors_without_a_plan():
     plan, cand = engine.div_plan(0.125)
     assert (plan.zh, plan.zl, plan.checked, cand.size) == (8.0, 0.0, 1, 0)
     assert "wafer_div_plan" in wafer_amd.engine.EXPORTS
+
+
+def test_the_fp32_plan_against_every_significand():
+    """WAFER_F32_FAST contexts: q = RN(x zh + RN(x zl)) in float.  The library tries all 2^23 significands; so does numpy here (a
+    float product is exact in float64, the sum of a 48-bit product and a float 2^-24 below it too, one rounding to float32 = fmaf)"""
+    X = np.arange(1 << 23, 1 << 24, dtype=np.float32)
+
+    def all_right(den, zh, zl):
+        t = (X * np.float32(zl)).astype(np.float32)
+        q = (X.astype(np.float64) * np.float64(np.float32(zh)) + t.astype(np.float64)).astype(np.float32)
+        return bool(np.array_equal(q, X / np.float32(den)))
+
+    rng = random.Random(9)
+    dens = [2 * 0.05 ** 2, 2 * 0.02 ** 2 * 2.35, 24 * 0.05 ** 2, 360 * 0.05 ** 2, 0.08, 0.5, 3.0] + [rng.uniform(1, 2) * 2.0 ** rng.randint(-20, 5) for _ in range(12)]
+    moved = 0
+    for den in dens:
+        p = engine.div_plan_f32(den)
+        den32 = np.float32(den)
+        assert p.den == den32 and p.zh == np.float32(1) / den32
+        zl0 = np.float32((1.0 - float(p.zh) * float(den32)) / float(den32))   # exact remainder (float64 holds it), one division
+        assert p.checked == 1, den
+        assert all_right(den, p.zh, p.zl)
+        if p.zl_shift == 0:
+            assert p.zl == zl0
+        else:
+            moved += 1
+            assert not all_right(den, p.zh, zl0)      # the move was needed
+    for den in (0.0, math.inf, math.nan, 1e-30, 1e30):
+        assert engine.div_plan_f32(den).checked == 0

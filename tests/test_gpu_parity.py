@@ -553,6 +553,24 @@ def test_the_plan_catches_what_the_device_gets_wrong(wa):
             assert ctx.div_planned_check(unmoved, 1 << 28, ops, seed=600 + i) == (0, 0)
 
 
+def test_planned_fp32_division_on_every_float(wa):
+    """WAFER_F32_FAST: the three-instruction fp32 division of the step kernels against the device's IEEE x / den on EVERY float of
+    201 binades (all 2^23 significands, both signs: 6.7e9 operands per denominator), bit for bit; below 2^-100 (x zl subnormal) and
+    without the plan's verdict the kernels' behaviour is the division itself"""
+    from wafer_amd import engine
+    with wa.Context(wa.Params(8, 8, 8, dn=0.2, dt=0.004, dtype="f32fast")) as ctx:
+        for den in (2 * 0.05 ** 2, 2 * 0.02 ** 2 * 2.35, 24 * 0.2 ** 2 * 1.3, 360 * 0.01 ** 2 * 0.7, 2 * 0.2 ** 2, 3.0, 0.06):
+            plan = engine.div_plan_f32(den)
+            assert plan.checked == 1
+            assert ctx.div_planned_check_f32(plan, 27, 227) == 0, den
+            plan.checked = 0
+            assert ctx.div_planned_check_f32(plan, 1, 254) == 0     # unchecked: x / den itself, everywhere
+        plan = engine.div_plan_f32(0.06)
+        assert plan.zl_shift != 0
+        unmoved = engine._DivPlanF32(plan.den, plan.zh, float(np.nextafter(np.float32(plan.zl), np.float32(-np.inf if plan.zl_shift > 0 else np.inf))), 1, 0)
+        assert ctx.div_planned_check_f32(unmoved, 27, 227) > 0      # the host's exhaustive check is not vacuous either
+
+
 def grid_spacing_whose_divisor_needs_a_moved_zl(lead, mass):
     from wafer_amd import engine
     rng = np.random.default_rng(3)

@@ -115,3 +115,50 @@ static inline WaferDivPlan wafer_divplan_make(double den)
     }
     return p;
 }
+
+// ---- the same plan in fp32, for the contexts whose step kernels compute in fp32 (WAFER_F32_FAST): q = RN(x*zh + RN(x*zl)) in float.
+// No enumeration needed: all 2^23 significands are tried (both signs by symmetry; the exponent of x plays no part while x*zl is a
+// normal float, |x/den| >= 2^-100).  ~10 ms per zl tried, once per context.
+struct WaferDivPlanF {
+    float den = 0.f, zh = 0.f, zl = 0.f;
+    int checked = 0;
+    int zl_shift = 0;
+};
+
+static inline float wafer_divplan_qf(float x, float zh, float zl)
+{
+    const float t = x * zl;
+    return std::fmaf(x, zh, t);
+}
+
+static inline WaferDivPlanF wafer_divplan_make_f32(float den)
+{
+    WaferDivPlanF p;
+    p.den = den;
+    p.zh = 1.0f / den;
+    const float zl0 = std::fmaf(-p.zh, den, 1.0f) / den;
+    p.zl = zl0;
+    // the scaling below must stay inside the normal floats: |den| in [2^-60, 2^60]
+    if (!std::isnormal(den) || !(std::fabs(den) >= 0x1p-60f && std::fabs(den) <= 0x1p60f)) {
+        p.zl = 0.f;
+        return p;
+    }
+    static const int shifts[] = {0, 1, -1, 2, -2};
+    for (int sh : shifts) {
+        float zl = zl0;
+        for (int i = 0; i < std::abs(sh); ++i) zl = std::nextafterf(zl, sh > 0 ? INFINITY : -INFINITY);
+        if (sh != 0 && zl0 == 0.f) break;
+        bool ok = true;
+        for (uint32_t X = 1u << 23; X < (1u << 24) && ok; ++X) {
+            const float x = (float)X;
+            ok = wafer_divplan_qf(x, p.zh, zl) == x / den;
+        }
+        if (ok) {
+            p.zl = zl;
+            p.zl_shift = sh;
+            p.checked = 1;
+            return p;
+        }
+    }
+    return p;
+}

@@ -253,6 +253,20 @@ static __global__ __launch_bounds__(256) void wafer_k_div_check(WaferDen<double>
     }
     if (bad) atomicAdd(mismatches, bad);
 }
+// ... the fp32 plan on EVERY float of the biased exponents [lo_exp, hi_exp]: all 2^23 significands, both signs
+static __global__ __launch_bounds__(256) void wafer_k_div_check_f32(WaferDen<float> dv, int lo_exp, int hi_exp, unsigned long long *__restrict__ mismatches)
+{
+    const unsigned long long n = (unsigned long long)(hi_exp - lo_exp + 1) << 24;   // exponent, sign, significand
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned int bits = ((unsigned int)(i & 0x7fffffu)) | ((unsigned int)(lo_exp + (int)(i >> 24)) << 23) | ((unsigned int)((i >> 23) & 1u) << 31);
+        const float x = __uint_as_float(bits);
+        const float q_fast = wafer_div_invariant<float>(x, dv);
+        const float q_ieee = x / dv.den;
+        bad += (unsigned long long)(__float_as_uint(q_fast) != __float_as_uint(q_ieee));
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
 // ... the planned division on a list of operands (the plan's candidates, scaled over the exponent range by the caller)
 static __global__ __launch_bounds__(256) void wafer_k_div_operands(WaferDen<double> dv, const double *__restrict__ x, unsigned long long n,
                                                             unsigned long long *__restrict__ mismatches)

@@ -121,6 +121,7 @@ struct wafer_ctx {
     int potsub_kind = WAFER_POTSUB_NONE;
     double potsub_scalar = 0.0;
     bool have_pot = false, have_phi = false;
+    WaferDivPlanF div_plan_f;   // ... in fp32, for WAFER_F32_FAST contexts (checked = 0 elsewhere)
     WaferDivPlan div_plan;   // x / (c dn^2 m) in the step kernels (wafer_divplan.h), made once, at wafer_ctx_create
     bool v_in_range = false; // 2^-400 < |1 + dt*V/2| < 2^400 everywhere (wafer_recip's short form is exact)
     int x2_agreed[4] = {-1, -1, -1, -1}; // [k]: every rank can take the two-step excited pass with k stored states (-1: not agreed yet; x2_agree)
@@ -192,12 +193,14 @@ static inline double wafer_stencil_den(int R, double dn, double mass)
     return lead * dn * dn * mass;
 }
 // WaferStepArgs::v_in_range: the kernels may take the short arithmetic forms (wafer_recip for b, three instructions for x / den)
-static inline bool short_forms(const wafer_ctx *c) { return c->v_in_range && c->div_plan.checked != 0; }
+static inline bool short_forms(const wafer_ctx *c) { return c->v_in_range && c->div_plan.checked != 0 && (!c->f32_arith || c->div_plan_f.checked != 0); }
 static inline void set_den_args(const wafer_ctx *c, WaferStepArgs &a)
 {
     a.den = c->div_plan.den;
     a.den_zh = c->div_plan.zh;
     a.den_zl = c->div_plan.zl;
+    a.den_zh_f = c->div_plan_f.checked ? c->div_plan_f.zh : 0.f;
+    a.den_zl_f = c->div_plan_f.checked ? c->div_plan_f.zl : 0.f;
 }
 static inline int nchunks_of(int nplanes, int zchunk) { return (nplanes + zchunk - 1) / zchunk; }
 template <typename T>

@@ -177,7 +177,8 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->bx = (c->g.px + 63) / 64; // covers both the work area and the padded extent
     c->by = (c->g.py + 3) / 4;
     c->div_plan = wafer_divplan_make(stencil_den);
-    if (p->flags & WAFER_FLAG_UNPLANNED_DIV) c->div_plan.checked = 0;
+    if (c->f32_arith) c->div_plan_f = wafer_divplan_make_f32((float)stencil_den);
+    if (p->flags & WAFER_FLAG_UNPLANNED_DIV) c->div_plan.checked = c->div_plan_f.checked = 0;
     c->overlap_mode = (c->tune.overlap >= 0 && c->tune.overlap <= 2) ? c->tune.overlap : 2; // the modes of wafer_set_overlap
     // fused passes per halo exchange: 1 unless the host asks for deep halos (wafer_set_halo_cycle) -- a
     // concentrated exchange outlasts the interior launch it hides behind on anything but a very fast link
@@ -879,6 +880,40 @@ int wafer_diag_div_planned(wafer_ctx *c, const wafer_div_plan_t *plan, uint64_t 
     if (!c || !plan) return fail(WAFER_ERR_INVALID, "null argument");
     return div_check_launch(c, WaferDen<double>{plan->den, plan->zh, plan->zl, plan->checked != 0}, true, seed, n_random, lo_exp, hi_exp, operands,
                             n_operands, mismatches_random, mismatches_operands);
+}
+
+int wafer_div_plan_f32(float den, wafer_div_plan_f32_t *out)
+{
+    if (!out) return fail(WAFER_ERR_INVALID, "null argument");
+    const WaferDivPlanF p = wafer_divplan_make_f32(den);
+    out->den = p.den;
+    out->zh = p.zh;
+    out->zl = p.zl;
+    out->checked = p.checked;
+    out->zl_shift = p.zl_shift;
+    return WAFER_OK;
+}
+
+int wafer_diag_div_planned_f32(wafer_ctx *c, const wafer_div_plan_f32_t *plan, int lo_exp, int hi_exp, uint64_t *mismatches)
+{
+    if (!c || !plan || !mismatches) return fail(WAFER_ERR_INVALID, "null argument");
+    if (lo_exp < 0 || hi_exp > 254 || lo_exp > hi_exp) return fail(WAFER_ERR_INVALID, "biased exponents in 0..254");
+    HIP_TRY(hipSetDevice(c->P.device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof *d));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof *d, c->s_main);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(wafer_k_div_check_f32, dim3((unsigned)c->num_cus * 16), dim3(256), 0, c->s_main,
+                           WaferDen<float>{plan->den, plan->zh, plan->zl, plan->checked != 0}, lo_exp, hi_exp, d);
+        e = hipGetLastError();
+    }
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, c->s_main);
+    const hipError_t e2 = hipStreamSynchronize(c->s_main);
+    (void)hipFree(d);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(WAFER_ERR_HIP, "division check failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    *mismatches = h;
+    return WAFER_OK;
 }
 
 int wafer_set_stream(wafer_ctx *c, void *hip_stream)

@@ -158,6 +158,11 @@ struct WaferDen<double> {
     double den, zh, zl;
     bool checked;
 };
+template <>
+struct WaferDen<float> {   // (WAFER_F32_FAST: the same plan in fp32, every significand tried on the host -- wafer_divplan_make_f32)
+    float den, zh, zl;
+    bool checked;
+};
 template <typename T>
 __device__ __forceinline__ T wafer_div_invariant(T x, const WaferDen<T> &d)
 {
@@ -172,6 +177,10 @@ __device__ __forceinline__ T wafer_div_invariant(T x, const WaferDen<T> &d)
             q = __builtin_fma(r, d.zh, q);
         }
         return __builtin_amdgcn_div_fixup(q, d.den, x);
+    } else if constexpr (std::is_same_v<T, float>) {
+        // 3 instructions against the 11 of the fp32 division sequence (v_div_scale x 2, v_rcp, 4 fma, mul, v_div_fmas, v_div_fixup)
+        if (d.checked) return __builtin_amdgcn_div_fixupf(__builtin_fmaf(x, d.zh, x * d.zl), d.den, x);
+        return x / d.den;
     } else
 #endif
         return x / d.den;
@@ -205,6 +214,7 @@ struct WaferStepArgs {
     // a launch that is one round of a longer schedule (wafer_f3_by_rounds): its first workgroup's index in the schedule and the
     // schedule's length (0: the launch is the schedule) -- kernels that derive their tile from blockIdx (wafer_k_step2_wide)
     int block0 = 0, nblocks_all = 0;
+    float den_zh_f = 0.f, den_zl_f = 0.f;   // the fp32 plan (contexts whose step kernels compute in fp32; 0: none)
     // observables mode of the LDS kernel (NLOW = -2): wafer_potsub_kind and the scalar pot_sub
     int potsub_kind = 0;
     double potsub_scalar = 0.0;
@@ -219,6 +229,7 @@ template <typename T>
 __device__ __forceinline__ WaferDen<T> wafer_den(const WaferStepArgs &a, bool short_forms)
 {
     if constexpr (std::is_same_v<T, double>) return WaferDen<double>{a.den, a.den_zh, a.den_zl, short_forms};
+    else if constexpr (std::is_same_v<T, float>) return WaferDen<float>{(float)a.den, a.den_zh_f, a.den_zl_f, short_forms && a.den_zh_f != 0.f};
     else return WaferDen<T>{(T)a.den};
 }
 

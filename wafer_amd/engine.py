@@ -41,7 +41,7 @@ EXPORTS = [
     "wafer_clone_state_to_phi", "wafer_num_states", "wafer_clear_states", "wafer_solve_state",
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_kernel_instance", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
-    "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check", "wafer_div_plan", "wafer_get_div_plan", "wafer_diag_div_planned",
+    "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check", "wafer_div_plan", "wafer_get_div_plan", "wafer_diag_div_planned", "wafer_div_plan_f32", "wafer_diag_div_planned_f32",
     "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_set_halo_cycle", "wafer_diag_x2_passes",
     "wafer_peer_export", "wafer_peer_connect", "wafer_peer_disconnect",
 ]
@@ -54,6 +54,11 @@ class _DivPlan(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class _DivPlanF32(C.Structure):
+    """wafer_div_plan_f32_t (include/wafer_hip.h)"""
+    _fields_ = [("den", C.c_float), ("zh", C.c_float), ("zl", C.c_float), ("checked", C.c_int32), ("zl_shift", C.c_int32)]
 
 
 class WaferError(RuntimeError):
@@ -159,6 +164,8 @@ def load_library():
     L.wafer_get_div_plan.argtypes = [vp, C.POINTER(_DivPlan)]
     L.wafer_diag_div_planned.argtypes = [vp, C.POINTER(_DivPlan), C.c_uint64, C.c_uint64, C.c_int, C.c_int, dp, C.c_size_t,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.wafer_div_plan_f32.argtypes = [C.c_float, C.POINTER(_DivPlanF32)]
+    L.wafer_diag_div_planned_f32.argtypes = [vp, C.POINTER(_DivPlanF32), C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.wafer_diag_copy_bw.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     L.wafer_diag_checksum.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.wafer_diag_x2_passes.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -256,6 +263,16 @@ def div_plan(den: float, max_candidates: int = 4096):
     if rc != 0:
         raise WaferError(rc, L.wafer_last_error().decode())
     return p, cand[:n.value].copy()
+
+
+def div_plan_f32(den: float) -> _DivPlanF32:
+    """wafer_div_plan_f32 -- host only: the fp32 plan of x / den (all 2^23 significands tried)"""
+    L = load_library()
+    p = _DivPlanF32()
+    rc = L.wafer_div_plan_f32(den, C.byref(p))
+    if rc != 0:
+        raise WaferError(rc, L.wafer_last_error().decode())
+    return p
 
 
 def _dp(a: np.ndarray):
@@ -366,6 +383,13 @@ class Context:
         self._check(self._L.wafer_diag_div_planned(self._h, C.byref(plan), seed, n_random, lo_exp, hi_exp,
                                                    _dp(ops) if ops.size else None, ops.size, C.byref(bad_r), C.byref(bad_o)))
         return int(bad_r.value), int(bad_o.value)
+
+    def div_planned_check_f32(self, plan: _DivPlanF32, lo_exp: int = 27, hi_exp: int = 227) -> int:
+        """floats (ALL significands, both signs, biased exponents lo_exp .. hi_exp) whose planned fp32 quotient differs from the
+        device's IEEE x / den in any bit (wafer_diag_div_planned_f32)"""
+        bad = C.c_uint64(0)
+        self._check(self._L.wafer_diag_div_planned_f32(self._h, C.byref(plan), lo_exp, hi_exp, C.byref(bad)))
+        return int(bad.value)
 
     def download_phi_owned(self) -> np.ndarray:
         """the work cells of the planes this context owns, (nx, ny, z_count)"""
