@@ -440,6 +440,26 @@ def test_division_by_the_invariant_denominator_over_the_exponent_range(wo, wa, v
         assert float(np.max(np.abs(got - phi))) <= 1e-319
 
 
+@pytest.mark.parametrize("ext,variant", [(2, 2), (2, 1), (3, 1)])
+@pytest.mark.parametrize("scale", [1e-280, 1.0, 1e290])
+def test_power_of_two_coefficients_as_fused_multiply_adds_over_the_exponent_range(wo, wa, ext, variant, scale):
+    """wafer_fma_pow2: the FivePoint / SevenPoint sums take t + 16 x (t + 2 x) as one fused multiply-add -- the product is exact, so
+    these are the reference's bits from tiny to huge wavefunctions (up to 2^1019, where the separate product would overflow)"""
+    cfg, par = make_pair((37, 22, 19), ext=ext, dn=0.2, dt=0.002)
+    v = wo.potential_generate(cfg)
+    a, b = wo.ab(cfg, v)
+    phi = random_phi(cfg, seed=34) * scale
+    with wa.Context(par) as ctx:
+        ctx.set_stencil_variant(variant)
+        ctx.set_potential("Harmonic")
+        ctx.upload_phi(phi)
+        ctx.evolve(0, 4)
+        wo.evolve(cfg, 0, a, b, phi, [], 4)
+        got = ctx.download_phi()
+    assert np.isfinite(phi).all() and np.abs(phi).max() > 0
+    assert ulp_diff(got, phi) == 0
+
+
 def test_hoisted_division_equals_the_ieee_division_on_2e10_operands(wa):
     """wafer_div_invariant against the device's own IEEE x / den, bit for bit: 2^31 random operands
     (uniform significand and sign, exponents 2^-959 ... 2^+960) for each of ten denominators -- the
