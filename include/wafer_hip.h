@@ -253,6 +253,14 @@ int wafer_diag_copy_bw(wafer_ctx *ctx, int iters, int unroll, int blocks_per_cu,
  * ranges of an undecomposed run whenever the bits agree: bench.py's N > 1 parity check. */
 int wafer_diag_checksum(wafer_ctx *ctx, uint32_t z_begin, uint32_t z_count, uint64_t *out);
 
+/* Diagnostic: global padded planes [zp_begin, zp_begin + zp_count) of one device array in the reference's layout,
+ * out[px][py][zp_count] (z contiguous) -- what wafer_download_array / wafer_download_phi return, restricted to a z-window, for
+ * grids whose arrays do not fit the host (1024^3, 2048^3: tests/test_gpu_fullsize.py compares such windows cell by cell with the
+ * oracle).  array_id: WAFER_ARRAY_V / _A / _B, or WAFER_ARRAY_PHI (the current wavefunction).  The planes must be among those the
+ * context holds (its owned planes + halo_depth ghost planes per side, and the global frame): WAFER_ERR_INVALID otherwise. */
+#define WAFER_ARRAY_PHI 4
+int wafer_diag_download_window(wafer_ctx *ctx, int array_id, uint32_t zp_begin, uint32_t zp_count, double *out);
+
 /* Diagnostic: how many passes of the two-excited-steps-per-pass kernel (wafer_stencil_x2.hip.h: ThreePoint fp64, one to three
  * stored states) this context has launched so far -- tests assert that the kernel they mean to test is the one that ran. */
 int wafer_diag_x2_passes(wafer_ctx *ctx, uint64_t *out);

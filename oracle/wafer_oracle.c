@@ -291,29 +291,42 @@ int wo_potential_at(const wo_config *c, int64_t ix, int64_t iy, int64_t iz, doub
     }
 }
 
-/* potential.rs:46-62 */
-int wo_potential_generate(const wo_config *c, double *v)
+/* potential.rs:46-62 on the global padded planes [zp0, zp0 + zcount) only: v is [px][py][zcount].  The same
+ * wo_potential_at on the same GLOBAL indices -- for grids whose arrays do not fit the host (1024^3, 2048^3). */
+int wo_potential_generate_zwindow(const wo_config *c, int64_t zp0, int64_t zcount, double *v)
 {
     wo_dims d = dims_of(c);
     double probe;
     if (wo_potential_at(c, 0, 0, 0, &probe)) return 1;
+    if (zp0 < 0 || zcount < 0 || zp0 + zcount > d.pz) return 2;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < d.px; ++i)
         for (int64_t j = 0; j < d.py; ++j)
-            for (int64_t k = 0; k < d.pz; ++k) wo_potential_at(c, i, j, k, &v[PIDX(d, i, j, k)]);
+            for (int64_t k = 0; k < zcount; ++k)
+                wo_potential_at(c, i, j, zp0 + k, &v[(((size_t)i) * (size_t)d.py + (size_t)j) * (size_t)zcount + (size_t)k]);
     return 0;
 }
 
-/* potential.rs:101-110 */
-void wo_ab(const wo_config *c, const double *v, double *a, double *b)
+/* potential.rs:46-62 */
+int wo_potential_generate(const wo_config *c, double *v)
 {
-    size_t n = wo_padded_len(c);
-    const double dt = c->dt;
+    return wo_potential_generate_zwindow(c, 0, c->nz + 2 * (int64_t)c->ext, v);
+}
+
+/* potential.rs:101-110 over n elements (elementwise: a z-window has its own length) */
+void wo_ab_n(double dt, const double *v, double *a, double *b, size_t n)
+{
 #pragma omp parallel for schedule(static)
     for (size_t p = 0; p < n; ++p) {
         b[p] = 1. / (1. + dt * v[p] / 2.);
         a[p] = (1. - dt * v[p] / 2.) * b[p];
     }
+}
+
+/* potential.rs:101-110 */
+void wo_ab(const wo_config *c, const double *v, double *a, double *b)
+{
+    wo_ab_n(c->dt, v, a, b, wo_padded_len(c));
 }
 
 /* potential.rs:112-153 (the no-file branch) with :326-363 */
@@ -379,17 +392,20 @@ static double gaussian_at(uint64_t seed, uint64_t counter, double sigma)
     return sigma * (sqrt(-2.0 * log(u1)) * cos(2.0 * WO_PI * u2));
 }
 
-/* config.rs:577-627 (FromFile is the caller's business) */
-int wo_initial_condition(const wo_config *c, int ic, uint64_t seed, double *phi)
+/* config.rs:577-627 (FromFile is the caller's business) on the global padded planes [zp0, zp0 + zcount): phi is
+ * [px][py][zcount]; every formula sees the GLOBAL index (the Gaussian counter is the global padded linear index) */
+int wo_initial_condition_zwindow(const wo_config *c, int ic, uint64_t seed, int64_t zp0, int64_t zcount, double *phi)
 {
     wo_dims d = dims_of(c);
     if (ic != WO_IC_GAUSSIAN && ic != WO_IC_COULOMB && ic != WO_IC_CONSTANT && ic != WO_IC_BOOLEAN)
         return 1;
+    if (zp0 < 0 || zcount < 0 || zp0 + zcount > d.pz) return 2;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < d.px; ++i)
         for (int64_t j = 0; j < d.py; ++j)
-            for (int64_t k = 0; k < d.pz; ++k) {
-                size_t p = PIDX(d, i, j, k);
+            for (int64_t kw = 0; kw < zcount; ++kw) {
+                const int64_t k = zp0 + kw;
+                size_t p = (((size_t)i) * (size_t)d.py + (size_t)j) * (size_t)zcount + (size_t)kw;
                 double val;
                 /* Dirichlet frame, config.rs:597-622 */
                 if (i < d.e || i >= d.px - d.e || j < d.e || j >= d.py - d.e || k < d.e ||
@@ -399,7 +415,7 @@ int wo_initial_condition(const wo_config *c, int ic, uint64_t seed, double *phi)
                 }
                 switch (ic) {
                 case WO_IC_GAUSSIAN: /* :636-642, own RNG keyed by the padded linear index */
-                    val = gaussian_at(seed, (uint64_t)p, c->sig);
+                    val = gaussian_at(seed, (uint64_t)PIDX(d, i, j, k), c->sig);
                     break;
                 case WO_IC_COULOMB: { /* :650-669 */
                     double dx = (double)i - ((double)d.px / 2.);
@@ -424,6 +440,11 @@ int wo_initial_condition(const wo_config *c, int ic, uint64_t seed, double *phi)
                 phi[p] = val;
             }
     return 0;
+}
+
+int wo_initial_condition(const wo_config *c, int ic, uint64_t seed, double *phi)
+{
+    return wo_initial_condition_zwindow(c, ic, seed, 0, c->nz + 2 * (int64_t)c->ext, phi);
 }
 
 /* ======================================================================== *
@@ -714,13 +735,14 @@ static void bracket(int64_t n, double look, int64_t *lo, int64_t *hi)
 
 static inline double lerp1(double c0, double c1, double t) { return c0 * (1. - t) + c1 * t; }
 
-/* `out` has dims (sx,sy,sz); the sample positions are the first sx (sy, sz)
+/* `out` has dims (sx,sy,sz): output planes zbegin .. zbegin + sz of the z axis (zbegin = 0 and all of them in
+ * wo_trilerp_resize_basis; a window of them for targets that do not fit the host); the sample positions are the first sx (sy, sz)
  * points of linspace(0, n, bx) (by, bz): input.rs:672-675 builds the basis from
  * the `size` argument while the loop runs over `output`'s own dims -- the
  * production call passes the PADDED target size with the unpadded work view
  * (input.rs:156-173, 640-656), the unit test passes the view's own dims. */
-int wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
-                            int64_t sx, int64_t sy, int64_t sz, int64_t bx, int64_t by, int64_t bz)
+int wo_trilerp_resize_basis_zwindow(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
+                                    int64_t sx, int64_t sy, int64_t zbegin, int64_t sz, int64_t bx, int64_t by, int64_t bz)
 {
     const int64_t nx = vx - 1, ny = vy - 1, nz = vz - 1;
     /* an axis of one point: (0..0).position(..) is None and the reference's (nx - 1, nx) underflows usize -- it panics
@@ -733,7 +755,7 @@ int wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz,
             for (int64_t z = 0; z < sz; ++z) {
                 double xl = linspace_at(0., (double)nx, bx, x);
                 double yl = linspace_at(0., (double)ny, by, y);
-                double zl = linspace_at(0., (double)nz, bz, z);
+                double zl = linspace_at(0., (double)nz, bz, zbegin + z);
                 int64_t x0, x1, y0, y1, z0, z1;
                 bracket(nx, xl, &x0, &x1);
                 bracket(ny, yl, &y0, &y1);
@@ -752,6 +774,12 @@ int wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz,
             }
 #undef VAT
     return 0;
+}
+
+int wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
+                            int64_t sx, int64_t sy, int64_t sz, int64_t bx, int64_t by, int64_t bz)
+{
+    return wo_trilerp_resize_basis_zwindow(v, vx, vy, vz, out, sx, sy, 0, sz, bx, by, bz);
 }
 
 int wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,

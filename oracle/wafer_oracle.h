@@ -133,6 +133,18 @@ int wo_trilerp_resize(const double *v, int64_t vx, int64_t vy, int64_t vz, doubl
 int wo_trilerp_resize_basis(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
                             int64_t sx, int64_t sy, int64_t sz, int64_t bx, int64_t by, int64_t bz);
 
+/* ---- z-windows of grids whose arrays do not fit the host (1024^3, 2048^3; tests/test_gpu_fullsize.py) --------------------
+ * The functions above ARE these with the window [0, pz): the same code on the same GLOBAL indices, restricted to the global
+ * padded planes [zp0, zp0 + zcount); arrays are [px][py][zcount].  A window is then evolved as a grid of its own -- a config
+ * with nz = zcount - 2 ext, wo_evolve / wo_stencil_step unchanged: the stencil has no notion of position -- and after s steps
+ * its planes [s ext, zcount - s ext) are those of the global run (a window end that IS the global frame stays valid). */
+int wo_potential_generate_zwindow(const wo_config *c, int64_t zp0, int64_t zcount, double *v);
+int wo_initial_condition_zwindow(const wo_config *c, int ic, uint64_t seed, int64_t zp0, int64_t zcount, double *phi);
+void wo_ab_n(double dt, const double *v, double *a, double *b, size_t n);
+/* output planes [zbegin, zbegin + sz) of wo_trilerp_resize_basis's (sx, sy, .) target */
+int wo_trilerp_resize_basis_zwindow(const double *v, int64_t vx, int64_t vy, int64_t vz, double *out,
+                                    int64_t sx, int64_t sy, int64_t zbegin, int64_t sz, int64_t bx, int64_t by, int64_t bz);
+
 void wo_set_threads(int n);
 int wo_get_threads(void);
 /* diagnostics of the timed baseline leg (bench.py cpu_baseline): the host's copy bandwidth on the same threads, and

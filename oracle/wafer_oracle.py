@@ -130,6 +130,12 @@ def _bind(L):
                                         C.c_int64, C.c_int64, C.c_int64]
         L.wo_trilerp_resize_basis.restype = C.c_int
         L.wo_trilerp_resize_basis.argtypes = [dp] + [C.c_int64] * 3 + [dp] + [C.c_int64] * 6
+        L.wo_potential_generate_zwindow.argtypes = [cp, C.c_int64, C.c_int64, dp]
+        L.wo_initial_condition_zwindow.argtypes = [cp, C.c_int, C.c_uint64, C.c_int64, C.c_int64, dp]
+        L.wo_ab_n.restype = None
+        L.wo_ab_n.argtypes = [C.c_double, dp, dp, dp, C.c_size_t]
+        L.wo_trilerp_resize_basis_zwindow.restype = C.c_int
+        L.wo_trilerp_resize_basis_zwindow.argtypes = [dp] + [C.c_int64] * 3 + [dp] + [C.c_int64] * 7
         L.wo_set_threads.argtypes = [C.c_int]
         L.wo_get_threads.restype = C.c_int
         L.wo_host_copy_gbps.restype = C.c_double
@@ -324,3 +330,61 @@ def trilerp_resize(v: np.ndarray, size, basis=None) -> np.ndarray:
                                      size[0], size[1], size[2], basis[0], basis[1], basis[2]) != 0:
         raise ValueError("trilerp_resize: every axis of the source needs at least two points (the reference panics)")
     return out
+
+
+# ---- z-windows of grids whose arrays do not fit the host (wafer_oracle.h) ---------------------------------------------------
+def potential_generate_zwindow(cfg: Config, zp0: int, zcount: int) -> np.ndarray:
+    """potential.rs:46-62 on the global padded planes [zp0, zp0 + zcount): (px, py, zcount)"""
+    px, py, _ = cfg.padded_shape
+    v = np.zeros((px, py, zcount))
+    rc = lib().wo_potential_generate_zwindow(C.byref(cfg.c()), zp0, zcount, _dp(v))
+    if rc:
+        raise ValueError("PotentialNotAvailable" if rc == 1 else "window outside the padded grid")
+    return v
+
+
+def initial_condition_zwindow(cfg: Config, ic: str, zp0: int, zcount: int, seed: int = 0) -> np.ndarray:
+    px, py, _ = cfg.padded_shape
+    phi = np.zeros((px, py, zcount))
+    rc = lib().wo_initial_condition_zwindow(C.byref(cfg.c()), INITIAL_CONDITIONS.index(ic), seed, zp0, zcount, _dp(phi))
+    if rc:
+        raise ValueError("unsupported initial condition " + ic if rc == 1 else "window outside the padded grid")
+    return phi
+
+
+def ab_n(dt: float, v: np.ndarray):
+    """potential.rs:101-110, elementwise over any array"""
+    a, b = np.empty_like(v), np.empty_like(v)
+    lib().wo_ab_n(dt, _dp(v), _dp(a), _dp(b), v.size)
+    return a, b
+
+
+def trilerp_resize_zwindow(v: np.ndarray, size_xy, zbegin: int, zcount: int, basis) -> np.ndarray:
+    """planes [zbegin, zbegin + zcount) of trilerp_resize(v, (sx, sy, .), basis): (sx, sy, zcount)"""
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    out = np.zeros((size_xy[0], size_xy[1], zcount))
+    if lib().wo_trilerp_resize_basis_zwindow(_dp(v), v.shape[0], v.shape[1], v.shape[2], _dp(out), size_xy[0], size_xy[1],
+                                             zbegin, zcount, basis[0], basis[1], basis[2]) != 0:
+        raise ValueError("trilerp_resize: every axis of the source needs at least two points (the reference panics)")
+    return out
+
+
+def evolve_zwindow(cfg: Config, zp0: int, a: np.ndarray, b: np.ndarray, phi: np.ndarray, steps: int, storage=None):
+    """`steps` ground-state steps (grid.rs:544-687) of the window phi = global padded planes [zp0, zp0 + zcount), in place, as a
+    grid of its own: wo_evolve on a config with nz = zcount - 2 ext (the stencil has no notion of position; a, b are the
+    window's).  Returns (lo, hi): the window planes [lo, hi) that equal the global run's afterwards -- a window end inside the
+    grid loses ext planes per step, one that is the global frame none.  `storage` (np.float32): the result of every step is
+    rounded to that type, which is what a device array of that type holds (dtype "f32": fp32 storage, fp64 arithmetic)."""
+    e = cfg.ext
+    zcount = phi.shape[2]
+    pz = cfg.nz + 2 * e
+    assert phi.shape[:2] == cfg.padded_shape[:2] and (zp0 == 0 or zp0 >= e) and zcount > 2 * e
+    local = Config(cfg.nx, cfg.ny, zcount - 2 * e, ext=e, potential=cfg.potential, dn=cfg.dn, dt=cfg.dt, mass=cfg.mass, sig=cfg.sig)
+    c = local.c()
+    for _ in range(steps):
+        lib().wo_evolve(C.byref(c), 0, _dp(a), _dp(b), _dp(phi), _store_ptrs([]), 1)
+        if storage is not None:
+            phi[...] = phi.astype(storage).astype(np.float64)
+    lo = 0 if zp0 == 0 else steps * e
+    hi = zcount if zp0 + zcount == pz else zcount - steps * e
+    return lo, hi

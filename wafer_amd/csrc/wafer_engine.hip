@@ -657,6 +657,30 @@ int wafer_download_phi_owned(wafer_ctx *c, double *out)
     return convert_host_array<false>(c, out, c->g.nx, c->g.ny, c->g.nzl, c->g.R, c->g.R, c->g.z_begin + c->g.R, c->phi[c->cur]);
 }
 
+int wafer_diag_download_window(wafer_ctx *c, int id, uint32_t zp_begin, uint32_t zp_count, double *out)
+{
+    if (!c || !out) return fail(WAFER_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->P.device));
+    const long long lo = c->g.zp_of(0), hi = c->g.zp_of(c->g.lz);   // global padded planes this context holds: [lo, hi)
+    if (zp_count == 0 || (long long)zp_begin < std::max(lo, 0LL) || (long long)zp_begin + zp_count > std::min<long long>(hi, c->g.pzg))
+        return fail(WAFER_ERR_INVALID, "planes [%u, %u) are not among the padded planes [%lld, %lld) this context holds", zp_begin,
+                    zp_begin + zp_count, std::max(lo, 0LL), std::min<long long>(hi, c->g.pzg));
+    void *dev = nullptr;
+    switch (id) {
+    case WAFER_ARRAY_V: dev = c->v; break;
+    case WAFER_ARRAY_A: TRY(ensure_ab(c)); dev = c->a; break;
+    case WAFER_ARRAY_B: TRY(ensure_ab(c)); dev = c->b; break;
+    case WAFER_ARRAY_PHI:
+        if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
+        HIP_TRY(hipStreamSynchronize(c->s_aux));
+        dev = c->phi[c->cur];
+        break;
+    default: return fail(WAFER_ERR_INVALID, "unknown array id %d", id);
+    }
+    // host element (0, 0, hz) = padded cell (0, 0, zp_begin + hz)
+    return convert_host_array<false>(c, out, c->g.px, c->g.py, (int)zp_count, 0, 0, (int)zp_begin, dev);
+}
+
 // ---- w_store ------------------------------------------------------------------------
 static int new_state_slot(wafer_ctx *c, void **slot)
 {

@@ -42,7 +42,7 @@ EXPORTS = [
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_kernel_instance", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
     "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check", "wafer_div_plan", "wafer_get_div_plan", "wafer_diag_div_planned", "wafer_div_plan_f32", "wafer_diag_div_planned_f32",
-    "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_set_halo_cycle", "wafer_diag_x2_passes",
+    "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_diag_download_window", "wafer_set_halo_cycle", "wafer_diag_x2_passes",
     "wafer_peer_export", "wafer_peer_connect", "wafer_peer_disconnect",
 ]
 
@@ -169,6 +169,7 @@ def load_library():
     L.wafer_diag_copy_bw.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     L.wafer_diag_checksum.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.wafer_diag_x2_passes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.wafer_diag_download_window.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, dp]
     L.wafer_peer_export.argtypes = [vp, C.POINTER(_PeerInfo)]
     L.wafer_peer_connect.argtypes = [vp, C.POINTER(_PeerInfo), C.POINTER(_PeerInfo)]
     L.wafer_peer_disconnect.argtypes = [vp]
@@ -335,6 +336,14 @@ class Context:
         idx = {"v": 0, "a": 1, "b": 2, "potsub": 3}[which]
         out = np.zeros(self.params.work_shape if which == "potsub" else self.params.padded_shape)
         self._check(self._L.wafer_download_array(self._h, idx, _dp(out)))
+        return out
+
+    def download_window(self, which: str, zp_begin: int, zp_count: int) -> np.ndarray:
+        """global padded planes [zp_begin, zp_begin + zp_count) of "v" / "a" / "b" / "phi" in the reference's layout:
+        (px, py, zp_count) -- download_array / download_phi restricted to a z-window (wafer_diag_download_window)"""
+        px, py, _ = self.params.padded_shape
+        out = np.zeros((px, py, zp_count))
+        self._check(self._L.wafer_diag_download_window(self._h, {"v": 0, "a": 1, "b": 2, "phi": 4}[which], zp_begin, zp_count, _dp(out)))
         return out
 
     def set_potsub(self, kind: int, scalar: float = 0.0, potsub: np.ndarray | None = None) -> None:
