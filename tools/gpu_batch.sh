@@ -27,6 +27,12 @@ for step in "$@"; do
     hv_sweep)     timeout 240 python3 tools/hv_sweep.py > $O/hv_sweep.jsonl 2> $O/hv_sweep.err; cat $O/hv_sweep.jsonl; tail -3 $O/hv_sweep.err ;;
     ar_latency)   timeout 300 python3 tools/allreduce_latency.py 2>/dev/null | grep "^{" > $O/allreduce_latency.json; cat $O/allreduce_latency.json ;;
     rows)         timeout 1500 python3 tools/secondary_rows.py $O/rows > $O/rows.log 2>&1; cat $O/rows.log | cut -c1-600 ;;
+    # BASELINE config #5's literal flow on ONE device: ./input/potential.csv (64^3) -> device resampler -> 2048^3 fp32 storage,
+    # a fixed number of blocks (max_steps; the run then ends with MaxStep, exit code 1), nothing written but the table
+    cli_fromfile) python3 examples/make_potential_64.py /tmp/in5/potential.csv
+                  sed "s/max_steps: 2000000/max_steps: ${CLI_STEPS:-4000}/; s/save_wavefns: true/save_wavefns: false/" examples/fromfile_2048_f32.yaml > /tmp/fromfile_2048_f32.yaml
+                  ( time timeout 1200 wafer_amd/wafer-hip -c /tmp/fromfile_2048_f32.yaml --progress --input-dir /tmp/in5 --output-dir /tmp/out5 ) > $O/fromfile_2048_cli.log 2>&1
+                  cat $O/fromfile_2048_cli.log ;;
     *)            echo "unknown step $step" ;;
   esac
 done
