@@ -262,21 +262,25 @@ def pmc_traffic(kernel_instance: str):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (a STATIC figure: counters cannot be read inside a
     timed run) -- only from the entry of EXACTLY this instantiation ("wafer_k_step3_fused<double, double, true, 0, true, 1>"
     against the profiler's "void wafer_k_step3_fused<...>(arguments)"): another instantiation's bytes (peer stores, marching
-    down, fp32) describe another kernel.  -> (bytes or None, the matched key or None)"""
+    down, fp32) describe another kernel.  -> (bytes or None, the matched key or None, stale: the kernel sources have changed
+    since the figure was measured -- tools/pmc_summary.py stores their hash, wafer_amd/provenance.py -- or None if unknown)"""
     if "<" not in kernel_instance:
-        return None, None
+        return None, None, None
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
+        from wafer_amd.provenance import kernel_sources_sha16
+        measured_on = d.get("kernel_sources_sha16")
         for k, v in d.get("kernels", {}).items():
             if "from" in v:   # entries tagged "from" are earlier builds / variants kept for the record
                 continue
             if k.startswith("void " + kernel_instance + "(") or k == kernel_instance:
-                return v.get("hbm_bytes_per_launch"), k
+                on = v.get("kernel_sources_sha16", measured_on)
+                return v.get("hbm_bytes_per_launch"), k, (None if on is None else on != kernel_sources_sha16())
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -534,7 +538,7 @@ def run_rank(args) -> int:
     kname = ctx.stencil_kernel_name()
     kinst = ctx.stencil_kernel_instance()         # the instantiation the timed passes launched, as a profiler prints it
     # (the committed counter figure belongs to one kernel on one workload: the default grid and potential only)
-    traffic, traffic_key = pmc_traffic(kinst) if (n_gpus == 1 and not args.grid and not args.potential) else (None, None)
+    traffic, traffic_key, traffic_stale = pmc_traffic(kinst) if (n_gpus == 1 and not args.grid and not args.potential) else (None, None, None)
 
     comm_info = None
     if comm is not None:
@@ -581,6 +585,9 @@ def run_rank(args) -> int:
             "traffic": traffic,
             "traffic_source": ("profiles/pmc_traffic.json (static: rocprofv3 --pmc of this kernel on this workload, "
                                "not re-measured in this run); entry: " + traffic_key) if traffic else None,
+            # True: the kernel sources have changed since that figure was measured (wafer_amd/provenance.py hashes them,
+            # tools/pmc_summary.py stores the hash with the figures); None: the committed file carries no hash
+            "traffic_stale": traffic_stale if traffic else None,
             "kernel": kinst,
             "avg_launch_ms": launch_s * 1e3,
             "steps_per_launch": spl,

@@ -231,7 +231,8 @@ int wafer_solve_state(wafer_ctx *ctx, uint32_t wnum, double tolerance, uint64_t 
 /* HIP-event time of the kernels of the last wafer_evolve call, on the stream
  * they ran on, and the number of steps it took.  Blocks until they finish. */
 int wafer_last_evolve_ms(wafer_ctx *ctx, float *ms, uint64_t *steps);
-/* name of the stencil kernel variant the context dispatches to */
+/* name of the stencil kernel a ground-state pass of this context launches (no template arguments): wafer_k_step3_fused,
+ * wafer_k_step2_wide (FivePoint), wafer_k_step2_fused, wafer_k_step_lds, wafer_k_step_direct */
 const char *wafer_stencil_kernel_name(wafer_ctx *ctx);
 /* the template-id of the kernel the last ground-state pass launched, as a profiler prints it (e.g.
  * "wafer_k_step3_fused<double, double, true, 0, true, 1>"); the family name where the family does not record it.  Valid until

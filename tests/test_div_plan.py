@@ -171,6 +171,16 @@ def test_divisors_without_a_plan():
     for den in (0.0, math.inf, math.nan, 5e-324, 1e-310):
         plan, cand = engine.div_plan(den)
         assert plan.checked == 0 and cand.size == 0
+    # outside [2^-900, 2^900] the enumeration's premise fails (zl subnormal above ~2^969; x zh near overflow for a tiny den): no
+    # verdict, the kernels keep the Markstein round -- except for powers of two, whose zl is 0 (wafer_divplan.h:88)
+    for den in (3.0 * 2.0 ** 1000, 1.7 * 2.0 ** 970, 1.3 * 2.0 ** -1000, -(5.0 / 3.0) * 2.0 ** 905):
+        plan, cand = engine.div_plan(den)
+        assert plan.checked == 0 and plan.den == den and plan.zh == 1.0 / den
+    for den in (2.0 ** 1000, 2.0 ** -1000):
+        plan, cand = engine.div_plan(den)
+        assert (plan.checked, plan.zl) == (1, 0.0)
+    for den in (1.3 * 2.0 ** 899, 1.3 * 2.0 ** -899):      # inside the window: planned as before
+        assert engine.div_plan(den)[0].n_candidates > 0
     # a power of two: 1/den is a double, zl = 0, nothing can go wrong
     plan, cand = engine.div_plan(0.125)
     assert (plan.zh, plan.zl, plan.checked, cand.size) == (8.0, 0.0, 1, 0)

@@ -158,10 +158,10 @@ def test_config3_512_cubed_stored_states_two_excited_steps(wo, wa, potential, k,
 
 
 @BIG
-@pytest.mark.parametrize("ext,kernel", [(2, "wafer_k_step2_fused"), (3, "wafer_k_step_lds")])
+@pytest.mark.parametrize("ext,kernel", [(2, "wafer_k_step2_wide"), (3, "wafer_k_step_lds")])
 def test_five_and_seven_point_256_cubed_four_steps_bit_exact(wo, wa, ext, kernel):
     """the default kernels of the wider stencils at a size where every workgroup marches a long column: FivePoint on the
-    fused two-step kernel, SevenPoint on the single-step LDS kernel, 256^3 Coulomb x 4 steps, every cell's bits
+    two-step kernel on 128 x 16 tiles, SevenPoint on the single-step LDS kernel, 256^3 Coulomb x 4 steps, every cell's bits
     against the oracle (grid.rs:593-663); dt = 0.2 dn^2 keeps both inside the true forward-Euler bound"""
     n = 256
     cfg, par = make_pair((n, n, n), ext=ext, potential="Coulomb", dn=0.05, dt=5e-4, mass=1.0)

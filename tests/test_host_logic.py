@@ -170,3 +170,24 @@ def test_halves_schedule_invariants(sched, ntx, nty, lo, nzl, nshort, nsub, layo
         assert sum(1 for x in b if x["bump"] == half) == ntiles
     halves_in_order = [0 if x["down"] else 1 for x in b]
     assert halves_in_order[0] == first and halves_in_order == sorted(halves_in_order, reverse=bool(first))
+
+
+def test_committed_counter_figures_name_the_kernel_sources_they_were_measured_on():
+    """profiles/pmc_traffic.json carries the hash of the kernel sources it was measured on (tools/pmc_summary.py,
+    wafer_amd/provenance.py); bench.py's roofline.traffic is labelled stale when the kernels have changed since"""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from wafer_amd import provenance
+    doc = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    assert len(doc["kernel_sources_sha16"]) == 16
+    files = [os.path.basename(f) for f in provenance.kernel_sources()]
+    assert "wafer_stencil_fused3.hip.h" in files and "wafer_tu_fused3.hip" in files and "wafer_engine.hip" not in files
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    traffic, key, stale = bench.pmc_traffic("wafer_k_step3_fused<double, double, true, 0, true, 1>")
+    assert traffic > 3e9 and key.startswith("void wafer_k_step3_fused<double, double, true, 0, true, 1>(")
+    assert stale == (doc["kernel_sources_sha16"] != provenance.kernel_sources_sha16())
+    assert bench.pmc_traffic("wafer_k_step3_fused") == (None, None, None)          # a family name matches nothing

@@ -51,7 +51,11 @@ def main():
             "write_bytes_per_launch": w_avg * 1024.0,
             "hbm_bytes_per_launch": 2.0 * f_avg * 1024.0 + w_avg * 1024.0,
         }
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from wafer_amd.provenance import kernel_sources_sha16
     doc = {
+        # the kernel sources these bytes were measured on: bench.py labels roofline.traffic stale when they have changed since
+        "kernel_sources_sha16": kernel_sources_sha16(),
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py at N=1",
         "corrections": "KiB->bytes x1024; FETCH_SIZE x2 (gfx950 wide coalesced reads); WRITE_SIZE exact; "
                        "Infinity-Cache hits are included, so this bounds HBM traffic from above",

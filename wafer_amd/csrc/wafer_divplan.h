@@ -91,6 +91,15 @@ static inline WaferDivPlan wafer_divplan_make(double den)
         p.zl = 0.0;
         return p;
     }
+    // The candidate set rests on |zh + zl - 1/den| <= 2.5 ulp(zl) with zl at FULL precision, and the trial runs significands at
+    // one exponent.  For |den| above ~2^969 zl is subnormal (its relative error far above 2^-106), and for a tiny den x*zh nears
+    // overflow for operands the trial never sees: outside [2^-900, 2^900] -- or with a subnormal non-zero zl -- no verdict:
+    // `checked` stays 0 and the kernels take the Markstein round, which is RN whatever the plan found.
+    {
+        int e = 0;
+        (void)std::frexp(den, &e);
+        if (zl0 != 0.0 && (e < -900 || e > 900 || !std::isnormal(zl0))) return p;   // (zl0 == 0: 1/den is a double, x*zh IS the quotient)
+    }
     const std::vector<double> cand = wafer_divplan_candidates(den);
     p.n_candidates = (int)cand.size();
     static const int shifts[] = {0, 1, -1, 2, -2};

@@ -837,6 +837,9 @@ const char *wafer_stencil_kernel_name(wafer_ctx *c)
     int v = active_variant(c);
     const int spl = wafer_stencil_steps_per_launch(c);
     if (v >= 2) v = spl == 3 ? 3 : spl == 2 ? 2 : 1; // what the fused variants fall back to where they do not apply
+    // the name of the kernel that is LAUNCHED, not of the variant family: the two-step entry point hands FivePoint on to the
+    // 128 x 16-tile kernel (wafer_entry_step2_fused -> wafer_entry_step2_wide unless WAFER_F2_WIDE=0)
+    if (v == 2 && c->g.R == 2 && c->tune.f2_wide != 0) return "wafer_k_step2_wide";
     return kVariants[(v >= 0 && v < kNumVariants) ? v : 0].name;
 }
 

@@ -165,7 +165,11 @@ static int run_slab(const wafer_params &p, int potential, uint64_t steps, wafer_
     WCHECK(wafer_ctx_create(&p, &ctx));
     WCHECK(wafer_set_comm_hooks(ctx, halo, allreduce, user));
     WCHECK(wafer_set_potential_builtin(ctx, potential));
-    if (peers && p.z_count >= 6) {
+    // try_peer_stores is COLLECTIVE (an all-gather and several all-reduces): whether it is entered must depend on a quantity every
+    // rank shares -- the thinnest slab of the partition (nz / world: nz = 47 over 8 ranks hands out 6, 6, 6, 6, 6, 6, 6, 5), never
+    // this rank's own thickness; wafer_set_overlap(3) needs 6 owned planes on every rank
+    const uint32_t thinnest = (p.z_count && world > 1) ? p.nz / (uint32_t)world : (p.z_count ? p.z_count : p.nz);
+    if (peers && thinnest >= 6) {
         if (try_peer_stores(ctx, p, fab, rank, world, self_loop, &out.peer_check)) return 1;
         out.overlap_mode = out.peer_check == 1 ? 3 : 2;
     }

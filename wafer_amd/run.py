@@ -246,7 +246,10 @@ def main(argv=None) -> int:
             # for it (=force: also with the host-staged test transport, ranks folded onto one GPU -- tests)
             want_peers = os.environ.get("WAFER_PEER_STORES", "0")
             if want_peers not in ("", "0") and (not host_transport or want_peers == "force"):
-                if slab.connect_peers(ctx, rank, world) and min(slab.partition(par.nz, world, r)[1] for r in range(world)) >= 6:
+                # (mode 3 is the ThreePoint three-step pass with 6 ext owned planes on every rank: a rank-invariant test -- a rank
+                #  that alone refused the mode would leave the others waiting for its planes)
+                thinnest = min(slab.partition(par.nz, world, r)[1] for r in range(world))
+                if slab.connect_peers(ctx, rank, world) and ext == 1 and thinnest >= 6 * ext:
                     use_peer_stores = True   # (switched on below, once the potential is set and the schedule has proved itself)
         def from_input(stem, pad, shape, what):
             a = staged_array(args.input_dir, stem, cfg["file_type"], pad, rank)

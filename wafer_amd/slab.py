@@ -203,10 +203,29 @@ def overlap_modes_agree(ctx, rank: int, world: int, mode: int, ref_mode: int, st
     import torch.distributed as dist
     from .engine import WaferError
     sums, bad = [], False
+
+    def any_rank(flag: bool) -> bool:
+        if world <= 1:
+            return flag
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return float(t[0]) != 0.0
+
     for m in (mode, ref_mode):
+        # a schedule this rank's context refuses (mode 3 on a slab thinner than 6 ext planes, no peers connected) must be known to
+        # EVERY rank before any of them evolves: evolve's halo hook posts sends and receives to the neighbours, and a rank that
+        # skipped it would sit in the barrier below while they wait for its planes
+        refused = False
         try:
             ctx.set_overlap(m)
             ctx.set_initial_condition("Boolean")
+        except WaferError:
+            refused = True
+        if any_rank(refused):
+            bad = True
+            sums.append(None)
+            continue
+        try:
             ctx.evolve(0, steps)
             ctx.synchronize()
             sums.append(ctx.checksum(ctx.params.z_begin, ctx.params.z_count))
@@ -548,11 +567,15 @@ class NativeRcclSlabComm:
 
         out = {}
         had = self.mailbox
-        if L.wafer_rccl_use_mailbox(self._handle, None) != 0:
-            raise RuntimeError("wafer_rccl_use_mailbox: " + L.wafer_rccl_last_error().decode())
+        # every decision below is taken by ALL ranks together (slowest() is an all-reduce): a rank that raised, skipped timed() or
+        # kept another transport on its own would leave the others inside their 200 collective calls
+        detach_failed = L.wafer_rccl_use_mailbox(self._handle, None) != 0
+        if slowest(1.0 if detach_failed else 0.0) != 0.0:
+            raise RuntimeError("wafer_rccl_use_mailbox(None) failed on some rank: " + L.wafer_rccl_last_error().decode())
         us_nccl, good_nccl = timed()
         out["ncclAllReduce_us"] = slowest(us_nccl)
-        if slowest(0.0 if good_nccl else 1.0) != 0.0:
+        nccl_ok = slowest(0.0 if good_nccl else 1.0) == 0.0
+        if not nccl_ok:
             out["ncclAllReduce_error"] = "a call failed or summed wrongly on some rank"
         mb = had
         if mb is None:
@@ -563,16 +586,23 @@ class NativeRcclSlabComm:
                 mb = None
         if mb is not None:
             attached = L.wafer_rccl_use_mailbox(self._handle, mb.handle) == 0
-            us_mb, good = timed() if attached else (float("inf"), False)
+            if slowest(0.0 if attached else 1.0) != 0.0:      # some rank could not attach: nobody times the mailbox
+                out["mailbox_error"] = "wafer_rccl_use_mailbox failed on some rank"
+                us_mb, good = float("inf"), False
+            else:
+                us_mb, good = timed()
             bad = slowest(0.0 if good else 1.0)
             out["mailbox_us"] = slowest(us_mb)
-            if bad == 0.0 and out["mailbox_us"] < out["ncclAllReduce_us"]:
+            if bad == 0.0 and (out["mailbox_us"] < out["ncclAllReduce_us"] or not nccl_ok):
                 self.mailbox = mb
                 out["chosen"] = "mailbox"
                 return out
             L.wafer_rccl_use_mailbox(self._handle, None)
             mb.close()          # whoever made it: a mailbox that lost (or died) serves nobody, and close() could no longer reach it
             self.mailbox = None
+        if not nccl_ok:   # (agreed above: every rank raises) -- never continue on an all-reduce that has just summed wrongly
+            raise RuntimeError("pick_allreduce: ncclAllReduce failed its own check on some rank and no working mailbox exists: "
+                               + str(out))
         out["chosen"] = "ncclAllReduce"
         return out
 
