@@ -406,16 +406,18 @@ def run_rank(args) -> int:
                 allreduce_choice = comm.pick_allreduce()
             except Exception as e:  # noqa: BLE001
                 allreduce_choice = {"error": repr(e)}
-        # peer stores (wafer_set_overlap mode 3): every rank maps its z-neighbours' buffers through HIP IPC; all ranks or none
-        peers_ok = False
+        # peer stores (wafer_set_overlap mode 3) and peer copies (mode 4): every rank maps its z-neighbours' buffers through HIP IPC; all
+        # ranks or none.  Mode 3 is the ThreePoint three-step pass on slabs of six planes or more; mode 4 is a transport and serves every pass.
+        peers_ok = copies_ok = False
         # (Not by default with the host-staged test transport: ranks folded onto ONE GPU poll for each other's stores from
         #  workgroups that hold the CUs the other rank's kernel needs.  WAFER_BENCH_PEERS=force connects them there as well -- HIP
         #  IPC between processes on one device -- so that a one-GPU box executes every line the first real multi-GPU run will; the
         #  tests keep the grids at a tile per CU per rank or less, and a schedule whose bounded waits give up is dropped below.)
         want_peers = os.environ.get("WAFER_BENCH_PEERS", "1")
-        if ext == 1 and want_peers != "0" and (not host_transport or want_peers == "force"):
+        if want_peers != "0" and (not host_transport or want_peers == "force"):
             try:
-                peers_ok = slab.connect_peers(ctx, rank, world) and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 6
+                copies_ok = slab.connect_peers(ctx, rank, world)
+                peers_ok = copies_ok and ext == 1 and min(slab.partition(nz, world, r)[1] for r in range(world)) >= 6
             except Exception as e:  # noqa: BLE001
                 print(f"bench.py: rank {rank}: peer connection failed: {e!r}", file=sys.stderr, flush=True)
     ctx.set_potential(potential)
@@ -459,7 +461,8 @@ def run_rank(args) -> int:
         device_info = {"error": repr(e)}
     ctx.set_initial_condition("Boolean")   # the copy used phi's second buffer as scratch
 
-    # N > 1: how the halo exchange is scheduled (wafer_set_overlap).  Mode 3: mode 2's single launch with the boundary workgroups
+    # N > 1: how the halo exchange is scheduled (wafer_set_overlap).  Mode 4: mode 2's single launch with every exchange a device copy
+    # into the neighbour's ghost planes (the copy engines between GPUs: no exchange kernel on any CU).  Mode 3: mode 2's single launch with the boundary workgroups
     # storing straight into the neighbours' ghost planes (HIP IPC / xGMI peer stores: no exchange kernels at all).  Mode 1: boundary planes and their exchange on a
     # second stream beside the interior update (three launches per pass); mode 2: ONE launch per three-step pass, the slab
     # as two halves marched outwards, each half's exchange released by its completion counter; mode 0: the exchange
@@ -473,16 +476,23 @@ def run_rank(args) -> int:
         # Peer stores have never crossed a link (tools/first_contact_8gpu.md): before the schedule is timed, let alone trusted with the
         # timed steps, it has to reproduce the bits of an exchange through the halo hook on every rank -- else it is dropped here
         # instead of surfacing as a parity failure of the whole run
-        peer_check = None
+        peer_check = copy_check = None
         if peers_ok:
             peers_ok = slab.overlap_modes_agree(ctx, rank, world, 3, 0, steps=15, device=coll_dev)
             peer_check = {"against": "overlap mode 0 (exchange through the halo hook), 15 steps, every rank's checksum", "identical": peers_ok}
             if not peers_ok and rank == 0:
                 print("bench.py: peer stores (overlap mode 3) do not reproduce the exchange's bits on this fabric: dropped", file=sys.stderr, flush=True)
+        # ... and so have the peer copies (mode 4: hipMemcpyAsync into the neighbour's ghost planes, a credit / arrival rendezvous
+        # of one-wave kernels instead of send / recv): the same check, the same consequence
+        if copies_ok:
+            copies_ok = slab.overlap_modes_agree(ctx, rank, world, 4, 0, steps=15, device=coll_dev)
+            copy_check = {"against": "overlap mode 0 (exchange through the halo hook), 15 steps, every rank's checksum", "identical": copies_ok}
+            if not copies_ok and rank == 0:
+                print("bench.py: peer copies (overlap mode 4) do not reproduce the exchange's bits on this fabric: dropped", file=sys.stderr, flush=True)
         # (slab.time_overlap_schedules: the same collective calls on every rank whatever happens on it; a schedule that fails
         #  anywhere is dropped everywhere)
         trial = slab.time_overlap_schedules(
-            ctx, ([(3, 1)] if peers_ok else []) + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []), rank, device=coll_dev,
+            ctx, ([(3, 1)] if peers_ok else []) + ([(4, 1)] if copies_ok else []) + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []), rank, device=coll_dev,
             log=lambda msg: print("bench.py: " + msg, file=sys.stderr, flush=True), device_sync=torch.cuda.synchronize)
         if not trial:
             print(f"bench.py: rank {rank}: every halo schedule failed in the set-up trial", file=sys.stderr)
@@ -490,10 +500,10 @@ def run_rank(args) -> int:
         best = min(trial, key=lambda k: trial[k] * (1.0 if k == DEFAULT_MODE else 1.02))
         ctx.set_overlap(best[0])
         ctx.set_halo_cycle(best[1])
-        names = {3: "3_single_launch_peer_stores", 2: "2_single_launch_two_halves", 1: "1_boundary_first_three_launches", 0: "0_no_overlap"}
+        names = {4: "4_single_launch_peer_copies", 3: "3_single_launch_peer_stores", 2: "2_single_launch_two_halves", 1: "1_boundary_first_three_launches", 0: "0_no_overlap"}
         overlap_choice = {"mode": best[0], "fused_passes_per_exchange": best[1],
                           "ms_per_step": {names[m] + ("" if cy == 1 else f"_exchange_every_{cy}_passes"): v for (m, cy), v in trial.items()},
-                          **({"peer_store_check": peer_check} if peer_check else {})}
+                          **({"peer_store_check": peer_check} if peer_check else {}), **({"peer_copy_check": copy_check} if copy_check else {})}
         ctx.set_initial_condition("Boolean")
     elif dist is not None:
         mode = int(os.environ.get("WAFER_OVERLAP", "") or DEFAULT_MODE[0])

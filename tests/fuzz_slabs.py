@@ -2,7 +2,7 @@
 """Randomised sweep of the DECOMPOSED ground-state path against the oracle (a development aid next to the fixed cases of
 tests/test_gpu_slab.py, and run by it in a process of its own): random grids, stencil orders, storage types, 2 - 4 uneven
 z-slabs as contexts of this process (device copies stand in for the fabric), every overlap mode the shape allows incl. peer
-stores (both pass layouts), deep halos, several evolve calls with step counts that leave every kind of remainder, potentials
+stores (both pass layouts) and peer copies (mode 4, its three schedules, thin slabs), deep halos, several evolve calls with step counts that leave every kind of remainder, potentials
 incl. the ones whose formula singles out z; then excited-state steps (one and two per pass, k = 1 .. 3, thin and uneven slabs).  fp64: the assembled slabs equal the ORACLE bit for bit (FullCornell: device libm,
 1e-12) and the all-reduced observables agree to 1e-11; fp32 storage: the slabs equal one context.
     N=40 SEED=3 python tests/fuzz_slabs.py"""
@@ -23,19 +23,21 @@ for it in range(int(os.environ.get("N", "30"))):
     nx = int(rng.choice([40, 64, 128, 130, 136, 200, 256, 264]))
     ny = int(rng.choice([16, 17, 24, 32, 33, 40, 48]))
     depth = int(rng.choice([3, 6])) * ext if ext == 1 else int(rng.choice([2, 4])) * ext
-    nz = int(rng.integers(max(world * depth, world * 2 * ext, 6 * world if ext == 1 else 0), 70))
+    # overlap modes: 3 (peer stores) is the ThreePoint three-step pass on slabs of six planes or more; 4 (peer copies) is a transport and
+    # serves every pass and thickness, under each of its three schedules
+    mode = int(rng.choice([0, 1, 2, 4, 4] + ([3, 3] if ext == 1 and depth >= 3 else [])))
+    nz = int(rng.integers(max(world * depth, world * 2 * ext, 6 * world if mode == 3 else 0), 70))
     pot, kw = [("Coulomb", {}), ("SimpleCornell", dict(mass=2.35, sig=0.223)), ("QuadWell", {}), ("Harmonic", {}), ("FullCornell", dict(mass=2.35, sig=0.223)),
                ("Periodic", {})][int(rng.integers(0, 6))]
     calls = [int(rng.integers(1, 14)) for _ in range(int(rng.integers(1, 4)))]
-    modes = [0, 1, 2] + ([3] if ext == 1 and depth >= 3 else [])
-    mode = int(rng.choice(modes))
     cycle = int(rng.choice([1, 2])) if (ext == 1 and depth == 6 and mode in (0, 1)) or (ext > 1 and depth == 4 * ext and mode in (0, 1)) else 1
     os.environ["WAFER_FUSE3_MIN_NY"] = "1"
     os.environ["WAFER_HV_LAYOUT"] = str(rng.choice([0, 3, 4]))
     os.environ["WAFER_ZCHUNK"] = str(rng.choice([0, 0, 3, 7]))
+    os.environ["WAFER_COPY_SCHED"] = str(rng.choice([2, 2, 1, 0]))
     params = dict(dn=0.2, dt=0.004, mass=1.0, sig=1.0)
     params.update(kw)
-    tag = (nx, ny, nz, ext, world, dtype, pot, calls, mode, cycle, depth, os.environ["WAFER_HV_LAYOUT"], os.environ["WAFER_ZCHUNK"])
+    tag = (nx, ny, nz, ext, world, dtype, pot, calls, mode, cycle, depth, os.environ["WAFER_HV_LAYOUT"], os.environ["WAFER_ZCHUNK"], os.environ["WAFER_COPY_SCHED"])
     try:
         base = wa.Params(nx, ny, nz, central_difference=ext, dtype=dtype, halo_depth=depth, **params)
 
@@ -49,7 +51,9 @@ for it in range(int(os.environ.get("N", "30"))):
                 ctx.evolve(0, n)
             return ctx.download_phi(), ctx.observables()
 
-        res, _ = run_slabs(wa, base, world, body)
+        res, fab = run_slabs(wa, base, world, body, connect=True if mode == 4 else None)
+        if mode == 4 and any(fab.halo_calls):
+            raise RuntimeError(f"peer copies went through the halo hook: {fab.halo_calls}")
         got = assemble(base, world, [r[0] for r in res])
         if dtype == "f64":
             cfg = wo.Config(nx, ny, nz, ext=ext, potential=pot, **params)
@@ -89,7 +93,8 @@ for it in range(int(os.environ.get("N", "30")) // 3):
     nz = int(rng.integers(max(world * depth, world * 2 * ext) + 1, 44))
     pot = str(rng.choice(["Harmonic", "Coulomb", "SimpleCornell", "Cube"]))
     calls = [int(rng.integers(1, 10)) for _ in range(int(rng.integers(1, 3)))]
-    mode = int(rng.choice([0, 1, 2]))
+    mode = int(rng.choice([0, 1, 2, 4]))
+    os.environ["WAFER_COPY_SCHED"] = str(rng.choice([2, 1, 0]))
     os.environ["WAFER_X2_MAX_K"] = "3"
     os.environ["WAFER_X2"] = str(rng.choice([1, 1, 0]))
     os.environ["WAFER_VGEN"] = str(rng.choice([1, 0]))
@@ -108,13 +113,14 @@ for it in range(int(os.environ.get("N", "30")) // 3):
                 ctx.push_state()
             ctx.set_initial_condition("Gaussian", seed=7 + it)
             start = ctx.download_phi()
+            getattr(ctx, "rendezvous", lambda: None)()   # (mode 4 with the ranks as contexts of one process on one device: test_gpu_slab.run_slabs)
             for n in calls:
                 ctx.evolve(wnum, n)
             return ctx.download_phi(), ctx.norm2(), start, [ctx.download_state(j) for j in range(wnum)]
 
         with wa.Context(single) as ctx:
             want, want_n2, start, lowers = body(ctx)
-        res, _ = run_slabs(wa, base, world, body)
+        res, _ = run_slabs(wa, base, world, body, connect=True if mode == 4 else None)
         got = assemble(base, world, [r[0] for r in res])
         scale = max(1.0, float(np.max(np.abs(want))))
         ok = float(np.max(np.abs(got - want))) / scale <= 1e-12 and all(abs(r[1] - want_n2) <= 1e-12 * max(1.0, abs(want_n2)) for r in res)
@@ -132,7 +138,7 @@ for it in range(int(os.environ.get("N", "30")) // 3):
         print("ERROR", tag, repr(e)[:300], flush=True)
 for name in ("WAFER_X2_MAX_K", "WAFER_X2", "WAFER_VGEN"):
     os.environ.pop(name, None)
-for name in ("WAFER_FUSE3_MIN_NY", "WAFER_HV_LAYOUT", "WAFER_ZCHUNK"):
+for name in ("WAFER_FUSE3_MIN_NY", "WAFER_HV_LAYOUT", "WAFER_ZCHUNK", "WAFER_COPY_SCHED"):
     os.environ.pop(name, None)
 print("slab fuzz done,", int(os.environ.get("N", "30")), "cases, bad =", bad)
 sys.exit(1 if bad else 0)

@@ -7,6 +7,8 @@ problem in one undecomposed context and compares:
   * all-reduced observables: 1e-12,
   * three-step passes with PEER STORES (overlap mode 3): every process maps its neighbours' buffers through HIP IPC and its
     boundary workgroups store straight into their ghost planes: bit for bit,
+  * the same passes with PEER COPIES (overlap mode 4): every exchange a hipMemcpyAsync into the neighbour process's ghost planes
+    through the same mapping, ordered by the credit / arrival rendezvous; the halo hook is never called: bit for bit,
   * solve of ground + first excited state from Gaussian starts: energies 5e-7.
 
 Prints "MP-OK <world>" on success."""
@@ -71,19 +73,24 @@ def main():
     shape3 = (140, 40, 45)
     whole3 = wa.Params(*shape3, dn=0.2, dt=0.004, central_difference=1)
     zb, zc = partition(shape3[2], world, rank)
-    with wa.Context(dataclasses.replace(whole3, z_begin=zb, z_count=zc, halo_depth=3)) as ctx:
-        comm = HostStagedSlabComm(ctx, rank, world, dev)
-        assert connect_peers(ctx, rank, world), "peer connection (HIP IPC) failed"
-        ctx.set_overlap(3)
-        ctx.set_potential("Coulomb")
-        ctx.set_initial_condition("Boolean")
-        ctx.evolve(0, 12)
-        ctx.evolve(0, 4)
-        ctx.evolve(0, 9)
-        got = ctx.download_phi()
-        n2 = ctx.norm2()
-    pieces = [None] * world if rank == 0 else None
-    dist.gather_object((zb, zc, got[:, :, zb + 1:zb + zc + 1], n2), pieces, dst=0)
+    results = {}
+    for mode in (3, 4):   # peer stores; peer COPIES (round 6: hipMemcpyAsync into the neighbour process's ghost planes through the same HIP IPC mapping)
+        with wa.Context(dataclasses.replace(whole3, z_begin=zb, z_count=zc, halo_depth=3)) as ctx:
+            comm = HostStagedSlabComm(ctx, rank, world, dev)
+            assert connect_peers(ctx, rank, world), "peer connection (HIP IPC) failed"
+            ctx.set_overlap(mode)
+            ctx.set_potential("Coulomb")
+            ctx.set_initial_condition("Boolean")
+            ctx.evolve(0, 12)
+            ctx.evolve(0, 4)
+            ctx.evolve(0, 9)
+            got = ctx.download_phi()
+            n2 = ctx.norm2()
+            if mode == 4:
+                assert comm.halo_calls == 0, "peer copies went through the halo hook"
+        pieces = [None] * world if rank == 0 else None
+        dist.gather_object((zb, zc, got[:, :, zb + 1:zb + zc + 1], n2), pieces, dst=0)
+        results[mode] = pieces
     if rank == 0:
         with wa.Context(whole3) as ctx:
             ctx.set_potential("Coulomb")
@@ -93,11 +100,12 @@ def main():
             ctx.evolve(0, 9)
             want = ctx.download_phi()
             want_n2 = ctx.norm2()
-        full = np.zeros_like(want)
-        for b, c, p, n2_ in pieces:
-            full[:, :, b + 1:b + c + 1] = p
-            assert abs(n2_ - want_n2) <= 1e-12 * want_n2
-        assert np.array_equal(full, want), "peer-store passes differ from the undecomposed run"
+        for mode, pieces in results.items():
+            full = np.zeros_like(want)
+            for b, c, p, n2_ in pieces:
+                full[:, :, b + 1:b + c + 1] = p
+                assert abs(n2_ - want_n2) <= 1e-12 * want_n2
+            assert np.array_equal(full, want), f"overlap mode {mode} ({'peer stores' if mode == 3 else 'peer copies'}) differs from the undecomposed run"
 
     # ---- ground + first excited state solve ----
     shape2 = (16, 16, 20)

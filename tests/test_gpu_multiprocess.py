@@ -49,11 +49,11 @@ def test_device_side_allreduce_between_processes(world):
 def _check_bench_two_rank_line(d, peers=False):
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["steps"] == 8 and d["scaling"] == "strong" and d["value"] > 0
     ho = d["config"]["halo_overlap"]      # the exchange schedules were tried during set-up, one was chosen for all ranks
-    assert ho["mode"] in (0, 1, 2, 3) and len(ho["ms_per_step"]) == (6 if peers else 5) and all(v > 0 for v in ho["ms_per_step"].values())
-    # the peer-store schedule (HIP IPC between the rank processes) was connected, timed and survived its bounded waits
-    assert ("3_single_launch_peer_stores" in ho["ms_per_step"]) == peers
-    if peers:   # ... after it had reproduced an exchange's bits on every rank (slab.overlap_modes_agree)
-        assert ho["peer_store_check"]["identical"] is True
+    assert ho["mode"] in (0, 1, 2, 3, 4) and len(ho["ms_per_step"]) == (7 if peers else 5) and all(v > 0 for v in ho["ms_per_step"].values())
+    # the peer-store and peer-copy schedules (HIP IPC between the rank processes) were connected, timed and survived their bounded waits
+    assert ("3_single_launch_peer_stores" in ho["ms_per_step"]) == peers and ("4_single_launch_peer_copies" in ho["ms_per_step"]) == peers
+    if peers:   # ... after they had reproduced an exchange's bits on every rank (slab.overlap_modes_agree)
+        assert ho["peer_store_check"]["identical"] is True and ho["peer_copy_check"]["identical"] is True
     assert d["roofline"]["kernel"].startswith("wafer_k_step3_fused<double, double, ")
     assert ho["fused_passes_per_exchange"] in (1, 2)
     assert d["config"]["parallelism"] == "zslab2" and d["config"]["points_per_gpu"] == 256 * 256 * 128
@@ -107,8 +107,8 @@ def test_bench_eight_rank_path():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["config"]["parallelism"] == "zslab8"
     ms = d["config"]["halo_overlap"]["ms_per_step"]
-    assert d["config"]["points_per_gpu"] == 128 * 128 * 32 and len(ms) in (4, 6) and "3_single_launch_peer_stores" in ms
-    assert d["config"]["halo_overlap"]["peer_store_check"]["identical"] is True
+    assert d["config"]["points_per_gpu"] == 128 * 128 * 32 and len(ms) in (5, 7) and "3_single_launch_peer_stores" in ms and "4_single_launch_peer_copies" in ms
+    assert d["config"]["halo_overlap"]["peer_store_check"]["identical"] is True and d["config"]["halo_overlap"]["peer_copy_check"]["identical"] is True
     assert d["parity"]["identical"] is True and d["parity"]["slabs"] == 8 and d["parity"]["differing_slabs"] == []
     assert d["single_gpu_ref"]["grid"] == [128, 128, 256] and d["comm"]["process_group_ranks"] == 8
 
@@ -150,12 +150,13 @@ def test_rccl_transport_self_neighbours(ext):
     assert "RCCL-OK" in r.stdout
 
 
-@pytest.mark.parametrize("peers", [False, True])
+@pytest.mark.parametrize("peers", [False, True, "copies"])
 def test_multi_rank_solve_driver_matches_the_native_driver(tmp_path, peers):
     """python -m wafer_amd.run on 2 ranks (z-slabs, host-staged transport on the one GPU) against
     wafer-hip on the whole grid: same table rows, same energies, the saved planes tile the state.
     peers: WAFER_PEER_STORES=force -- the driver connects the z-neighbours (HIP IPC between the two processes) and its
-    ground-state passes run in overlap mode 3"""
+    ground-state passes run in overlap mode 3; "copies": WAFER_PEER_STORES=copies -- every exchange of the whole solve (ground AND excited
+    state) is a device copy into the neighbour process's ghost planes (overlap mode 4)"""
     import re
     import numpy as np
     case = os.path.join(ROOT, "tests", "golden", "cli_case.yaml")
@@ -165,14 +166,17 @@ def test_multi_rank_solve_driver_matches_the_native_driver(tmp_path, peers):
     assert one.returncode == 0, one.stderr
     os.environ["WAFER_TRANSPORT"] = "host"
     if peers:
-        os.environ["WAFER_PEER_STORES"] = "force"
+        os.environ["WAFER_PEER_STORES"] = "force" if peers is True else "copies"
+        os.environ["WAFER_PEER_SAME_DEVICE"] = "1"      # the two ranks share the box's one GPU on purpose
     try:
         two = launch(2, "-m", "wafer_amd.run", "-c", case, "--progress", "--output-dir", str(tmp_path / "two"))
     finally:
         os.environ.pop("WAFER_TRANSPORT", None)
         os.environ.pop("WAFER_PEER_STORES", None)
+        os.environ.pop("WAFER_PEER_SAME_DEVICE", None)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
-    assert ("halo schedule: overlap mode 3 (peer stores)" in two.stderr) == peers
+    assert ("halo schedule: overlap mode 3 (peer stores)" in two.stderr) == (peers is True)
+    assert ("halo schedule: overlap mode 4 (peer copies)" in two.stderr) == (peers == "copies")
 
     def rows(text):
         return [l for l in text.splitlines() if re.match(r"^\s+│\s*[0-9.]+ │", l)]
@@ -296,6 +300,8 @@ def test_native_rccl_host_self_neighbours():
     assert "SELF-OK" in r.stdout and "halo_calls=" in r.stdout
     # the third run of --self: peer stores (overlap mode 3), connected and checked against an exchange's bits as a multi-rank run does it
     assert "ms_per_step_peer_stores=" in r.stdout
+    # the fourth: peer copies (overlap mode 4), after the same check
+    assert "ms_per_step_peer_copies=" in r.stdout
     # the same binary as an ordinary single-rank run prints one JSON record
     import json
     r = subprocess.run([exe, "64", "48", "40", "10"], capture_output=True, text=True, env=env, timeout=300)

@@ -129,8 +129,9 @@ class FakeFabric:
         return halo, allreduce
 
 
-def run_slabs(wa, base, world, body):
-    """body(ctx, rank) runs in one thread per slab; returns the list of results"""
+def run_slabs(wa, base, world, body, connect=None):
+    """body(ctx, rank) runs in one thread per slab; returns the list of results.  connect: wafer_peer_connect between the slabs
+    (None: where overlap mode 3 could apply -- ThreePoint with three ghost planes)"""
     from wafer_amd.slab import partition
     import dataclasses
     fabric = FakeFabric(world)
@@ -141,8 +142,14 @@ def run_slabs(wa, base, world, body):
             zb, zc = partition(base.nz, world, rank)
             par = dataclasses.replace(base, z_begin=zb, z_count=zc)
             with wa.Context(par) as ctx:
+                # Overlap mode 4 in THIS harness (several contexts of one process on ONE device): a one-wave kernel of rank B that
+                # waits for rank A's credit keeps the device busy, and a device-wide synchronisation on A's host thread (hipFree
+                # inside download_phi, hipMalloc) then waits for that kernel while A has not yet enqueued the signal it waits for.
+                # Bodies call ctx.rendezvous() between their last blocking call and an evolve under mode 4.  One process per GPU
+                # (every real run): a device-wide synchronisation sees one rank's work only.
+                ctx.rendezvous = fabric.bar.wait
                 ctx.set_comm_hooks(*fabric.hooks(rank))
-                if par.ext == 1 and par.halo_depth >= 3:
+                if connect or (connect is None and par.ext == 1 and par.halo_depth >= 3):
                     fabric.connect_peers(ctx, rank)
                 results[rank] = body(ctx, rank)
         except BaseException as e:  # noqa: BLE001
@@ -399,13 +406,79 @@ def test_peer_store_pass_uneven_slabs_bit_exact(wa, world, shape, steps, layout,
     assert all(n <= 8 for n in fabric.halo_calls), fabric.halo_calls
 
 
+@pytest.mark.parametrize("sched", ["2", "1", "0"])   # the schedule under the copies: single launch on two halves / boundary planes first / exchange after the pass
+@pytest.mark.parametrize("world,shape,steps", [(2, (40, 24, 12), 12), (3, (140, 40, 19), 9), (2, (300, 70, 96), 15), (3, (130, 33, 20), 6),
+                                               (3, (260, 50, 40), 30), (4, (64, 20, 13), 8)])
+@peer_store_process
+def test_peer_copy_pass_uneven_slabs_bit_exact(wa, world, shape, steps, sched, monkeypatch):
+    """overlap mode 4 (round 6): every exchange of phi's ghost planes is a device copy from this rank's boundary planes INTO the
+    neighbour's ghost planes (hipMemcpyAsync through the mapping wafer_peer_connect holds: the copy engines between GPUs),
+    ordered by a credit / arrival rendezvous of one-wave kernels; the halo hook is never called.  Uneven partitions, slabs down
+    to three planes (as thin as an exchange is deep), several evolve calls,
+    an operation in between that invalidates the ghost planes, under each of the three schedules; norm through the all-reduce hook"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    monkeypatch.setenv("WAFER_COPY_SCHED", sched)
+    base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1, halo_depth=3)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1)) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)
+        ctx.normalise(0.25)        # (a power of two: the slabs' all-reduced norm would differ from one context's in its last bits)
+        ctx.evolve(0, 7)
+        want = ctx.download_phi()
+        want_n2 = ctx.norm2()
+
+    def body(ctx, rank):
+        ctx.set_overlap(4)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 3)           # ONE single-launch pass: the order of the halves flips between calls
+        ctx.normalise(0.25)
+        ctx.evolve(0, 7)
+        return ctx.download_phi(), ctx.norm2()
+
+    res, fabric = run_slabs(wa, base, world, body)
+    assert np.array_equal(assemble(base, world, [r[0] for r in res]), want)
+    assert all(r[1] == pytest.approx(want_n2, rel=1e-12) for r in res)
+    assert fabric.halo_calls == [0] * world, fabric.halo_calls       # nothing went through the hook
+
+
+@pytest.mark.parametrize("ext,dtype", [(2, "f64"), (3, "f64"), (1, "f32"), (2, "f32fast")])
+@peer_store_process
+def test_peer_copies_serve_every_stencil_and_storage_type(wa, ext, dtype, monkeypatch):
+    """mode 4 is a transport, not a kernel: FivePoint / SevenPoint passes (two steps / one step per pass, 4 / 3 ghost planes) and
+    fp32 storage exchange their planes through the same copies -- against one context, bit for bit"""
+    shape, world = (140, 40, 36), 3
+    kw = dict(dn=0.2, dt=0.004, mass=1.0, central_difference=ext, dtype=dtype)
+    with wa.Context(wa.Params(*shape, **kw)) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 11)
+        want = ctx.download_phi()
+    depth = {1: 3, 2: 4, 3: 3}[ext]
+    base = wa.Params(*shape, halo_depth=depth, **kw)
+
+    def connect_and_run(ctx, rank):
+        ctx.set_overlap(4)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 11)
+        return ctx.download_phi()
+
+    res, fabric = run_slabs(wa, base, world, connect_and_run, connect=True)
+    assert np.array_equal(assemble(base, world, res), want)
+    assert fabric.halo_calls == [0] * world
+
+
 # potential, its parameters (BASELINE config #4's for SimpleCornell: m = 2.35, sig = 0.223, dn = 0.02, dt = 0.2 dn^2), per-cell bar
 _ORACLE_CASES = [("SimpleCornell", dict(dn=0.02, dt=8e-5, mass=2.35, sig=0.223), 0.0),
                  ("QuadWell", dict(dn=0.2, dt=0.004, mass=1.0, sig=1.0), 0.0),         # z-special: the short side of the well lies along z
                  ("FullCornell", dict(dn=0.1, dt=0.002, mass=2.35, sig=0.223), 1e-12)]  # z-special (the anisotropic Debye mass; device libm: not bit exact); pot_sub is an ARRAY sharded with the slabs
 
 
-@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("mode", [2, 3, 4])
 @pytest.mark.parametrize("world,shape", [(2, (136, 40, 48)), (3, (130, 33, 50)), (4, (72, 36, 61))])
 @pytest.mark.parametrize("case", _ORACLE_CASES, ids=[c[0] for c in _ORACLE_CASES])
 @peer_store_process
@@ -413,7 +486,7 @@ def test_decomposed_ground_state_against_the_oracle_directly(wa, oracle, case, w
     """Every other test of this file compares slabs with ONE CONTEXT of the same engine (itself held against the oracle
     elsewhere): a slab whose potential were generated from the wrong global z would pass there if the single context shared
     the mistake.  Here the assembled slabs are held against the ORACLE: three-step passes in overlap modes 2 (single launch,
-    exchange through the halo hook) and 3 (peer stores), 2 - 4 uneven slabs, config #4's potential and two whose formula
+    exchange through the halo hook), 3 (peer stores) and 4 (peer copies), 2 - 4 uneven slabs, config #4's potential and two whose formula
     singles out z; the potential arrays themselves, the ground-state evolve (bit for bit where the potential is algebraic)
     and the all-reduced observables (pot_sub: a scalar for SimpleCornell, an array sharded with the slabs for FullCornell;
     r2 from the work-area index, grid.rs:428-437)."""
@@ -493,6 +566,18 @@ def test_randomised_slab_sweep_against_the_oracle(seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_slabs.py")], capture_output=True, text=True,
                        env=dict(os.environ, N="40", SEED=str(seed), GPU_MAX_HW_QUEUES="16", WAFER_PEER_SAME_DEVICE="1"), timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "bad = 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_peer_copy_mode_needs_a_connection(wa):
+    with wa.Context(wa.Params(64, 32, 32, dn=0.2, dt=0.004, z_begin=8, z_count=12, halo_depth=3)) as ctx:
+        with pytest.raises(wa.WaferError) as e:
+            ctx.set_overlap(4)
+        assert "wafer_peer_connect" in str(e.value)
+    with wa.Context(wa.Params(64, 32, 32, dn=0.2, dt=0.004)) as ctx:   # an undecomposed grid: nothing to connect, nothing to copy
+        ctx.set_overlap(4)
+        ctx.set_potential("Harmonic")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 7)
 
 
 def test_peer_store_mode_needs_a_connection(wa):
@@ -709,6 +794,46 @@ def test_two_excited_steps_per_pass_on_slabs(wa, world, shape, wnum, depth, monk
     assert err <= 1e-12, f"max error {err:.3e}, halo calls {fabric.halo_calls}"
     for _, n2 in res:
         assert n2 == pytest.approx(want_n2, rel=1e-12)
+
+
+@pytest.mark.parametrize("world,shape,ext,wnum,depth,steps", [(2, (40, 24, 32), 1, 1, 2, (8, 5)), (3, (33, 17, 30), 2, 2, 2, (5, 2)), (4, (130, 20, 40), 1, 3, 3, (8, 5)),
+                                                               (4, (140, 40, 9), 1, 3, 1, (5, 2))])
+@peer_store_process
+def test_excited_state_steps_through_peer_copies(wa, world, shape, ext, wnum, depth, steps, monkeypatch):
+    """overlap mode 4 under the excited-state steps: one plane per side and step (two per two-step pass) travels as a device copy
+    into the neighbour's ghost planes, the sums through the all-reduce hook; the stored states' own ghost planes (exchanged once)
+    keep the halo hook -- against one context, 1e-12 per cell; one-step and two-steps-per-pass kernels, thin uneven slabs"""
+    import sys
+    sys.setswitchinterval(1e-4)
+    monkeypatch.setenv("WAFER_X2_MAX_K", "3")
+    kw = dict(dn=0.25, dt=0.006, mass=1.0, central_difference=ext, max_states=wnum)
+    base = wa.Params(*shape, halo_depth=depth, **kw)
+
+    def body(ctx, rank=0):
+        ctx.set_overlap(4)
+        ctx.set_potential("Coulomb")
+        for j in range(wnum):      # orthonormalised random stored states, identical on every slab
+            ctx.set_initial_condition("Gaussian", seed=40 + j)
+            ctx.normalise(ctx.norm2())
+            ctx.orthogonalise(j)
+            ctx.normalise(ctx.norm2())
+            ctx.push_state()
+        ctx.set_initial_condition("Gaussian", seed=7)
+        for n in steps:
+            ctx.evolve(wnum, n)
+        return ctx.download_phi(), ctx.norm2(), ctx.x2_passes()
+
+    with wa.Context(wa.Params(*shape, **kw)) as ctx:
+        want, want_n2, _ = body(ctx)
+    res, fabric = run_slabs(wa, base, world, body, connect=True)
+    got = assemble(base, world, [r[0] for r in res])
+    err = float(np.max(np.abs(got - want))) / max(1.0, float(np.max(np.abs(want))))
+    assert err <= 1e-12, f"max error {err:.3e}, halo calls {fabric.halo_calls}"
+    for _, n2, _ in res:
+        assert n2 == pytest.approx(want_n2, rel=1e-12)
+    assert len(set(r[2] for r in res)) == 1                      # every rank took the same kernels
+    # the hook served the stored states' ghost planes only (never a step): a handful of calls, the same on every rank
+    assert len(set(fabric.halo_calls)) == 1 and fabric.halo_calls[0] <= 4 * wnum
 
 
 def test_slab_without_hooks_fails_loudly(wa):

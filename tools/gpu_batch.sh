@@ -23,7 +23,7 @@ for step in "$@"; do
                       WAFER_HIP_LIB=$PWD/$d/libwafer_hip.so timeout 200 python3 tools/stencil_sweep.py ${AB_ARGS:---grid 512,512,512 --rounds 5 --steps 60 --configs v=3} 2>&1 | grep config | sed "s/^/$(basename $d) /"
                     done
                   done > $O/ab_alt.jsonl; cut -c1-130 $O/ab_alt.jsonl ;;
-    slab)         NCCL_MAX_P2P_NCHANNELS=8 timeout 300 python3 tools/slab_overhead.py --rccl --steps 60 --modes ${SLAB_MODES:-3,2,1,0} > $O/slab_overhead.json 2> $O/slab_overhead.err; cat $O/slab_overhead.json ;;
+    slab)         NCCL_MAX_P2P_NCHANNELS=8 timeout 300 python3 tools/slab_overhead.py --rccl --steps 60 --modes ${SLAB_MODES:-3,4,2,1,0} > $O/slab_overhead.json 2> $O/slab_overhead.err; cat $O/slab_overhead.json ;;
     hv_sweep)     timeout 240 python3 tools/hv_sweep.py > $O/hv_sweep.jsonl 2> $O/hv_sweep.err; cat $O/hv_sweep.jsonl; tail -3 $O/hv_sweep.err ;;
     ar_latency)   timeout 300 python3 tools/allreduce_latency.py 2>/dev/null | grep "^{" > $O/allreduce_latency.json; cat $O/allreduce_latency.json ;;
     rows)         timeout 1500 python3 tools/secondary_rows.py $O/rows > $O/rows.log 2>&1; cat $O/rows.log | cut -c1-600 ;;

@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--cd", type=int, default=1)
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--wnum", type=int, default=0, help="excited-state steps against this many stored states")
-    ap.add_argument("--modes", default="2,1,0", help="halo schedules to time (wafer_set_overlap modes)")
+    ap.add_argument("--modes", default="2,1,0", help="halo schedules to time (wafer_set_overlap modes; 4 = peer copies, its schedule from WAFER_COPY_SCHED)")
     ap.add_argument("--cycles", default="1", help="fused passes per halo exchange to time (wafer_set_halo_cycle): e.g. 1,2,3")
     ap.add_argument("--torch-hooks", action="store_true", help="with --rccl: also the torch.distributed hooks")
     ap.add_argument("--per-pass", type=int, default=0, help="ghost planes one fused pass consumes (default: 3 for --cd 1 = the three-step kernel, else 2*cd)")
@@ -54,7 +54,7 @@ def main():
         with wafer_amd.Context(par) as ctx:
             if hooks:
                 ctx.set_comm_hooks(*hooks)
-                if int(overlap) == 3:   # peer stores, the slab as its own neighbour on both sides
+                if int(overlap) in (3, 4):   # peer stores / peer copies, the slab as its own neighbour on both sides
                     rec = ctx.peer_export()
                     ctx.peer_connect(rec, rec)
                 ctx.set_overlap(overlap)
@@ -143,7 +143,7 @@ def main():
             with wafer_amd.Context(mid_params(cycle)) as ctx:
                 comm = NativeRcclSlabComm(ctx, 0, 1, dev, self_neighbours=True)
                 comm.warm_up()
-                if int(overlap) == 3:
+                if int(overlap) in (3, 4):
                     rec = ctx.peer_export()
                     ctx.peer_connect(rec, rec)
                 ctx.set_overlap(overlap)

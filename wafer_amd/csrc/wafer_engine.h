@@ -141,7 +141,15 @@ struct wafer_ctx {
     wafer_halo_fn halo_hook = nullptr;
     wafer_allreduce_fn allreduce_hook = nullptr;
     void *hook_user = nullptr;
-    int overlap_mode = 2;   // wafer_set_overlap: 0 exchange after the pass, 1 boundary-first split pass, 2 single-launch half-slab pass
+    int overlap_mode = 2;   // wafer_set_overlap: 0 exchange after the pass, 1 boundary-first split pass, 2 single-launch half-slab pass,
+                            // 3 peer stores, 4 = COPY transport (below) under the schedule `sched`
+    int sched = 2;          // the schedule wafer_evolve follows: overlap_mode, except in mode 4 (tune.copy_sched: 2, 1 or 0)
+    // Overlap mode 4: every exchange of phi's ghost planes is a device copy (hipMemcpyAsync: the copy engines between GPUs) from
+    // this rank's boundary planes INTO the z-neighbour's ghost planes through the mapping wafer_peer_connect holds, instead of
+    // the halo hook.  A rendezvous of four words per link replaces the two-sided semantics of send / recv (wafer_engine_comm.hip,
+    // copy_exchange): cp_sent[n] / cp_recv[n] count the exchanges sent to / received from the lower (0) / upper (1) neighbour.
+    bool halo_copy = false;
+    unsigned long long cp_sent[2] = {0, 0}, cp_recv[2] = {0, 0};
     WaferTuning tune;       // WAFER_* knobs, read once in wafer_ctx_create
     // three-step kernel: workgroup tables by launch shape (device copies), and the words of the single-launch slab pass
     struct F3Table {
@@ -241,6 +249,7 @@ int recompute_gram(wafer_ctx *c);
 int exchange_halo_array(wafer_ctx *c, void *array, hipStream_t s, int planes);
 int exchange_halo(wafer_ctx *c, int buf, hipStream_t s, int planes);
 int exchange_halo_side(wafer_ctx *c, int buf, hipStream_t s, int planes, int side);
+int copy_exchange(wafer_ctx *c, int buf, hipStream_t s, int planes, bool send_lo, bool send_hi, bool recv_lo, bool recv_hi);
 int ensure_halo(wafer_ctx *c, int need);
 int ensure_hv(wafer_ctx *c);
 int check_hv_err(wafer_ctx *c);

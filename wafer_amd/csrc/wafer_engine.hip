@@ -179,7 +179,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
     c->div_plan = wafer_divplan_make(stencil_den);
     if (c->f32_arith) c->div_plan_f = wafer_divplan_make_f32((float)stencil_den);
     if (p->flags & WAFER_FLAG_UNPLANNED_DIV) c->div_plan.checked = c->div_plan_f.checked = 0;
-    c->overlap_mode = (c->tune.overlap >= 0 && c->tune.overlap <= 2) ? c->tune.overlap : 2; // the modes of wafer_set_overlap
+    c->overlap_mode = c->sched = (c->tune.overlap >= 0 && c->tune.overlap <= 2) ? c->tune.overlap : 2; // the modes of wafer_set_overlap
     // fused passes per halo exchange: 1 unless the host asks for deep halos (wafer_set_halo_cycle) -- a
     // concentrated exchange outlasts the interior launch it hides behind on anything but a very fast link
     c->halo_cycle = 1;

@@ -11,6 +11,10 @@ namespace wafer_eng __attribute__((visibility("hidden"))) {
 int exchange_halo_array(wafer_ctx *c, void *array, hipStream_t s, int planes)
 {
     if (!c->sharded()) return WAFER_OK;
+    // overlap mode 4: phi's ghost planes travel as device copies into the neighbours' buffers (the stored states and their images,
+    // exchanged once per change of w_store, keep the hook: the peers map each other's two phi buffers only)
+    if (c->halo_copy && (array == c->phi[0] || array == c->phi[1]))
+        return copy_exchange(c, array == c->phi[0] ? 0 : 1, s, planes, c->has_lo(), c->has_hi(), c->has_lo(), c->has_hi());
     if (!c->halo_hook) return fail(WAFER_ERR_COMM, "context owns a z-slab but no halo hook is installed");
     RoctxRange range_("wafer_halo_exchange");
     const WaferGeom &g = c->g;
@@ -30,11 +34,13 @@ int exchange_halo_array(wafer_ctx *c, void *array, hipStream_t s, int planes)
 
 int exchange_halo(wafer_ctx *c, int buf, hipStream_t s, int planes) { return exchange_halo_array(c, c->phi[buf], s, planes); }
 
-// One direction of the exchange (wafer_set_overlap mode 4).  side 0: the LOWEST owned planes go to the lower
+// One direction of the exchange (the single-launch pass of wafer_set_overlap modes 2 and 4).  side 0: the LOWEST owned planes go to the lower
 // neighbour, the upper neighbour's lowest planes arrive in the UPPER ghost planes; side 1: the mirror image.  Every
 // rank calls the same side at the same point of a pass, so the sends and receives pair up.
 int exchange_halo_side(wafer_ctx *c, int buf, hipStream_t s, int planes, int side)
 {
+    if (c->halo_copy)
+        return copy_exchange(c, buf, s, planes, side == 0 && c->has_lo(), side == 1 && c->has_hi(), side == 1 && c->has_lo(), side == 0 && c->has_hi());
     if (!c->halo_hook) return fail(WAFER_ERR_COMM, "context owns a z-slab but no halo hook is installed");
     RoctxRange range_("wafer_halo_exchange");
     const WaferGeom &g = c->g;
@@ -140,19 +146,84 @@ int check_hv_err(wafer_ctx *c)
     return WAFER_OK;
 }
 
-// ---- peer stores (wafer_set_overlap mode 3) --------------------------------------------------------------------------
+// ---- peer stores (wafer_set_overlap mode 3) and peer copies (mode 4): the words a neighbour writes ------------------------
+// One allocation of six 64-byte lines per context, mapped by both z-neighbours (wafer_peer_info::flags_addr / flags_ipc):
+//   line 0, 1   mode 3: workgroups arrived in the lower / upper ghost planes
+//   line 2, 3   mode 4: exchanges whose copy has LANDED in the lower / upper ghost planes (written by that side's neighbour, behind its copy)
+//   line 4, 5   mode 4: exchanges for which the lower / upper neighbour has declared ITS ghost planes facing this rank free to be overwritten
+enum { PEER_WORD_ARRIVED = 2, PEER_WORD_CREDIT = 4, PEER_FLAG_LINES = 6 };
 int ensure_peer_flags(wafer_ctx *c)
 {
     if (c->peer_flags) return WAFER_OK;
     // fine-grained where the runtime offers it (coherent for peers without cache maintenance); every access is a system-scope atomic
     void *p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, 2 * 64, hipDeviceMallocFinegrained);
+    hipError_t e = hipExtMallocWithFlags(&p, PEER_FLAG_LINES * 64, hipDeviceMallocFinegrained);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        HIP_TRY(hipMalloc(&p, 2 * 64));
+        HIP_TRY(hipMalloc(&p, PEER_FLAG_LINES * 64));
     }
-    HIP_TRY(hipMemset(p, 0, 2 * 64));
+    HIP_TRY(hipMemset(p, 0, PEER_FLAG_LINES * 64));
     c->peer_flags = static_cast<unsigned long long *>(p);
+    return WAFER_OK;
+}
+
+// ---- peer copies (wafer_set_overlap mode 4) ----------------------------------------------------------------------------------
+// The halo hook's contract is two-sided: a rank's ghost planes are overwritten only once it has posted the receive, and the call
+// returns (in stream order) with its own ghost planes filled.  A copy INTO the neighbour's memory has neither property by itself,
+// so every exchange is a rendezvous over the words above, all of it enqueued on the stream the hook would have been called with:
+//   1. for every side I receive on: tell that neighbour "receive number k posted" (credit word in ITS memory) -- never waits;
+//   2. for every side I send to: wait for that neighbour's credit number k (a one-wave kernel polling my own memory), copy my
+//      boundary planes into its ghost planes (hipMemcpyAsync: a copy engine between GPUs, no CU of either), then tell it "copy
+//      number k has landed" (arrival word in its memory; stream order puts the store behind the completed copy);
+//   3. for every side I receive on: wait for arrival number k.
+// Every rank grants before it waits, so a chain of ranks cannot lock up; the counts are per link and direction and only ever grow.
+// What follows on the stream starts after the arrival and, being another kernel, sees the copied planes the way any kernel sees a
+// completed memcpy; the workgroups of a single-launch pass that is already RUNNING read them behind their flag wait and a
+// system-scope acquire fence, as they read what RCCL's receive kernel or a neighbour's peer stores wrote (schedule 2; schedules
+// 1 and 0 -- WAFER_COPY_SCHED -- start every reader after the copy).  Waits are bounded like the pass's own (WAFER_ERR_COMM).
+__global__ __launch_bounds__(64) void wafer_k_signal(unsigned long long *word, unsigned long long value)
+{
+    // (relaxed: what the word announces -- a completed copy, or nothing at all -- precedes this kernel in stream order; a release
+    //  fence here would write back the L2 lines of whatever stencil workgroups share the XCD)
+    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int copy_exchange(wafer_ctx *c, int buf, hipStream_t s, int planes, bool send_lo, bool send_hi, bool recv_lo, bool recv_hi)
+{
+    if (!send_lo && !send_hi && !recv_lo && !recv_hi) return WAFER_OK;
+    if (!c->peer_ready) return fail(WAFER_ERR_STATE, "overlap mode 4 (peer copies) needs wafer_peer_connect first");
+    RoctxRange range_("wafer_halo_exchange_copy");
+    const WaferGeom &g = c->g;
+    if (planes > g.G || planes > g.nzl) return fail(WAFER_ERR_INVALID, "halo exchange deeper than the slab allows");
+    const size_t plane_b = (size_t)g.plane * c->esz;
+    // from row 0 of the first plane to the last padded row of the last plane (guard rows in between ride along)
+    const size_t bytes = ((size_t)(planes - 1) * (size_t)g.plane + (size_t)g.py * (size_t)g.pitch) * c->esz;
+    char *mine = static_cast<char *>(c->phi[buf]);
+    const bool recv[2] = {recv_lo, recv_hi}, send[2] = {send_lo, send_hi};
+    auto signal = [&](unsigned long long *word, unsigned long long value) -> int {
+        hipLaunchKernelGGL(wafer_k_signal, dim3(1), dim3(64), 0, s, word, value);
+        HIP_TRY(hipGetLastError());
+        return WAFER_OK;
+    };
+    auto wait_for = [&](const unsigned long long *word, unsigned long long value) -> int {
+        hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, s, word, value, c->hv_err, hv_spins(c, 4), 1);
+        HIP_TRY(hipGetLastError());
+        return WAFER_OK;
+    };
+    // the neighbour on side n knows this rank as ITS neighbour on side 1 - n
+    for (int n = 0; n < 2; ++n)
+        if (recv[n]) TRY(signal(c->peer[n].flags + (PEER_WORD_CREDIT + (1 - n)) * WAFER_F3_SYNC_STRIDE, ++c->cp_recv[n]));
+    for (int n = 0; n < 2; ++n) {
+        if (!send[n]) continue;
+        TRY(wait_for(c->peer_flags + (PEER_WORD_CREDIT + n) * WAFER_F3_SYNC_STRIDE, c->cp_sent[n] + 1));
+        // my lowest planes fill the lower neighbour's UPPER ghost planes [G + nzl_n, ...); my highest its upper neighbour's LOWER [G - planes, G)
+        const char *src = mine + (size_t)(n == 0 ? g.G : g.G + g.nzl - planes) * plane_b;
+        char *dst = static_cast<char *>(c->peer[n].phi[buf]) + (size_t)(n == 0 ? g.G + c->peer[n].nzl : g.G - planes) * plane_b;
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+        TRY(signal(c->peer[n].flags + (PEER_WORD_ARRIVED + (1 - n)) * WAFER_F3_SYNC_STRIDE, ++c->cp_sent[n]));
+    }
+    for (int n = 0; n < 2; ++n)
+        if (recv[n]) TRY(wait_for(c->peer_flags + (PEER_WORD_ARRIVED + n) * WAFER_F3_SYNC_STRIDE, c->cp_recv[n]));
     return WAFER_OK;
 }
 
@@ -218,7 +289,8 @@ int launch_halves_pass(wafer_ctx *c, int src, int dst, int E)
     const int lo = g.G, hi = g.G + g.nzl, mid = lo + g.nzl / 2;
     const int first = c->hv_first;
     const wafer_ctx::F3Table *tab = nullptr;
-    TRY(f3_table(c, F3_HALVES, lo, hi, first, &tab));
+    // (copy transport: no exchange kernel to hand CUs to, so no column is cut short -- aux bit 32)
+    TRY(f3_table(c, F3_HALVES, lo, hi, first | (c->halo_copy ? 32 : 0), &tab));
     WaferF3Sync sy;
     sy.cnt = hv_cnt(c, 0);
     sy.flag = hv_flag(c, 0);
@@ -228,6 +300,14 @@ int launch_halves_pass(wafer_ctx *c, int src, int dst, int E)
     sy.debug = c->tune.hv_debug;
     sy.max_spins = hv_spins(c, 1);
     const WaferStepArgs a = step_args(c, lo, hi);
+    // A half thinner than the pass is deep (slabs of fewer than six planes) reads across the other half into the OTHER side's ghost
+    // planes, and a workgroup waits for one flag only, its own side's: such a slab launches its pass behind both of the previous
+    // pass's exchanges.  (Found in round 6 by the peer copies, the first transport of this pass that is asynchronous in the
+    // one-process tests; with RCCL the planes had always arrived long before.)  Local: the exchanges themselves stay where they are.
+    if (mid - lo < E || hi - mid < E) {
+        HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[0], 0));
+        HIP_TRY(hipStreamWaitEvent(c->s_main, c->ev_ex[1], 0));
+    }
     if (wafer_entry_step3_fused(type_combo(c, true), c->tune, a, tab->dev, tab->nblocks, sy, c->phi[src], c->v, c->phi[dst], c->s_main, tab->dir) != hipSuccess)
         return fail(WAFER_ERR_HIP, "three-step stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
     c->last_instance_valid = true;
@@ -264,12 +344,19 @@ int wafer_set_comm_hooks(wafer_ctx *c, wafer_halo_fn halo, wafer_allreduce_fn al
 int wafer_set_overlap(wafer_ctx *c, int mode)
 {
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
-    if (mode < 0 || mode > 3) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 3");
+    if (mode < 0 || mode > 4) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 4");
     if (mode == 3) {
         if (c->sharded() && !c->peer_ready) return fail(WAFER_ERR_STATE, "overlap mode 3 (peer stores) needs wafer_peer_connect first");
         if (c->sharded() && c->g.nzl < 6 * c->g.R) return fail(WAFER_ERR_INVALID, "overlap mode 3 needs at least %d owned planes", 6 * c->g.R);
     }
+    if (mode == 4) {
+        if (c->sharded() && !c->peer_ready) return fail(WAFER_ERR_STATE, "overlap mode 4 (peer copies) needs wafer_peer_connect first");
+        HIP_TRY(hipSetDevice(c->P.device));
+        TRY(ensure_hv(c));   // the bounded waits report through hv_err
+    }
     c->overlap_mode = mode;
+    c->halo_copy = mode == 4 && c->sharded();
+    c->sched = mode == 4 ? c->tune.copy_sched : mode;
     // a fresh start for the single-launch pass: every rank dispatches the lower half first again and nothing in the ghost
     // planes is taken for current (a host that has just seen WAFER_ERR_COMM on some rank calls this on all of them)
     c->hv_first = 0;
@@ -299,6 +386,12 @@ int wafer_peer_export(wafer_ctx *c, wafer_peer_info *out)
     HIP_TRY(hipSetDevice(c->P.device));
     TRY(ensure_hv(c));
     TRY(ensure_peer_flags(c));
+    // a fresh export starts the peer copies' rendezvous (mode 4) from zero on every link of this rank: the host exports on all
+    // ranks, carries the records around and connects -- nothing is in flight in between.  (After a WAFER_ERR_COMM under mode 4
+    // the counts of a link's two ends may differ: export and connect again.)
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(c->peer_flags + PEER_WORD_ARRIVED * WAFER_F3_SYNC_STRIDE, 0, (PEER_FLAG_LINES - PEER_WORD_ARRIVED) * 64));
+    c->cp_sent[0] = c->cp_sent[1] = c->cp_recv[0] = c->cp_recv[1] = 0;
     memset(out, 0, sizeof *out);
     out->struct_size = (uint32_t)sizeof *out;
     out->z_begin = (uint32_t)c->g.z_begin;
@@ -338,7 +431,10 @@ int wafer_peer_disconnect(wafer_ctx *c)
         c->peer[h] = wafer_ctx::PeerSide();
     }
     c->peer_ready = false;
-    if (c->overlap_mode == 3) c->overlap_mode = 2;
+    if (c->overlap_mode == 3 || c->overlap_mode == 4) {
+        c->overlap_mode = c->sched = 2;
+        c->halo_copy = false;
+    }
     return WAFER_OK;
 }
 

@@ -240,10 +240,12 @@ int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const wafer_
         // passes later has completed
         // aux & 4: peer stores (mode 3) -- a side waits only where a neighbour delivers (bits 8: below, 16: above), and no column
         // is cut short: there is no exchange kernel to hand CUs to (WAFER_HV_SHORT_TILES still applies if set)
+        // aux & 32: peer copies (mode 4) -- mode 2's waits (the flag of a side also says that the COPY of the planes about to be
+        // overwritten has completed), and no short columns either: the copies need no CU
         const bool peer = (aux & 4) != 0;
         const bool need_wait[2] = {peer ? (aux & 8) != 0 : true, peer ? (aux & 16) != 0 : true};
         const int ntiles = ntx * nty;
-        const int nshort = c->tune.hv_short_tiles >= 0 ? c->tune.hv_short_tiles : (peer ? 0 : (ntiles >= 64 ? ntiles / 16 : 0));
+        const int nshort = c->tune.hv_short_tiles >= 0 ? c->tune.hv_short_tiles : ((peer || (aux & 32)) ? 0 : (ntiles >= 64 ? ntiles / 16 : 0));
         wafer_f3_schedule_halves(host, ntx, nty, lz_lo, lz_hi, lz_lo + (lz_hi - lz_lo) / 2, aux & 1, need_wait,
                                  (c->tune.hv_debug & 8) ? 0 : nshort, 4 /* pieces per short column */, 3 * c->g.R /* planes per exchange */, !(aux & 2),
                                  c->tune.hv_debug, c->tune.hv_layout);
@@ -669,8 +671,8 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
             const int E = c->sharded() ? std::max(H, std::min(g.G, H * c->halo_cycle) / H * H) : H;
             // Mode 2: the whole slab in one launch (three-step passes with one exchange per pass; every rank takes this
             // branch or none: K, E and H depend on nothing local)
-            if (c->sharded() && (c->overlap_mode == 2 || c->overlap_mode == 3) && K == 3 && E == H) {
-                const bool peer = c->overlap_mode == 3;
+            if (c->sharded() && (c->sched == 2 || c->sched == 3) && K == 3 && E == H) {
+                const bool peer = c->sched == 3;
                 if (!hv_active) {
                     TRY(ensure_hv(c));
                     // the first pass's ghost planes: a plain exchange in stream order.  (Peer mode: always, also when they are
@@ -701,7 +703,7 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 s += K;
                 continue;
             }
-            const bool split = c->sharded() && c->overlap_mode != 0 && g.nzl > 2 * E;
+            const bool split = c->sharded() && c->sched != 0 && g.nzl > 2 * E;
             if (split) {
                 // Mode 1.  Second stream: boundary planes, then their exchange.  Main stream: the interior, released
                 // by an event recorded after the boundary kernels.  The exchange is enqueued BEFORE the
@@ -739,7 +741,7 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
         TRY(hv_drain());
         TRY(ensure_halo(c, R));
         if (wnum == 0) {
-            const bool split = c->sharded() && c->overlap_mode != 0 && g.nzl > 2 * R;
+            const bool split = c->sharded() && c->sched != 0 && g.nzl > 2 * R;
             if (split) {
                 // boundary planes and their exchange on the second stream, the interior behind an event (as above)
                 HIP_TRY(hipEventRecord(c->ev_fork, c->s_main));
@@ -783,7 +785,7 @@ int wafer_evolve(wafer_ctx *c, uint32_t wnum, uint64_t n_steps)
                 // or ranks that took different branches would queue a send / receive and a collective on one communicator in
                 // different orders and wait for each other for ever (found by tests/fuzz_slabs.py, round 5, with the in-process
                 // fabric; RCCL would have hung).
-                const bool split = one_pass && !last && c->sharded() && c->overlap_mode == 1 && g.nzl > 2 * R;
+                const bool split = one_pass && !last && c->sharded() && c->sched == 1 && g.nzl > 2 * R;
                 if (split) {
                     TRY(excited_step_launch_overlapped(c, src, dst, wnum, one_pass));
                 } else if (one_pass && !last) {

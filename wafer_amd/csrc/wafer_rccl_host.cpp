@@ -89,7 +89,7 @@ struct RunResult {
     float ms = 0.f;
     uint64_t steps = 0;
     int overlap_mode = 2;        // what the timed steps ran under
-    int peer_check = -1;         // -1: peer stores not tried, 0: tried and dropped (connection or bits), 1: checked and in use
+    int peer_check = -1;         // -1: peer stores / copies not tried, 0: tried and dropped (connection or bits), 3 / 4: that overlap mode checked and in use
 };
 
 // all ranks: is `mine` true everywhere?  (world 1: yes if mine)
@@ -112,7 +112,7 @@ static int all_agree(Fabric *fab, int world, bool mine, bool *out)
 // its z-neighbours', and -- nothing in this repository has crossed a link -- the mode has to reproduce the bits of an exchange
 // through the halo hook on EVERY rank (15 steps from the Boolean start, the checksum of the rank's own planes) before it is used;
 // any failure anywhere leaves every rank on mode 2.  Collective.  self_loop: the one rank is its own neighbour on both sides.
-static int try_peer_stores(wafer_ctx *ctx, const wafer_params &p, Fabric *fab, int rank, int world, bool self_loop, int *result)
+static int try_peer_stores(wafer_ctx *ctx, const wafer_params &p, Fabric *fab, int rank, int world, bool self_loop, uint32_t thinnest, int *result)
 {
     *result = 0;
     wafer_peer_info mine;
@@ -135,24 +135,38 @@ static int try_peer_stores(wafer_ctx *ctx, const wafer_params &p, Fabric *fab, i
     if (!ok) fprintf(stderr, "rank %d: wafer_peer_connect: %s\n", rank, wafer_last_error());
     if (all_agree(fab, world, ok, &all_ok)) return 1;
     if (!all_ok) { (void)wafer_peer_disconnect(ctx); return 0; }
-    uint64_t sum[2] = {0, 0};
-    ok = true;
-    for (int i = 0; i < 2 && ok; ++i) {
-        // (self_loop: the generated start carries the GLOBAL grid's values in its ghost planes, the wrap-around exchange delivers this
-        //  slab's own; dividing by sqrt(1) changes no bit and marks the ghost planes stale, so both schedules start from an exchange)
-        ok = wafer_set_overlap(ctx, i == 0 ? 3 : 2) == WAFER_OK && wafer_set_initial_condition(ctx, WAFER_IC_BOOLEAN, 0) == WAFER_OK &&
-             (!self_loop || wafer_normalise(ctx, 1.0) == WAFER_OK) &&
-             wafer_evolve(ctx, 0, 15) == WAFER_OK && wafer_synchronize(ctx) == WAFER_OK &&
-             wafer_diag_checksum(ctx, p.z_begin, p.z_count, &sum[i]) == WAFER_OK;
-        bool everyone = false;   // the same collectives on every rank whatever happened here
-        if (all_agree(fab, world, ok, &everyone)) return 1;
-        ok = everyone;
+    // mode 3 needs six owned planes on EVERY rank (`thinnest`: a quantity all ranks share); mode 4 -- peer copies: every exchange a
+    // device copy into the neighbour's ghost planes -- serves any slab and is tried where mode 3 does not apply or fails its check
+    // (WAFER_PEER_MODE=4: peer copies only -- the self test times both)
+    const int candidates[2] = {(thinnest >= 6 && env_int("WAFER_PEER_MODE", 3) != 4) ? 3 : 4, 4};
+    for (int ci = 0; ci < 2; ++ci) {
+        const int mode = candidates[ci];
+        if (ci == 1 && candidates[0] == 4) break;
+        uint64_t sum[2] = {0, 0};
+        ok = true;
+        for (int i = 0; i < 2; ++i) {
+            // (self_loop: the generated start carries the GLOBAL grid's values in its ghost planes, the wrap-around exchange delivers this
+            //  slab's own; dividing by sqrt(1) changes no bit and marks the ghost planes stale, so both schedules start from an exchange)
+            const bool mine_ok = ok && wafer_set_overlap(ctx, i == 0 ? mode : 2) == WAFER_OK && wafer_set_initial_condition(ctx, WAFER_IC_BOOLEAN, 0) == WAFER_OK &&
+                                 (!self_loop || wafer_normalise(ctx, 1.0) == WAFER_OK) &&
+                                 wafer_evolve(ctx, 0, 15) == WAFER_OK && wafer_synchronize(ctx) == WAFER_OK &&
+                                 wafer_diag_checksum(ctx, p.z_begin, p.z_count, &sum[i]) == WAFER_OK;
+            bool everyone = false;   // the same collectives on every rank whatever happened here
+            if (all_agree(fab, world, mine_ok, &everyone)) return 1;
+            ok = everyone;
+        }
+        ok = ok && sum[0] == sum[1];
+        if (all_agree(fab, world, ok, &all_ok)) return 1;
+        if (!all_ok && rank == 0)
+            fprintf(stderr, "%s (overlap mode %d) do not reproduce the exchange's bits on this fabric\n", mode == 3 ? "peer stores" : "peer copies", mode);
+        if (all_ok) {
+            WCHECK(wafer_set_overlap(ctx, mode));
+            *result = mode;
+            return 0;
+        }
     }
-    ok = ok && sum[0] == sum[1];
-    if (all_agree(fab, world, ok, &all_ok)) return 1;
-    if (!all_ok && rank == 0) fprintf(stderr, "peer stores (overlap mode 3) do not reproduce the exchange's bits on this fabric: overlap mode 2\n");
-    WCHECK(wafer_set_overlap(ctx, all_ok ? 3 : 2));
-    *result = all_ok ? 1 : 0;
+    WCHECK(wafer_set_overlap(ctx, 2));
+    *result = 0;
     return 0;
 }
 
@@ -167,11 +181,11 @@ static int run_slab(const wafer_params &p, int potential, uint64_t steps, wafer_
     WCHECK(wafer_set_potential_builtin(ctx, potential));
     // try_peer_stores is COLLECTIVE (an all-gather and several all-reduces): whether it is entered must depend on a quantity every
     // rank shares -- the thinnest slab of the partition (nz / world: nz = 47 over 8 ranks hands out 6, 6, 6, 6, 6, 6, 6, 5), never
-    // this rank's own thickness; wafer_set_overlap(3) needs 6 owned planes on every rank
+    // this rank's own thickness; wafer_set_overlap(3) needs 6 owned planes on every rank (thinner partitions go to mode 4, peer copies)
     const uint32_t thinnest = (p.z_count && world > 1) ? p.nz / (uint32_t)world : (p.z_count ? p.z_count : p.nz);
-    if (peers && thinnest >= 6) {
-        if (try_peer_stores(ctx, p, fab, rank, world, self_loop, &out.peer_check)) return 1;
-        out.overlap_mode = out.peer_check == 1 ? 3 : 2;
+    if (peers) {
+        if (try_peer_stores(ctx, p, fab, rank, world, self_loop, thinnest, &out.peer_check)) return 1;
+        out.overlap_mode = out.peer_check > 0 ? out.peer_check : 2;
     }
     WCHECK(wafer_set_initial_condition(ctx, WAFER_IC_BOOLEAN, 0));
     if (wrap) WCHECK(wafer_normalise(ctx, 1.0));   // --self: every schedule takes its first ghost planes from the (wrap-around) exchange
@@ -304,22 +318,30 @@ int main(int argc, char **argv)
         if (per < 4) { fprintf(stderr, "--self needs NZ >= 32\n"); return 2; }
         p.z_begin = 4 * per; p.z_count = per; // a middle slab: neighbours on both sides
         fab.lower = fab.upper = 0;
-        RunResult via_rccl, via_copies, via_peers;
+        RunResult via_rccl, via_copies, via_peers, via_peer_copies;
         if ((rc = run_slab(p, potential, steps, rccl_halo, rccl_allreduce, &fab, true, via_rccl, false, nullptr, 0, 1, false, true))) return rc;
         if ((rc = run_slab(p, potential, steps, copy_halo, copy_allreduce, nullptr, true, via_copies, false, nullptr, 0, 1, false, true))) return rc;
         // ... and with the boundary workgroups storing into the neighbour's (= this slab's own) ghost planes themselves, after the
         // self-check every rank of a real run makes (try_peer_stores)
         if ((rc = run_slab(p, potential, steps, rccl_halo, rccl_allreduce, &fab, true, via_peers, true, &fab, 0, 1, true, true))) return rc;
+        // ... and with every exchange a device copy into the neighbour's (= this slab's own) ghost planes behind the credit / arrival
+        // rendezvous (overlap mode 4), after the same self-check
+        setenv("WAFER_PEER_MODE", "4", 1);
+        if ((rc = run_slab(p, potential, steps, rccl_halo, rccl_allreduce, &fab, true, via_peer_copies, true, &fab, 0, 1, true, true))) return rc;
+        unsetenv("WAFER_PEER_MODE");
+        const bool same_peer_copies = via_peer_copies.peer_check == 4 && via_peer_copies.overlap_mode == 4 && via_peer_copies.phi.size() == via_rccl.phi.size() &&
+                                      memcmp(via_peer_copies.phi.data(), via_rccl.phi.data(), via_rccl.phi.size() * sizeof(double)) == 0 &&
+                                      memcmp(&via_peer_copies.obs, &via_rccl.obs, sizeof(wafer_observables_t)) == 0;
         const bool same_copies = via_rccl.phi.size() == via_copies.phi.size() &&
                                  memcmp(via_rccl.phi.data(), via_copies.phi.data(), via_rccl.phi.size() * sizeof(double)) == 0 &&
                                  memcmp(&via_rccl.obs, &via_copies.obs, sizeof(wafer_observables_t)) == 0;
-        const bool same_peers = via_peers.peer_check == 1 && via_peers.overlap_mode == 3 && via_peers.phi.size() == via_rccl.phi.size() &&
+        const bool same_peers = via_peers.peer_check == 3 && via_peers.overlap_mode == 3 && via_peers.phi.size() == via_rccl.phi.size() &&
                                 memcmp(via_peers.phi.data(), via_rccl.phi.data(), via_rccl.phi.size() * sizeof(double)) == 0 &&
                                 memcmp(&via_peers.obs, &via_rccl.obs, sizeof(wafer_observables_t)) == 0;
-        const bool same = same_copies && same_peers;
+        const bool same = same_copies && same_peers && same_peer_copies;
         if (!same) {
-            fprintf(stderr, "rccl vs copies: %d; peer stores vs rccl: %d (peer check %d, mode %d)\n", (int)same_copies, (int)same_peers,
-                    via_peers.peer_check, via_peers.overlap_mode);
+            fprintf(stderr, "rccl vs copies: %d; peer stores vs rccl: %d (peer check %d, mode %d); peer copies vs rccl: %d (peer check %d, mode %d)\n", (int)same_copies,
+                    (int)same_peers, via_peers.peer_check, via_peers.overlap_mode, (int)same_peer_copies, via_peer_copies.peer_check, via_peer_copies.overlap_mode);
             // which z planes (padded index) differ: ghost planes of the slab, or owned ones?
             const size_t pz = nz + 2;
             std::vector<long> per_plane(pz, 0);
@@ -334,9 +356,9 @@ int main(int argc, char **argv)
             fprintf(stderr, "SELF-FAIL same=%d sum=%g halo_calls=%ld reduce_calls=%ld\n", (int)same, sum, fab.halo_calls, fab.reduce_calls);
             return 1;
         }
-        printf("SELF-OK halo_calls=%ld reduce_calls=%ld ms_per_step_rccl=%.4f ms_per_step_copies=%.4f ms_per_step_peer_stores=%.4f\n", fab.halo_calls,
+        printf("SELF-OK halo_calls=%ld reduce_calls=%ld ms_per_step_rccl=%.4f ms_per_step_copies=%.4f ms_per_step_peer_stores=%.4f ms_per_step_peer_copies=%.4f\n", fab.halo_calls,
                fab.reduce_calls, via_rccl.ms / (double)via_rccl.steps, via_copies.ms / (double)via_copies.steps,
-               via_peers.ms / (double)via_peers.steps);
+               via_peers.ms / (double)via_peers.steps, via_peer_copies.ms / (double)via_peer_copies.steps);
     } else {
         // contiguous balanced z-ranges, the rule of wafer_amd.slab.partition
         const uint32_t base = nz / (uint32_t)world, extra = nz % (uint32_t)world;

@@ -45,6 +45,9 @@ struct WaferTuning {
                             // the two halves, 4 = always whole columns (default: whole columns where there is a tile per CU)
     int hv_wait_ms = 20000; // WAFER_HV_WAIT_MS: how long a workgroup of the single-launch pass waits for its ghost planes before it gives up
                             // (WAFER_ERR_COMM; the gate kernels wait four times as long)
+    int copy_sched = 2;     // WAFER_COPY_SCHED: the schedule under overlap mode 4 (copies instead of the halo hook): 2 = the single launch on two
+                            // halves (default), 1 = boundary planes first (three launches per pass), 0 = the exchange after the pass -- in 1 and 0
+                            // every kernel that reads ghost planes starts after the copy that filled them has completed
     int peer_same_device = 0; // WAFER_PEER_SAME_DEVICE: 1 = wafer_peer_connect accepts a neighbour that is another context on this device (tests: ranks folded onto one GPU)
     int f3_xs = 1;          // WAFER_F3_XS: the three-step kernel with an exact store count per plane iteration where it applies (plain launches, grids of whole tiles); 0 = never
     int f3_plain_down = 0;  // WAFER_F3_PLAIN_DOWN: 1 = the plain schedule's workgroups march their columns downwards (the same bits; the two directions are separate copies of the loop, and the compiler's register allocation differs between them)
@@ -95,6 +98,8 @@ static inline WaferTuning wafer_tuning_from_env()
     t.hv_whole_max = wafer_env_int("WAFER_HV_WHOLE_MAX", t.hv_whole_max);
     t.hv_wait_ms = wafer_env_int("WAFER_HV_WAIT_MS", t.hv_wait_ms);
     if (t.hv_wait_ms < 1) t.hv_wait_ms = 1;
+    t.copy_sched = wafer_env_int("WAFER_COPY_SCHED", t.copy_sched);
+    if (t.copy_sched < 0 || t.copy_sched > 2) t.copy_sched = 2;
     t.peer_same_device = wafer_env_int("WAFER_PEER_SAME_DEVICE", t.peer_same_device);
     return t;
 }

@@ -231,7 +231,7 @@ def main(argv=None) -> int:
     exit_code = 0
     with wafer_amd.Context(par) as ctx:
         comm = None
-        use_peer_stores = False
+        use_peer_stores = use_peer_copies = False
         if world > 1:
             comm, _name = slab.make_slab_comm(ctx, rank, world, torch.device("cuda", local_rank),
                                               "host" if host_transport else None)
@@ -242,15 +242,18 @@ def main(argv=None) -> int:
                 choice = comm.pick_allreduce()
                 if rank == 0:
                     print(f"scalar all-reduce: {choice}", file=sys.stderr, flush=True)
-            # peer stores for the ground-state passes where every rank can map its neighbours (HIP IPC) and WAFER_PEER_STORES=1 asks
-            # for it (=force: also with the host-staged test transport, ranks folded onto one GPU -- tests)
+            # peer stores (overlap mode 3) for the ground-state passes, or peer copies (mode 4: every exchange a device copy into the
+            # neighbour's ghost planes, the copy engines between GPUs) where every rank can map its neighbours (HIP IPC):
+            # WAFER_PEER_STORES=1 asks for mode 3 with mode 4 as its fallback, WAFER_PEER_STORES=copies for mode 4 alone
+            # (=force: mode 3 also with the host-staged test transport, ranks folded onto one GPU -- tests)
             want_peers = os.environ.get("WAFER_PEER_STORES", "0")
-            if want_peers not in ("", "0") and (not host_transport or want_peers == "force"):
+            if want_peers not in ("", "0") and (not host_transport or want_peers in ("force", "copies")):
                 # (mode 3 is the ThreePoint three-step pass with 6 ext owned planes on every rank: a rank-invariant test -- a rank
                 #  that alone refused the mode would leave the others waiting for its planes)
                 thinnest = min(slab.partition(par.nz, world, r)[1] for r in range(world))
-                if slab.connect_peers(ctx, rank, world) and ext == 1 and thinnest >= 6 * ext:
-                    use_peer_stores = True   # (switched on below, once the potential is set and the schedule has proved itself)
+                if slab.connect_peers(ctx, rank, world):
+                    use_peer_copies = True
+                    use_peer_stores = want_peers != "copies" and ext == 1 and thinnest >= 6 * ext   # (switched on below, once the potential is set and the schedule has proved itself)
         def from_input(stem, pad, shape, what):
             a = staged_array(args.input_dir, stem, cfg["file_type"], pad, rank)
             if a is not None and (a.dtype != np.float64 or tuple(a.shape) != tuple(shape)):
@@ -267,15 +270,20 @@ def main(argv=None) -> int:
             del v
         else:
             ctx.set_potential(cfg["potential"])
-        if use_peer_stores:
-            # peer stores have never crossed a link: they have to reproduce the bits of an exchange through the halo hook on every
-            # rank (15 ground-state steps from the Boolean start, every cell) before the solve is handed to them
-            ok = slab.overlap_modes_agree(ctx, rank, world, 3, 2, steps=15, device="cpu" if host_transport else f"cuda:{local_rank}")
-            if ok:
-                ctx.set_overlap(3)
+        if use_peer_stores or use_peer_copies:
+            # neither has ever crossed a link: a schedule has to reproduce the bits of an exchange through the halo hook on every
+            # rank (15 ground-state steps from the Boolean start, every cell) before the solve is handed to it
+            dev = "cpu" if host_transport else f"cuda:{local_rank}"
+            chosen = 2
+            if use_peer_stores and slab.overlap_modes_agree(ctx, rank, world, 3, 2, steps=15, device=dev):
+                chosen = 3
+            elif use_peer_copies and slab.overlap_modes_agree(ctx, rank, world, 4, 2, steps=15, device=dev):
+                chosen = 4
+            ctx.set_overlap(chosen)
             if rank == 0:
-                print("halo schedule: overlap mode 3 (peer stores)" if ok else
-                      "halo schedule: peer stores do not reproduce the exchange's bits on this fabric; overlap mode 2", file=sys.stderr, flush=True)
+                print({3: "halo schedule: overlap mode 3 (peer stores)", 4: "halo schedule: overlap mode 4 (peer copies)",
+                       2: "halo schedule: neither peer stores nor peer copies reproduce the exchange's bits on this fabric; overlap mode 2"}[chosen],
+                      file=sys.stderr, flush=True)
         sub = staged_array(args.input_dir, "potential_sub", cfg["file_type"], 0, rank)   # potential.rs:113-131
         if sub is not None:
             variable = cfg["potential"] == "FullCornell"

@@ -108,7 +108,8 @@ class TorchSlabComm(SlabComm):
         self.ctx = ctx
         self._tensors = {}
         self._streams = {}
-        ctx.set_comm_hooks(self._halo_hook, self._allreduce_hook)
+        self.halo_calls = 0   # calls of the halo hook so far (overlap mode 4 -- peer copies -- must leave it alone)
+        ctx.set_comm_hooks(self._counted_halo_hook, self._allreduce_hook)
 
     def warm_up(self):
         """Establish the neighbour connections and the all-reduce ring before anything is timed
@@ -144,6 +145,10 @@ class TorchSlabComm(SlabComm):
             t = self.torch.as_tensor(_DeviceView(ptr, count, "<f8"), device=self.device)
             self._tensors[key] = t
         return t
+
+    def _counted_halo_hook(self, *a):
+        self.halo_calls += 1
+        return self._halo_hook(*a)
 
     def _halo_hook(self, send_lo, send_hi, recv_lo, recv_hi, nbytes, stream):
         with self.torch.cuda.stream(self._stream(stream)):
