@@ -325,7 +325,7 @@ int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn 
 /* The halo hook may be called with only one direction non-NULL (send_lo + recv_hi, or send_hi + recv_lo: the
  * single-launch pass of wafer_set_overlap mode 2 exchanges the two sides at different times): a hook must
  * tolerate a NULL on a side that has a neighbour, and pair send_lo with the lower neighbour's recv_hi. */
-/* z-slabs, how the halo exchange is scheduled.  All modes give identical results.
+/* z-slabs, how the halo exchange is scheduled (modes 0 .. 4; 3 and 4 below).  All modes give identical results.
  *  0 = the exchange follows the whole slab's update (nothing overlaps);
  *  1 = boundary planes first, then their exchange, both on a second stream, beside the interior update:
  *      three launches per pass;
@@ -348,7 +348,20 @@ int wafer_set_overlap(wafer_ctx *ctx, int mode);
  *      kernels (RCCL's need whole CUs), no gate kernels, no second stream, no short columns.  Needs wafer_peer_connect on every
  *      rank first and at least 6 owned planes per rank; the host switches all ranks or none.  The first pass of a run of passes
  *      still takes its ghost planes from the halo hook (it is the run's rendezvous).  Other passes as in mode 2. */
-/* Peer stores: what a rank publishes about itself, and the connection to its z-neighbours.  wafer_peer_export fills `out`
+/*  4 = PEER COPIES (round 6): every exchange of phi's ghost planes -- the passes' of modes 2 / 1 / 0, the excited-state steps', the ones
+ *      observables and wafer_push_state ask for -- is a device copy (hipMemcpyAsync: a copy engine between GPUs, no CU of either) from
+ *      this rank's boundary planes INTO the z-neighbour's ghost planes through the mapping wafer_peer_connect holds; the halo hook is
+ *      not called for phi at all (the stored states' own ghost planes, exchanged once per change of w_store, keep it; so does the
+ *      all-reduce).  The hook's two-sided contract is kept by a rendezvous of four words per link in the neighbours' memory
+ *      (one-wave kernels in stream order: "receive k posted" -> wait -> copy -> "copy k landed" -> wait), so a rank's ghost planes are
+ *      overwritten only once it would have posted the receive.  Ground-state three-step passes run as mode 2's single launch, without
+ *      its short columns (no exchange kernel needs a CU); WAFER_COPY_SCHED = 1 / 0 runs them as modes 1 / 0 instead, where every
+ *      kernel that reads ghost planes is launched after the copy that filled them has completed (nothing then rests on what a
+ *      running kernel sees of a peer's writes).  Needs wafer_peer_connect on every rank first; any stencil, storage type and slab
+ *      thickness.  After a WAFER_ERR_COMM under this mode the two ends of a link may disagree on their counts: export and connect
+ *      again (a fresh export restarts them).  As for mode 3, contexts of ONE process on ONE device must not sit in a device-wide
+ *      synchronisation (hipFree, hipDeviceSynchronize) while a neighbour context waits for their signal -- one process per GPU cannot.
+ * Peer stores: what a rank publishes about itself, and the connection to its z-neighbours.  wafer_peer_export fills `out`
  * (device addresses valid in this process + HIP IPC handles of the allocations for other processes); the host carries the
  * records to the neighbours (any transport) and calls wafer_peer_connect with the lower / upper neighbour's record (NULL: no
  * neighbour on that side; a record exported by this same process is used by address, without IPC -- several contexts in one
