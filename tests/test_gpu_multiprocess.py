@@ -164,6 +164,7 @@ def test_multi_rank_solve_driver_matches_the_native_driver(tmp_path, peers):
     one = subprocess.run([cli, "-c", case, "--progress", "--output-dir", str(tmp_path / "one"), "--input-dir", str(tmp_path / "none")],
                          capture_output=True, text=True)
     assert one.returncode == 0, one.stderr
+    saved = {k: os.environ.get(k) for k in ("WAFER_TRANSPORT", "WAFER_PEER_STORES", "WAFER_PEER_SAME_DEVICE")}
     os.environ["WAFER_TRANSPORT"] = "host"
     if peers:
         os.environ["WAFER_PEER_STORES"] = "force" if peers is True else "copies"
@@ -171,9 +172,11 @@ def test_multi_rank_solve_driver_matches_the_native_driver(tmp_path, peers):
     try:
         two = launch(2, "-m", "wafer_amd.run", "-c", case, "--progress", "--output-dir", str(tmp_path / "two"))
     finally:
-        os.environ.pop("WAFER_TRANSPORT", None)
-        os.environ.pop("WAFER_PEER_STORES", None)
-        os.environ.pop("WAFER_PEER_SAME_DEVICE", None)
+        for k, v in saved.items():      # (test_gpu_slab.py sets WAFER_PEER_SAME_DEVICE for its own module at import: leave it as found)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
     assert ("halo schedule: overlap mode 3 (peer stores)" in two.stderr) == (peers is True)
     assert ("halo schedule: overlap mode 4 (peer copies)" in two.stderr) == (peers == "copies")
