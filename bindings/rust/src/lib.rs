@@ -184,6 +184,8 @@ extern "C" {
     pub fn wafer_set_halo_cycle(ctx: *mut wafer_ctx, passes: c_int) -> c_int;
     pub fn wafer_diag_copy_bw(ctx: *mut wafer_ctx, iters: c_int, unroll: c_int, blocks_per_cu: c_int, gbps: *mut f64) -> c_int;
     pub fn wafer_diag_checksum(ctx: *mut wafer_ctx, z_begin: u32, z_count: u32, out: *mut u64) -> c_int;
+    /// which kernel a pass of `wafer_evolve(ctx, wnum, .)` launches, as one line of `key=value` pairs
+    pub fn wafer_diag_dispatch(ctx: *mut wafer_ctx, wnum: u32, buf: *mut c_char, n: usize) -> c_int;
     /// padded planes [zp_begin, zp_begin + zp_count) of V / a / b (0 / 1 / 2) or phi (WAFER_ARRAY_PHI = 4), `[px][py][zp_count]`
     pub fn wafer_diag_download_window(ctx: *mut wafer_ctx, array_id: c_int, zp_begin: u32, zp_count: u32, out: *mut f64) -> c_int;
     pub fn wafer_diag_x2_passes(ctx: *mut wafer_ctx, out: *mut u64) -> c_int;

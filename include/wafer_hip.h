@@ -262,6 +262,11 @@ int wafer_diag_checksum(wafer_ctx *ctx, uint32_t z_begin, uint32_t z_count, uint
 #define WAFER_ARRAY_PHI 4
 int wafer_diag_download_window(wafer_ctx *ctx, int array_id, uint32_t zp_begin, uint32_t zp_count, double *out);
 
+/* Diagnostic: which kernel a pass of wafer_evolve(ctx, wnum, .) launches for this context, as one line of key=value pairs ("wnum=0 stencil=1
+ * dtype=f64 kernel=wafer_k_step3_fused steps_per_pass=3 ghost_planes_per_pass=3 tile=128x16 v=streamed remainder=wafer_k_step2_fused,wafer_k_step_lds"):
+ * the launch path's own predicates, nothing launched.  tools/dispatch_table.py tabulates it (profiles/r06_dispatch_table.md). */
+int wafer_diag_dispatch(wafer_ctx *ctx, uint32_t wnum, char *buf, size_t n);
+
 /* Diagnostic: how many passes of the two-excited-steps-per-pass kernel (wafer_stencil_x2.hip.h: ThreePoint fp64, one to three
  * stored states) this context has launched so far -- tests assert that the kernel they mean to test is the one that ran. */
 int wafer_diag_x2_passes(wafer_ctx *ctx, uint64_t *out);

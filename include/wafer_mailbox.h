@@ -10,7 +10,7 @@
  * (system-scope stores, the epoch behind a release); the same lanes then poll this rank's own mailbox until
  * every sender's epoch has arrived, and the sums are formed in rank order -- the same bits on every rank --
  * and written in place.  Two buffers alternate by epoch parity: a rank can be at most one all-reduce ahead of
- * another (it needs the other's contribution to finish).  Waits are bounded (WAFER_MAILBOX_WAIT_SPINS); a wait that
+ * another (it needs the other's contribution to finish).  Waits are bounded (2^26 spins, several seconds); a wait that
  * gives up turns that call's results into NaN on the rank, makes every later call of the rank post and return NaN, and
  * is reported by wafer_mailbox_check and by every later wafer_mailbox_allreduce (non-zero return): the failure is
  * sticky, a mailbox that timed out once is not used again.

@@ -278,3 +278,89 @@ gpu:
     for dtype in ("f32", "f32fast"):
         assert res[dtype][0] == pytest.approx(res["f64"][0], rel=1e-5), dtype
         assert abs(res[dtype][1] - res["f64"][1]) <= 1, dtype         # the same number of blocks to converge
+
+
+DISPATCH_CASES = [  # (shape, ext, dtype, slab kwargs)
+    ((128, 128, 128), 1, "f64", {}), ((64, 64, 64), 1, "f64", {}), ((128, 128, 128), 1, "f32", {}), ((128, 128, 128), 1, "f32fast", {}),
+    ((128, 64, 64), 2, "f64", {}), ((128, 64, 64), 2, "f32", {}), ((128, 64, 64), 3, "f64", {}), ((128, 64, 64), 3, "f32", {}),
+    ((128, 128, 128), 1, "f64", dict(z_begin=32, z_count=32, halo_depth=3)), ((128, 128, 128), 1, "f64", dict(z_begin=32, z_count=32, halo_depth=2)),
+    ((128, 64, 64), 2, "f64", dict(z_begin=16, z_count=16, halo_depth=4)), ((128, 64, 64), 2, "f64", dict(z_begin=16, z_count=16, halo_depth=2)),
+]
+
+
+@pytest.mark.parametrize("shape,ext,dtype,slab", DISPATCH_CASES)
+def test_dispatch_description_is_what_runs(wa, shape, ext, dtype, slab):
+    """wafer_diag_dispatch (what tools/dispatch_table.py tabulates into profiles/r06_dispatch_table.md) against what then ran: the
+    kernel family and the steps per pass of a ground-state evolve (wafer_stencil_kernel_instance, wafer_stencil_steps_per_launch),
+    and whether excited-state steps took the two-steps-per-pass kernel (wafer_diag_x2_passes) -- on undecomposed grids and on a
+    slab as its own neighbour, for every stencil and storage type"""
+    par = wa.Params(*shape, dn=0.2, dt=0.004, central_difference=ext, dtype=dtype, max_states=3, **slab)
+    with wa.Context(par) as ctx:
+        if slab:   # a self-loop: the slab's own planes stand in for the neighbours' (what is checked is the dispatch, not the physics)
+            import ctypes as C
+            from tests.test_gpu_slab import _loaded_hip_runtime
+            hip = C.CDLL(_loaded_hip_runtime())
+            hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+
+            def halo(slo, shi, rlo, rhi, nbytes, stream):
+                if rlo and shi:
+                    assert hip.hipMemcpyAsync(rlo, shi, nbytes, 3, stream) == 0
+                if rhi and slo:
+                    assert hip.hipMemcpyAsync(rhi, slo, nbytes, 3, stream) == 0
+                return 0
+            ctx.set_comm_hooks(halo, lambda ptr, count, stream: 0)
+        ctx.set_potential("Coulomb")
+        d = ctx.dispatch(0)
+        assert d["stencil"] == ext and d["dtype"] == dtype and d["kernel"] == ctx.stencil_kernel_name()
+        assert d["steps_per_pass"] == ctx.steps_per_launch() and d["ghost_planes_per_pass"] == d["steps_per_pass"] * ext
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, 6)
+        assert ctx.stencil_kernel_instance().startswith(d["kernel"])            # the kernel that ran
+        if d["kernel"] == "wafer_k_step3_fused":
+            assert d["tile"] == ("256x16" if dtype == "f32fast" else "128x16")
+        for k in (1, 2, 3):
+            ctx.set_initial_condition("Gaussian", seed=k)
+            ctx.normalise(ctx.norm2())
+            ctx.orthogonalise(k - 1)
+            ctx.normalise(ctx.norm2())
+            ctx.push_state()
+            if dtype == "f32fast":
+                continue
+            d = ctx.dispatch(k)
+            before = ctx.x2_passes()
+            ctx.set_initial_condition("Gaussian", seed=10 + k)
+            ctx.evolve(k, 8)
+            assert np.isfinite(ctx.norm2())
+            took_x2 = ctx.x2_passes() > before
+            assert took_x2 == (d["kernel"] == "wafer_k_xstep2"), (k, d)
+            assert d["steps_per_pass"] == (2 if took_x2 else 1)
+            if took_x2:
+                assert ext == 1 and dtype == "f64" and d["tile"] == ("128x16" if k <= 2 else "128x8")
+            else:
+                assert d["kernel"] == "wafer_k_step_lds" and d["nlow"] == k and d["waves"] in (4, 8)
+        d5 = ctx.dispatch(5)                                     # more stored states than the fused overlaps carry (WAFER_MAX_LOW = 4)
+        assert d5["kernel"] == "wafer_k_step_lds" and d5["nlow"] == 0 and "gram_schmidt" in d5["then"]
+
+
+def test_committed_dispatch_table_is_current(wa):
+    """profiles/r06_dispatch_table.json (tools/dispatch_table.py) still says what the library says, row by row, for the grids that
+    cost nothing to create"""
+    import json
+    path = os.path.join(ROOT, "profiles", "r06_dispatch_table.json")
+    if not os.path.exists(path):
+        pytest.skip("table not generated yet")
+    table = [r for r in json.load(open(path)) if "error" not in r and r["grid"] in ("64^3", "256^3")]
+    assert len(table) > 60
+    shapes = {"64^3": (64, 64, 64), "256^3": (256, 256, 256)}
+    ctxs = {}
+    try:
+        for r in table:
+            key = (r["grid"], r["stencil"], r["dtype"])
+            if key not in ctxs:
+                ctxs[key] = wa.Context(wa.Params(*shapes[r["grid"]], dn=0.05, dt=5e-4, central_difference=r["stencil"], dtype=r["dtype"], max_states=1))
+                ctxs[key].set_potential("Coulomb")
+            now = ctxs[key].dispatch(r["wnum"])
+            assert {k: v for k, v in r.items() if k != "grid"} == now, (r, now)
+    finally:
+        for c in ctxs.values():
+            c.close()

@@ -96,7 +96,6 @@ def main():
         ("mode2_no_acquire", {"WAFER_HV_DEBUG": "4"}, True, 2),
         ("mode3", {}, True, 3),
         ("mode3_halves", {"WAFER_HV_LAYOUT": "3"}, True, 3),
-        ("mode3_short_columns", {"WAFER_HV_SHORT_TILES": "32"}, True, 3),
         ("mode2_no_shorts", {"WAFER_HV_DEBUG": "8"}, True, 2),
         ("mode2_xcd_order_no_shorts", {"WAFER_HV_DEBUG": "24"}, True, 2),
     ]

@@ -27,9 +27,9 @@ def parse_cfg(s):
 
 
 ENV_KEYS = (("WAFER_ZCHUNK", "zchunk"), ("WAFER_TARGET_BLOCKS", "blocks"), ("WAFER_LDS_RY", "ry"), ("WAFER_XCD_SWIZZLE", "xcd"),
-            ("WAFER_NT", "nt"), ("WAFER_LDS_PAD", "pad"), ("WAFER_ABV", "abv"), ("WAFER_F2_NW2", "nw2"),
+            ("WAFER_NT", "nt"), ("WAFER_ABV", "abv"),
             ("WAFER_VGEN", "vgen"), ("WAFER_XF_NW", "xfnw"), ("WAFER_XF_DEEP", "deep"),
-            ("WAFER_SEVEN_VG", "s8vg"), ("WAFER_LDS_NW", "nw"), ("WAFER_F3_SCHED", "sched"), ("WAFER_X2", "x2"), ("WAFER_X2_RY", "x2ry"), ("WAFER_X2_MAX_K", "x2k"), ("WAFER_F3_XS", "xs"), ("WAFER_F2_WIDE", "f2w"), ("WAFER_F3_PLAIN_DOWN", "down"), ("WAFER_F3_ROUNDS", "rounds"))
+            ("WAFER_F3_SCHED", "sched"), ("WAFER_X2", "x2"), ("WAFER_X2_RY", "x2ry"), ("WAFER_X2_MAX_K", "x2k"), ("WAFER_F3_XS", "xs"), ("WAFER_F2_WIDE", "f2w"), ("WAFER_F3_PLAIN_DOWN", "down"), ("WAFER_F3_ROUNDS", "rounds"))
 
 
 def make_ctx(par, cfg, args):

@@ -239,13 +239,13 @@ int f3_table(wafer_ctx *c, int kind, int lz_lo, int lz_hi, int aux, const wafer_
         // neighbour exists there: the flag also says that this rank's SEND of the planes about to be overwritten two
         // passes later has completed
         // aux & 4: peer stores (mode 3) -- a side waits only where a neighbour delivers (bits 8: below, 16: above), and no column
-        // is cut short: there is no exchange kernel to hand CUs to (WAFER_HV_SHORT_TILES still applies if set)
+        // is cut short: there is no exchange kernel to hand CUs to
         // aux & 32: peer copies (mode 4) -- mode 2's waits (the flag of a side also says that the COPY of the planes about to be
         // overwritten has completed), and no short columns either: the copies need no CU
         const bool peer = (aux & 4) != 0;
         const bool need_wait[2] = {peer ? (aux & 8) != 0 : true, peer ? (aux & 16) != 0 : true};
         const int ntiles = ntx * nty;
-        const int nshort = c->tune.hv_short_tiles >= 0 ? c->tune.hv_short_tiles : ((peer || (aux & 32)) ? 0 : (ntiles >= 64 ? ntiles / 16 : 0));
+        const int nshort = (peer || (aux & 32)) ? 0 : (ntiles >= 64 ? ntiles / 16 : 0);
         wafer_f3_schedule_halves(host, ntx, nty, lz_lo, lz_hi, lz_lo + (lz_hi - lz_lo) / 2, aux & 1, need_wait,
                                  (c->tune.hv_debug & 8) ? 0 : nshort, 4 /* pieces per short column */, 3 * c->g.R /* planes per exchange */, !(aux & 2),
                                  c->tune.hv_debug, c->tune.hv_layout);
@@ -870,6 +870,50 @@ int wafer_stencil_steps_per_launch(wafer_ctx *c)
     if (!c) return 0;
     if (fuse3_applies(c)) return 3;
     return fuse2_applies(c) ? 2 : 1;
+}
+
+// Diagnostic: which kernel a pass of wafer_evolve(ctx, wnum, n) launches for this context, in one line of key=value pairs --
+// the SAME predicates the launch path evaluates (fuse3_applies / fuse2_applies / x2_applies / wafer_excited_nw / closed_form_vg),
+// nothing launched.  tools/dispatch_table.py tabulates it over stencil x dtype x wnum x grid x slab; tests/test_gpu_configs.py
+// holds it against what then ran (wafer_stencil_kernel_instance, wafer_diag_x2_passes).
+int wafer_diag_dispatch(wafer_ctx *c, uint32_t wnum, char *buf, size_t n)
+{
+    if (!c || !buf || n == 0) return fail(WAFER_ERR_INVALID, "null argument");
+    const int R = c->g.R;
+    const char *dtype = !c->f32 ? "f64" : (c->f32_arith ? "f32fast" : "f32");
+    if (wnum == 0) {
+        const int K = wafer_stencil_steps_per_launch(c);
+        const char *kernel = wafer_stencil_kernel_name(c);
+        int tx = 0, ty = 0;
+        if (K == 3) wafer_step3_tile(type_combo(c, true), &tx, &ty);
+        // what advances the steps a whole pass does not cover (wafer_evolve: three while three remain, then two, then one)
+        const char *single = active_variant(c) == 0 ? "wafer_k_step_direct" : "wafer_k_step_lds";
+        const char *two = (fuse2_applies(c) && K == 3) ? "wafer_k_step2_fused" : nullptr;
+        char tile[32] = "";
+        if (tx) snprintf(tile, sizeof tile, " tile=%dx%d", tx, ty);
+        snprintf(buf, n, "wnum=0 stencil=%d dtype=%s kernel=%s steps_per_pass=%d ghost_planes_per_pass=%d%s v=%s remainder=%s%s%s", R, dtype, kernel, K, K * R,
+                 tile, "streamed", K >= 2 ? (two ? two : single) : "-", (K == 3 && two) ? "," : "", (K == 3 && two) ? single : "");
+        return WAFER_OK;
+    }
+    const int vg = closed_form_vg(c);
+    if (x2_applies(c, wnum)) {
+        int tx = 0, ty = 0;
+        wafer_x2_tile_host(c->tune, (int)wnum, vg, &tx, &ty);
+        snprintf(buf, n, "wnum=%u stencil=%d dtype=%s kernel=wafer_k_xstep2 steps_per_pass=2 ghost_planes_per_pass=2 tile=%dx%d v=%s head=wafer_k_step_lds "
+                         "condition=every_rank_agrees,n_steps>=4", wnum, R, dtype, tx, ty, vg ? "closed_form" : "streamed");
+        return WAFER_OK;
+    }
+    if (wnum <= WAFER_MAX_LOW && active_variant(c) >= 1) {
+        const int nw = wafer_excited_nw(c->tune, (int)wnum, R, c->f32);
+        // the closed form is evaluated by the fp64 transform-on-load kernel on 8-wave tiles only (wafer_launch_step_lds_excited)
+        const bool cf = vg != 0 && !c->f32 && c->tune.one_pass != 0 && nw == 8 && short_forms(c);
+        snprintf(buf, n, "wnum=%u stencil=%d dtype=%s kernel=wafer_k_step_lds nlow=%u steps_per_pass=1 ghost_planes_per_pass=%d tile=128x%d waves=%d v=%s", wnum, R,
+                 dtype, wnum, R, nw * 2, nw, cf ? "closed_form" : "streamed");
+        return WAFER_OK;
+    }
+    snprintf(buf, n, "wnum=%u stencil=%d dtype=%s kernel=%s nlow=0 steps_per_pass=1 ghost_planes_per_pass=%d then=wafer_k_row_op(normalise),wafer_k_row_op(gram_schmidt)x%u",
+             wnum, R, dtype, active_variant(c) == 0 ? "wafer_k_step_direct" : "wafer_k_step_lds", R, wnum);
+    return WAFER_OK;
 }
 
 int wafer_set_stencil_variant(wafer_ctx *c, int variant)

@@ -72,3 +72,4 @@ hipError_t wafer_entry_x2_apply(const WaferGeom &g, int lz_lo, int lz_hi, int k,
                                 const double *coef, double *partials, size_t partials_cap, int num_cus, hipStream_t s, int *nblocks_out);
 long long wafer_entry_x2_blocks(const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks);
 int wafer_entry_x2_nsums(int k);
+void wafer_x2_tile_host(const WaferTuning &t, int k, int vg, int *tx, int *ty);   // the kernel's tile for k stored states

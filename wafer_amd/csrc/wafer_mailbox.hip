@@ -16,7 +16,7 @@ struct MailboxDev {
     double *peer[WAFER_MAILBOX_MAX_RANKS];   // every rank's mailbox as mapped here (peer[rank] is this rank's own)
     unsigned *err;        // host memory: 1 + the rank whose contribution never arrived
     unsigned *dead;       // device memory: sticky, set with err
-    unsigned max_spins;   // bound of one wait (WAFER_MAILBOX_WAIT_SPINS, default 2^26: several seconds)
+    unsigned max_spins;   // bound of one wait (2^26 spins: several seconds)
     int rank, world;
 };
 } // namespace
@@ -113,10 +113,6 @@ int wafer_mailbox_create(int rank, int world, int device, wafer_mailbox **out)
     // the sticky word sits behind the two parity buffers of the same allocation
     mb->d.dead = reinterpret_cast<unsigned *>(static_cast<double *>(mb->own) + 2 * WAFER_MAILBOX_MAX_RANKS * SLOT);
     mb->d.max_spins = 1u << 26;
-    if (const char *e_ = getenv("WAFER_MAILBOX_WAIT_SPINS")) {
-        const long long v = atoll(e_);
-        if (v > 0 && v < (1ll << 31)) mb->d.max_spins = (unsigned)v;
-    }
     mb->d.peer[rank] = static_cast<double *>(mb->own);
     if (world == 1) mb->connected = true;
     *out = mb;

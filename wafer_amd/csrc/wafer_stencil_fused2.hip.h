@@ -589,7 +589,7 @@ static inline hipError_t wafer_launch_step2_fused(const WaferTuning &t, WaferSte
     //   ext 2: 128x8 tiles, a and b formed from V as well (0.53 ms/step against 0.66 with a, b
     //          streamed and 0.58 for the single-step kernel, since wafer_recip shortened b's reciprocal).
     // Ordinary (cache-retaining) loads: the halo-row wave re-reads rows its neighbour tile streams.
-    const int nw2 = t.f2_nw2 ? t.f2_nw2 : ((R == 1 && a.g.ny >= 16) ? 8 : 4);
+    const int nw2 = (R == 1 && a.g.ny >= 16) ? 8 : 4;
     if (o.abv < 0) o.abv = 1;
     if (t.nt < 0) o.nt = 0;
     if constexpr (R == 1) {

@@ -496,8 +496,8 @@ static inline hipError_t wafer_launch_step2_wide(const WaferTuning &t, WaferStep
     for (long long first = 0; first < nblocks; first += per_launch) {
         const dim3 grid((unsigned)std::min(per_launch, nblocks - first));
         a.block0 = (int)first;
-        if (a.v_in_range != 0) hipLaunchKernelGGL((wafer_k_step2_wide<TS, C, true>), grid, block, (size_t)t.lds_pad, s, a, ntx, nty, t.swz, phi, pv, out);
-        else hipLaunchKernelGGL((wafer_k_step2_wide<TS, C, false>), grid, block, (size_t)t.lds_pad, s, a, ntx, nty, t.swz, phi, pv, out);
+        if (a.v_in_range != 0) hipLaunchKernelGGL((wafer_k_step2_wide<TS, C, true>), grid, block, 0, s, a, ntx, nty, t.swz, phi, pv, out);
+        else hipLaunchKernelGGL((wafer_k_step2_wide<TS, C, false>), grid, block, 0, s, a, ntx, nty, t.swz, phi, pv, out);
     }
     return hipGetLastError();
 }

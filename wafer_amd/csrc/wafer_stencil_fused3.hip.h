@@ -759,7 +759,7 @@ static inline hipError_t wafer_launch_step3_fused(const WaferTuning &t, const Wa
     const bool xs = t.f3_xs != 0 && a.g.nx % Cfg::TX == 0 && a.g.ny % Cfg::TY == 0;
 #define WAFER_F3_LAUNCH3(VIR_, MODE_, XS_, DIR_)                                                                                                  \
     do {                                                                                                                                          \
-        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_, DIR_>), grid, block, (size_t)t.lds_pad, s, a, ntx, table, sy, phi, pv, out); \
+        hipLaunchKernelGGL((wafer_k_step3_fused<T, C, VIR_, MODE_, XS_, DIR_>), grid, block, 0, s, a, ntx, table, sy, phi, pv, out); \
         WaferF3Instance &li_ = wafer_f3_last_instance();                                                                                          \
         li_.tsize = std::is_same<T, wafer_f32_wide>::value ? -4 : (int)sizeof(T); li_.csize = (int)sizeof(C); li_.vir = (VIR_); li_.mode = (MODE_); li_.xs = (XS_); li_.dir = (DIR_);           \
     } while (0)

@@ -53,7 +53,7 @@ struct WaferLdsOpts {
 // 4 rows per lane: 6 halo rows per 16 instead of per 8 -- 0.60 vs 0.63 ms/step at 512^3)
 static inline WaferLdsOpts wafer_lds_opts(const WaferTuning &t, int R = 1)
 {
-    WaferLdsOpts o{R == 3 ? 4 : 2, t.swz, t.nt >= 0 ? t.nt : 1, t.lds_pad, t.abv};
+    WaferLdsOpts o{R == 3 ? 4 : 2, t.swz, t.nt >= 0 ? t.nt : 1, 0, t.abv};
     if (t.lds_ry) o.ry = t.lds_ry;
     // abv < 0: kernel default (both the single-step and the fused kernel form a, b from V)
     return o;
@@ -829,11 +829,11 @@ static inline hipError_t wafer_launch_step_lds(const WaferTuning &t, WaferStepAr
     const size_t partials_cap = 0;
     if constexpr (std::is_same<T, double>::value && std::is_same<C, double>::value) {
         // closed-form V (fp64, the default tuning of each stencil order): 16 B per update instead of 24
-        const bool dflt = t.lds_nw == 0 && t.lds_ry == 0 && o.abv != 0 && o.nt != 0 && a.v_in_range != 0;
+        const bool dflt = t.lds_ry == 0 && o.abv != 0 && o.nt != 0 && a.v_in_range != 0;
         // (ThreePoint 0.546 -> 0.422 ms/step at 512^3, FivePoint 0.556 -> 0.475; SevenPoint, 4 rows per lane on 4
         //  waves, is short of issue slots: 0.617 -> 0.634 with Coulomb, so it keeps streaming V)
         {
-            if (vg != 0 && dflt && (R <= 2 || t.seven_vg != 0)) {
+            if (vg != 0 && dflt && R <= 2) {   // (SevenPoint: the closed form measured slower than the stream, profiles/NOTES.md)
                 a.target_blocks = (a.target_blocks + 1) / 2; // one workgroup per CU, as below
                 if (vg == 4) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 4, 1>(t, a, o, phi, pv, pb, out, partials, partials_cap, s);
                 if (vg == 7) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8, 7, 1>(t, a, o, phi, pv, pb, out, partials, partials_cap, s);
@@ -843,12 +843,12 @@ static inline hipError_t wafer_launch_step_lds(const WaferTuning &t, WaferStepAr
         }
     }
     { // ThreePoint / FivePoint with a, b from V: 8 waves on a 128x16 tile, one workgroup per CU (half the
-      // halo rows per tile: 0.56 -> 0.54 ms/step at 512^3); WAFER_LDS_NW=4 or an explicit WAFER_LDS_RY
+      // halo rows per tile: 0.56 -> 0.54 ms/step at 512^3); an explicit WAFER_LDS_RY
       // select the 4-wave kernels
         // SevenPoint as well (round 2): 8 waves x 2 rows on the 128x16 tile -- two waves per SIMD with half the
         // registers each -- against 4 waves x 4 rows (256 VGPRs + 54 AGPRs, one wave per SIMD): 0.561 against
         // 0.605 ms/step at 512^3.  (8 waves x 4 rows on 128x32 tiles spill 240 B/lane: 1.69 ms.)
-        const bool eight = t.lds_nw ? t.lds_nw == 8 : t.lds_ry == 0;
+        const bool eight = t.lds_ry == 0;
         if (eight && o.abv != 0) {
             a.target_blocks = (a.target_blocks + 1) / 2; // one workgroup per CU
             if (o.nt != 0) return wafer_launch_step_lds_ry<T, C, R, 2, -1, true, true, false, 8>(t, a, o, phi, pv, pb, out, partials, partials_cap, s);

@@ -43,3 +43,4 @@ long long wafer_entry_x2_blocks(const WaferTuning &t, const WaferGeom &g, int k,
 }
 
 int wafer_entry_x2_nsums(int k) { return wafer_x2_nsums(k); }
+void wafer_x2_tile_host(const WaferTuning &t, int k, int vg, int *tx, int *ty) { wafer_x2_tile(t, k, vg, tx, ty); }

@@ -4,6 +4,9 @@
 // and the tests drive A/B runs through them) and every launcher takes it by reference: nothing on a
 // launch path -- wafer_evolve, wafer_observables, the per-pass loop -- calls getenv.  A value of 0 / -1
 // means "the kernel's own default" unless stated otherwise.
+//
+// Retired in round 6 (nothing set them any more; what they measured is in profiles/NOTES.md): WAFER_LDS_PAD, WAFER_LDS_NW,
+// WAFER_SEVEN_VG, WAFER_F2_NW2, WAFER_HV_SHORT_TILES, WAFER_MAILBOX_WAIT_SPINS.
 #pragma once
 #include <cstdlib>
 
@@ -12,13 +15,10 @@ struct WaferTuning {
     int zchunk = 0;         // WAFER_ZCHUNK: planes per workgroup (0: from the CU count)
     int target_blocks = 0;  // WAFER_TARGET_BLOCKS: workgroups per launch (0: from the CU count)
     int swz = 1;            // WAFER_XCD_SWIZZLE: XCD-aware workgroup -> tile map
-    int lds_pad = 0;        // WAFER_LDS_PAD: extra dynamic LDS bytes per workgroup (caps workgroups per CU)
     // single-step LDS kernel
     int lds_ry = 0;         // WAFER_LDS_RY: rows per lane, 2 or 4 (0: default per stencil order)
-    int lds_nw = 0;         // WAFER_LDS_NW: waves per workgroup, 4 or 8 (0: default)
     int nt = -1;            // WAFER_NT: non-temporal streams (-1: default per kernel)
     int abv = -1;           // WAFER_ABV: 0 = stream the stored a, b arrays instead of forming them from V
-    int seven_vg = 0;       // WAFER_SEVEN_VG: closed-form V in SevenPoint's single-step kernel (measured slower)
     // excited-state step kernels
     int xf_nw = 0;          // WAFER_XF_NW: excited-state step kernels forced onto 8 waves / 128 x 16 tiles or 4 waves / 128 x 8 (0: by stencil, storage type and number of stored states, wafer_excited_nw)
     int xf_deep = 1;        // WAFER_XF_DEEP: the raw staging pipeline
@@ -29,7 +29,6 @@ struct WaferTuning {
                             // (k = 3 runs on 128 x 8 tiles: -4 % per step at 512 x 512 planes, +3 ... +5 % at 1024 x 1024, profiles/r04_x2_shapes.log)
     int x2_ry = 0;          // WAFER_X2_RY: rows per lane of that kernel (1: 128 x 8 tiles, 2: 128 x 16, k = 1 and 2; 0: default = 2 where it exists)
     // fused kernels
-    int f2_nw2 = 0;         // WAFER_F2_NW2: main waves of the two-step kernel (0: default)
     int f2_wide = 1;        // WAFER_F2_WIDE: 0 keeps FivePoint on the two-step kernel with dedicated helper waves (128 x 8 tiles)
     int fuse3 = 1;          // WAFER_FUSE3: 0 keeps ThreePoint fp64 on the two-step kernel
     int fuse3_min_ny = -1;  // WAFER_FUSE3_MIN_NY (tests; lifts the cell threshold too)
@@ -39,7 +38,6 @@ struct WaferTuning {
     int hv_debug = 0;       // WAFER_HV_DEBUG: experiments on the single-launch pass (bits: 4 no acquire fence
                             // (timing only), 8 no short pieces, 16 XCD-contiguous tile order inside each half, 32 no counters / gates (timing only),
                             // 64 exchange stream at normal priority)
-    int hv_short_tiles = -1; // WAFER_HV_SHORT_TILES: tiles per half cut into short pieces (-1: 1/16 of the tiles)
     int hv_whole_max = 384; // WAFER_HV_WHOLE_MAX: peer-store passes march whole columns on slabs of up to this many planes, the two halves on thicker ones
     int hv_layout = 0;      // WAFER_HV_LAYOUT: where the short columns go (wafer_f3_schedule_halves); peer-store passes (mode 3): 3 = always
                             // the two halves, 4 = always whole columns (default: whole columns where there is a tile per CU)
@@ -68,13 +66,10 @@ static inline WaferTuning wafer_tuning_from_env()
     t.zchunk = wafer_env_int("WAFER_ZCHUNK", t.zchunk);
     t.target_blocks = wafer_env_int("WAFER_TARGET_BLOCKS", t.target_blocks);
     t.swz = wafer_env_int("WAFER_XCD_SWIZZLE", t.swz);
-    t.lds_pad = wafer_env_int("WAFER_LDS_PAD", t.lds_pad);
     t.lds_ry = wafer_env_int("WAFER_LDS_RY", t.lds_ry);
     if (t.lds_ry != 2 && t.lds_ry != 4) t.lds_ry = 0;
-    t.lds_nw = wafer_env_int("WAFER_LDS_NW", t.lds_nw);
     t.nt = wafer_env_int("WAFER_NT", t.nt);
     t.abv = wafer_env_int("WAFER_ABV", t.abv);
-    t.seven_vg = wafer_env_int("WAFER_SEVEN_VG", t.seven_vg);
     t.xf_nw = wafer_env_int("WAFER_XF_NW", t.xf_nw);
     t.xf_deep = wafer_env_int("WAFER_XF_DEEP", t.xf_deep);
     t.one_pass = wafer_env_int("WAFER_ONE_PASS", t.one_pass);
@@ -82,7 +77,6 @@ static inline WaferTuning wafer_tuning_from_env()
     t.x2 = wafer_env_int("WAFER_X2", t.x2);
     t.x2_ry = wafer_env_int("WAFER_X2_RY", t.x2_ry);
     t.x2_max_k = wafer_env_int("WAFER_X2_MAX_K", t.x2_max_k);
-    t.f2_nw2 = wafer_env_int("WAFER_F2_NW2", t.f2_nw2);
     t.f2_wide = wafer_env_int("WAFER_F2_WIDE", t.f2_wide);
     t.fuse3 = wafer_env_int("WAFER_FUSE3", t.fuse3);
     t.fuse3_min_ny = wafer_env_int("WAFER_FUSE3_MIN_NY", t.fuse3_min_ny);
@@ -93,7 +87,6 @@ static inline WaferTuning wafer_tuning_from_env()
     t.f3_plain_down = wafer_env_int("WAFER_F3_PLAIN_DOWN", t.f3_plain_down);
     t.f3_rounds = wafer_env_int("WAFER_F3_ROUNDS", t.f3_rounds);
     t.f3_xs = wafer_env_int("WAFER_F3_XS", t.f3_xs);
-    t.hv_short_tiles = wafer_env_int("WAFER_HV_SHORT_TILES", t.hv_short_tiles);
     t.hv_layout = wafer_env_int("WAFER_HV_LAYOUT", t.hv_layout);
     t.hv_whole_max = wafer_env_int("WAFER_HV_WHOLE_MAX", t.hv_whole_max);
     t.hv_wait_ms = wafer_env_int("WAFER_HV_WAIT_MS", t.hv_wait_ms);

@@ -42,7 +42,7 @@ EXPORTS = [
     "wafer_last_evolve_ms", "wafer_stencil_kernel_name", "wafer_stencil_kernel_instance", "wafer_stencil_steps_per_launch", "wafer_set_stencil_variant",
     "wafer_set_comm_hooks", "wafer_set_overlap", "wafer_set_stream", "wafer_get_slab_info",
     "wafer_get_device_info", "wafer_set_potsub", "wafer_set_potsub_resampled", "wafer_symmetrise", "wafer_download_phi_owned", "wafer_diag_div_check", "wafer_div_plan", "wafer_get_div_plan", "wafer_diag_div_planned", "wafer_div_plan_f32", "wafer_diag_div_planned_f32",
-    "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_diag_download_window", "wafer_set_halo_cycle", "wafer_diag_x2_passes",
+    "wafer_diag_copy_bw", "wafer_diag_checksum", "wafer_diag_download_window", "wafer_diag_dispatch", "wafer_set_halo_cycle", "wafer_diag_x2_passes",
     "wafer_peer_export", "wafer_peer_connect", "wafer_peer_disconnect",
 ]
 
@@ -169,6 +169,7 @@ def load_library():
     L.wafer_diag_copy_bw.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     L.wafer_diag_checksum.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.wafer_diag_x2_passes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.wafer_diag_dispatch.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t]
     L.wafer_diag_download_window.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, dp]
     L.wafer_peer_export.argtypes = [vp, C.POINTER(_PeerInfo)]
     L.wafer_peer_connect.argtypes = [vp, C.POINTER(_PeerInfo), C.POINTER(_PeerInfo)]
@@ -523,6 +524,17 @@ class Context:
         v = C.c_double(0.0)
         self._check(self._L.wafer_diag_copy_bw(self._h, iters, unroll, blocks_per_cu, C.byref(v)))
         return v.value
+
+    def dispatch(self, wnum: int = 0) -> dict:
+        """which kernel a pass of evolve(wnum, .) launches for this context (wafer_diag_dispatch): {"kernel": ..., "steps_per_pass": ...,
+        "ghost_planes_per_pass": ..., "tile": ..., "v": "streamed" | "closed_form", ...} -- the launch path's own predicates"""
+        buf = C.create_string_buffer(512)
+        self._check(self._L.wafer_diag_dispatch(self._h, wnum, buf, len(buf)))
+        out = dict(kv.split("=", 1) for kv in buf.value.decode().split())
+        for k in ("wnum", "stencil", "steps_per_pass", "ghost_planes_per_pass", "nlow", "waves"):
+            if k in out:
+                out[k] = int(out[k])
+        return out
 
     def x2_passes(self) -> int:
         """passes of the two-excited-steps-per-pass kernel launched so far (include/wafer_hip.h)"""
