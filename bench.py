@@ -290,6 +290,11 @@ def run_rank(args) -> int:
     # RCCL caches its parameters at first use, which is torch's own communicator: the channel limit the
     # slab transport wants (wafer_rccl_hooks.h) has to be in the environment before that
     os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "8")
+    # Every rank of this benchmark reaches every wafer_evolve behind a barrier, so a workgroup or gate kernel that waits for a
+    # neighbour's planes for seconds is waiting for something that will not come: 5 s (gate kernels: 20 s) instead of the library's
+    # 20 s / 80 s, which are sized for hosts that write files between calls.  A schedule whose wait gives up in the set-up trial is
+    # dropped on every rank; the shorter bound keeps a fabric that cannot serve one of them from eating the run's time budget.
+    os.environ.setdefault("WAFER_HV_WAIT_MS", "5000")
     # stdout carries exactly ONE line, the JSON result: native libraries that write to the C stdout
     # (RCCL prints a version banner there, flushed at exit) are sent to stderr instead
     sys.stdout.flush()

@@ -324,7 +324,12 @@ def test_three_step_kernel_on_slabs_bit_exact(wa, world, shape, steps, cycle, ov
         return ctx.download_phi()
 
     res, fabric = run_slabs(wa, base, world, body)
-    assert np.array_equal(assemble(base, world, res), want)
+    got = assemble(base, world, res)
+    if not np.array_equal(got, want):   # say where: which padded planes, against the slabs' boundaries
+        from wafer_amd.slab import partition
+        planes = sorted(set(np.argwhere(got != want)[:, 2].tolist()))
+        raise AssertionError(f"{int(np.sum(got != want))} cells differ on padded planes {planes}; slabs (z_begin, z_count): "
+                             f"{[partition(shape[2], world, r) for r in range(world)]}; halo calls {fabric.halo_calls}")
     passes = -(-steps // 3) + 2 + 3
     per_pass = 2 if (overlap == 2 and cycle == 1) else 1   # mode 2: one hook call per half of the slab
     assert all(n <= per_pass * passes // cycle + 6 for n in fabric.halo_calls), fabric.halo_calls

@@ -3,7 +3,9 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r4sq}; mkdir -p $O
-B="python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0"
+# usage: bash tools/sq_probe.sh <tag> ["extra bench.py arguments", e.g. "--dtype f32"] [kernel-name substring to summarise]
+B="python3 bench.py --no-cpu-baseline --no-parity --no-excited --steps 60 --warmup 6 --preheat 0 ${2:-}"
+MATCH=${3:-wafer_k_step3_fused}
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY" \
@@ -16,7 +18,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_V
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- $B > /dev/null 2> $O/p$i.err || echo "set $i failed: $set"
 done
-python3 tools/pmc_counters.py $(for k in $(seq 1 $i); do echo $O/p$k; done) --match wafer_k_step3_fused > $O/sq_fused3.json 2> $O/sq.err
+python3 tools/pmc_counters.py $(for k in $(seq 1 $i); do echo $O/p$k; done) --match "$MATCH" > $O/sq_fused3.json 2> $O/sq.err
 python3 - <<PY
 import json
 d = json.load(open("$O/sq_fused3.json"))
