@@ -298,6 +298,7 @@ F3_SLAB_CASES = [(2, (40, 24, 32), 12), (3, (140, 17, 37), 7), (4, (130, 33, 48)
 # exchanges (four contexts on ONE GPU share hardware queues: that case runs in test_peer_store_four_slabs_in_a_subprocess)
 @pytest.mark.parametrize("world,shape,steps,cycle,overlap",
                          [(w, sh, st, cy, ov) for (w, sh, st) in F3_SLAB_CASES for cy in (1, 2) for ov in (True, False, 2, 3) if not (ov == 3 and w > 3)])
+@peer_store_process   # (mode 3 among the parameters: in a long-lived process two of the 3 x 2 streams can land on one of the four default hardware queues -- round 6)
 def test_three_step_kernel_on_slabs_bit_exact(wa, world, shape, steps, cycle, overlap, monkeypatch):
     """three fused ThreePoint steps per pass on z-slabs (3 ghost planes per pass and side; 6 with one exchange
     per two passes): boundary-first overlap, the mixed long / short interior launch, two-step and single-step

@@ -644,7 +644,8 @@ int wafer_download_phi(wafer_ctx *c, double *phi)
     if (!c->have_phi) return fail(WAFER_ERR_STATE, "phi not set");
     HIP_TRY(hipSetDevice(c->P.device));
     HIP_TRY(hipStreamSynchronize(c->s_aux));
-    return download_padded(c, phi, c->phi[c->cur]);
+    TRY(download_padded(c, phi, c->phi[c->cur]));
+    return check_hv_err(c);   // a wait of a decomposed pass that gave up has poisoned what it stored: say so with the data
 }
 
 int wafer_download_phi_owned(wafer_ctx *c, double *out)
@@ -654,7 +655,8 @@ int wafer_download_phi_owned(wafer_ctx *c, double *out)
     HIP_TRY(hipSetDevice(c->P.device));
     HIP_TRY(hipStreamSynchronize(c->s_aux));
     // host element (0, 0, 0) = work cell (0, 0, z_begin): padded coordinates (R, R, z_begin + R)
-    return convert_host_array<false>(c, out, c->g.nx, c->g.ny, c->g.nzl, c->g.R, c->g.R, c->g.z_begin + c->g.R, c->phi[c->cur]);
+    TRY((convert_host_array<false>(c, out, c->g.nx, c->g.ny, c->g.nzl, c->g.R, c->g.R, c->g.z_begin + c->g.R, c->phi[c->cur])));
+    return check_hv_err(c);
 }
 
 int wafer_diag_download_window(wafer_ctx *c, int id, uint32_t zp_begin, uint32_t zp_count, double *out)
@@ -678,7 +680,8 @@ int wafer_diag_download_window(wafer_ctx *c, int id, uint32_t zp_begin, uint32_t
     default: return fail(WAFER_ERR_INVALID, "unknown array id %d", id);
     }
     // host element (0, 0, hz) = padded cell (0, 0, zp_begin + hz)
-    return convert_host_array<false>(c, out, c->g.px, c->g.py, (int)zp_count, 0, 0, (int)zp_begin, dev);
+    TRY((convert_host_array<false>(c, out, c->g.px, c->g.py, (int)zp_count, 0, 0, (int)zp_begin, dev)));
+    return check_hv_err(c);
 }
 
 // ---- w_store ------------------------------------------------------------------------
@@ -818,7 +821,7 @@ int wafer_diag_checksum(wafer_ctx *c, uint32_t z_begin, uint32_t z_count, uint64
     HIP_TRY(hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, c->s_main));
     HIP_TRY(hipStreamSynchronize(c->s_main));
     *out = (uint64_t)h;
-    return WAFER_OK;
+    return check_hv_err(c);
 }
 
 static int div_check_launch(wafer_ctx *c, const WaferDen<double> &dv, bool planned, uint64_t seed, uint64_t n_random, int lo_exp, int hi_exp,
