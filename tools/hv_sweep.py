@@ -71,7 +71,7 @@ def main():
                 comm.warm_up()
             else:
                 ctx.set_comm_hooks(hook or halo, lambda p, c, s: 0)
-            if mode == 3:   # peer stores, the slab as its own neighbour
+            if mode in (3, 4):   # peer stores / peer copies, the slab as its own neighbour
                 rec = ctx.peer_export()
                 ctx.peer_connect(rec, rec)
             ctx.set_overlap(mode)
@@ -96,6 +96,9 @@ def main():
         ("mode2_no_acquire", {"WAFER_HV_DEBUG": "4"}, True, 2),
         ("mode3", {}, True, 3),
         ("mode3_halves", {"WAFER_HV_LAYOUT": "3"}, True, 3),
+        ("mode4", {}, True, 4),                                       # peer copies under the single launch on two halves
+        ("mode4_boundary_first", {"WAFER_COPY_SCHED": "1"}, True, 4),
+        ("mode4_exchange_after", {"WAFER_COPY_SCHED": "0"}, True, 4),
         ("mode2_no_shorts", {"WAFER_HV_DEBUG": "8"}, True, 2),
         ("mode2_xcd_order_no_shorts", {"WAFER_HV_DEBUG": "24"}, True, 2),
     ]

@@ -20,7 +20,7 @@ rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --o
 python3 tools/pmc_counters.py $O/sq1 $O/sq2 --match wafer_k_step3_fused > $O/sq_counters_fused3.json
 rm -rf $O/sq1 $O/sq2
 for try in 1 2; do   # (once in this round the first attempt left an empty file: the c10d store's port was still in TIME_WAIT)
-  NCCL_MAX_P2P_NCHANNELS=8 MASTER_PORT=$((29455 + try)) python3 tools/slab_overhead.py --rccl --steps 60 --modes 3,2,1,0 2> $O/slab_overhead.err | grep "^{" > $O/slab_overhead.json
+  NCCL_MAX_P2P_NCHANNELS=8 MASTER_PORT=$((29455 + try)) python3 tools/slab_overhead.py --rccl --steps 60 --modes 3,4,2,1,0 2> $O/slab_overhead.err | grep "^{" > $O/slab_overhead.json
   [ -s $O/slab_overhead.json ] && break
 done
 NCCL_MAX_P2P_NCHANNELS=8 rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -o t -- python3 tools/slab_trace.py --rccl --mode 2 > /dev/null 2>&1
@@ -42,7 +42,7 @@ rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONF
 python3 tools/pmc_counters.py $O/psq1 $O/psq2 $O/psq3 --match step > $O/sq_counters_path_512.json
 rm -rf $O/psq1 $O/psq2 $O/psq3
 # the schedules of the slab pass, interleaved in one process (undecomposed, peer stores whole / halves, mode 2)
-python3 tools/hv_sweep.py --configs undecomposed,undecomposed_halves_schedule_no_shorts,mode3,mode3_halves,mode2,mode1,mode0 2>/dev/null | grep variant > $O/slab_pass_breakdown.jsonl
+python3 tools/hv_sweep.py --configs undecomposed,undecomposed_halves_schedule_no_shorts,mode3,mode3_halves,mode4,mode4_boundary_first,mode4_exchange_after,mode2,mode1,mode0 2>/dev/null | grep variant > $O/slab_pass_breakdown.jsonl
 # excited-state steps, one against two steps per pass, same box
 for w in 1 2 3; do python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 4 --steps 62 --configs x2=0 x2=1 x2=0 x2=1 2>&1 | grep config | sed "s/^/k=$w /"; done > $O/sweep_x2.jsonl
 python3 tools/secondary_rows.py $O/rows > $O/rows.log 2>&1
