@@ -295,6 +295,13 @@ def run_rank(args) -> int:
     # 20 s / 80 s, which are sized for hosts that write files between calls.  A schedule whose wait gives up in the set-up trial is
     # dropped on every rank; the shorter bound keeps a fabric that cannot serve one of them from eating the run's time budget.
     os.environ.setdefault("WAFER_HV_WAIT_MS", "5000")
+    # N > 1: a rank's process runs the engine's two streams beside RCCL's and torch's.  The overlap schedules keep kernels resident
+    # that wait for a word another stream's kernel (or copy) writes -- a gate kernel for a count, a workgroup for a flag -- and the
+    # runtime folds a process's streams onto FOUR hardware queues by default, in order within a queue: two such streams on one
+    # queue serialise at best and, where the waited-for work sits behind the waiter, stall until the bounded wait gives up (seen
+    # with 30 streams in one process, tools/hv_sweep.py, round 6).  Read by the HIP runtime when it initialises (nothing has yet).
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     # stdout carries exactly ONE line, the JSON result: native libraries that write to the C stdout
     # (RCCL prints a version banner there, flushed at exit) are sent to stderr instead
     sys.stdout.flush()

@@ -30,7 +30,7 @@ for it in range(int(os.environ.get("N", "30"))):
     pot, kw = [("Coulomb", {}), ("SimpleCornell", dict(mass=2.35, sig=0.223)), ("QuadWell", {}), ("Harmonic", {}), ("FullCornell", dict(mass=2.35, sig=0.223)),
                ("Periodic", {})][int(rng.integers(0, 6))]
     calls = [int(rng.integers(1, 14)) for _ in range(int(rng.integers(1, 4)))]
-    cycle = int(rng.choice([1, 2])) if (ext == 1 and depth == 6 and mode in (0, 1)) or (ext > 1 and depth == 4 * ext and mode in (0, 1)) else 1
+    cycle = int(rng.choice([1, 2])) if (ext == 1 and depth == 6 and mode in (0, 1, 4)) or (ext > 1 and depth == 4 * ext and mode in (0, 1, 4)) else 1
     os.environ["WAFER_FUSE3_MIN_NY"] = "1"
     os.environ["WAFER_HV_LAYOUT"] = str(rng.choice([0, 3, 4]))
     os.environ["WAFER_ZCHUNK"] = str(rng.choice([0, 0, 3, 7]))

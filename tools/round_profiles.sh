@@ -41,8 +41,8 @@ rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --o
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT --output-format csv -d $O/psq3 -- python3 tools/path_bench.py --steps 10 > /dev/null 2>&1
 python3 tools/pmc_counters.py $O/psq1 $O/psq2 $O/psq3 --match step > $O/sq_counters_path_512.json
 rm -rf $O/psq1 $O/psq2 $O/psq3
-# the schedules of the slab pass, interleaved in one process (undecomposed, peer stores whole / halves, mode 2)
-python3 tools/hv_sweep.py --configs undecomposed,undecomposed_halves_schedule_no_shorts,mode3,mode3_halves,mode4,mode4_boundary_first,mode4_exchange_after,mode2,mode1,mode0 2>/dev/null | grep variant > $O/slab_pass_breakdown.jsonl
+# the schedules of the slab pass, interleaved in one process (ten contexts, thirty streams: more hardware queues than the default four)
+GPU_MAX_HW_QUEUES=16 python3 tools/hv_sweep.py --configs undecomposed,undecomposed_halves_schedule_no_shorts,mode3,mode3_halves,mode4,mode4_boundary_first,mode4_exchange_after,mode2,mode1,mode0 2>/dev/null | grep variant > $O/slab_pass_breakdown.jsonl
 # excited-state steps, one against two steps per pass, same box
 for w in 1 2 3; do python3 tools/stencil_sweep.py --grid 512,512,512 --wnum $w --rounds 4 --steps 62 --configs x2=0 x2=1 x2=0 x2=1 2>&1 | grep config | sed "s/^/k=$w /"; done > $O/sweep_x2.jsonl
 python3 tools/secondary_rows.py $O/rows > $O/rows.log 2>&1

@@ -216,6 +216,9 @@ int main(int argc, char **argv)
     const uint64_t steps = (uint64_t)atoll(argv[a0 + 3]);
     const int potential = argc > a0 + 4 ? atoi(argv[a0 + 4]) : (int)WAFER_POT_SIMPLECORNELL;
     const int rank = self ? 0 : env_int("RANK", 0), world = self ? 1 : env_int("WORLD_SIZE", 1);
+    // this rank's two engine streams run beside RCCL's: more hardware queues than the runtime's default of four, so that a kernel
+    // waiting for a flag and the kernel (or copy) that sets it never share one; read by the HIP runtime when it initialises (below)
+    if (world > 1) setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int device = env_int("LOCAL_RANK", rank), visible = 0;
     HIPCHECK(hipGetDeviceCount(&visible));
     if (visible > 0 && device >= visible) device %= visible; // a launcher that shows each rank only its own GPU

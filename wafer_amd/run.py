@@ -183,6 +183,10 @@ def main(argv=None) -> int:
         raise SystemExit("wafer_amd.run: script potentials are a single-GPU feature (wafer-hip -s); "
                          "save the potential there and use potential: FromFile")
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # the engine's two streams beside RCCL's and torch's: more hardware queues than the runtime's default of four, so that a kernel
+        # waiting for a flag and the kernel (or copy) that sets it never share one (bench.py says why); read when HIP initialises
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import wafer_amd
     from wafer_amd import slab
