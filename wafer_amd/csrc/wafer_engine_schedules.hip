@@ -477,7 +477,8 @@ bool x2_applies(const wafer_ctx *c, uint32_t wnum)
     // (-4 % per step at 512 x 512, -2 ... -4 % at 256^2 / 384^2) and loses on 1024 x 1024 planes (+3 ... +5 %,
     // profiles/r04_x2_shapes.log).  The plane extent is the same on every rank of a decomposed run.
     const int kmax = c->tune.x2_max_k > 0 ? c->tune.x2_max_k : ((long long)c->g.nx * c->g.ny <= 300000 ? 3 : 2);
-    return c->tune.x2 != 0 && c->tune.one_pass != 0 && !c->f32 && c->g.R == 1 && wnum >= 1 && wnum <= 3 && (int)wnum <= kmax &&
+    // (fp32 storage -- dtype f32 and f32fast, whose excited-state steps compute in fp64 -- since round 6: the storage tag of the three-step kernel)
+    return c->tune.x2 != 0 && c->tune.one_pass != 0 && c->g.R == 1 && wnum >= 1 && wnum <= 3 && (int)wnum <= kmax &&
            active_variant(c) >= 1 && (!c->sharded() || c->g.G >= 2);
 }
 
@@ -531,7 +532,7 @@ int ensure_x2(wafer_ctx *c, uint32_t wnum)
         // carries one ghost plane from wafer_push_state; the second, and M_j's two, come from the neighbours now)
         TRY(exchange_halo_array(c, c->states[j], c->s_main, 2));
         const WaferStepArgs a = step_args(c, g.G, g.G + g.nzl);
-        if (wafer_entry_step_lds(WAFER_TC_F64, g.R, c->tune, a, c->states[j], c->a, c->b, c->v, c->mstates[j], c->s_main, closed_form_vg(c)) != hipSuccess)
+        if (wafer_entry_step_lds(type_combo(c, false), g.R, c->tune, a, c->states[j], c->a, c->b, c->v, c->mstates[j], c->s_main, closed_form_vg(c)) != hipSuccess)
             return fail(WAFER_ERR_HIP, "stencil launch (image of a stored state) failed: %s", hipGetErrorString(hipGetLastError()));
         TRY(exchange_halo_array(c, c->mstates[j], c->s_main, 2));
     }
@@ -566,7 +567,7 @@ int x2_run(wafer_ctx *c, uint32_t wnum, uint64_t pairs, hipStream_t s)
     TRY(ensure_halo(c, 2));   // z-slabs: two ghost planes of the raw input per side and pass
     for (uint64_t p = 0; p < pairs; ++p) {
         const int src = c->cur, dst = c->cur ^ 1;
-        if (wafer_entry_xstep2(c->tune, a, k, closed_form_vg(c), c->phi[src], c->v, c->phi[dst], c->partials, c->partials_stride, l, m,
+        if (wafer_entry_xstep2(type_combo(c, false), c->tune, a, k, closed_form_vg(c), c->phi[src], c->v, c->phi[dst], c->partials, c->partials_stride, l, m,
                                c->x2coef, s) != hipSuccess)
             return fail(WAFER_ERR_HIP, "two-step excited-state stencil launch failed: %s", hipGetErrorString(hipGetLastError()));
         ++c->x2_passes;
@@ -578,7 +579,7 @@ int x2_run(wafer_ctx *c, uint32_t wnum, uint64_t pairs, hipStream_t s)
     }
     // phi = x~ / n_c: the last step's normalisation (grid.rs:679), its norm taken directly as the sum of squares of Y2
     int nap = 0;
-    if (wafer_entry_x2_apply(g, g.G, g.G + g.nzl, k, c->phi[c->cur], l, m, c->x2coef, c->partials, c->partials_stride, c->num_cus, s, &nap) != hipSuccess)
+    if (wafer_entry_x2_apply(type_combo(c, false), g, g.G, g.G + g.nzl, k, c->phi[c->cur], l, m, c->x2coef, c->partials, c->partials_stride, c->num_cus, s, &nap) != hipSuccess)
         return fail(WAFER_ERR_HIP, "apply launch failed");
     TRY(reduce_to_scal(c, 1, nap, X2_SUM_SLOT, s));
     TRY(launch_normalise(c, c->cur, c->scal + X2_SUM_SLOT, 0.0, nullptr, 0, s));

@@ -59,16 +59,16 @@ void wafer_step3_tile(int tc, int *tx, int *ty);
 // ("wafer_k_step3_fused<double, double, true, 0, true, 1>"); empty before the first launch
 void wafer_step3_last_instance(char *buf, size_t n);
 
-// two excited-state steps per pass (ThreePoint fp64, 1 <= k <= 3 stored states; wafer_stencil_x2.hip.h): out = A A x with x the
+// two excited-state steps per pass (ThreePoint, fp64 or fp32 storage with fp64 arithmetic -- tc --, 1 <= k <= 3 stored states; wafer_stencil_x2.hip.h): out = A A x with x the
 // load transform of phi by `coef`; l / m: the stored states and their images M_j = A l_j; the 1 + 2k sums of the pass go to
 // partials[q * partials_cap + workgroup]
-hipError_t wafer_entry_xstep2(const WaferTuning &t, const WaferStepArgs &a, int k, int vg, const void *phi, const void *pv, void *out,
+hipError_t wafer_entry_xstep2(int tc, const WaferTuning &t, const WaferStepArgs &a, int k, int vg, const void *phi, const void *pv, void *out,
                               double *partials, size_t partials_cap, const void *const *l, const void *const *m, const double *coef,
                               hipStream_t s);
 // the transform's coefficients from the sums of the last pass (kind 2) or of the last one-step kernel (kind 1)
 hipError_t wafer_entry_x2_coeffs(int kind, int k, const double *sums, const double *gram, const double *amat, double *coef, hipStream_t s);
 // phi materialised in place after the last pass, up to the last step's norm: its square is summed into partials[0 .. *nblocks_out)
-hipError_t wafer_entry_x2_apply(const WaferGeom &g, int lz_lo, int lz_hi, int k, void *phi, const void *const *l, const void *const *m,
+hipError_t wafer_entry_x2_apply(int tc, const WaferGeom &g, int lz_lo, int lz_hi, int k, void *phi, const void *const *l, const void *const *m,
                                 const double *coef, double *partials, size_t partials_cap, int num_cus, hipStream_t s, int *nblocks_out);
 long long wafer_entry_x2_blocks(const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks);
 int wafer_entry_x2_nsums(int k);

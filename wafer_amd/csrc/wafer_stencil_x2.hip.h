@@ -41,6 +41,7 @@
 #include "wafer_stencil_lds.hip.h"
 #include "wafer_stencil_fused2.hip.h"
 #include "wafer_rowwalk.h"
+#include "wafer_storage.h"
 
 // the coefficient block the load transform reads (device memory, doubles):  x~ = w * W0 - sum_j m_j SB_j - sum_j l_j SC_j
 enum {
@@ -51,9 +52,9 @@ enum {
 };
 enum { WAFER_X2_MAX_LOW = 3 };
 
-struct WaferX2Ptrs {
-    const double *l[WAFER_X2_MAX_LOW] = {nullptr, nullptr, nullptr};   // stored states
-    const double *m[WAFER_X2_MAX_LOW] = {nullptr, nullptr, nullptr};   // M_j = A l_j
+struct WaferX2Ptrs {   // arrays of the context's storage type (double, or float for fp32 storage: the kernels' first template argument)
+    const void *l[WAFER_X2_MAX_LOW] = {nullptr, nullptr, nullptr};   // stored states
+    const void *m[WAFER_X2_MAX_LOW] = {nullptr, nullptr, nullptr};   // M_j = A l_j
 };
 
 // sums a pass leaves: partials[q * pstride + workgroup], q in this order
@@ -113,9 +114,14 @@ __device__ __forceinline__ double wafer_x2_xform(const WaferX2Coef<NL> &k, doubl
 // pipeline store into the column's first plane, which the first real store overwrites; their sums are not taken), so that the
 // wait for the prefetched planes behind the loop's barrier is an exact count that leaves the stores in flight -- with the stores
 // inside conditions it was vmcnt(0): every wave sat out the completion of the store it had issued just before the barrier.
-template <int RY, int NL, int VG, bool VIR, bool XS = false>
-__global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, int nty, int swz, const double *__restrict__ phi,
-                                                       const double *__restrict__ pv, double *__restrict__ out,
+// TS: the storage tag of the fused ground-state kernels (wafer_storage.h): double, or wafer_f32_wide = fp32 STORAGE with fp64 arithmetic
+// (round 6: dtype f32 / f32fast, whose excited-state steps compute in fp64) -- the raw pass result Z, V, the stored states and their images
+// are float in HBM (8 bytes per lane and request); queues, LDS tiles, the lane-private queue of the l_j and every sum are double, the fp64
+// kernel's.  What arrives is widened where the pipelines rotate, behind the barrier; Z is rounded to float BEFORE its sums are taken, so the
+// coefficients of the next pass's transform belong to exactly the numbers that pass will load.
+template <typename TS, int RY, int NL, int VG, bool VIR, bool XS = false>
+__global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, int nty, int swz, const typename WaferF3Store<TS>::S *__restrict__ phi,
+                                                       const typename WaferF3Store<TS>::S *__restrict__ pv, typename WaferF3Store<TS>::S *__restrict__ out,
                                                        double *__restrict__ partials, long long pstride, WaferX2Ptrs st,
                                                        const double *__restrict__ coef)
 {
@@ -123,6 +129,13 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     typedef double T;
     typedef double C;
     using VT = typename WaferVec<double>::type;
+    using ST = typename WaferF3Store<TS>::S;                       // the arrays in HBM
+    typedef ST __attribute__((ext_vector_type(2))) SVT;            // a lane's request
+    [[maybe_unused]] constexpr bool WIDE = !std::is_same<ST, T>::value;
+    auto widen = [](const SVT &x) -> VT { return wafer_f3_widen<SVT, VT, 2>(x); };
+    auto as_stored = [](T x) -> T { return (T)(ST)x; };          // what the array will hold (fp32 storage: rounded once, like a store and a load)
+#define WAFER_X2_L(j) (static_cast<const ST *>(st.l[j]))
+#define WAFER_X2_M(j) (static_cast<const ST *>(st.m[j]))
     constexpr int R = 1;
     constexpr int VEC = Cfg::VEC, TX = Cfg::TX, TY = Cfg::TY;
     constexpr int HX0 = Cfg::HX0, HX1 = Cfg::HX1, LP0 = Cfg::LP0, LP1 = Cfg::LP1;
@@ -176,6 +189,8 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
 
     VT zero;
     zero[0] = zero[1] = 0.0;
+    SVT szero;
+    szero[0] = szero[1] = ST(0);
     const int xl = lane * VEC, xi = x0 + xl;
     const unsigned xlu = (unsigned)(lane * VEC);
 
@@ -268,37 +283,37 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
             VT l[NL], mm[NL];
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
-                l[j] = *reinterpret_cast<const VT *>((st.l[j] + po + rowoff[r]) + xlu);
-                mm[j] = *reinterpret_cast<const VT *>((st.m[j] + po + rowoff[r]) + xlu);
+                l[j] = widen(*reinterpret_cast<const SVT *>((WAFER_X2_L(j) + po + rowoff[r]) + xlu));
+                mm[j] = widen(*reinterpret_cast<const SVT *>((WAFER_X2_M(j) + po + rowoff[r]) + xlu));
                 if (m == 2) {
                     if constexpr (HOLD) hold_l[j][r] = l[j];
                     else *reinterpret_cast<VT *>(qslot(z1 + 1) + j * QS + qoff[r]) = l[j];
                 }
             }
-            q0[m][r] = xform_vec(*reinterpret_cast<const VT *>((phi + po + rowoff[r]) + xlu), l, mm);
+            q0[m][r] = xform_vec(widen(*reinterpret_cast<const SVT *>((phi + po + rowoff[r]) + xlu)), l, mm);
         }
         if (x_row) {
             VT l[NL], mm[NL];
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
-                l[j] = *reinterpret_cast<const VT *>((st.l[j] + po + xoff_row) + xlu);
-                mm[j] = *reinterpret_cast<const VT *>((st.m[j] + po + xoff_row) + xlu);
+                l[j] = widen(*reinterpret_cast<const SVT *>((WAFER_X2_L(j) + po + xoff_row) + xlu));
+                mm[j] = widen(*reinterpret_cast<const SVT *>((WAFER_X2_M(j) + po + xoff_row) + xlu));
             }
-            xq0[m] = xform_vec(*reinterpret_cast<const VT *>((phi + po + xoff_row) + xlu), l, mm);
+            xq0[m] = xform_vec(widen(*reinterpret_cast<const SVT *>((phi + po + xoff_row) + xlu)), l, mm);
         } else {
             double l[NL], mm[NL];
 #pragma unroll
-            for (int j = 0; j < NL; ++j) { l[j] = st.l[j][po + c_off]; mm[j] = st.m[j][po + c_off]; }
+            for (int j = 0; j < NL; ++j) { l[j] = (double)WAFER_X2_L(j)[po + c_off]; mm[j] = (double)WAFER_X2_M(j)[po + c_off]; }
             xq0[m] = zero;
-            xq0[m][0] = wafer_x2_xform<NL>(kf, phi[po + c_off], l, mm);
+            xq0[m][0] = wafer_x2_xform<NL>(kf, (double)phi[po + c_off], l, mm);
         }
     }
     if constexpr (VG == 0) {
         const long long po = (long long)z1 * g.plane;
 #pragma unroll
-        for (int r = 0; r < RY; ++r) vcur[r] = *reinterpret_cast<const VT *>((pv + po + rowoff[r]) + xlu);
-        if (x_row) xv = *reinterpret_cast<const VT *>((pv + po + xoff_row) + xlu);
-        else xv[0] = pv[po + c_off];
+        for (int r = 0; r < RY; ++r) vcur[r] = widen(*reinterpret_cast<const SVT *>((pv + po + rowoff[r]) + xlu));
+        if (x_row) xv = widen(*reinterpret_cast<const SVT *>((pv + po + xoff_row) + xlu));
+        else xv[0] = (T)pv[po + c_off];
     }
     for (int i = tid; i < 2 * Cfg::TILE0; i += Cfg::NT_) lds0[i] = T(0);
     for (int i = tid; i < 2 * Cfg::TILE1; i += Cfg::NT_) lds1[i] = T(0);
@@ -351,6 +366,8 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     }
 #undef WAFER_X2_Q0
 #undef WAFER_X2_Q1
+#undef WAFER_X2_L
+#undef WAFER_X2_M
     // ---- the workgroup's partial sums
     {
         int q = 0;
@@ -408,11 +425,14 @@ __global__ void wafer_k_x2_coeffs(int kind, int k, const double *__restrict__ su
 
 // ---- phi materialised after the last pass: x~ written in place, sum Y2^2 (= n_c^2 in the pass's scale) to partials[workgroup];
 //      the caller divides by its square root (wafer_k_row_op<2>: grid.rs:467) ------------------------------------------------
-template <int NL>
-__global__ __launch_bounds__(256) void wafer_k_x2_apply(WaferRowArgs a, double *__restrict__ phi, WaferX2Ptrs st,
+template <typename TS, int NL>
+__global__ __launch_bounds__(256) void wafer_k_x2_apply(WaferRowArgs a, typename WaferF3Store<TS>::S *__restrict__ phi, WaferX2Ptrs st,
                                                         const double *__restrict__ coef, double *__restrict__ partials)
 {
     using VT = typename WaferRowVec<double>::type;
+    using ST = typename WaferF3Store<TS>::S;
+    typedef ST __attribute__((ext_vector_type(2))) SVT;
+    auto widen = [](const SVT &x) -> VT { return wafer_f3_widen<SVT, VT, 2>(x); };
     constexpr int VEC = 2;
     __shared__ double red[4];
     const WaferGeom &g = a.g;
@@ -432,12 +452,12 @@ __global__ __launch_bounds__(256) void wafer_k_x2_apply(WaferRowArgs a, double *
         const int xi = xs * 64 * VEC + lane * VEC;
         if (xi >= wlim || xi >= g.nx) continue;
         const long long p = rowp + xi;
-        const VT w = *reinterpret_cast<const VT *>(phi + p);
+        const VT w = widen(*reinterpret_cast<const SVT *>(phi + p));
         VT l[NL], m[NL];
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            l[j] = __builtin_nontemporal_load(reinterpret_cast<const VT *>(st.l[j] + p));
-            m[j] = __builtin_nontemporal_load(reinterpret_cast<const VT *>(st.m[j] + p));
+            l[j] = widen(__builtin_nontemporal_load(reinterpret_cast<const SVT *>(static_cast<const ST *>(st.l[j]) + p)));
+            m[j] = widen(__builtin_nontemporal_load(reinterpret_cast<const SVT *>(static_cast<const ST *>(st.m[j]) + p)));
         }
         VT r;
 #pragma unroll
@@ -448,12 +468,15 @@ __global__ __launch_bounds__(256) void wafer_k_x2_apply(WaferRowArgs a, double *
             r[v] = wafer_x2_xform<NL>(kf, w[v], lv, mv, &u);
             if (xi + v < g.nx) acc += u * u;
         }
+        SVT rs;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) rs[v] = (ST)r[v];
         if (xi + VEC <= g.nx) {
-            *reinterpret_cast<VT *>(phi + p) = r;
+            *reinterpret_cast<SVT *>(phi + p) = rs;
         } else {
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
-                if (xi + v < g.nx) phi[p + v] = r[v];
+                if (xi + v < g.nx) phi[p + v] = rs[v];
         }
     }
     WAFER_ROW_WALK_END(g)
@@ -495,8 +518,9 @@ static inline long long wafer_x2_blocks(const WaferTuning &t, const WaferGeom &g
     return (long long)((g.nx + tx - 1) / tx) * ((g.ny + ty - 1) / ty) * ((lz_hi - lz_lo + zc - 1) / zc);
 }
 
-template <int RY, int NL, int VG>
-static inline hipError_t wafer_launch_xstep2_one(const WaferTuning &t, WaferStepArgs a, const double *phi, const double *pv, double *out,
+template <typename TS, int RY, int NL, int VG>
+static inline hipError_t wafer_launch_xstep2_one(const WaferTuning &t, WaferStepArgs a, const typename WaferF3Store<TS>::S *phi,
+                                                 const typename WaferF3Store<TS>::S *pv, typename WaferF3Store<TS>::S *out,
                                                  double *partials, size_t partials_cap, const WaferX2Ptrs &st, const double *coef,
                                                  hipStream_t s)
 {
@@ -508,24 +532,27 @@ static inline hipError_t wafer_launch_xstep2_one(const WaferTuning &t, WaferStep
     const long long nblocks = (long long)ntx * nty * ntz;
     if ((size_t)nblocks > partials_cap) return hipErrorInvalidValue;
     if (t.f3_xs != 0 && g.nx % Cfg::TX == 0 && g.ny % Cfg::TY == 0)
-        hipLaunchKernelGGL((wafer_k_xstep2<RY, NL, VG, true, true>), dim3((unsigned)nblocks), dim3(Cfg::NT_), 0, s, a, ntx, nty, t.swz, phi, pv,
+        hipLaunchKernelGGL((wafer_k_xstep2<TS, RY, NL, VG, true, true>), dim3((unsigned)nblocks), dim3(Cfg::NT_), 0, s, a, ntx, nty, t.swz, phi, pv,
                            out, partials, (long long)partials_cap, st, coef);
     else
-        hipLaunchKernelGGL((wafer_k_xstep2<RY, NL, VG, true, false>), dim3((unsigned)nblocks), dim3(Cfg::NT_), 0, s, a, ntx, nty, t.swz, phi, pv,
+        hipLaunchKernelGGL((wafer_k_xstep2<TS, RY, NL, VG, true, false>), dim3((unsigned)nblocks), dim3(Cfg::NT_), 0, s, a, ntx, nty, t.swz, phi, pv,
                            out, partials, (long long)partials_cap, st, coef);
     return hipGetLastError();
 }
 
 // out = A A x with x = the load transform of `phi` (coef); the 2 + 3k sums of the pass go to partials[q * partials_cap + wg].
 // Needs a.v_in_range (the short reciprocal); vg: the closed form V was generated from, or 0 (streamed).
-static inline hipError_t wafer_launch_xstep2(const WaferTuning &t, const WaferStepArgs &a, int k, int vg, const double *phi, const double *pv,
-                                             double *out, double *partials, size_t partials_cap, const WaferX2Ptrs &st, const double *coef,
-                                             hipStream_t s)
+template <typename TS>
+static inline hipError_t wafer_launch_xstep2(const WaferTuning &t, const WaferStepArgs &a, int k, int vg, const typename WaferF3Store<TS>::S *phi,
+                                             const typename WaferF3Store<TS>::S *pv, typename WaferF3Store<TS>::S *out, double *partials,
+                                             size_t partials_cap, const WaferX2Ptrs &st, const double *coef, hipStream_t s)
 {
     const int ry = wafer_x2_ry(t, k, vg);
+    constexpr bool WIDE = !std::is_same<typename WaferF3Store<TS>::S, double>::value;   // fp32 storage: V is streamed (no closed form there)
 #define WAFER_X2_CASE(RY_, NL_, VG_)                                                                                               \
-    if (ry == RY_ && k == NL_ && vg == VG_)                                                                                        \
-        return wafer_launch_xstep2_one<RY_, NL_, VG_>(t, a, phi, pv, out, partials, partials_cap, st, coef, s);
+    if constexpr (!WIDE || VG_ == 0)                                                                                               \
+        if (ry == RY_ && k == NL_ && vg == VG_)                                                                                    \
+            return wafer_launch_xstep2_one<TS, RY_, NL_, VG_>(t, a, phi, pv, out, partials, partials_cap, st, coef, s);
 #define WAFER_X2_CASES(RY_, NL_) WAFER_X2_CASE(RY_, NL_, 0) WAFER_X2_CASE(RY_, NL_, 4) WAFER_X2_CASE(RY_, NL_, 7) WAFER_X2_CASE(RY_, NL_, 9)
     WAFER_X2_CASES(2, 1)
     WAFER_X2_CASES(2, 2)
@@ -538,16 +565,17 @@ static inline hipError_t wafer_launch_xstep2(const WaferTuning &t, const WaferSt
 }
 
 // x~ in place and the partial sums of Y2^2 (one per workgroup; *nblocks_out of them)
-static inline hipError_t wafer_launch_x2_apply(const WaferRowArgs &ra, int k, double *phi, const WaferX2Ptrs &st, const double *coef,
+template <typename TS>
+static inline hipError_t wafer_launch_x2_apply(const WaferRowArgs &ra, int k, typename WaferF3Store<TS>::S *phi, const WaferX2Ptrs &st, const double *coef,
                                                double *partials, size_t partials_cap, int num_cus, hipStream_t s, int *nblocks_out)
 {
     const dim3 grid((unsigned)(num_cus * 8)), block(256);
     if ((size_t)grid.x > partials_cap) return hipErrorInvalidValue;
     *nblocks_out = (int)grid.x;
     switch (k) {
-    case 1: hipLaunchKernelGGL((wafer_k_x2_apply<1>), grid, block, 0, s, ra, phi, st, coef, partials); break;
-    case 2: hipLaunchKernelGGL((wafer_k_x2_apply<2>), grid, block, 0, s, ra, phi, st, coef, partials); break;
-    case 3: hipLaunchKernelGGL((wafer_k_x2_apply<3>), grid, block, 0, s, ra, phi, st, coef, partials); break;
+    case 1: hipLaunchKernelGGL((wafer_k_x2_apply<TS, 1>), grid, block, 0, s, ra, phi, st, coef, partials); break;
+    case 2: hipLaunchKernelGGL((wafer_k_x2_apply<TS, 2>), grid, block, 0, s, ra, phi, st, coef, partials); break;
+    case 3: hipLaunchKernelGGL((wafer_k_x2_apply<TS, 3>), grid, block, 0, s, ra, phi, st, coef, partials); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

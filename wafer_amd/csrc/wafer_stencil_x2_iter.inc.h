@@ -9,15 +9,16 @@
         const long long zo = (long long)z * g.plane;
 #endif
         // ---- 1. prefetch, raw: input and stored states two planes ahead, V one plane ahead
-        VT pre[RY], pre_l[NL][RY], pre_m[NL][RY], pre_v[RY], xpre = zero, xpre_l[NL], xpre_m[NL], xpre_v = zero;
+        //         (in the storage type: what arrives is widened in step 5, behind the barrier)
+        SVT pre[RY], pre_l[NL][RY], pre_m[NL][RY], pre_v[RY], xpre = szero, xpre_l[NL], xpre_m[NL], xpre_v = szero;
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            pre[r] = pre_v[r] = zero;
+            pre[r] = pre_v[r] = szero;
 #pragma unroll
-            for (int j = 0; j < NL; ++j) pre_l[j][r] = pre_m[j][r] = zero;
+            for (int j = 0; j < NL; ++j) pre_l[j][r] = pre_m[j][r] = szero;
         }
 #pragma unroll
-        for (int j = 0; j < NL; ++j) xpre_l[j] = xpre_m[j] = zero;
+        for (int j = 0; j < NL; ++j) xpre_l[j] = xpre_m[j] = szero;
         // The requests of a wave are spread over the iteration (as in the three-step kernel: all eight waves leave the barrier at
         // once, and (2 + 4k) x 8 requests of 1 KiB queueing at the CU's one address unit kept every wave from its arithmetic):
         // which group goes where was measured per tile shape (profiles/r04_ab_x2_request_placement.jsonl): A (the main rows' input and V)
@@ -27,39 +28,39 @@
             if (pos == 0) {   // A
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
-                    pre[r] = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + rowoff[r]) + xlu);
-                    if constexpr (VG == 0) pre_v[r] = *reinterpret_cast<const VT *>((pv + zo + g.plane + rowoff[r]) + xlu);
+                    pre[r] = *reinterpret_cast<const SVT *>((phi + zo + 2 * g.plane + rowoff[r]) + xlu);
+                    if constexpr (VG == 0) pre_v[r] = *reinterpret_cast<const SVT *>((pv + zo + g.plane + rowoff[r]) + xlu);
                 }
             }
             if (pos == 0) {   // L
 #pragma unroll
                 for (int r = 0; r < RY; ++r)
 #pragma unroll
-                    for (int j = 0; j < NL; ++j) pre_l[j][r] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
+                    for (int j = 0; j < NL; ++j) pre_l[j][r] = *reinterpret_cast<const SVT *>((WAFER_X2_L(j) + zo + 2 * g.plane + rowoff[r]) + xlu);
             }
             if (pos == (RY == 2 ? 2 : 0)) {   // M
 #pragma unroll
                 for (int r = 0; r < RY; ++r)
 #pragma unroll
-                    for (int j = 0; j < NL; ++j) pre_m[j][r] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + rowoff[r]) + xlu);
+                    for (int j = 0; j < NL; ++j) pre_m[j][r] = *reinterpret_cast<const SVT *>((WAFER_X2_M(j) + zo + 2 * g.plane + rowoff[r]) + xlu);
             }
             if (pos == 3) {   // X
                 if (x_row) {
-                    xpre = *reinterpret_cast<const VT *>((phi + zo + 2 * g.plane + xoff_row) + xlu);
+                    xpre = *reinterpret_cast<const SVT *>((phi + zo + 2 * g.plane + xoff_row) + xlu);
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
-                        xpre_l[j] = *reinterpret_cast<const VT *>((st.l[j] + zo + 2 * g.plane + xoff_row) + xlu);
-                        xpre_m[j] = *reinterpret_cast<const VT *>((st.m[j] + zo + 2 * g.plane + xoff_row) + xlu);
+                        xpre_l[j] = *reinterpret_cast<const SVT *>((WAFER_X2_L(j) + zo + 2 * g.plane + xoff_row) + xlu);
+                        xpre_m[j] = *reinterpret_cast<const SVT *>((WAFER_X2_M(j) + zo + 2 * g.plane + xoff_row) + xlu);
                     }
                     // (every row wave, also the two that only stage their row: a request inside one more branch makes the wait-count pass
                     //  wait for the requests issued before it)
-                    if constexpr (VG == 0) xpre_v = *reinterpret_cast<const VT *>((pv + zo + g.plane + xoff_row) + xlu);
+                    if constexpr (VG == 0) xpre_v = *reinterpret_cast<const SVT *>((pv + zo + g.plane + xoff_row) + xlu);
                 } else {
                     xpre[0] = phi[zo + 2 * g.plane + c_off];
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
-                        xpre_l[j][0] = st.l[j][zo + 2 * g.plane + c_off];
-                        xpre_m[j][0] = st.m[j][zo + 2 * g.plane + c_off];
+                        xpre_l[j][0] = WAFER_X2_L(j)[zo + 2 * g.plane + c_off];
+                        xpre_m[j][0] = WAFER_X2_M(j)[zo + 2 * g.plane + c_off];
                     }
                     if constexpr (VG == 0) xpre_v[0] = pv[zo + g.plane + c_off];
                 }
@@ -224,7 +225,7 @@
                             ys[0] = (r >= 1) ? (C)q1[WAFER_X2_Q1(1)][r >= 1 ? r - 1 : 0][v] : (C)nbu[1][v];
                             ys[2] = (r + 1 < RY) ? (C)q1[WAFER_X2_Q1(1)][r + 1 < RY ? r + 1 : RY - 1][v] : (C)nbd[1][v];
                             const C S = wafer_stencil_sum<C, 1>(xs, ys, zz, w);
-                            const T rs = update_with(w, (C)caq[r][v], (C)cbq[r][v], S);
+                            const T rs = as_stored(update_with(w, (C)caq[r][v], (C)cbq[r][v], S));   // (the sums below see what the array will hold)
                             res2[r][v] = (INTERIOR || xi + v < g.nx) ? rs : T(0);
                         }
                     }
@@ -250,13 +251,16 @@
 #if WAFER_DIAG & 4   // timing experiment: nothing is stored (the compiler cannot know)
                         if (a.dt > -1.0) continue;
 #endif
-                        T *dst = (out + (long long)(XS && zp2 < zs ? zs : zp2) * g.plane + rowoff[r]) + xlu;
+                        ST *dst = (out + (long long)(XS && zp2 < zs ? zs : zp2) * g.plane + rowoff[r]) + xlu;
+                        SVT st2;   // (a storage-type number already: as_stored)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) st2[v] = (ST)res2[r][v];
                         if (INTERIOR || xi + VEC <= g.nx) {
-                            wafer_store_result(reinterpret_cast<VT *>(dst), res2[r]);   // (streamed: wafer_stencil_fused3.hip.h, gstore)
+                            wafer_store_result(reinterpret_cast<SVT *>(dst), st2);   // (streamed: wafer_stencil_fused3.hip.h, gstore)
                         } else {
 #pragma unroll
                             for (int v = 0; v < VEC; ++v)
-                                if (xi + v < g.nx) dst[v] = res2[r][v];
+                                if (xi + v < g.nx) dst[v] = st2[v];
                         }
                     }
                 }
@@ -303,14 +307,14 @@
             VT l[NL], mm[NL];
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
-                l[j] = pre_l[j][r];
-                mm[j] = pre_m[j][r];
+                l[j] = widen(pre_l[j][r]);
+                mm[j] = widen(pre_m[j][r]);
                 // plane z + 2: read at iteration z + 3, as plane (z + 3) - 1 -- its slot (z + 2) % 3 was last read at iteration z
                 if constexpr (HOLD) hold_l[j][r] = l[j];
                 else *reinterpret_cast<VT *>(qslot(z + 2) + j * QS + qoff[r]) = l[j];
             }
-            q0[RING ? WAFER_X2_Q0(0) : 2][r] = xform_vec(pre[r], l, mm);
-            vcur[r] = pre_v[r];
+            q0[RING ? WAFER_X2_Q0(0) : 2][r] = xform_vec(widen(pre[r]), l, mm);
+            vcur[r] = widen(pre_v[r]);
             caq[r] = canew[r];
             cbq[r] = cbnew[r];
         }
@@ -319,12 +323,15 @@
             xq0[1] = xq0[2];
         }
         if (x_row) {
-            xq0[RING ? WAFER_X2_Q0(0) : 2] = xform_vec(xpre, xpre_l, xpre_m);
+            VT l[NL], mm[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { l[j] = widen(xpre_l[j]); mm[j] = widen(xpre_m[j]); }
+            xq0[RING ? WAFER_X2_Q0(0) : 2] = xform_vec(widen(xpre), l, mm);
         } else {
             double l[NL], mm[NL];
 #pragma unroll
-            for (int j = 0; j < NL; ++j) { l[j] = xpre_l[j][0]; mm[j] = xpre_m[j][0]; }
+            for (int j = 0; j < NL; ++j) { l[j] = (double)xpre_l[j][0]; mm[j] = (double)xpre_m[j][0]; }
             // (a halo-column lane keeps component 0 only: the slot's other component is never read)
-            xq0[RING ? WAFER_X2_Q0(0) : 2][0] = wafer_x2_xform<NL>(kf, xpre[0], l, mm);
+            xq0[RING ? WAFER_X2_Q0(0) : 2][0] = wafer_x2_xform<NL>(kf, (double)xpre[0], l, mm);
         }
-        xv = xpre_v;
+        xv = widen(xpre_v);
