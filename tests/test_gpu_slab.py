@@ -765,9 +765,10 @@ def test_excited_state_steps_on_slabs(wa, world, shape, ext, wnum, overlap):
         assert n2 == pytest.approx(want_n2, rel=1e-12)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("world,shape,wnum,depth", [(2, (40, 24, 32), 1, 2), (3, (140, 17, 30), 2, 2), (4, (130, 20, 40), 3, 3),
                                                     (2, (24, 40, 9), 1, 2)])
-def test_two_excited_steps_per_pass_on_slabs(wa, world, shape, wnum, depth, monkeypatch):
+def test_two_excited_steps_per_pass_on_slabs(wa, world, shape, wnum, depth, dtype, monkeypatch):
     """the two-steps-per-pass excited-state kernels (wafer_stencil_x2.hip.h) on z-slabs with two (or three) ghost planes:
     the raw result's two boundary planes per side travel after every pass, the stored states and their images A l_j carry
     two current ghost planes, the 2 + 3k sums are all-reduced -- against one context, 1e-12 per cell (sums associate per
@@ -775,8 +776,11 @@ def test_two_excited_steps_per_pass_on_slabs(wa, world, shape, wnum, depth, monk
     import sys
     sys.setswitchinterval(1e-4)
     monkeypatch.setenv("WAFER_X2_MAX_K", "3")
-    base = wa.Params(*shape, dn=0.25, dt=0.006, mass=1.0, central_difference=1, max_states=wnum, halo_depth=depth)
-    single = wa.Params(*shape, dn=0.25, dt=0.006, mass=1.0, central_difference=1, max_states=wnum)
+    base = wa.Params(*shape, dn=0.25, dt=0.006, mass=1.0, central_difference=1, max_states=wnum, halo_depth=depth, dtype=dtype)
+    single = wa.Params(*shape, dn=0.25, dt=0.006, mass=1.0, central_difference=1, max_states=wnum, dtype=dtype)
+    # fp32 storage (round 6: the two-step kernels on a storage tag): the slabs' sums associate differently in their last bits, the
+    # transform's coefficients with them, and a cell's rounding to float can then fall the other way: one float ulp, not 1e-12
+    bar = 1e-12 if dtype == "f64" else 3e-7
 
     def body(ctx, rank=0):
         ctx.set_potential("Coulomb")
@@ -797,9 +801,9 @@ def test_two_excited_steps_per_pass_on_slabs(wa, world, shape, wnum, depth, monk
     res, fabric = run_slabs(wa, base, world, body)
     got = assemble(base, world, [r[0] for r in res])
     err = float(np.max(np.abs(got - want))) / max(1.0, float(np.max(np.abs(want))))
-    assert err <= 1e-12, f"max error {err:.3e}, halo calls {fabric.halo_calls}"
+    assert err <= bar, f"max error {err:.3e}, halo calls {fabric.halo_calls}"
     for _, n2 in res:
-        assert n2 == pytest.approx(want_n2, rel=1e-12)
+        assert n2 == pytest.approx(want_n2, rel=1e-12 if dtype == "f64" else 1e-6)
 
 
 @pytest.mark.parametrize("world,shape,ext,wnum,depth,steps", [(2, (40, 24, 32), 1, 1, 2, (8, 5)), (3, (33, 17, 30), 2, 2, 2, (5, 2)), (4, (130, 20, 40), 1, 3, 3, (8, 5)),
