@@ -98,11 +98,12 @@ for it in range(int(os.environ.get("N", "30")) // 3):
     os.environ["WAFER_X2_MAX_K"] = "3"
     os.environ["WAFER_X2"] = str(rng.choice([1, 1, 0]))
     os.environ["WAFER_VGEN"] = str(rng.choice([1, 0]))
-    tag = ("excited", nx, ny, nz, ext, world, wnum, pot, calls, mode, depth, os.environ["WAFER_X2"], os.environ["WAFER_VGEN"])
+    xdtype = str(rng.choice(["f64", "f64", "f32"]))   # fp32 storage: the one- and (round 6) two-step kernels on float arrays, fp64 arithmetic
+    tag = ("excited", nx, ny, nz, ext, world, wnum, pot, calls, mode, depth, os.environ["WAFER_X2"], os.environ["WAFER_VGEN"], xdtype)
     try:
         params = dict(dn=0.25, dt=0.006, mass=1.3, sig=0.3)
-        base = wa.Params(nx, ny, nz, central_difference=ext, max_states=wnum, halo_depth=depth, **params)
-        single = wa.Params(nx, ny, nz, central_difference=ext, max_states=wnum, **params)
+        base = wa.Params(nx, ny, nz, central_difference=ext, max_states=wnum, halo_depth=depth, dtype=xdtype, **params)
+        single = wa.Params(nx, ny, nz, central_difference=ext, max_states=wnum, dtype=xdtype, **params)
 
         def body(ctx, rank=0):
             ctx.set_overlap(mode)
@@ -123,13 +124,15 @@ for it in range(int(os.environ.get("N", "30")) // 3):
         res, _ = run_slabs(wa, base, world, body, connect=True if mode == 4 else None)
         got = assemble(base, world, [r[0] for r in res])
         scale = max(1.0, float(np.max(np.abs(want))))
-        ok = float(np.max(np.abs(got - want))) / scale <= 1e-12 and all(abs(r[1] - want_n2) <= 1e-12 * max(1.0, abs(want_n2)) for r in res)
+        # (fp32 storage: the slabs' sums differ in their last bits, and a cell's rounding to float can then fall the other way: a float ulp)
+        bar1, bar2 = (1e-12, 1e-10) if xdtype == "f64" else (5e-7, 1e-5)
+        ok = float(np.max(np.abs(got - want))) / scale <= bar1 and all(abs(r[1] - want_n2) <= max(bar1, 1e-12) * max(1.0, abs(want_n2)) for r in res)
         cfg = wo.Config(nx, ny, nz, ext=ext, potential=pot, **params)
         v = wo.potential_generate(cfg); a, b = wo.ab(cfg, v)
         ref = start.copy()
         for n in calls:
             wo.evolve(cfg, wnum, a, b, ref, lowers, n)
-        ok2 = float(np.max(np.abs(got - ref))) / max(1.0, float(np.max(np.abs(ref)))) <= 1e-10
+        ok2 = float(np.max(np.abs(got - ref))) / max(1.0, float(np.max(np.abs(ref)))) <= bar2
         if not (ok and ok2):
             bad += 1
             print("MISMATCH", tag, ok, ok2, float(np.max(np.abs(got - want))), float(np.max(np.abs(got - ref))), flush=True)
