@@ -2,7 +2,7 @@
 """Randomised parity sweep of the HIP path against the oracle (a development aid next to the
 fixed cases of tests/test_gpu_parity.py): random shapes incl. 1-cell axes, stencil orders,
 potentials, step counts and kernel variants; ground state bit for bit, excited states (random
-stored states, Gram-Schmidt every step) to 1e-10.   N=200 SEED=3 python tests/fuzz_parity.py   (it lives under tests/ because it drives the oracle)"""
+stored states, Gram-Schmidt every step) to 1e-10; on fp32 storage (one and two steps per pass) to the fp32-storage bar.   N=200 SEED=3 python tests/fuzz_parity.py   (it lives under tests/ because it drives the oracle)"""
 import os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -119,6 +119,48 @@ for it in range(int(os.environ.get("N", "60")) // 2):
     except Exception as e:
         bad += 1
         print("ERROR excited", shape, ext, pot, wnum, steps, one_pass, repr(e)[:200], flush=True)
+# excited states on fp32 STORAGE (round 6: the two-steps-per-pass kernels on a storage tag): no reference to the bit -- against the fp64 oracle
+# (5e-6 of the state's largest value) and against the one-step fp32-storage kernels (2e-6), random tiles / z-chunks / tile heights / store counts
+for it in range(int(os.environ.get("N", "60")) // 4):
+    shape = (int(rng.choice([128, 256, 130, 64, 200])), int(rng.choice([8, 16, 24, 32, 17, 5])), int(rng.integers(2, 30)))
+    wnum, steps = int(rng.integers(1, 4)), int(rng.integers(4, 13))
+    dtype = str(rng.choice(["f32", "f32fast"]))
+    os.environ["WAFER_X2_MAX_K"] = "3"
+    os.environ["WAFER_X2_RY"] = str(rng.choice([0, 1, 2]))
+    os.environ["WAFER_ZCHUNK"] = str(rng.choice([0, 1, 2, 3, 5]))
+    os.environ["WAFER_F3_XS"] = str(rng.choice([1, 1, 0]))
+    os.environ["WAFER_ONE_PASS"] = "1"
+    pot = str(rng.choice(["Harmonic", "Coulomb", "SimpleCornell", "Cube"]))
+    try:
+        cfg, par = make_pair(shape, ext=1, potential=pot, dn=0.2, dt=0.004, mass=1.3, sig=0.3, max_states=wnum, dtype=dtype)
+        r32 = lambda x: np.ascontiguousarray(x.astype(np.float32).astype(np.float64))
+        v = r32(wo.potential_generate(cfg)); a, b = wo.ab(cfg, v)
+        lowers = []
+        for j in range(wnum):
+            l = random_phi(cfg, seed=2000 + 10 * it + j)
+            wo.normalise(l, wo.norm2(cfg, l)); wo.orthogonalise(j, l, lowers); wo.normalise(l, wo.norm2(cfg, l))
+            lowers.append(r32(l))
+        phi = r32(random_phi(cfg, seed=it))
+        want = phi.copy(); wo.evolve(cfg, wnum, a, b, want, lowers, steps)
+        got = {}
+        for x2 in ("1", "0"):
+            os.environ["WAFER_X2"] = x2
+            with wa.Context(par) as ctx:
+                ctx.set_potential(pot)
+                for j, l in enumerate(lowers):
+                    ctx.load_state(j, l)
+                ctx.upload_phi(phi); ctx.evolve(wnum, steps)
+                got[x2] = (ctx.download_phi(), ctx.x2_passes())
+        scale = max(1e-300, float(np.max(np.abs(want))))
+        e1, e0, e10 = (float(np.max(np.abs(got["1"][0] - want))) / scale, float(np.max(np.abs(got["0"][0] - want))) / scale,
+                       float(np.max(np.abs(got["1"][0] - got["0"][0]))) / scale)
+        if not (e1 <= 5e-6 and e0 <= 5e-6 and e10 <= 2e-6 and got["1"][1] > 0 and got["0"][1] == 0):
+            bad += 1
+            print("MISMATCH excited fp32 storage", shape, dtype, pot, wnum, steps, e1, e0, e10, got["1"][1], got["0"][1], flush=True)
+    except Exception as e:
+        bad += 1
+        print("ERROR excited fp32 storage", shape, dtype, pot, wnum, steps, repr(e)[:200], flush=True)
+os.environ.pop("WAFER_X2", None)
 os.environ.pop("WAFER_ONE_PASS", None)
 os.environ.pop("WAFER_VGEN", None)
 os.environ.pop("WAFER_XF_DEEP", None)
