@@ -476,7 +476,9 @@ bool x2_applies(const wafer_ctx *c, uint32_t wnum)
     // three stored states: the 128 x 8-tile kernel wins where a plane is small enough for the halo rows to stay in the XCDs' L2
     // (-4 % per step at 512 x 512, -2 ... -4 % at 256^2 / 384^2) and loses on 1024 x 1024 planes (+3 ... +5 %,
     // profiles/r04_x2_shapes.log).  The plane extent is the same on every rank of a decomposed run.
-    const int kmax = c->tune.x2_max_k > 0 ? c->tune.x2_max_k : ((long long)c->g.nx * c->g.ny <= 300000 ? 3 : 2);
+    // fp32 storage (round 6): the one-step kernels are bound in the CU there, and the two-step pass wins on wide planes too -- 1024 x 1024 x 128,
+    // k = 3: 0.68-0.69 against 0.78 ms/step (profiles/r06_sweep_x2_f32_wide_planes.jsonl)
+    const int kmax = c->tune.x2_max_k > 0 ? c->tune.x2_max_k : ((c->f32 || (long long)c->g.nx * c->g.ny <= 300000) ? 3 : 2);
     // (fp32 storage -- dtype f32 and f32fast, whose excited-state steps compute in fp64 -- since round 6: the storage tag of the three-step kernel)
     return c->tune.x2 != 0 && c->tune.one_pass != 0 && c->g.R == 1 && wnum >= 1 && wnum <= 3 && (int)wnum <= kmax &&
            active_variant(c) >= 1 && (!c->sharded() || c->g.G >= 2);

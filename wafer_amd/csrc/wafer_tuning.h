@@ -25,7 +25,7 @@ struct WaferTuning {
     int one_pass = 1;       // WAFER_ONE_PASS: transform-on-load (0: the two-pass scheme)
     int vgen = 1;           // WAFER_VGEN: evaluate Coulomb / SimpleCornell / Harmonic per cell instead of streaming V
     int x2 = 1;             // WAFER_X2: two excited-state steps per pass (ThreePoint fp64, 1..3 stored states); 0: one step per pass
-    int x2_max_k = 0;       // WAFER_X2_MAX_K: most stored states the two-step kernel takes (1 .. 3); 0 = by plane size: 3 up to 300 000 cells per plane, else 2 (wafer_engine.hip, x2_applies)
+    int x2_max_k = 0;       // WAFER_X2_MAX_K: most stored states the two-step kernel takes (1 .. 3); 0 = by plane size: 3 up to 300 000 cells per plane (fp32 storage: always), else 2 (wafer_engine_schedules.hip, x2_applies)
                             // (k = 3 runs on 128 x 8 tiles: -4 % per step at 512 x 512 planes, +3 ... +5 % at 1024 x 1024, profiles/r04_x2_shapes.log)
     int x2_ry = 0;          // WAFER_X2_RY: rows per lane of that kernel (1: 128 x 8 tiles, 2: 128 x 16, k = 1 and 2; 0: default = 2 where it exists)
     // fused kernels
