@@ -564,7 +564,7 @@ int x2_run(wafer_ctx *c, uint32_t wnum, uint64_t pairs, hipStream_t s)
     if (wafer_entry_x2_coeffs(1, k, c->scal, c->gram, amat, c->x2coef, s) != hipSuccess)
         return fail(WAFER_ERR_HIP, "coefficient kernel launch failed");
     const WaferStepArgs a = step_args(c, g.G, g.G + g.nzl);
-    const long long nb = wafer_entry_x2_blocks(c->tune, g, k, closed_form_vg(c), g.G, g.G + g.nzl, c->num_cus);
+    const long long nb = wafer_entry_x2_blocks(type_combo(c, false), c->tune, g, k, closed_form_vg(c), g.G, g.G + g.nzl, c->num_cus);
     if (nb > (long long)c->partials_stride) return fail(WAFER_ERR_INVALID, "partials buffer too small");
     TRY(ensure_halo(c, 2));   // z-slabs: two ghost planes of the raw input per side and pass
     for (uint64_t p = 0; p < pairs; ++p) {
@@ -901,7 +901,7 @@ int wafer_diag_dispatch(wafer_ctx *c, uint32_t wnum, char *buf, size_t n)
     const int vg = closed_form_vg(c);
     if (x2_applies(c, wnum)) {
         int tx = 0, ty = 0;
-        wafer_x2_tile_host(c->tune, (int)wnum, vg, &tx, &ty);
+        wafer_x2_tile_host(type_combo(c, false), c->tune, (int)wnum, vg, &tx, &ty);
         snprintf(buf, n, "wnum=%u stencil=%d dtype=%s kernel=wafer_k_xstep2 steps_per_pass=2 ghost_planes_per_pass=2 tile=%dx%d v=%s head=wafer_k_step_lds "
                          "condition=every_rank_agrees,n_steps>=4", wnum, R, dtype, tx, ty, vg ? "closed_form" : "streamed");
         return WAFER_OK;

@@ -70,6 +70,6 @@ hipError_t wafer_entry_x2_coeffs(int kind, int k, const double *sums, const doub
 // phi materialised in place after the last pass, up to the last step's norm: its square is summed into partials[0 .. *nblocks_out)
 hipError_t wafer_entry_x2_apply(int tc, const WaferGeom &g, int lz_lo, int lz_hi, int k, void *phi, const void *const *l, const void *const *m,
                                 const double *coef, double *partials, size_t partials_cap, int num_cus, hipStream_t s, int *nblocks_out);
-long long wafer_entry_x2_blocks(const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks);
+long long wafer_entry_x2_blocks(int tc, const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks);
 int wafer_entry_x2_nsums(int k);
-void wafer_x2_tile_host(const WaferTuning &t, int k, int vg, int *tx, int *ty);   // the kernel's tile for k stored states
+void wafer_x2_tile_host(int tc, const WaferTuning &t, int k, int vg, int *tx, int *ty);   // the kernel's tile for k stored states

@@ -147,11 +147,15 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     // three slots per state (written right after the transform, read when that plane's Z is produced; private to each lane, no
     // barrier), or -- 128 x 16 tiles with two stored states, where LDS has room for two slots only -- two slots plus one plane
     // in registers (HOLD).  Only the l_j wait: the M_j are used by the transform alone (see the head of this file).
-    constexpr bool HOLD = (RY == 2 && NL == 2);
+    // fp32 storage: the queue holds the stored states as they arrived, in float -- half the bytes, so three slots fit beside the tall tile's
+    // LDS for two AND three stored states (154 KB at k = 3), and nothing is held in registers
+    using QT = ST;
+    typedef QT __attribute__((ext_vector_type(2))) QVT;
+    constexpr bool HOLD = (RY == 2 && NL == 2 && !WIDE);
     // ring z-queues (the plane loop unrolled by three, no shifts): the kernels with exact store counts, as in the three-step kernel
     constexpr bool RING = XS;
     constexpr int NSLOT = HOLD ? 2 : 3;
-    __shared__ __attribute__((aligned(16))) T ldsq[NSLOT * NL * QS];   // [slot][state][row][x]
+    __shared__ __attribute__((aligned(16))) QT ldsq[NSLOT * NL * QS];   // [slot][state][row][x]
     __shared__ double red[Cfg::NW];
 
     const WaferGeom &g = a.g;
@@ -265,7 +269,8 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
     VT q0[3][RY], q1[3][RY], vcur[RY], caq[RY], cbq[RY];
     [[maybe_unused]] VT hold_l[NL][RY];     // HOLD: the stored states at the lane's own cells, plane z + 1 (transformed last iteration)
     // queue slot of plane p (HOLD: two slots by parity, written one iteration late from hold_l)
-    auto qslot = [&](int p) -> T * { return ldsq + ((HOLD ? (p & 1) : (p % 3)) * NL) * QS; };
+    auto qslot = [&](int p) -> QT * { return ldsq + ((HOLD ? (p & 1) : (p % 3)) * NL) * QS; };
+    auto narrow_q = [](const VT &x) -> QVT { QVT r; r[0] = (QT)x[0]; r[1] = (QT)x[1]; return r; };   // (exact: the value came from a QT)
     VT xq0[3], xv;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(512) void wafer_k_xstep2(WaferStepArgs a, int ntx, 
                 mm[j] = widen(*reinterpret_cast<const SVT *>((WAFER_X2_M(j) + po + rowoff[r]) + xlu));
                 if (m == 2) {
                     if constexpr (HOLD) hold_l[j][r] = l[j];
-                    else *reinterpret_cast<VT *>(qslot(z1 + 1) + j * QS + qoff[r]) = l[j];
+                    else *reinterpret_cast<QVT *>(qslot(z1 + 1) + j * QS + qoff[r]) = narrow_q(l[j]);
                 }
             }
             q0[m][r] = xform_vec(widen(*reinterpret_cast<const SVT *>((phi + po + rowoff[r]) + xlu)), l, mm);
@@ -489,32 +494,34 @@ __global__ __launch_bounds__(256) void wafer_k_x2_apply(WaferRowArgs a, typename
 // and streamed V alike); for two the tall tile needs 256 VGPRs + 72 B of scratch per lane and loses to the lower one (512^3
 // Coulomb, same box: 0.793 against 0.755 ms/step; one step per pass 0.817), so two and three run on 128 x 8 tiles (RY = 1).
 // WAFER_X2_RY overrides for k <= 2 (tests, sweeps).
-static inline int wafer_x2_ry(const WaferTuning &t, int k, int vg)
+static inline int wafer_x2_ry(const WaferTuning &t, int k, int vg, bool wide = false)
 {
     (void)vg;
-    if (k > 2) return 1;   // (three stored states: the lane-private queue of the tall tile does not fit the LDS)
+    // three stored states: the lane-private queue of the tall tile does not fit the LDS in double (176 KB); in float -- fp32 storage -- it does
+    // (154 KB), and there the tall tile is the default at every k (fewer halo rows per row: what the wide planes of a slab want)
+    if (k > 2 && !wide) return 1;
     if (t.x2_ry == 1 || t.x2_ry == 2) return t.x2_ry;
     return 2;              // 128 x 16 (k = 2: since the requests are spread over the iteration the kernel fits 229 VGPRs; 0.648 against 0.677 ms/step)
 }
-static inline void wafer_x2_tile(const WaferTuning &t, int k, int vg, int *tx, int *ty)
+static inline void wafer_x2_tile(const WaferTuning &t, int k, int vg, int *tx, int *ty, bool wide = false)
 {
     *tx = 128;
-    *ty = 8 * wafer_x2_ry(t, k, vg);
+    *ty = 8 * wafer_x2_ry(t, k, vg, wide);
 }
-static inline int wafer_x2_zchunk(const WaferTuning &t, const WaferGeom &g, int k, int vg, int nplanes, int target_blocks)
+static inline int wafer_x2_zchunk(const WaferTuning &t, const WaferGeom &g, int k, int vg, int nplanes, int target_blocks, bool wide = false)
 {
     int tx, ty;
-    wafer_x2_tile(t, k, vg, &tx, &ty);
+    wafer_x2_tile(t, k, vg, &tx, &ty, wide);
     if (t.zchunk > 0) return t.zchunk;
     const long long per_layer = (long long)((g.nx + tx - 1) / tx) * ((g.ny + ty - 1) / ty);
     const long long target = t.target_blocks > 0 ? t.target_blocks : (target_blocks > 0 ? target_blocks : 256);
     return wafer_pick_zchunk(per_layer, nplanes, target, 5);   // two iterations of pipeline fill + the prologue's three planes
 }
-static inline long long wafer_x2_blocks(const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks)
+static inline long long wafer_x2_blocks(const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks, bool wide = false)
 {
     int tx, ty;
-    wafer_x2_tile(t, k, vg, &tx, &ty);
-    const int zc = wafer_x2_zchunk(t, g, k, vg, lz_hi - lz_lo, target_blocks);
+    wafer_x2_tile(t, k, vg, &tx, &ty, wide);
+    const int zc = wafer_x2_zchunk(t, g, k, vg, lz_hi - lz_lo, target_blocks, wide);
     return (long long)((g.nx + tx - 1) / tx) * ((g.ny + ty - 1) / ty) * ((lz_hi - lz_lo + zc - 1) / zc);
 }
 
@@ -526,7 +533,7 @@ static inline hipError_t wafer_launch_xstep2_one(const WaferTuning &t, WaferStep
 {
     using Cfg = WaferX2Cfg<RY>;
     const WaferGeom &g = a.g;
-    a.zchunk = wafer_x2_zchunk(t, g, NL, VG, a.lz_hi - a.lz_lo, a.target_blocks);
+    a.zchunk = wafer_x2_zchunk(t, g, NL, VG, a.lz_hi - a.lz_lo, a.target_blocks, !std::is_same<typename WaferF3Store<TS>::S, double>::value);
     const int ntx = (g.nx + Cfg::TX - 1) / Cfg::TX, nty = (g.ny + Cfg::TY - 1) / Cfg::TY;
     const int ntz = (a.lz_hi - a.lz_lo + a.zchunk - 1) / a.zchunk;
     const long long nblocks = (long long)ntx * nty * ntz;
@@ -547,7 +554,7 @@ static inline hipError_t wafer_launch_xstep2(const WaferTuning &t, const WaferSt
                                              const typename WaferF3Store<TS>::S *pv, typename WaferF3Store<TS>::S *out, double *partials,
                                              size_t partials_cap, const WaferX2Ptrs &st, const double *coef, hipStream_t s)
 {
-    const int ry = wafer_x2_ry(t, k, vg);
+    const int ry = wafer_x2_ry(t, k, vg, !std::is_same<typename WaferF3Store<TS>::S, double>::value);
     constexpr bool WIDE = !std::is_same<typename WaferF3Store<TS>::S, double>::value;   // fp32 storage: V is streamed (no closed form there)
 #define WAFER_X2_CASE(RY_, NL_, VG_)                                                                                               \
     if constexpr (!WIDE || VG_ == 0)                                                                                               \
@@ -559,6 +566,7 @@ static inline hipError_t wafer_launch_xstep2(const WaferTuning &t, const WaferSt
     WAFER_X2_CASES(1, 1)
     WAFER_X2_CASES(1, 2)
     WAFER_X2_CASES(1, 3)
+    if constexpr (WIDE) { WAFER_X2_CASE(2, 3, 0) }
 #undef WAFER_X2_CASES
 #undef WAFER_X2_CASE
     return hipErrorInvalidValue;

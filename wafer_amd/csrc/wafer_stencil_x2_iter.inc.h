@@ -145,11 +145,11 @@
         VT lq[NL][RY];
         if (XS || act2) {
             nbload(std::integral_constant<int, 1>{});
-            const T *qs = qslot(z - 1);
+            const QT *qs = qslot(z - 1);
 #pragma unroll
             for (int j = 0; j < NL; ++j)
 #pragma unroll
-                for (int r = 0; r < RY; ++r) lq[j][r] = *reinterpret_cast<const VT *>(qs + j * QS + qoff[r]);
+                for (int r = 0; r < RY; ++r) lq[j][r] = wafer_f3_widen<QVT, VT, 2>(*reinterpret_cast<const QVT *>(qs + j * QS + qoff[r]));
         }
         // ---- 3x. level 1, the extra slot
         if (x_row) {
@@ -272,11 +272,11 @@
         issue_group(3);
         // HOLD: the plane transformed last iteration (z + 1) takes the queue slot just read (same lanes: program order suffices)
         if constexpr (HOLD) {
-            T *qd = qslot(z + 1);
+            QT *qd = qslot(z + 1);
 #pragma unroll
             for (int j = 0; j < NL; ++j)
 #pragma unroll
-                for (int r = 0; r < RY; ++r) *reinterpret_cast<VT *>(qd + j * QS + qoff[r]) = hold_l[j][r];
+                for (int r = 0; r < RY; ++r) *reinterpret_cast<QVT *>(qd + j * QS + qoff[r]) = narrow_q(hold_l[j][r]);
         }
         __syncthreads();
         // ---- 5. rotate the pipelines; the plane requested at the top of the iteration is transformed here -- BEHIND the
@@ -311,7 +311,7 @@
                 mm[j] = widen(pre_m[j][r]);
                 // plane z + 2: read at iteration z + 3, as plane (z + 3) - 1 -- its slot (z + 2) % 3 was last read at iteration z
                 if constexpr (HOLD) hold_l[j][r] = l[j];
-                else *reinterpret_cast<VT *>(qslot(z + 2) + j * QS + qoff[r]) = l[j];
+                else *reinterpret_cast<QVT *>(qslot(z + 2) + j * QS + qoff[r]) = pre_l[j][r];   // (as it arrived: the storage type IS the queue's)
             }
             q0[RING ? WAFER_X2_Q0(0) : 2][r] = xform_vec(widen(pre[r]), l, mm);
             vcur[r] = widen(pre_v[r]);

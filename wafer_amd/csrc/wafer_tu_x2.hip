@@ -46,10 +46,10 @@ hipError_t wafer_entry_x2_apply(int tc, const WaferGeom &g, int lz_lo, int lz_hi
     return wafer_launch_x2_apply<double>(ra, k, static_cast<double *>(phi), x2_ptrs(k, l, m), coef, partials, partials_cap, num_cus, s, nblocks_out);
 }
 
-long long wafer_entry_x2_blocks(const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks)
+long long wafer_entry_x2_blocks(int tc, const WaferTuning &t, const WaferGeom &g, int k, int vg, int lz_lo, int lz_hi, int target_blocks)
 {
-    return wafer_x2_blocks(t, g, k, vg, lz_lo, lz_hi, target_blocks);
+    return wafer_x2_blocks(t, g, k, vg, lz_lo, lz_hi, target_blocks, tc == WAFER_TC_F32_F64);
 }
 
 int wafer_entry_x2_nsums(int k) { return wafer_x2_nsums(k); }
-void wafer_x2_tile_host(const WaferTuning &t, int k, int vg, int *tx, int *ty) { wafer_x2_tile(t, k, vg, tx, ty); }
+void wafer_x2_tile_host(int tc, const WaferTuning &t, int k, int vg, int *tx, int *ty) { wafer_x2_tile(t, k, vg, tx, ty, tc == WAFER_TC_F32_F64); }
