@@ -33,6 +33,12 @@ for step in "$@"; do
                   sed "s/max_steps: 2000000/max_steps: ${CLI_STEPS:-4000}/; s/save_wavefns: true/save_wavefns: false/" examples/fromfile_2048_f32.yaml > /tmp/fromfile_2048_f32.yaml
                   ( time timeout 1200 wafer_amd/wafer-hip -c /tmp/fromfile_2048_f32.yaml --progress --input-dir /tmp/in5 --output-dir /tmp/out5 ) > $O/fromfile_2048_cli.log 2>&1
                   cat $O/fromfile_2048_cli.log ;;
+    # BASELINE config #3 (512^3 Coulomb, ground + 3 excited states) end to end through the driver, in fp64 and on fp32 storage
+    cli_hydrogen) for dt in f64 f32; do
+                    ( cat examples/hydrogen_512.yaml; printf "gpu:\n    dtype: $dt\n" ) > /tmp/hydrogen_512_$dt.yaml
+                    ( time timeout 900 wafer_amd/wafer-hip -c /tmp/hydrogen_512_$dt.yaml --input-dir /tmp/none --output-dir /tmp/out_h512_$dt ) > $O/hydrogen_512_${dt}_cli.log 2>&1
+                    grep "^state\|energy =" $O/hydrogen_512_${dt}_cli.log
+                  done ;;
     *)            echo "unknown step $step" ;;
   esac
 done
