@@ -496,15 +496,23 @@ def run_rank(args) -> int:
                 print("bench.py: peer stores (overlap mode 3) do not reproduce the exchange's bits on this fabric: dropped", file=sys.stderr, flush=True)
         # ... and so have the peer copies (mode 4: hipMemcpyAsync into the neighbour's ghost planes, a credit / arrival rendezvous
         # of one-wave kernels instead of send / recv): the same check, the same consequence
+        copy_modes = []
         if copies_ok:
-            copies_ok = slab.overlap_modes_agree(ctx, rank, world, 4, 0, steps=15, device=coll_dev)
-            copy_check = {"against": "overlap mode 0 (exchange through the halo hook), 15 steps, every rank's checksum", "identical": copies_ok}
-            if not copies_ok and rank == 0:
-                print("bench.py: peer copies (overlap mode 4) do not reproduce the exchange's bits on this fabric: dropped", file=sys.stderr, flush=True)
+            # mode 4: under the single launch (its workgroups read the copied planes behind a flag wait, while they run); modes 5 / 6:
+            # under mode 1's / mode 0's launches (every reader starts after the copy) -- each has to pass on its own
+            copy_check = {"against": "overlap mode 0 (exchange through the halo hook), 15 steps, every rank's checksum"}
+            for m in (4, 5, 6):
+                good = slab.overlap_modes_agree(ctx, rank, world, m, 0, steps=15, device=coll_dev)
+                copy_check["identical" if m == 4 else f"identical_mode_{m}"] = good
+                if good:
+                    copy_modes.append((m, 1))
+                elif rank == 0:
+                    print(f"bench.py: peer copies (overlap mode {m}) do not reproduce the exchange's bits on this fabric: dropped", file=sys.stderr, flush=True)
+            copies_ok = bool(copy_modes)
         # (slab.time_overlap_schedules: the same collective calls on every rank whatever happens on it; a schedule that fails
         #  anywhere is dropped everywhere)
         trial = slab.time_overlap_schedules(
-            ctx, ([(3, 1)] if peers_ok else []) + ([(4, 1)] if copies_ok else []) + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []), rank, device=coll_dev,
+            ctx, ([(3, 1)] if peers_ok else []) + copy_modes + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []), rank, device=coll_dev,
             log=lambda msg: print("bench.py: " + msg, file=sys.stderr, flush=True), device_sync=torch.cuda.synchronize)
         if not trial:
             print(f"bench.py: rank {rank}: every halo schedule failed in the set-up trial", file=sys.stderr)
@@ -512,7 +520,7 @@ def run_rank(args) -> int:
         best = min(trial, key=lambda k: trial[k] * (1.0 if k == DEFAULT_MODE else 1.02))
         ctx.set_overlap(best[0])
         ctx.set_halo_cycle(best[1])
-        names = {4: "4_single_launch_peer_copies", 3: "3_single_launch_peer_stores", 2: "2_single_launch_two_halves", 1: "1_boundary_first_three_launches", 0: "0_no_overlap"}
+        names = {6: "6_no_overlap_peer_copies", 5: "5_boundary_first_peer_copies", 4: "4_single_launch_peer_copies", 3: "3_single_launch_peer_stores", 2: "2_single_launch_two_halves", 1: "1_boundary_first_three_launches", 0: "0_no_overlap"}
         overlap_choice = {"mode": best[0], "fused_passes_per_exchange": best[1],
                           "ms_per_step": {names[m] + ("" if cy == 1 else f"_exchange_every_{cy}_passes"): v for (m, cy), v in trial.items()},
                           **({"peer_store_check": peer_check} if peer_check else {}), **({"peer_copy_check": copy_check} if copy_check else {})}

@@ -330,7 +330,7 @@ int wafer_set_comm_hooks(wafer_ctx *ctx, wafer_halo_fn halo, wafer_allreduce_fn 
 /* The halo hook may be called with only one direction non-NULL (send_lo + recv_hi, or send_hi + recv_lo: the
  * single-launch pass of wafer_set_overlap mode 2 exchanges the two sides at different times): a hook must
  * tolerate a NULL on a side that has a neighbour, and pair send_lo with the lower neighbour's recv_hi. */
-/* z-slabs, how the halo exchange is scheduled (modes 0 .. 4; 3 and 4 below).  All modes give identical results.
+/* z-slabs, how the halo exchange is scheduled (modes 0 .. 6; 3 .. 6 below).  All modes give identical results.
  *  0 = the exchange follows the whole slab's update (nothing overlaps);
  *  1 = boundary planes first, then their exchange, both on a second stream, beside the interior update:
  *      three launches per pass;
@@ -360,9 +360,11 @@ int wafer_set_overlap(wafer_ctx *ctx, int mode);
  *      all-reduce).  The hook's two-sided contract is kept by a rendezvous of four words per link in the neighbours' memory
  *      (one-wave kernels in stream order: "receive k posted" -> wait -> copy -> "copy k landed" -> wait), so a rank's ghost planes are
  *      overwritten only once it would have posted the receive.  Ground-state three-step passes run as mode 2's single launch, without
- *      its short columns (no exchange kernel needs a CU); WAFER_COPY_SCHED = 1 / 0 runs them as modes 1 / 0 instead, where every
- *      kernel that reads ghost planes is launched after the copy that filled them has completed (nothing then rests on what a
- *      running kernel sees of a peer's writes).  Needs wafer_peer_connect on every rank first; any stencil, storage type and slab
+ *      its short columns (no exchange kernel needs a CU).
+ *  5, 6 = peer copies under mode 1's (boundary planes first, three launches per pass) / mode 0's (exchange after the pass) launches:
+ *      every kernel that reads ghost planes is launched after the copy that filled them has completed, so nothing rests on what a
+ *      RUNNING kernel sees of a peer's writes -- the one assumption mode 4 shares with mode 3 on the consumer side.  (WAFER_COPY_SCHED =
+ *      1 / 0 turns mode 4 into these.)  Needs wafer_peer_connect on every rank first; any stencil, storage type and slab
  *      thickness.  After a WAFER_ERR_COMM under this mode the two ends of a link may disagree on their counts: export and connect
  *      again (a fresh export restarts them).  As for mode 3, contexts of ONE process on ONE device must not sit in a device-wide
  *      synchronisation (hipFree, hipDeviceSynchronize) while a neighbour context waits for their signal -- one process per GPU cannot.

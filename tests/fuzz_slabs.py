@@ -25,12 +25,12 @@ for it in range(int(os.environ.get("N", "30"))):
     depth = int(rng.choice([3, 6])) * ext if ext == 1 else int(rng.choice([2, 4])) * ext
     # overlap modes: 3 (peer stores) is the ThreePoint three-step pass on slabs of six planes or more; 4 (peer copies) is a transport and
     # serves every pass and thickness, under each of its three schedules
-    mode = int(rng.choice([0, 1, 2, 4, 4] + ([3, 3] if ext == 1 and depth >= 3 else [])))
+    mode = int(rng.choice([0, 1, 2, 4, 4, 5, 6] + ([3, 3] if ext == 1 and depth >= 3 else [])))
     nz = int(rng.integers(max(world * depth, world * 2 * ext, 6 * world if mode == 3 else 0), 70))
     pot, kw = [("Coulomb", {}), ("SimpleCornell", dict(mass=2.35, sig=0.223)), ("QuadWell", {}), ("Harmonic", {}), ("FullCornell", dict(mass=2.35, sig=0.223)),
                ("Periodic", {})][int(rng.integers(0, 6))]
     calls = [int(rng.integers(1, 14)) for _ in range(int(rng.integers(1, 4)))]
-    cycle = int(rng.choice([1, 2])) if (ext == 1 and depth == 6 and mode in (0, 1, 4)) or (ext > 1 and depth == 4 * ext and mode in (0, 1, 4)) else 1
+    cycle = int(rng.choice([1, 2])) if (ext == 1 and depth == 6 and mode in (0, 1, 4, 5, 6)) or (ext > 1 and depth == 4 * ext and mode in (0, 1, 4, 5, 6)) else 1
     os.environ["WAFER_FUSE3_MIN_NY"] = "1"
     os.environ["WAFER_HV_LAYOUT"] = str(rng.choice([0, 3, 4]))
     os.environ["WAFER_ZCHUNK"] = str(rng.choice([0, 0, 3, 7]))
@@ -51,8 +51,8 @@ for it in range(int(os.environ.get("N", "30"))):
                 ctx.evolve(0, n)
             return ctx.download_phi(), ctx.observables()
 
-        res, fab = run_slabs(wa, base, world, body, connect=True if mode == 4 else None)
-        if mode == 4 and any(fab.halo_calls):
+        res, fab = run_slabs(wa, base, world, body, connect=True if mode >= 4 else None)
+        if mode >= 4 and any(fab.halo_calls):
             raise RuntimeError(f"peer copies went through the halo hook: {fab.halo_calls}")
         got = assemble(base, world, [r[0] for r in res])
         if dtype == "f64":
@@ -93,7 +93,7 @@ for it in range(int(os.environ.get("N", "30")) // 3):
     nz = int(rng.integers(max(world * depth, world * 2 * ext) + 1, 44))
     pot = str(rng.choice(["Harmonic", "Coulomb", "SimpleCornell", "Cube"]))
     calls = [int(rng.integers(1, 10)) for _ in range(int(rng.integers(1, 3)))]
-    mode = int(rng.choice([0, 1, 2, 4]))
+    mode = int(rng.choice([0, 1, 2, 4, 5, 6]))
     os.environ["WAFER_COPY_SCHED"] = str(rng.choice([2, 1, 0]))
     os.environ["WAFER_X2_MAX_K"] = "3"
     os.environ["WAFER_X2"] = str(rng.choice([1, 1, 0]))
@@ -121,7 +121,7 @@ for it in range(int(os.environ.get("N", "30")) // 3):
 
         with wa.Context(single) as ctx:
             want, want_n2, start, lowers = body(ctx)
-        res, _ = run_slabs(wa, base, world, body, connect=True if mode == 4 else None)
+        res, _ = run_slabs(wa, base, world, body, connect=True if mode >= 4 else None)
         got = assemble(base, world, [r[0] for r in res])
         scale = max(1.0, float(np.max(np.abs(want))))
         # (fp32 storage: the slabs' sums differ in their last bits, and a cell's rounding to float can then fall the other way: a float ulp)

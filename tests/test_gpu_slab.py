@@ -451,6 +451,36 @@ def test_peer_copy_pass_uneven_slabs_bit_exact(wa, world, shape, steps, sched, m
     assert fabric.halo_calls == [0] * world, fabric.halo_calls       # nothing went through the hook
 
 
+@pytest.mark.parametrize("mode", [5, 6])
+@pytest.mark.parametrize("world,shape,steps", [(3, (140, 40, 19), 9), (4, (64, 20, 13), 8), (2, (300, 70, 96), 15)])
+@peer_store_process
+def test_peer_copies_under_the_split_and_the_unsplit_launches(wa, world, shape, steps, mode, monkeypatch):
+    """overlap modes 5 / 6: the peer copies under mode 1's (boundary planes first) / mode 0's (exchange after the pass) launches, where
+    every kernel that reads ghost planes starts after the copy that filled them has completed -- the forms of mode 4 that rest on
+    nothing but what a completed memcpy guarantees; WAFER_COPY_SCHED plays no part; bit for bit against one context"""
+    monkeypatch.setenv("WAFER_FUSE3_MIN_NY", "1")
+    monkeypatch.setenv("WAFER_COPY_SCHED", "2")     # (mode 4's knob: must not matter here)
+    base = wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1, halo_depth=3)
+    with wa.Context(wa.Params(*shape, dn=0.2, dt=0.004, mass=1.0, central_difference=1)) as ctx:
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 5)
+        want = ctx.download_phi()
+
+    def body(ctx, rank):
+        ctx.set_overlap(mode)
+        ctx.set_potential("Coulomb")
+        ctx.set_initial_condition("Boolean")
+        ctx.evolve(0, steps)
+        ctx.evolve(0, 5)
+        return ctx.download_phi()
+
+    res, fabric = run_slabs(wa, base, world, body)
+    assert np.array_equal(assemble(base, world, res), want)
+    assert fabric.halo_calls == [0] * world
+
+
 @pytest.mark.parametrize("ext,dtype", [(2, "f64"), (3, "f64"), (1, "f32"), (2, "f32fast")])
 @peer_store_process
 def test_peer_copies_serve_every_stencil_and_storage_type(wa, ext, dtype, monkeypatch):

@@ -344,19 +344,21 @@ int wafer_set_comm_hooks(wafer_ctx *c, wafer_halo_fn halo, wafer_allreduce_fn al
 int wafer_set_overlap(wafer_ctx *c, int mode)
 {
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
-    if (mode < 0 || mode > 4) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 4");
+    if (mode < 0 || mode > 6) return fail(WAFER_ERR_INVALID, "overlap mode 0 .. 6");
     if (mode == 3) {
         if (c->sharded() && !c->peer_ready) return fail(WAFER_ERR_STATE, "overlap mode 3 (peer stores) needs wafer_peer_connect first");
         if (c->sharded() && c->g.nzl < 6 * c->g.R) return fail(WAFER_ERR_INVALID, "overlap mode 3 needs at least %d owned planes", 6 * c->g.R);
     }
-    if (mode == 4) {
-        if (c->sharded() && !c->peer_ready) return fail(WAFER_ERR_STATE, "overlap mode 4 (peer copies) needs wafer_peer_connect first");
+    if (mode >= 4) {
+        if (c->sharded() && !c->peer_ready) return fail(WAFER_ERR_STATE, "overlap modes 4 .. 6 (peer copies) need wafer_peer_connect first");
         HIP_TRY(hipSetDevice(c->P.device));
         TRY(ensure_hv(c));   // the bounded waits report through hv_err
     }
     c->overlap_mode = mode;
-    c->halo_copy = mode == 4 && c->sharded();
-    c->sched = mode == 4 ? c->tune.copy_sched : mode;
+    // 4: peer copies under the single launch (WAFER_COPY_SCHED overrides the schedule); 5 / 6: peer copies under mode 1's / mode 0's
+    // launches -- every kernel that reads ghost planes starts after the copy that filled them has completed
+    c->halo_copy = mode >= 4 && c->sharded();
+    c->sched = mode == 4 ? c->tune.copy_sched : mode == 5 ? 1 : mode == 6 ? 0 : mode;
     // a fresh start for the single-launch pass: every rank dispatches the lower half first again and nothing in the ghost
     // planes is taken for current (a host that has just seen WAFER_ERR_COMM on some rank calls this on all of them)
     c->hv_first = 0;
@@ -431,7 +433,7 @@ int wafer_peer_disconnect(wafer_ctx *c)
         c->peer[h] = wafer_ctx::PeerSide();
     }
     c->peer_ready = false;
-    if (c->overlap_mode == 3 || c->overlap_mode == 4) {
+    if (c->overlap_mode >= 3) {
         c->overlap_mode = c->sched = 2;
         c->halo_copy = false;
     }

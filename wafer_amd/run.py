@@ -283,9 +283,11 @@ def main(argv=None) -> int:
                 chosen = 3
             elif use_peer_copies and slab.overlap_modes_agree(ctx, rank, world, 4, 2, steps=15, device=dev):
                 chosen = 4
+            elif use_peer_copies and slab.overlap_modes_agree(ctx, rank, world, 5, 2, steps=15, device=dev):
+                chosen = 5      # the copies under mode 1's launches: every reader of ghost planes starts after the copy
             ctx.set_overlap(chosen)
             if rank == 0:
-                print({3: "halo schedule: overlap mode 3 (peer stores)", 4: "halo schedule: overlap mode 4 (peer copies)",
+                print({3: "halo schedule: overlap mode 3 (peer stores)", 4: "halo schedule: overlap mode 4 (peer copies)", 5: "halo schedule: overlap mode 5 (peer copies, boundary planes first)",
                        2: "halo schedule: neither peer stores nor peer copies reproduce the exchange's bits on this fabric; overlap mode 2"}[chosen],
                       file=sys.stderr, flush=True)
         sub = staged_array(args.input_dir, "potential_sub", cfg["file_type"], 0, rank)   # potential.rs:113-131
