@@ -89,7 +89,7 @@ struct RunResult {
     float ms = 0.f;
     uint64_t steps = 0;
     int overlap_mode = 2;        // what the timed steps ran under
-    int peer_check = -1;         // -1: peer stores / copies not tried, 0: tried and dropped (connection or bits), 3 / 4: that overlap mode checked and in use
+    int peer_check = -1;         // -1: peer stores / copies not tried, 0: tried and dropped (connection or bits), 3 / 4 / 5: that overlap mode checked and in use
 };
 
 // all ranks: is `mine` true everywhere?  (world 1: yes if mine)
@@ -138,10 +138,12 @@ static int try_peer_stores(wafer_ctx *ctx, const wafer_params &p, Fabric *fab, i
     // mode 3 needs six owned planes on EVERY rank (`thinnest`: a quantity all ranks share); mode 4 -- peer copies: every exchange a
     // device copy into the neighbour's ghost planes -- serves any slab and is tried where mode 3 does not apply or fails its check
     // (WAFER_PEER_MODE=4: peer copies only -- the self test times both)
-    const int candidates[2] = {(thinnest >= 6 && env_int("WAFER_PEER_MODE", 3) != 4) ? 3 : 4, 4};
-    for (int ci = 0; ci < 2; ++ci) {
+    // then 5: the copies under the boundary-first launches, where every reader of ghost planes starts after the copy
+    const bool try3 = thinnest >= 6 && env_int("WAFER_PEER_MODE", 3) != 4;
+    const int candidates[3] = {try3 ? 3 : 4, try3 ? 4 : 5, try3 ? 5 : 0};
+    for (int ci = 0; ci < 3; ++ci) {
         const int mode = candidates[ci];
-        if (ci == 1 && candidates[0] == 4) break;
+        if (mode == 0) break;
         uint64_t sum[2] = {0, 0};
         ok = true;
         for (int i = 0; i < 2; ++i) {
