@@ -335,7 +335,8 @@ def test_dispatch_description_is_what_runs(wa, shape, ext, dtype, slab):
             assert took_x2 == (d["kernel"] == "wafer_k_xstep2"), (k, d)
             assert d["steps_per_pass"] == (2 if took_x2 else 1)
             if took_x2:
-                assert ext == 1 and dtype in ("f64", "f32") and d["tile"] == ("128x16" if k <= 2 else "128x8")   # (fp32 storage since round 6)
+                # (fp32 storage since round 6, there on the tall tile at every k: the stored states' LDS queue is float)
+                assert ext == 1 and dtype in ("f64", "f32") and d["tile"] == ("128x16" if (k <= 2 or dtype == "f32") else "128x8")
             else:
                 assert d["kernel"] == "wafer_k_step_lds" and d["nlow"] == k and d["waves"] in (4, 8)
         d5 = ctx.dispatch(5)                                     # more stored states than the fused overlaps carry (WAFER_MAX_LOW = 4)
