@@ -15,9 +15,9 @@ sys.path.insert(0, ROOT)
 def parse(path):
     rows = [r for r in csv.DictReader(open(path)) if "step2_fused" in r["Kernel_Name"] or "step3_fused" in r["Kernel_Name"]
             or "ccl" in r["Kernel_Name"].lower() or "copyBuffer" in r["Kernel_Name"] or "wafer_k_gate" in r["Kernel_Name"]
-            or "wafer_k_post" in r["Kernel_Name"]]
+            or "wafer_k_post" in r["Kernel_Name"] or "wafer_k_signal" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    rows = rows[-24:]
+    rows = rows[-(40 if any('wafer_k_signal' in r['Kernel_Name'] for r in rows) else 24):]
     t0 = int(rows[0]["Start_Timestamp"])
     for r in rows:
         s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
@@ -46,6 +46,9 @@ def main():
     mode = int(sys.argv[sys.argv.index("--mode") + 1]) if "--mode" in sys.argv else 2
     par = wafer_amd.Params(1024, 1024, 1024, dn=0.02, dt=8e-5, mass=2.35, sig=0.223, z_begin=512, z_count=128, halo_depth=3)
     with wafer_amd.Context(par) as ctx:
+        if mode >= 3:   # peer stores / peer copies: the slab as its own neighbour
+            rec = ctx.peer_export()
+            ctx.peer_connect(rec, rec)
         ctx.set_overlap(mode)
         comm = None
         if "--rccl" in sys.argv:
