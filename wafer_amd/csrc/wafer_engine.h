@@ -106,6 +106,7 @@ struct wafer_ctx {
     size_t esz = 8;
 
     hipStream_t s_main = nullptr, s_aux = nullptr, s_own = nullptr;
+    hipStream_t s_aux2 = nullptr;   // the upper side's exchanges of the single-launch pass under the copy transport (launch_halves_pass)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_bdry = nullptr;
 
     void *phi[2] = {nullptr, nullptr};

@@ -201,6 +201,7 @@ int wafer_ctx_create(const wafer_params *p, wafer_ctx **out)
         int prio_lo = 0, prio_hi = 0;
         HIP_TRYC(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         HIP_TRYC(hipStreamCreateWithPriority(&c->s_aux, hipStreamNonBlocking, (c->tune.hv_debug & 64) ? prio_lo : prio_hi));
+        HIP_TRYC(hipStreamCreateWithPriority(&c->s_aux2, hipStreamNonBlocking, (c->tune.hv_debug & 64) ? prio_lo : prio_hi));
     }
     HIP_TRYC(hipEventCreate(&c->ev_start));
     HIP_TRYC(hipEventCreate(&c->ev_stop));
@@ -236,6 +237,7 @@ int wafer_ctx_destroy(wafer_ctx *c)
     (void)hipSetDevice(c->P.device);
     if (c->s_own) (void)hipStreamSynchronize(c->s_own);
     if (c->s_aux) (void)hipStreamSynchronize(c->s_aux);
+    if (c->s_aux2) (void)hipStreamSynchronize(c->s_aux2);
     for (void *p : {c->phi[0], c->phi[1], c->v, c->a, c->b, c->potsub})
         if (p) (void)hipFree(alloc_base(c, p));
     for (void *p : c->states)
@@ -258,6 +260,7 @@ int wafer_ctx_destroy(wafer_ctx *c)
     if (c->hv_err) (void)hipHostFree(c->hv_err);
     if (c->s_own) (void)hipStreamDestroy(c->s_own);
     if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
+    if (c->s_aux2) (void)hipStreamDestroy(c->s_aux2);
     delete c;
     return WAFER_OK;
 }
@@ -267,6 +270,7 @@ int wafer_synchronize(wafer_ctx *c)
     if (!c) return fail(WAFER_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->P.device));
     HIP_TRY(hipStreamSynchronize(c->s_aux));
+    HIP_TRY(hipStreamSynchronize(c->s_aux2));
     HIP_TRY(hipStreamSynchronize(c->s_main));
     return check_hv_err(c);
 }

@@ -119,18 +119,18 @@ unsigned hv_spins(const wafer_ctx *c, int mul)
 }
 
 // exchange stream: wait until every workgroup of `half` of the current launch has finished
-int hv_gate(wafer_ctx *c, int half)
+int hv_gate(wafer_ctx *c, int half, hipStream_t sx)
 {
-    hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, c->s_aux, hv_cnt(c, half), c->hv_cnt_target[half], c->hv_err, hv_spins(c, 4), 0);
+    hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, sx, hv_cnt(c, half), c->hv_cnt_target[half], c->hv_err, hv_spins(c, 4), 0);
     HIP_TRY(hipGetLastError());
     return WAFER_OK;
 }
 // exchange stream: ghost side g has been filled once more (in stream order behind the exchange: its kernels have
 // completed, their writes are visible device-wide)
-int hv_post(wafer_ctx *c, int g)
+int hv_post(wafer_ctx *c, int g, hipStream_t sx)
 {
     const unsigned long long v = ++c->hv_flag_epoch[g];
-    hipLaunchKernelGGL(wafer_k_post, dim3(1), dim3(64), 0, c->s_aux, hv_flag(c, g), v);
+    hipLaunchKernelGGL(wafer_k_post, dim3(1), dim3(64), 0, sx, hv_flag(c, g), v);
     HIP_TRY(hipGetLastError());
     return WAFER_OK;
 }
@@ -315,13 +315,19 @@ int launch_halves_pass(wafer_ctx *c, int src, int dst, int E)
     c->hv_cnt_target[1] += (unsigned long long)tab->nbump[1];
     for (int i = 0; i < 2; ++i) {
         const int half = (first + i) & 1;
-        if (!(c->tune.hv_debug & 32)) TRY(hv_gate(c, half));
+        // The two sides' exchanges go to different neighbours over different links.  Under the copy transport each side has a stream of its
+        // own, so that the second half's copy does not queue behind the first's (26.6 MB per side and pass: a few hundred microseconds on
+        // a link, two of them in a row are most of a pass; profiles/r06_slab_mode4_timeline.txt): a side's chain of passes stays in order on
+        // its stream, the per-link counts are disjoint, and a flag still implies that this rank's copy of the planes about to be overwritten
+        // has landed -- the neighbour that posts it has consumed them.  The hook transports (mode 2) keep the one stream they were proved on.
+        const hipStream_t sx = (c->halo_copy && half == 1) ? c->s_aux2 : c->s_aux;
+        if (!(c->tune.hv_debug & 32)) TRY(hv_gate(c, half, sx));
         // a half thinner than the exchange depth: its side's boundary planes reach into the other half
-        if ((half == 0 ? mid - lo : hi - mid) < E) TRY(hv_gate(c, half ^ 1));
+        if ((half == 0 ? mid - lo : hi - mid) < E) TRY(hv_gate(c, half ^ 1, sx));
         // side 0: the lowest owned planes go down, the upper ghost planes are filled (read by half B); side 1: the mirror image
-        TRY(exchange_halo_side(c, dst, c->s_aux, E, half));
-        TRY(hv_post(c, half ^ 1));
-        HIP_TRY(hipEventRecord(c->ev_ex[half], c->s_aux));
+        TRY(exchange_halo_side(c, dst, sx, E, half));
+        TRY(hv_post(c, half ^ 1, sx));
+        HIP_TRY(hipEventRecord(c->ev_ex[half], sx));
     }
     c->hv_first ^= 1;
     return WAFER_OK;
