@@ -106,6 +106,7 @@ int ensure_hv(wafer_ctx *c)
     *c->hv_err = 0;
     HIP_TRY(hipMalloc((void **)&c->hv_words, 4 * 64));
     HIP_TRY(hipMemset(c->hv_words, 0, 4 * 64));
+    HIP_TRY(hipDeviceSynchronize());   // (the engine's streams are non-blocking: they do not wait for the null stream's memset)
     return WAFER_OK;
 }
 unsigned long long *hv_cnt(wafer_ctx *c, int half) { return c->hv_words + half * WAFER_F3_SYNC_STRIDE; }
@@ -163,6 +164,7 @@ int ensure_peer_flags(wafer_ctx *c)
         HIP_TRY(hipMalloc(&p, PEER_FLAG_LINES * 64));
     }
     HIP_TRY(hipMemset(p, 0, PEER_FLAG_LINES * 64));
+    HIP_TRY(hipDeviceSynchronize());   // (as in ensure_hv)
     c->peer_flags = static_cast<unsigned long long *>(p);
     return WAFER_OK;
 }
@@ -399,6 +401,7 @@ int wafer_peer_export(wafer_ctx *c, wafer_peer_info *out)
     // the counts of a link's two ends may differ: export and connect again.)
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(c->peer_flags + PEER_WORD_ARRIVED * WAFER_F3_SYNC_STRIDE, 0, (PEER_FLAG_LINES - PEER_WORD_ARRIVED) * 64));
+    HIP_TRY(hipDeviceSynchronize());   // the zeros are in memory before any neighbour learns the address
     c->cp_sent[0] = c->cp_sent[1] = c->cp_recv[0] = c->cp_recv[1] = 0;
     memset(out, 0, sizeof *out);
     out->struct_size = (uint32_t)sizeof *out;
