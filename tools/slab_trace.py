@@ -15,9 +15,9 @@ sys.path.insert(0, ROOT)
 def parse(path):
     rows = [r for r in csv.DictReader(open(path)) if "step2_fused" in r["Kernel_Name"] or "step3_fused" in r["Kernel_Name"]
             or "ccl" in r["Kernel_Name"].lower() or "copyBuffer" in r["Kernel_Name"] or "wafer_k_gate" in r["Kernel_Name"]
-            or "wafer_k_post" in r["Kernel_Name"] or "wafer_k_signal" in r["Kernel_Name"]]
+            or "wafer_k_post" in r["Kernel_Name"] or "wafer_k_rendezvous" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    rows = rows[-(40 if any('wafer_k_signal' in r['Kernel_Name'] for r in rows) else 24):]
+    rows = rows[-(40 if any('wafer_k_rendezvous' in r['Kernel_Name'] for r in rows) else 24):]
     t0 = int(rows[0]["Start_Timestamp"])
     for r in rows:
         s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0

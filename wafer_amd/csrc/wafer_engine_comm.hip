@@ -173,21 +173,46 @@ int ensure_peer_flags(wafer_ctx *c)
 // The halo hook's contract is two-sided: a rank's ghost planes are overwritten only once it has posted the receive, and the call
 // returns (in stream order) with its own ghost planes filled.  A copy INTO the neighbour's memory has neither property by itself,
 // so every exchange is a rendezvous over the words above, all of it enqueued on the stream the hook would have been called with:
-//   1. for every side I receive on: tell that neighbour "receive number k posted" (credit word in ITS memory) -- never waits;
-//   2. for every side I send to: wait for that neighbour's credit number k (a one-wave kernel polling my own memory), copy my
-//      boundary planes into its ghost planes (hipMemcpyAsync: a copy engine between GPUs, no CU of either), then tell it "copy
-//      number k has landed" (arrival word in its memory; stream order puts the store behind the completed copy);
-//   3. for every side I receive on: wait for arrival number k.
+//   1. one one-wave kernel: for every side I receive on, tell that neighbour "receive number k posted" (credit word in ITS memory);
+//      THEN, for every side I send to, wait for that neighbour's credit number k (polling my own memory);
+//   2. copy my boundary planes into the neighbours' ghost planes (hipMemcpyAsync: a copy engine between GPUs, no CU of either);
+//   3. one one-wave kernel: tell each neighbour "copy number k has landed" (arrival word in its memory; stream order puts the store
+//      behind the completed copies), then wait for the arrivals on the sides I receive on.
 // Every rank grants before it waits, so a chain of ranks cannot lock up; the counts are per link and direction and only ever grow.
 // What follows on the stream starts after the arrival and, being another kernel, sees the copied planes the way any kernel sees a
 // completed memcpy; the workgroups of a single-launch pass that is already RUNNING read them behind their flag wait and a
 // system-scope acquire fence, as they read what RCCL's receive kernel or a neighbour's peer stores wrote (schedule 2; schedules
 // 1 and 0 -- WAFER_COPY_SCHED -- start every reader after the copy).  Waits are bounded like the pass's own (WAFER_ERR_COMM).
-__global__ __launch_bounds__(64) void wafer_k_signal(unsigned long long *word, unsigned long long value)
+// One wave does a whole step of the rendezvous: up to two stores ("receive k posted" / "copy k landed" in the neighbours' memory) and
+// then up to two bounded waits on this rank's own words.  (One kernel per store and per wait it had been: ten launches and two
+// copies per two-sided exchange, each launch a few microseconds of the chain -- profiles/r06_slab_mode4_timeline.txt.)
+struct WaferRendezvous {
+    unsigned long long *set_word[2] = {nullptr, nullptr};
+    unsigned long long set_value[2] = {0, 0};
+    const unsigned long long *wait_word[2] = {nullptr, nullptr};
+    unsigned long long wait_value[2] = {0, 0};
+};
+__global__ __launch_bounds__(64) void wafer_k_rendezvous(WaferRendezvous r, unsigned *err, unsigned max_spins)
 {
-    // (relaxed: what the word announces -- a completed copy, or nothing at all -- precedes this kernel in stream order; a release
+    if (threadIdx.x != 0) return;
+    // (relaxed stores: what a word announces -- a completed copy, or nothing at all -- precedes this kernel in stream order; a release
     //  fence here would write back the L2 lines of whatever stencil workgroups share the XCD)
-    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = 0; i < 2; ++i)
+        if (r.set_word[i]) __hip_atomic_store(r.set_word[i], r.set_value[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    bool waited = false;
+    for (int i = 0; i < 2; ++i) {
+        if (!r.wait_word[i]) continue;
+        waited = true;
+        unsigned spins = 0;
+        while (__hip_atomic_load(r.wait_word[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < r.wait_value[i]) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > max_spins) {   // (as wafer_k_gate: the host reports WAFER_ERR_COMM at its next synchronisation)
+                __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // what the neighbour's copy wrote is visible to what follows in the stream
 }
 
 int copy_exchange(wafer_ctx *c, int buf, hipStream_t s, int planes, bool send_lo, bool send_hi, bool recv_lo, bool recv_hi)
@@ -202,30 +227,39 @@ int copy_exchange(wafer_ctx *c, int buf, hipStream_t s, int planes, bool send_lo
     const size_t bytes = ((size_t)(planes - 1) * (size_t)g.plane + (size_t)g.py * (size_t)g.pitch) * c->esz;
     char *mine = static_cast<char *>(c->phi[buf]);
     const bool recv[2] = {recv_lo, recv_hi}, send[2] = {send_lo, send_hi};
-    auto signal = [&](unsigned long long *word, unsigned long long value) -> int {
-        hipLaunchKernelGGL(wafer_k_signal, dim3(1), dim3(64), 0, s, word, value);
-        HIP_TRY(hipGetLastError());
-        return WAFER_OK;
-    };
-    auto wait_for = [&](const unsigned long long *word, unsigned long long value) -> int {
-        hipLaunchKernelGGL(wafer_k_gate, dim3(1), dim3(64), 0, s, word, value, c->hv_err, hv_spins(c, 4), 1);
+    auto launch = [&](const WaferRendezvous &r) -> int {
+        hipLaunchKernelGGL(wafer_k_rendezvous, dim3(1), dim3(64), 0, s, r, c->hv_err, hv_spins(c, 4));
         HIP_TRY(hipGetLastError());
         return WAFER_OK;
     };
     // the neighbour on side n knows this rank as ITS neighbour on side 1 - n
-    for (int n = 0; n < 2; ++n)
-        if (recv[n]) TRY(signal(c->peer[n].flags + (PEER_WORD_CREDIT + (1 - n)) * WAFER_F3_SYNC_STRIDE, ++c->cp_recv[n]));
+    WaferRendezvous pre, post;
+    for (int n = 0; n < 2; ++n) {
+        if (recv[n]) {   // "my receive number k is posted": the credit word facing me in the neighbour's memory
+            pre.set_word[n] = c->peer[n].flags + (PEER_WORD_CREDIT + (1 - n)) * WAFER_F3_SYNC_STRIDE;
+            pre.set_value[n] = ++c->cp_recv[n];
+        }
+        if (send[n]) {   // ... and its credit for what I am about to send
+            pre.wait_word[n] = c->peer_flags + (PEER_WORD_CREDIT + n) * WAFER_F3_SYNC_STRIDE;
+            pre.wait_value[n] = c->cp_sent[n] + 1;
+        }
+    }
+    TRY(launch(pre));
     for (int n = 0; n < 2; ++n) {
         if (!send[n]) continue;
-        TRY(wait_for(c->peer_flags + (PEER_WORD_CREDIT + n) * WAFER_F3_SYNC_STRIDE, c->cp_sent[n] + 1));
         // my lowest planes fill the lower neighbour's UPPER ghost planes [G + nzl_n, ...); my highest its upper neighbour's LOWER [G - planes, G)
         const char *src = mine + (size_t)(n == 0 ? g.G : g.G + g.nzl - planes) * plane_b;
         char *dst = static_cast<char *>(c->peer[n].phi[buf]) + (size_t)(n == 0 ? g.G + c->peer[n].nzl : g.G - planes) * plane_b;
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
-        TRY(signal(c->peer[n].flags + (PEER_WORD_ARRIVED + (1 - n)) * WAFER_F3_SYNC_STRIDE, ++c->cp_sent[n]));
+        post.set_word[n] = c->peer[n].flags + (PEER_WORD_ARRIVED + (1 - n)) * WAFER_F3_SYNC_STRIDE;   // "copy number k has landed"
+        post.set_value[n] = ++c->cp_sent[n];
     }
     for (int n = 0; n < 2; ++n)
-        if (recv[n]) TRY(wait_for(c->peer_flags + (PEER_WORD_ARRIVED + n) * WAFER_F3_SYNC_STRIDE, c->cp_recv[n]));
+        if (recv[n]) {
+            post.wait_word[n] = c->peer_flags + (PEER_WORD_ARRIVED + n) * WAFER_F3_SYNC_STRIDE;
+            post.wait_value[n] = c->cp_recv[n];
+        }
+    TRY(launch(post));
     return WAFER_OK;
 }
 
