@@ -512,7 +512,7 @@ def run_rank(args) -> int:
         # (slab.time_overlap_schedules: the same collective calls on every rank whatever happens on it; a schedule that fails
         #  anywhere is dropped everywhere)
         trial = slab.time_overlap_schedules(
-            ctx, ([(3, 1)] if peers_ok else []) + copy_modes + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] if deep else []), rank, device=coll_dev,
+            ctx, ([(3, 1)] if peers_ok else []) + copy_modes + [(2, 1), (1, 1), (0, 1)] + ([(1, 2), (0, 2)] + [(m, 2) for m, _ in copy_modes if m in (5, 6)] if deep else []), rank, device=coll_dev,
             log=lambda msg: print("bench.py: " + msg, file=sys.stderr, flush=True), device_sync=torch.cuda.synchronize)
         if not trial:
             print(f"bench.py: rank {rank}: every halo schedule failed in the set-up trial", file=sys.stderr)
