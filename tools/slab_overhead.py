@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--planes", type=int, default=128)
     ap.add_argument("--xy", type=int, default=1024)
     ap.add_argument("--cd", type=int, default=1)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "f32fast"], help="storage / arithmetic of the contexts (config #5: f32)")
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--wnum", type=int, default=0, help="excited-state steps against this many stored states")
     ap.add_argument("--modes", default="2,1,0", help="halo schedules to time (wafer_set_overlap modes; 4 = peer copies, its schedule from WAFER_COPY_SCHED)")
@@ -47,7 +48,7 @@ def main():
     hip = hip_runtime()
     hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     n, pl, ext = args.xy, args.planes, args.cd
-    kw = dict(dn=0.02, dt=8e-5, mass=2.35, sig=0.223, central_difference=ext, max_states=max(1, args.wnum))
+    kw = dict(dn=0.02, dt=8e-5, mass=2.35, sig=0.223, central_difference=ext, max_states=max(1, args.wnum), dtype=args.dtype)
     out = {}
 
     def run(par, hooks, overlap=True):
